@@ -1,0 +1,77 @@
+"""ctypes binding of the C-ABI in include/gbx_qlinear.h (libgbx_qlinear.so, gfx950 HIP kernels).
+
+There is NO fallback: if the shared library is missing or a call fails, this raises.  The CPU
+oracle under ``oracle/`` is test infrastructure and is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+_SO = os.path.join(_CSRC, "libgbx_qlinear.so")
+
+GBX_OK, GBX_ERR_INVALID, GBX_ERR_HIP, GBX_ERR_UNSUPPORTED = 0, 1, 2, 3
+GBX_F16, GBX_BF16, GBX_F32 = 0, 1, 2
+
+_lib = None
+
+
+def build(force: bool = False, jobs: int = 8) -> str:
+    """Compile every HIP source for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", _CSRC, f"-j{jobs}"]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def so_path() -> str:
+    return _SO
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise RuntimeError(
+                f"gbx_lm_amd: HIP extension {_SO} is not built. Run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or `make -C gbx-lm_amd/csrc`). There is no CPU fallback for QuantizedLinear.")
+        L = ctypes.CDLL(_SO)
+        i64, i32, p = ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p
+        L.gbx_version.restype = ctypes.c_int
+        L.gbx_last_error.restype = ctypes.c_char_p
+        L.gbx_qlinear_check.argtypes = [i64, i32, i32, i32, i32]
+        L.gbx_qlinear_workspace_bytes.argtypes = [i64, i32, i32, i32, i32]
+        L.gbx_qlinear_workspace_bytes.restype = ctypes.c_size_t
+        L.gbx_qlinear_forward.argtypes = [p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, p]
+        L.gbx_unpack.argtypes = [p, p, i32, i32, i32, p]
+        L.gbx_dequantize.argtypes = [p, p, p, p, i32, i32, i32, i32, i32, i32, p]
+        _declare_optional(L)
+        _lib = L
+    return _lib
+
+
+def _declare_optional(L) -> None:
+    """argtypes of entry points added after ABI 1000 (present in the same .so)."""
+    i64, i32, p, f32 = ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_float
+    opt = {
+        "gbx_rmsnorm": [p, p, p, i64, i32, f32, i32, p],
+        "gbx_dense_gemv": [p, p, p, p, i64, i32, i32, i32, p],
+    }
+    for name, argt in opt.items():
+        if hasattr(L, name):
+            getattr(L, name).argtypes = argt
+
+
+def check(rc: int) -> None:
+    """Map a C return code to the reference's exception behaviour."""
+    if rc == GBX_OK:
+        return
+    msg = lib().gbx_last_error().decode("utf-8", "replace")
+    if rc == GBX_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == GBX_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise RuntimeError(msg)

@@ -1,0 +1,5 @@
+// 4-bit instantiations of the decode GEMV (one TU per width so the three compile in parallel).
+#include "gemv_impl.h"
+namespace gbx {
+GBX_DEFINE_LAUNCH_GEMV(4)
+}  // namespace gbx

@@ -1,0 +1,142 @@
+// Support kernels of the GBA QuantizedLinear path: kernel-side unpack dump, dequantize
+// (mx.dequantize role, gbx_lm/tuner/lora.py:62-68) and a shape-generic qlinear used for shapes
+// the streaming kernels do not cover (K not a multiple of 128, very long rows).
+#include "gbx_device.h"
+#include "kernels.h"
+
+namespace gbx {
+
+// ---- unpack: q[n,k] --------------------------------------------------------------------------
+template <int BITS>
+__global__ __launch_bounds__(256) void unpack_kernel(const uint32_t* __restrict__ qw, int32_t* __restrict__ q,
+                                                     int N, int K) {
+  const int W = K / 32 * BITS;
+  const size_t total = static_cast<size_t>(N) * K;
+  for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < total;
+       i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    const int n = static_cast<int>(i / K), k = static_cast<int>(i % K);
+    q[i] = static_cast<int32_t>(field_of_row<BITS>(qw + static_cast<size_t>(n) * W, k));
+  }
+}
+
+hipError_t launch_unpack(const uint32_t* qw, int32_t* q, int N, int K, int bits, hipStream_t s) {
+  const size_t total = static_cast<size_t>(N) * K;
+  const int blocks = static_cast<int>(std::min<size_t>((total + 255) / 256, 4096));
+  switch (bits) {
+    case 2: hipLaunchKernelGGL(unpack_kernel<2>, dim3(blocks), dim3(256), 0, s, qw, q, N, K); break;
+    case 3: hipLaunchKernelGGL(unpack_kernel<3>, dim3(blocks), dim3(256), 0, s, qw, q, N, K); break;
+    case 4: hipLaunchKernelGGL(unpack_kernel<4>, dim3(blocks), dim3(256), 0, s, qw, q, N, K); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// ---- dequantize: w = s*q + z -----------------------------------------------------------------
+// fp32 output is bit-exact against the oracle: one multiply and one add, never contracted to an fma.
+template <int BITS, bool SZ_BF16, int OUT>
+__global__ __launch_bounds__(256) void dequant_kernel(const uint32_t* __restrict__ qw, const unsigned short* __restrict__ sc,
+                                                      const unsigned short* __restrict__ ze, void* __restrict__ w,
+                                                      int N, int K, int log2g) {
+  const int W = K / 32 * BITS, G = K >> log2g;
+  const size_t total = static_cast<size_t>(N) * K;
+  for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < total;
+       i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    const int n = static_cast<int>(i / K), k = static_cast<int>(i % K);
+    const float q = static_cast<float>(field_of_row<BITS>(qw + static_cast<size_t>(n) * W, k));
+    const float s = act_to_f32<SZ_BF16>(sc[static_cast<size_t>(n) * G + (k >> log2g)]);
+    const float z = act_to_f32<SZ_BF16>(ze[static_cast<size_t>(n) * G + (k >> log2g)]);
+    const float v = __fadd_rn(__fmul_rn(q, s), z);
+    if constexpr (OUT == 2) static_cast<float*>(w)[i] = v;
+    else if constexpr (OUT == 1) static_cast<unsigned short*>(w)[i] = f32_to_act<true>(v);
+    else static_cast<unsigned short*>(w)[i] = f32_to_act<false>(v);
+  }
+}
+
+template <int BITS, bool SZ_BF16>
+static void launch_dequant_o(const uint32_t* qw, const void* sc, const void* ze, void* w, int N, int K, int log2g,
+                             int out, int blocks, hipStream_t s) {
+  auto S = static_cast<const unsigned short*>(sc);
+  auto Z = static_cast<const unsigned short*>(ze);
+  if (out == 2) hipLaunchKernelGGL((dequant_kernel<BITS, SZ_BF16, 2>), dim3(blocks), dim3(256), 0, s, qw, S, Z, w, N, K, log2g);
+  else if (out == 1) hipLaunchKernelGGL((dequant_kernel<BITS, SZ_BF16, 1>), dim3(blocks), dim3(256), 0, s, qw, S, Z, w, N, K, log2g);
+  else hipLaunchKernelGGL((dequant_kernel<BITS, SZ_BF16, 0>), dim3(blocks), dim3(256), 0, s, qw, S, Z, w, N, K, log2g);
+}
+
+hipError_t launch_dequant(const uint32_t* qw, const void* sc, const void* ze, void* w, int N, int K, int bits,
+                          int log2g, bool sz_bf16, int out, hipStream_t s) {
+  const size_t total = static_cast<size_t>(N) * K;
+  const int blocks = static_cast<int>(std::min<size_t>((total + 255) / 256, 8192));
+#define GBX_DQ(B)                                                                         \
+  if (sz_bf16) launch_dequant_o<B, true>(qw, sc, ze, w, N, K, log2g, out, blocks, s);   \
+  else launch_dequant_o<B, false>(qw, sc, ze, w, N, K, log2g, out, blocks, s);
+  switch (bits) {
+    case 2: GBX_DQ(2) break;
+    case 3: GBX_DQ(3) break;
+    case 4: GBX_DQ(4) break;
+    default: return hipErrorInvalidValue;
+  }
+#undef GBX_DQ
+  return hipGetLastError();
+}
+
+// ---- shape-generic qlinear (any K % 32 == 0, any M): one wave per (row n, activation row m) ----
+// Lanes stride over 32-value chunks (always a whole number of words); fp32 math throughout.
+template <int BITS, bool BF16>
+__global__ __launch_bounds__(256) void qlinear_generic_kernel(const unsigned short* __restrict__ x, const uint32_t* __restrict__ qw,
+                                                              const unsigned short* __restrict__ sc, const unsigned short* __restrict__ ze,
+                                                              const unsigned short* __restrict__ bias, unsigned short* __restrict__ y,
+                                                              int N, int K, int log2g) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 4 + wave;
+  const int m = blockIdx.y;
+  if (n >= N) return;
+  const int W = K / 32 * BITS, G = K >> log2g;
+  const uint32_t* row = qw + static_cast<size_t>(n) * W;
+  const unsigned short* xr = x + static_cast<size_t>(m) * K;
+  float acc = 0.f;
+  for (int c = lane; c < K / 32; c += 64) {
+    uint32_t wv[BITS + 1];
+#pragma unroll
+    for (int i = 0; i < BITS; ++i) wv[i] = row[c * BITS + i];
+    wv[BITS] = 0;
+    float qx = 0.f, sx = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const float xv = act_to_f32<BF16>(xr[c * 32 + j]);
+      qx = fmaf(static_cast<float>(field_of_row<BITS>(wv, j)), xv, qx);
+      sx += xv;
+    }
+    const int g = (c * 32) >> log2g;
+    acc = fmaf(act_to_f32<BF16>(sc[static_cast<size_t>(n) * G + g]), qx, acc);
+    acc = fmaf(act_to_f32<BF16>(ze[static_cast<size_t>(n) * G + g]), sx, acc);
+  }
+  const float tot = wave_sum(acc);
+  if (lane == 0) {
+    float v = tot;
+    if (bias) v += act_to_f32<BF16>(bias[n]);
+    y[static_cast<size_t>(m) * N + n] = f32_to_act<BF16>(v);
+  }
+}
+
+hipError_t launch_qlinear_generic(const void* x, const uint32_t* qw, const void* sc, const void* ze, const void* bias,
+                                  void* y, int M, int N, int K, int bits, int log2g, bool bf16, hipStream_t s) {
+  dim3 grid((N + 3) / 4, M), block(256);
+  auto X = static_cast<const unsigned short*>(x);
+  auto S = static_cast<const unsigned short*>(sc);
+  auto Z = static_cast<const unsigned short*>(ze);
+  auto B = static_cast<const unsigned short*>(bias);
+  auto Y = static_cast<unsigned short*>(y);
+#define GBX_GEN(BITS)                                                                                              \
+  if (bf16) hipLaunchKernelGGL((qlinear_generic_kernel<BITS, true>), grid, block, 0, s, X, qw, S, Z, B, Y, N, K, log2g); \
+  else hipLaunchKernelGGL((qlinear_generic_kernel<BITS, false>), grid, block, 0, s, X, qw, S, Z, B, Y, N, K, log2g);
+  switch (bits) {
+    case 2: GBX_GEN(2) break;
+    case 3: GBX_GEN(3) break;
+    case 4: GBX_GEN(4) break;
+    default: return hipErrorInvalidValue;
+  }
+#undef GBX_GEN
+  return hipGetLastError();
+}
+
+}  // namespace gbx

@@ -1,0 +1,61 @@
+"""Model-graph glue shared by the dense families (host side of gbx_lm/models/base.py).
+
+Only what the QuantizedLinear callers need: ``BaseModelArgs.from_dict`` (base.py:15-24), the additive
+causal mask with cache offset (base.py:27-62) and the SDPA dispatch (base.py:101-122; the quantised-KV
+branch :65-98 is out of scope and raises).
+"""
+from __future__ import annotations
+
+import inspect
+from dataclasses import dataclass
+from typing import Any, Optional
+
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class BaseModelArgs:
+    @classmethod
+    def from_dict(cls, params):
+        return cls(**{k: v for k, v in params.items() if k in inspect.signature(cls).parameters})
+
+
+def create_causal_mask(N: int, offset: int = 0, window_size: Optional[int] = None, device=None) -> torch.Tensor:
+    rinds = torch.arange(offset + N, device=device)
+    linds = torch.arange(offset, offset + N, device=device) if offset else rinds
+    linds = linds[:, None]
+    rinds = rinds[None]
+    mask = linds < rinds
+    if window_size is not None:
+        mask = mask | (linds > rinds + window_size)
+    return mask * -1e9
+
+
+def create_attention_mask(h: torch.Tensor, cache: Optional[Any] = None) -> Optional[torch.Tensor]:
+    T = h.shape[1]
+    if T > 1:
+        window_size = None
+        offset = 0
+        if cache is not None and cache[0] is not None:
+            c = cache[0]
+            if hasattr(c, "max_size"):
+                offset = min(c.max_size, c.offset)
+                window_size = c.max_size
+            else:
+                offset = c.offset
+        mask = create_causal_mask(T, offset, window_size=window_size, device=h.device)
+        return mask.to(h.dtype)
+    return None
+
+
+def scaled_dot_product_attention(queries, keys, values, cache, scale: float, mask: Optional[torch.Tensor]):
+    """[B, Hq, L, D] x [B, Hkv, S, D] -> [B, Hq, L, D]; GQA by head repetition like mx.fast.sdpa."""
+    if getattr(cache, "bits", None) is not None:
+        raise NotImplementedError("quantised KV cache is outside the QuantizedLinear hot path")
+    n_q, n_kv = queries.shape[1], keys.shape[1]
+    if n_q != n_kv:
+        rep = n_q // n_kv
+        keys = keys.repeat_interleave(rep, dim=1)
+        values = values.repeat_interleave(rep, dim=1)
+    return F.scaled_dot_product_attention(queries, keys, values, attn_mask=mask, scale=scale)

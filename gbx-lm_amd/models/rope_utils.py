@@ -1,0 +1,91 @@
+"""Rotary embeddings needed by the Llama graph: default / linear and Llama-3 frequency smoothing
+(gbx_lm/models/rope_utils.py:70-122,197-257).  YaRN / su-rope belong to other families and raise.
+
+``mx.fast.rope(x, dims, traditional=False, freqs=...)`` semantics restated in torch: angle of pair i at
+position t is ``t * scale / freqs[i]``; non-traditional pairs element i with i + dims/2; computed in fp32,
+returned in x.dtype.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+
+
+def apply_rope(x: torch.Tensor, inv_freq: torch.Tensor, offset: int, scale: float, traditional: bool) -> torch.Tensor:
+    """x [B, H, L, D]; rotates the first 2*len(inv_freq) features."""
+    L = x.shape[-2]
+    dims = inv_freq.numel() * 2
+    pos = (torch.arange(offset, offset + L, device=x.device, dtype=torch.float32) * scale)
+    ang = pos[:, None] * inv_freq[None, :].to(x.device)
+    cos, sin = torch.cos(ang), torch.sin(ang)
+    xf = x[..., :dims].to(torch.float32)
+    if traditional:
+        x1, x2 = xf[..., 0::2], xf[..., 1::2]
+        out = torch.stack([x1 * cos - x2 * sin, x1 * sin + x2 * cos], dim=-1).flatten(-2)
+    else:
+        x1, x2 = xf[..., : dims // 2], xf[..., dims // 2:]
+        out = torch.cat([x1 * cos - x2 * sin, x1 * sin + x2 * cos], dim=-1)
+    out = out.to(x.dtype)
+    if dims < x.shape[-1]:
+        out = torch.cat([out, x[..., dims:]], dim=-1)
+    return out
+
+
+class RoPE(nn.Module):
+    def __init__(self, dims: int, traditional: bool = False, base: float = 10000, scale: float = 1.0):
+        super().__init__()
+        self.dims, self.traditional, self.scale = dims, traditional, scale
+        inv = 1.0 / (base ** (torch.arange(0, dims, 2, dtype=torch.float32) / dims))
+        self.register_buffer("inv_freq", inv, persistent=False)
+
+    def forward(self, x, offset: int = 0):
+        return apply_rope(x, self.inv_freq, offset, self.scale, self.traditional)
+
+
+class Llama3RoPE(nn.Module):
+    """rope_utils.py:70-122: low-frequency wavelengths scaled by ``factor``, medium ones smoothed."""
+
+    def __init__(self, dims: int, max_position_embeddings: int = 2048, traditional: bool = False,
+                 base: float = 10000, scaling_config: dict = None):
+        super().__init__()
+        self.dims, self.traditional = dims, traditional
+        self.max_position_embeddings = max_position_embeddings
+        factor = scaling_config["factor"]
+        low_freq_factor = scaling_config.get("low_freq_factor", 1.0)
+        high_freq_factor = scaling_config.get("high_freq_factor", 4.0)
+        old_context_len = scaling_config.get("original_max_position_embeddings", 8192)
+        low_freq_wavelen = old_context_len / low_freq_factor
+        high_freq_wavelen = old_context_len / high_freq_factor
+        freqs = base ** (torch.arange(0, dims, 2, dtype=torch.float32) / dims)
+        wavelens = 2 * math.pi * freqs
+        freqs = torch.where(wavelens > low_freq_wavelen, freqs * factor, freqs)
+        is_medium = (wavelens > high_freq_wavelen) & (wavelens < low_freq_wavelen)
+        smooth = (old_context_len / wavelens - low_freq_factor) / (high_freq_factor - low_freq_factor)
+        smooth_freqs = freqs / ((1 - smooth) / factor + smooth)
+        freqs = torch.where(is_medium, smooth_freqs, freqs)
+        self.register_buffer("inv_freq", 1.0 / freqs, persistent=False)
+        self.scale = 1.0
+
+    def forward(self, x, offset: int = 0):
+        return apply_rope(x, self.inv_freq, offset, 1.0, self.traditional)
+
+
+def initialize_rope(dims, base, traditional, scaling_config: Optional[dict] = None,
+                    max_position_embeddings: Optional[int] = None):
+    """rope_utils.py:197-257 (dispatch on ``type`` / ``rope_type``)."""
+    if scaling_config is not None:
+        rope_type = scaling_config.get("type") or scaling_config.get("rope_type", "default")
+    else:
+        rope_type = "default"
+    if rope_type in ["default", "linear"]:
+        scale = 1 / scaling_config["factor"] if rope_type == "linear" else 1.0
+        return RoPE(dims, traditional=traditional, base=base, scale=scale)
+    if rope_type == "llama3":
+        return Llama3RoPE(dims=dims, max_position_embeddings=max_position_embeddings, traditional=traditional,
+                          base=base, scaling_config=scaling_config)
+    if rope_type in ("yarn", "longrope"):
+        raise NotImplementedError(f"RoPE type {rope_type} belongs to model families outside the Llama hot path")
+    raise ValueError(f"Unsupported RoPE type {rope_type}")

@@ -1,0 +1,110 @@
+"""Python-side operator wrappers: torch tensors in, raw device pointers across the C-ABI.
+
+``quantized_matmul`` mirrors the one MLX call the reference makes on this path
+(``mx.quantized_matmul(x, w, scales=, biases=, transpose=True, group_size=, bits=)``,
+gbx_lm/models/quantized_linear_gba.py:195-203): same argument names and meaning.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+_DT = {torch.float16: _lib.GBX_F16, torch.bfloat16: _lib.GBX_BF16, torch.float32: _lib.GBX_F32}
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require_cuda(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"gbx_lm_amd: `{name}` lives on {t.device}; the GBA QuantizedLinear path runs only as HIP kernels on an "
+            "MI355X (no CPU fallback).")
+
+
+def quantized_matmul(x: torch.Tensor, w: torch.Tensor, scales: torch.Tensor, biases: torch.Tensor,
+                     transpose: bool = True, group_size: int = 64, bits: int = 4,
+                     bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y[..., n] = sum_k x[..., k] * (scales[n, k//g] * q[n, k] + biases[n, k//g])  (+ bias[n]).
+
+    ``w`` is the packed uint32 ``qweight [N, K*bits/32]``; ``biases`` are the GBA "zeros"
+    (already MLX-signed, quantized_linear_gba.py:151-155).  Only ``transpose=True`` exists on
+    this path.  Raises ValueError on shape/bits/group violations like the reference's asserts.
+    """
+    if not transpose:
+        raise NotImplementedError("quantized_matmul(transpose=False) is not on the QuantizedLinear path")
+    for t, nm in ((x, "x"), (w, "w"), (scales, "scales"), (biases, "biases")):
+        _require_cuda(t, nm)
+    if x.dtype not in (torch.float16, torch.bfloat16):
+        raise ValueError(f"activations must be float16 or bfloat16, got {x.dtype}")
+    if w.dtype not in (torch.uint32, torch.int32):
+        raise ValueError(f"packed weight must be uint32, got {w.dtype}")
+    if w.dim() != 2 or scales.dim() != 2 or biases.shape != scales.shape:
+        raise ValueError("w must be [N, K*bits/32]; scales/biases must be [N, K/group_size]")
+    n = w.shape[0]
+    if (w.shape[1] * 32) % bits:
+        raise ValueError(f"packed row of {w.shape[1]} words is not a whole number of {bits}-bit fields")
+    k = w.shape[1] * 32 // bits
+    if x.shape[-1] != k:
+        raise ValueError(f"last dim of x ({x.shape[-1]}) != input_dims ({k}) implied by w and bits")
+    if k % group_size or scales.shape != (n, k // group_size):
+        raise ValueError(f"scales must be [{n}, {k}//{group_size}], got {tuple(scales.shape)}")
+    if scales.dtype != x.dtype:
+        scales = scales.to(x.dtype)
+    if biases.dtype != x.dtype:
+        biases = biases.to(x.dtype)
+    if bias is not None:
+        _require_cuda(bias, "bias")
+        if bias.shape != (n,):
+            raise ValueError(f"bias must be [{n}]")
+        if bias.dtype != x.dtype:
+            bias = bias.to(x.dtype)
+        bias = bias.contiguous()
+    x2 = x.reshape(-1, k).contiguous()
+    m = x2.shape[0]
+    w = w.contiguous()
+    scales = scales.contiguous()
+    biases = biases.contiguous()
+    if out is None:
+        out = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    elif out.shape != (m, n) or out.dtype != x.dtype or not out.is_contiguous():
+        raise ValueError("out must be a contiguous [M, N] tensor of the activation dtype")
+    rc = _lib.lib().gbx_qlinear_forward(
+        x2.data_ptr(), w.data_ptr(), scales.data_ptr(), biases.data_ptr(),
+        bias.data_ptr() if bias is not None else None, out.data_ptr(),
+        m, n, k, bits, group_size, _DT[x.dtype], _stream_ptr(x.device))
+    _lib.check(rc)
+    return out.reshape(*x.shape[:-1], n)
+
+
+def unpack(w: torch.Tensor, bits: int) -> torch.Tensor:
+    """Kernel-side unpack dump: packed uint32 [N, W] -> int32 [N, K] (bit-exact parity surface)."""
+    _require_cuda(w, "w")
+    n = w.shape[0]
+    k = w.shape[1] * 32 // bits
+    q = torch.empty((n, k), dtype=torch.int32, device=w.device)
+    w = w.contiguous()
+    _lib.check(_lib.lib().gbx_unpack(w.data_ptr(), q.data_ptr(), n, k, bits, _stream_ptr(w.device)))
+    return q
+
+
+def dequantize(w: torch.Tensor, scales: torch.Tensor, biases: torch.Tensor, group_size: int = 64, bits: int = 4,
+               dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """``mx.dequantize`` role (gbx_lm/tuner/lora.py:62-68): scales*q + biases, shape [N, K]."""
+    for t, nm in ((w, "w"), (scales, "scales"), (biases, "biases")):
+        _require_cuda(t, nm)
+    if scales.dtype not in (torch.float16, torch.bfloat16) or biases.dtype != scales.dtype:
+        raise ValueError("scales/biases must both be float16 or bfloat16")
+    dtype = dtype or scales.dtype
+    n = w.shape[0]
+    k = w.shape[1] * 32 // bits
+    out = torch.empty((n, k), dtype=dtype, device=w.device)
+    rc = _lib.lib().gbx_dequantize(w.contiguous().data_ptr(), scales.contiguous().data_ptr(),
+                                   biases.contiguous().data_ptr(), out.data_ptr(), n, k, bits, group_size,
+                                   _DT[scales.dtype], _DT[dtype], _stream_ptr(w.device))
+    _lib.check(rc)
+    return out

@@ -1,0 +1,162 @@
+"""Synthetic GBA checkpoints with the real tensor names / shapes / dtypes (no network, no real weights).
+
+Distributions follow SURVEY.md 8d: uniform random packed words, ``scales ~ U(0.5,1.5)*2/(2^b-1)*0.02``,
+``zeros = -scales*(2^b-1)/2 + N(0, 0.1*scales)`` (MLX-signed, i.e. added), embeddings ``N(0, 0.02)``.
+Used by bench.py, the tests and ``__graft_entry__.smoke()``; the layout written to disk is exactly what
+``load()`` reads (gbx_lm/utils.py:752-879 contract).
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, Optional
+
+import torch
+
+from .models import qllama
+from .models.quantized_linear_gba import QuantizedLinear
+
+PROJ = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")
+
+LLAMA3_8B = dict(model_type="llama", hidden_size=4096, intermediate_size=14336, num_hidden_layers=32,
+                 num_attention_heads=32, num_key_value_heads=8, rms_norm_eps=1e-5, vocab_size=128256,
+                 rope_theta=500000.0, max_position_embeddings=8192, tie_word_embeddings=False,
+                 eos_token_id=128009)
+LLAMA32_3B = dict(model_type="llama", hidden_size=3072, intermediate_size=8192, num_hidden_layers=28,
+                  num_attention_heads=24, num_key_value_heads=8, head_dim=128, rms_norm_eps=1e-5, vocab_size=128256,
+                  rope_theta=500000.0, max_position_embeddings=131072, tie_word_embeddings=True,
+                  rope_scaling=dict(factor=32.0, high_freq_factor=4.0, low_freq_factor=1.0,
+                                    original_max_position_embeddings=8192, rope_type="llama3"),
+                  eos_token_id=128009)
+TINY = dict(model_type="llama", hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+            num_attention_heads=4, num_key_value_heads=2, rms_norm_eps=1e-5, vocab_size=512,
+            rope_theta=10000.0, max_position_embeddings=512, tie_word_embeddings=False, eos_token_id=511)
+
+
+def strategy_bits(name: str, layer: int, n_layers: int) -> int:
+    """S40: all 4-bit.  S22: first/last layer 4-bit, layers 1,2 and n-2 3-bit, else 2-bit."""
+    if name == "S40":
+        return 4
+    if name == "S22":
+        if layer in (0, n_layers - 1):
+            return 4
+        if layer in (1, 2, n_layers - 2):
+            return 3
+        return 2
+    if name == "S30":
+        return 3
+    if name == "S20":
+        return 2
+    raise ValueError(f"unknown synthetic strategy {name}")
+
+
+def make_strategy(name: str, n_layers: int, group_size: int = 128) -> Dict:
+    """quant_strategy.json["measurement"] in the reference's schema (quantized_linear_gba.py:256-272)."""
+    strat = {}
+    for i in range(n_layers):
+        b = strategy_bits(name, i, n_layers)
+        strat[f"model.layers.{i}"] = {p: {"bits": [b], "group_size": {str(b): group_size}} for p in PROJ}
+    return strat
+
+
+def _fill_qlinear(m: QuantizedLinear, gen: torch.Generator, device, act_dtype) -> None:
+    n, k, b, g = m.output_dims, m.input_dims, m.bits, m.group_size
+    words = k // 32 * b
+    qw = torch.randint(0, 2**32, (n, words), dtype=torch.int64, device=device, generator=gen).to(torch.int32)
+    qmax = float((1 << b) - 1)
+    sc = (torch.rand((n, k // g), device=device, generator=gen) + 0.5) * (2.0 / qmax) * 0.02
+    ze = -sc * qmax / 2.0 + torch.randn((n, k // g), device=device, generator=gen) * 0.1 * sc
+    m._buffers["qweight"] = qw.view(torch.uint32)
+    m._buffers["scales"] = sc.to(act_dtype)
+    m._buffers["zeros"] = ze.to(act_dtype)
+    m._buffers["channel_scale"] = torch.ones((1, 1, k), dtype=torch.float16, device=device)
+    if m.bias is not None:
+        m._buffers["bias"] = (torch.randn((n,), device=device, generator=gen) * 0.01).to(act_dtype)
+
+
+def build_model(config: Dict, strategy: Optional[Dict] = None, device="cpu", seed: int = 0,
+                act_dtype=torch.bfloat16, bits: int = 4, group_size: int = 64) -> qllama.Model:
+    """Random-init model with real shapes, generated directly on ``device`` (no files)."""
+    device = torch.device(device)
+    args = qllama.ModelArgs.from_dict(config)
+    with torch.device("meta"):
+        model = qllama.Model(args)
+    model = model.to_empty(device=device)
+    QuantizedLinear.reinit_module(model, group_size=group_size, bits=bits, strategy=strategy)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    for m in model.modules():
+        if isinstance(m, QuantizedLinear):
+            for nm in list(m._buffers):
+                if m._buffers[nm] is not None and m._buffers[nm].device != device:
+                    m._buffers[nm] = torch.empty_like(m._buffers[nm], device=device)
+            _fill_qlinear(m, gen, device, act_dtype)
+        elif isinstance(m, qllama.RMSNorm):
+            m.weight = torch.nn.Parameter(torch.ones(m.weight.shape, dtype=act_dtype, device=device), requires_grad=False)
+        elif isinstance(m, torch.nn.Embedding):
+            w = torch.randn(m.weight.shape, device=device, generator=gen) * 0.02
+            m.weight = torch.nn.Parameter(w.to(act_dtype), requires_grad=False)
+        elif isinstance(m, torch.nn.Linear):
+            w = torch.randn(m.weight.shape, device=device, generator=gen) * 0.02
+            m.weight = torch.nn.Parameter(w.to(act_dtype), requires_grad=False)
+        elif hasattr(m, "inv_freq") and isinstance(getattr(m, "inv_freq"), torch.Tensor):
+            pass
+    # rope tables are non-persistent buffers created on meta: rebuild them for real
+    from .models.rope_utils import initialize_rope
+    for blk in model.model.layers:
+        at = blk.self_attn
+        at.rope = initialize_rope(at.head_dim, args.rope_theta, args.rope_traditional, args.rope_scaling,
+                                  args.max_position_embeddings).to(device)
+    model.eval()
+    return model
+
+
+def state_dict_for_disk(model: qllama.Model) -> Dict[str, torch.Tensor]:
+    """Checkpoint keys exactly as a ``-mlx`` GBA repo stores them."""
+    out = {}
+    for name, m in model.named_modules():
+        if isinstance(m, QuantizedLinear):
+            for nm in ("qweight", "scales", "zeros", "bias", "channel_scale"):
+                t = getattr(m, nm, None)
+                if t is not None:
+                    out[f"{name}.{nm}"] = t.detach().cpu().contiguous()
+        elif isinstance(m, (qllama.RMSNorm, torch.nn.Embedding, torch.nn.Linear)):
+            out[f"{name}.weight"] = m.weight.detach().cpu().contiguous()
+    return out
+
+
+def write_tokenizer(path: str, vocab_size: int, eos_token_id: int) -> None:
+    """Tiny offline WordLevel tokenizer so that ``load()`` / ``generate(str)`` run end to end."""
+    from tokenizers import Tokenizer, models, pre_tokenizers, decoders
+    vocab = {f"w{i}": i for i in range(vocab_size)}
+    vocab["<eos>"] = eos_token_id
+    vocab = {k: v for k, v in vocab.items() if not (k == f"w{eos_token_id}")}
+    vocab["hello"], vocab["world"] = vocab.pop("w1"), vocab.pop("w2")
+    tok = Tokenizer(models.WordLevel(vocab=vocab, unk_token="w0"))
+    tok.pre_tokenizer = pre_tokenizers.Whitespace()
+    tok.decoder = decoders.Fuse()
+    tok.save(os.path.join(path, "tokenizer.json"))
+    with open(os.path.join(path, "tokenizer_config.json"), "w") as f:
+        json.dump({"tokenizer_class": "PreTrainedTokenizerFast", "eos_token": "<eos>", "unk_token": "w0"}, f)
+
+
+def write_checkpoint(path: str, config: Dict, strategy: Optional[Dict], seed: int = 0,
+                     quantization: Optional[Dict] = None, extra_tensors: Optional[Dict] = None) -> qllama.Model:
+    """config.json + quant_strategy.json + model.safetensors (+ tokenizer) for ``load(path)``."""
+    from safetensors.torch import save_file
+    os.makedirs(path, exist_ok=True)
+    q = quantization or {"group_size": 64, "bits": 4}
+    model = build_model(config, strategy, device="cpu", seed=seed, bits=q["bits"], group_size=q["group_size"])
+    cfg = dict(config)
+    cfg["quantization"] = q
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(cfg, f, indent=1)
+    if strategy is not None:
+        with open(os.path.join(path, "quant_strategy.json"), "w") as f:
+            json.dump({"measurement": strategy}, f)
+    sd = state_dict_for_disk(model)
+    if extra_tensors:
+        sd.update(extra_tensors)
+    save_file(sd, os.path.join(path, "model.safetensors"))
+    write_tokenizer(path, config["vocab_size"], config.get("eos_token_id", config["vocab_size"] - 1))
+    return model

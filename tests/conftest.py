@@ -1,0 +1,59 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU tests must never pass silently without a GPU: on a box with no device they fail, not skip,
+    unless the run deselected them with -m 'not gpu'."""
+    return
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import gba_oracle
+    return gba_oracle
+
+
+@pytest.fixture(scope="session")
+def c_oracle():
+    from oracle import c_oracle as co
+    co.build()
+    return co
+
+
+def oracle_matmul(x, w, scales, biases, transpose=True, group_size=64, bits=4, bias=None, out=None):
+    """CPU stand-in for gbx_lm_amd.ops.quantized_matmul backed by the oracle.  TEST USE ONLY: lets the host
+    graph / generate loop run on CPU so host logic is covered without a GPU."""
+    import numpy as np
+    import torch
+    from oracle import gba_oracle as O
+    qw = w.detach().cpu().view(torch.int32).numpy().view(np.uint32)
+    y = O.qlinear_ref(x.detach().cpu().reshape(-1, x.shape[-1]), qw, scales.cpu(), biases.cpu(), bits, group_size,
+                      bias=None if bias is None else bias.cpu())
+    yt = torch.from_numpy(y.astype(np.float32)).to(x.dtype).reshape(*x.shape[:-1], w.shape[0])
+    return yt
+
+
+@pytest.fixture
+def cpu_oracle_op(monkeypatch):
+    """Route QuantizedLinear.forward through the oracle on CPU (host-logic tests only)."""
+    from gbx_lm_amd import ops
+    monkeypatch.setattr(ops, "quantized_matmul", oracle_matmul)
+    return oracle_matmul
