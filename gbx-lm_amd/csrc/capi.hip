@@ -61,12 +61,12 @@ int gbx_qlinear_forward(const void* x, const uint32_t* qweight, const void* scal
   int rc = check_shape(M, N, K, bits, group_size);
   if (rc) return rc;
   if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  if (M == 0) return GBX_OK;   /* empty batch: nothing to enqueue (x / y may legitimately be null) */
   if (!x || !qweight || !scales || !zeros || !y) return fail(GBX_ERR_INVALID, "null device pointer");
   if (!aligned(qweight, 16) || !aligned(x, 16))
     return fail(GBX_ERR_INVALID, "x and qweight must be 16-byte aligned");
   if (!aligned(scales, 2) || !aligned(zeros, 2) || !aligned(y, 2) || (bias && !aligned(bias, 2)))
     return fail(GBX_ERR_INVALID, "scales/zeros/bias/y must be 2-byte aligned");
-  if (M == 0) return GBX_OK;
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   const bool bf16 = act_dtype == GBX_BF16;
   const int log2g = log2_group(group_size);

@@ -13,6 +13,11 @@ using h2 = _Float16 __attribute__((ext_vector_type(2)));
 
 constexpr int WAVE = 64;
 
+// NOTE (hipcc / ROCm 7.2): __builtin_bit_cast applied directly to an ext-vector ELEMENT expression (v.y) reads
+// element 0.  Always go through a by-value scalar parameter.
+__device__ __forceinline__ h2 as_h2(unsigned u) { return __builtin_bit_cast(h2, u); }
+__device__ __forceinline__ unsigned as_u32(h2 v) { return __builtin_bit_cast(unsigned, v); }
+
 // ---- 16-bit activation formats ------------------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(unsigned short b) {
   return __uint_as_float(static_cast<unsigned>(b) << 16);

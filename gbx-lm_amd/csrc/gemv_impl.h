@@ -33,29 +33,37 @@ struct GemvArgs {
   int rows_per_wave;
 };
 
+// Per bit width: slot geometry and the pair table.  Pair i of a unit holds fields (ka(i), kb(i)) sitting at bit
+// pos(i) of the low / high 16-bit half of the register the dot routine masks.  (constexpr functions, not static
+// arrays: a static constexpr array odr-used in device code has no device-side storage.)
 template <int BITS> struct Fmt;
 template <> struct Fmt<2> {
   static constexpr int SLOT_WORDS = 4, VPL = 64, NSUB = 2, UNIT_VALS = 16, UNIT_PAIRS = 8;
-  // pair i of a unit = fields (KA[i], KB[i]) sitting at bit POS[i] of the low / high 16-bit half
-  static constexpr int KA[8] = {0, 1, 2, 3, 4, 5, 6, 7};
-  static constexpr int KB[8] = {8, 9, 10, 11, 12, 13, 14, 15};
-  static constexpr int POS[8] = {0, 2, 4, 6, 8, 0, 2, 4};
+  __host__ __device__ static constexpr int ka(int i) { return i; }
+  __host__ __device__ static constexpr int kb(int i) { return 8 + i; }
+  __host__ __device__ static constexpr int pos(int i) { return i < 5 ? 2 * i : 2 * (i - 5); }
 };
 template <> struct Fmt<4> {
   static constexpr int SLOT_WORDS = 4, VPL = 32, NSUB = 1, UNIT_VALS = 8, UNIT_PAIRS = 4;
-  static constexpr int KA[4] = {0, 1, 2, 3};
-  static constexpr int KB[4] = {4, 5, 6, 7};
-  static constexpr int POS[4] = {0, 4, 0, 4};
+  __host__ __device__ static constexpr int ka(int i) { return i; }
+  __host__ __device__ static constexpr int kb(int i) { return 4 + i; }
+  __host__ __device__ static constexpr int pos(int i) { return (i & 1) ? 4 : 0; }
 };
 template <> struct Fmt<3> {
   static constexpr int SLOT_WORDS = 3, VPL = 32, NSUB = 1, UNIT_VALS = 32, UNIT_PAIRS = 16;
-  static constexpr int KA[16] = {0, 1, 2, 3, 4, 6, 7, 8, 9, 11, 12, 13, 14, 15, 5, 10};
-  static constexpr int KB[16] = {16, 17, 18, 19, 20, 22, 23, 24, 25, 27, 28, 29, 30, 31, 21, 26};
-  static constexpr int POS[16] = {0, 3, 6, 0, 3, 2, 5, 0, 3, 1, 4, 7, 0, 3, 0, 0};
+  __host__ __device__ static constexpr int ka(int i) {
+    constexpr int t[16] = {0, 1, 2, 3, 4, 6, 7, 8, 9, 11, 12, 13, 14, 15, 5, 10};
+    return t[i];
+  }
+  __host__ __device__ static constexpr int kb(int i) { return ka(i) + 16; }
+  __host__ __device__ static constexpr int pos(int i) {
+    constexpr int t[16] = {0, 3, 6, 0, 3, 2, 5, 0, 3, 1, 4, 7, 0, 3, 0, 0};
+    return t[i];
+  }
 };
 
 __device__ __forceinline__ float dot2h(unsigned wbits, h2 xv, float acc) {
-  return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, wbits), xv, acc, false);
+  return __builtin_amdgcn_fdot2(as_h2(wbits), xv, acc, false);
 }
 
 // ---- per-unit dot products: masks select fields in place (fp16 subnormals) ---------------------
@@ -224,10 +232,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
       h2* dst = xp_lds + static_cast<size_t>(slot) * SSTR + uin * F::UNIT_PAIRS;
 #pragma unroll
       for (int i = 0; i < F::UNIT_PAIRS; ++i) {
-        const float sc = exp2i(E - F::POS[i]);
+        const float sc = exp2i(E - F::pos(i));
         h2 v;
-        v.x = static_cast<_Float16>(xf[F::KA[i]] * sc);
-        v.y = static_cast<_Float16>(xf[F::KB[i]] * sc);
+        v.x = static_cast<_Float16>(xf[F::ka(i)] * sc);
+        v.y = static_cast<_Float16>(xf[F::kb(i)] * sc);
         dst[i] = v;
       }
       constexpr int UPSUB = 32 / F::UNIT_VALS == 0 ? 1 : 32 / F::UNIT_VALS;   // units per 32-value sub-slot
@@ -247,10 +255,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
       for (int q = 0; q < PAIRS / 4; ++q) {
         const u32x4 v = src[q];
-        xv[p][4 * q + 0] = __builtin_bit_cast(h2, v.x);
-        xv[p][4 * q + 1] = __builtin_bit_cast(h2, v.y);
-        xv[p][4 * q + 2] = __builtin_bit_cast(h2, v.z);
-        xv[p][4 * q + 3] = __builtin_bit_cast(h2, v.w);
+        xv[p][4 * q + 0] = as_h2(v.x);
+        xv[p][4 * q + 1] = as_h2(v.y);
+        xv[p][4 * q + 2] = as_h2(v.z);
+        xv[p][4 * q + 3] = as_h2(v.w);
       }
 #pragma unroll
       for (int s = 0; s < NSUB; ++s) xs[p][s] = xs_lds[slot * NSUB + s];
