@@ -70,6 +70,20 @@ __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_f32<0x143, 0xC>(v);   // row_bcast31 into rows 2,3 -> lane 63 holds the total
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// Sums of TWO accumulators at once: v_permlane32_swap folds the wave in half (lanes 0-31 carry `a`, lanes 32-63 carry
+// `b`), four DPP steps finish the 16-lane rows, row_bcast15 joins the two rows of each half.
+// Result: a's total in lanes 16..31, b's total in lanes 48..63 (callers read lane 31 / lane 63).
+__device__ __forceinline__ float wave_sum2(float a, float b) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  const unsigned rx = r[0], ry = r[1];
+  float v = __uint_as_float(rx) + __uint_as_float(ry);
+  v += dpp_f32<0xB1>(v);
+  v += dpp_f32<0x4E>(v);
+  v += dpp_f32<0x141>(v);
+  v += dpp_f32<0x140>(v);
+  v += dpp_f32<0x142, 0xA>(v);
+  return v;
+}
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
   v = max(v, dpp_u32<0xB1>(v));
   v = max(v, dpp_u32<0x4E>(v));

@@ -18,6 +18,7 @@
 //     s*sum(q*x) + z*sum(x), then one DPP wave reduction per row.
 #pragma once
 #include "gbx_device.h"
+#include <cstdlib>
 
 namespace gbx {
 
@@ -143,34 +144,49 @@ __device__ __forceinline__ void dot_slot(const typename SlotWords<BITS>::type& w
 }
 
 // LDS geometry: slot s keeps its VPL/2 fp16 pairs at h2 index s*SSTR (16 B of padding per slot keeps the
-// one-time ds_read_b128 of 64 lanes at distinct bank quads).
+// one-time ds_read_b128 of 64 lanes at distinct bank quads); then one {sum(x), 2^(24-E)} pair per 32-value sub-slot.
 template <int BITS> struct Lds {
   static constexpr int PAIRS = Fmt<BITS>::VPL / 2;
   static constexpr int SSTR = PAIRS + 4;
   __host__ __device__ static constexpr size_t bytes(int K) {
     const int nslots = K / Fmt<BITS>::VPL;
-    return static_cast<size_t>(nslots) * SSTR * 4 + static_cast<size_t>(nslots) * Fmt<BITS>::NSUB * 4 + 64;
+    return static_cast<size_t>(nslots) * SSTR * 4 + static_cast<size_t>(nslots) * Fmt<BITS>::NSUB * 8;
   }
 };
 
-// P = number of 64-slot passes one lane makes over a row (K <= P*64*VPL); R = rows in flight per wave.
-template <int BITS, int P, bool BF16>
+// One batch = R rows as they sit in registers between issue and use.
+constexpr int GEMV_R = 2;
+template <int BITS, int P>
+struct RowBatch {
+  typename SlotWords<BITS>::type w[GEMV_R][P];
+  unsigned short s[GEMV_R][P][Fmt<BITS>::NSUB], z[GEMV_R][P][Fmt<BITS>::NSUB];
+};
+
+// P  = 64-slot passes one lane makes over its part of a row.
+// KS = wavefronts that share one row (1: a wave owns whole rows; 4: the workgroup's four waves each own a quarter of
+//      K and their partial sums meet in LDS once, after the last row) -- long rows (down_proj) stay at P = 1 and
+//      a small register footprint this way.
+// D  = batches in flight per wave (ring of register buffers).  Every row owner gets a multiple of D*R rows and every
+//      issue is unconditional, so hipcc can count vmcnt exactly: activations are waited for with the whole first
+//      ring still in flight, and batch b+D is requested the moment batch b has been consumed.
+template <int BITS, int P, int KS, int D, bool BF16>
 __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   using F = Fmt<BITS>;
   using L = Lds<BITS>;
   using WT = typename SlotWords<BITS>::type;
   constexpr int PAIRS = L::PAIRS, SSTR = L::SSTR, NSUB = F::NSUB;
-  constexpr int R = (P == 1) ? 4 : (P <= 4 ? 2 : 1);
+  constexpr int R = GEMV_R;
   constexpr int UPS = F::VPL / F::UNIT_VALS;                 // units per slot
-  constexpr int UPT = (P * 64 * UPS + 255) / 256;            // units per thread in the prologue
+  constexpr int UPT = (P * KS * 64 * UPS + 255) / 256;       // units per thread in the prologue
   constexpr int UW = F::UNIT_VALS / 2;                       // 32-bit words of activations per unit
+  constexpr int UPSUB = (32 / F::UNIT_VALS) ? (32 / F::UNIT_VALS) : 1;   // units per 32-value sub-slot
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int K = a.K, N = a.N;
   const int nslots = K / F::VPL;
   h2* xp_lds = reinterpret_cast<h2*>(smem);
-  float* xs_lds = reinterpret_cast<float*>(smem + static_cast<size_t>(nslots) * SSTR * 4);
-  unsigned* red_lds = reinterpret_cast<unsigned*>(xs_lds + nslots * NSUB);
+  float2* xs_lds = reinterpret_cast<float2*>(smem + static_cast<size_t>(nslots) * SSTR * 4);
+  float* part_lds = reinterpret_cast<float*>(xs_lds + nslots * NSUB);   // KS == 4: [rows of the block][4]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int W = K / 32 * BITS;                    // words per packed row
@@ -179,54 +195,80 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   const unsigned short* __restrict__ xg = static_cast<const unsigned short*>(a.x) + static_cast<size_t>(m) * K;
   const unsigned short* __restrict__ sg = static_cast<const unsigned short*>(a.scales);
   const unsigned short* __restrict__ zg = static_cast<const unsigned short*>(a.zeros);
+  const int gshift = a.log2g - 5;                 // 32-value sub-slot index -> group index
+  const int split1 = ((NSUB == 2) && (gshift == 0)) ? 1 : 0;
+  const int rpw = a.rows_per_wave;                // rows per owner (wave, or workgroup when KS == 4); multiple of D*R
+  const int row_begin = (KS == 1 ? (blockIdx.x * 4 + wave) : blockIdx.x) * rpw;
+  const int slot0 = (KS == 1 ? 0 : wave * 64) + lane;      // this lane's slot in pass 0
+  constexpr int PSTRIDE = 64 * KS;                          // slot stride between passes
 
-  // ---------------- prologue: activations -> pre-shifted fp16 pairs + per-sub-slot sums ----------
+  // ---------------- 1. activation loads first (vmcnt retires in order: they must not queue behind weights) ------
   const int nunits = K / F::UNIT_VALS;
   unsigned xr[UPT][UW];
-  unsigned amax = 0;
 #pragma unroll
   for (int j = 0; j < UPT; ++j) {
-    const int u = tid + 256 * j;
-    if (u < nunits) {
-      const unsigned* src = reinterpret_cast<const unsigned*>(xg + static_cast<size_t>(u) * F::UNIT_VALS);
+    const int u = min(tid + 256 * j, nunits - 1);
+    const unsigned* src = reinterpret_cast<const unsigned*>(xg + static_cast<size_t>(u) * F::UNIT_VALS);
 #pragma unroll
-      for (int q = 0; q < UW; q += 4) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(src + q);
-        xr[j][q] = v.x; xr[j][q + 1] = v.y; xr[j][q + 2] = v.z; xr[j][q + 3] = v.w;
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < UW; ++q) xr[j][q] = 0;
-    }
-#pragma unroll
-    for (int q = 0; q < UW; ++q) {
-      amax = max(amax, __float_as_uint(act_lo<BF16>(xr[j][q])) & 0x7FFFFFFFu);
-      amax = max(amax, __float_as_uint(act_hi<BF16>(xr[j][q])) & 0x7FFFFFFFu);
+    for (int q = 0; q < UW; q += 4) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(src + q);
+      xr[j][q] = v.x; xr[j][q + 1] = v.y; xr[j][q + 2] = v.z; xr[j][q + 3] = v.w;
     }
   }
-  amax = wave_max_u32(amax);
-  if (lane == 0) red_lds[wave] = amax;
-  __syncthreads();
-  amax = max(max(red_lds[0], red_lds[1]), max(red_lds[2], red_lds[3]));
-  // block exponent: largest |x| lands in [2^14, 2^15) as fp16
-  int E = 141 - static_cast<int>(amax >> 23);
-  E = min(max(E, -100), 110);
-  const float cfix = exp2i(24 - E);               // undoes 2^(E-24) after the integer dot
 
+  // ---------------- 2. the first D batches of packed rows go in flight before any activation math ---------------
+  // Branch-free on purpose: a load in one arm and a register write in the other makes hipcc drain vmcnt at the join
+  // (write-after-pending-load), which serialises the whole stream.  Out-of-range lanes / rows re-read the last valid
+  // slot / row and are nulled through their zero activations or the store guard.
+  auto issue = [&](RowBatch<BITS, P>& b, int r0) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int row = min(r0 + i, N - 1);
+      const uint32_t* wrow = a.qweight + static_cast<size_t>(row) * W;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int slot = min(p * PSTRIDE + slot0, nslots - 1);
+        b.w[i][p] = __builtin_nontemporal_load(reinterpret_cast<const WT*>(wrow + static_cast<size_t>(slot) * F::SLOT_WORDS));
+        const size_t gi = static_cast<size_t>(row) * G + ((slot * NSUB) >> gshift);
+        b.s[i][p][0] = sg[gi];
+        b.z[i][p][0] = zg[gi];
+        if constexpr (NSUB == 2) {   // second 32-value half: its own group only when g == 32
+          b.s[i][p][1] = sg[gi + split1];
+          b.z[i][p][1] = zg[gi + split1];
+        }
+      }
+    }
+  };
+  RowBatch<BITS, P> ring[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) issue(ring[d], row_begin + d * R);
+
+  // ---------------- 3. activations -> pre-shifted fp16 pairs, one block exponent per 32-value sub-slot ----------
 #pragma unroll
   for (int j = 0; j < UPT; ++j) {
     const int u = tid + 256 * j;
     float xf[F::UNIT_VALS];
+    unsigned amax = 0;
 #pragma unroll
-    for (int q = 0; q < UW; ++q) { xf[2 * q] = act_lo<BF16>(xr[j][q]); xf[2 * q + 1] = act_hi<BF16>(xr[j][q]); }
+    for (int q = 0; q < UW; ++q) {
+      xf[2 * q] = act_lo<BF16>(xr[j][q]);
+      xf[2 * q + 1] = act_hi<BF16>(xr[j][q]);
+      amax = max(amax, max(__float_as_uint(xf[2 * q]) & 0x7FFFFFFFu, __float_as_uint(xf[2 * q + 1]) & 0x7FFFFFFFu));
+    }
     float usum = 0.f;
 #pragma unroll
     for (int q = 0; q < F::UNIT_VALS; ++q) usum += xf[q];
-    // every lane takes part in the DPP sums (inactive units contribute 0)
+    // every lane takes part in the DPP exchanges; units past the end only ever pair with each other
     float ssum;
-    if constexpr (BITS == 2) ssum = pair_sum(usum);
-    else if constexpr (BITS == 4) ssum = quad_sum(usum);
-    else ssum = usum;
+    if constexpr (BITS == 2) { ssum = pair_sum(usum); amax = max(amax, dpp_u32<0xB1>(amax)); }
+    else if constexpr (BITS == 4) {
+      ssum = quad_sum(usum);
+      amax = max(amax, dpp_u32<0xB1>(amax));
+      amax = max(amax, dpp_u32<0x4E>(amax));
+    } else ssum = usum;
+    // largest |x| of the sub-slot lands in [2^14, 2^15) as fp16; products with q*2^(pos-24) stay exact
+    int E = 141 - static_cast<int>(amax >> 23);
+    E = min(max(E, -100), 110);
     if (u < nunits) {
       const int slot = u / UPS, uin = u % UPS;
       h2* dst = xp_lds + static_cast<size_t>(slot) * SSTR + uin * F::UNIT_PAIRS;
@@ -238,72 +280,38 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
         v.y = static_cast<_Float16>(xf[F::kb(i)] * sc);
         dst[i] = v;
       }
-      constexpr int UPSUB = 32 / F::UNIT_VALS == 0 ? 1 : 32 / F::UNIT_VALS;   // units per 32-value sub-slot
-      if ((u % UPSUB) == 0) xs_lds[u / UPSUB] = ssum;
+      if ((u % UPSUB) == 0) xs_lds[u / UPSUB] = make_float2(ssum, exp2i(24 - E));
     }
   }
   __syncthreads();
 
-  // ---------------- lane-resident activations ----------------------------------------------------
+  // ---------------- 4. lane-resident activations (zeros for lanes past the end of the row) ------------------------
   h2 xv[P][PAIRS];
-  float xs[P][NSUB];
+  float xs[P][NSUB], cf[P][NSUB];
 #pragma unroll
   for (int p = 0; p < P; ++p) {
-    const int slot = p * 64 + lane;
-    if (slot < nslots) {
-      const u32x4* src = reinterpret_cast<const u32x4*>(xp_lds + static_cast<size_t>(slot) * SSTR);
+    const int slot = p * PSTRIDE + slot0;
+    const bool live = slot < nslots;
+    const int sl = min(slot, nslots - 1);
+    const u32x4* src = reinterpret_cast<const u32x4*>(xp_lds + static_cast<size_t>(sl) * SSTR);
 #pragma unroll
-      for (int q = 0; q < PAIRS / 4; ++q) {
-        const u32x4 v = src[q];
-        xv[p][4 * q + 0] = as_h2(v.x);
-        xv[p][4 * q + 1] = as_h2(v.y);
-        xv[p][4 * q + 2] = as_h2(v.z);
-        xv[p][4 * q + 3] = as_h2(v.w);
-      }
+    for (int q = 0; q < PAIRS / 4; ++q) {
+      const u32x4 v = src[q];
+      xv[p][4 * q + 0] = as_h2(live ? v.x : 0u);
+      xv[p][4 * q + 1] = as_h2(live ? v.y : 0u);
+      xv[p][4 * q + 2] = as_h2(live ? v.z : 0u);
+      xv[p][4 * q + 3] = as_h2(live ? v.w : 0u);
+    }
 #pragma unroll
-      for (int s = 0; s < NSUB; ++s) xs[p][s] = xs_lds[slot * NSUB + s];
-    } else {
-#pragma unroll
-      for (int q = 0; q < PAIRS; ++q) xv[p][q] = h2{0, 0};
-#pragma unroll
-      for (int s = 0; s < NSUB; ++s) xs[p][s] = 0.f;
+    for (int s = 0; s < NSUB; ++s) {
+      const float2 t = xs_lds[sl * NSUB + s];
+      xs[p][s] = live ? t.x : 0.f;
+      cf[p][s] = live ? t.y : 0.f;
     }
   }
 
-  // ---------------- stream the rows ---------------------------------------------------------------
-  const int rpw = a.rows_per_wave;
-  const int row_begin = (blockIdx.x * 4 + wave) * rpw;
-  const int row_end = min(row_begin + rpw, N);
-  const int gshift = a.log2g - 5;                 // 32-value sub-slot index -> group index
-  const bool split = (NSUB == 2) && (gshift == 0);
-
-  for (int r0 = row_begin; r0 < row_end; r0 += R) {
-    WT w[R][P];
-    unsigned short sraw[R][P][NSUB], zraw[R][P][NSUB];
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-      const int row = min(r0 + i, N - 1);
-      const uint32_t* wrow = a.qweight + static_cast<size_t>(row) * W;
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        const int slot = p * 64 + lane;
-        if (slot < nslots) {
-          w[i][p] = __builtin_nontemporal_load(reinterpret_cast<const WT*>(wrow + static_cast<size_t>(slot) * F::SLOT_WORDS));
-          const int ss = slot * NSUB;
-          const size_t gi = static_cast<size_t>(row) * G + (ss >> gshift);
-          sraw[i][p][0] = sg[gi];
-          zraw[i][p][0] = zg[gi];
-          if constexpr (NSUB == 2) {
-            if (split) { sraw[i][p][1] = sg[gi + 1]; zraw[i][p][1] = zg[gi + 1]; }
-            else { sraw[i][p][1] = sraw[i][p][0]; zraw[i][p][1] = zraw[i][p][0]; }
-          }
-        } else {
-          w[i][p] = WT{};
-#pragma unroll
-          for (int s = 0; s < NSUB; ++s) { sraw[i][p][s] = 0; zraw[i][p][s] = 0; }
-        }
-      }
-    }
+  // ---------------- 5. stream the rows: consume ring slot d, refill it D batches ahead ----------------------------
+  auto consume = [&](const RowBatch<BITS, P>& cur, int r0) {
     float acc[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) {
@@ -311,62 +319,109 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         float d[NSUB];
-        dot_slot<BITS>(w[i][p], xv[p], d);
+        dot_slot<BITS>(cur.w[i][p], xv[p], d);
 #pragma unroll
         for (int s = 0; s < NSUB; ++s) {
-          const float sc = act_to_f32<BF16>(sraw[i][p][s]) * cfix;
-          const float ze = act_to_f32<BF16>(zraw[i][p][s]);
+          const float sc = act_to_f32<BF16>(cur.s[i][p][s]) * cf[p][s];
+          const float ze = act_to_f32<BF16>(cur.z[i][p][s]);
           acc[i] = fmaf(sc, d[s], acc[i]);
           acc[i] = fmaf(ze, xs[p][s], acc[i]);
         }
       }
     }
+    const float tot = wave_sum2(acc[0], acc[1]);            // row r0 in lane 31, row r0+1 in lane 63
+    const int row = r0 + (lane >> 5);
+    if ((lane & 31) == 31 && row < N) {
+      if constexpr (KS == 1) static_cast<unsigned short*>(a.y)[static_cast<size_t>(m) * N + row] = f32_to_act<BF16>(tot);
+      else part_lds[(row - row_begin) * 4 + wave] = tot;
+    }
+  };
+  const int steps = rpw / (D * R);
+  int base = row_begin;
+  for (int st = 1; st < steps; ++st) {
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
-      const float tot = wave_sum(acc[i]);
-      const int row = r0 + i;
-      if (lane == 0 && row < row_end) {
-        float v = tot;
-        if (a.bias) v += act_to_f32<BF16>(static_cast<const unsigned short*>(a.bias)[row]);
-        static_cast<unsigned short*>(a.y)[static_cast<size_t>(m) * N + row] = f32_to_act<BF16>(v);
-      }
+    for (int d = 0; d < D; ++d) {
+      consume(ring[d], base + d * R);
+      issue(ring[d], base + (D + d) * R);
+    }
+    base += D * R;
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) consume(ring[d], base + d * R);
+
+  if constexpr (KS == 4) {
+    __syncthreads();
+    const int nrows = min(rpw, N - row_begin);
+    for (int r = tid; r < nrows; r += 256) {
+      const float4 pv = *reinterpret_cast<const float4*>(part_lds + r * 4);
+      const float v = (pv.x + pv.y) + (pv.z + pv.w);
+      static_cast<unsigned short*>(a.y)[static_cast<size_t>(m) * N + row_begin + r] = f32_to_act<BF16>(v);
     }
   }
+}
+
+// y[m, n] += bias[n] (second rounding, like the reference's separate `x + self.bias`, quantized_linear_gba.py:204-205)
+template <bool BF16>
+__global__ __launch_bounds__(256) void add_bias_kernel(unsigned short* __restrict__ y, const unsigned short* __restrict__ bias,
+                                                       int N, size_t total) {
+  for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < total;
+       i += static_cast<size_t>(gridDim.x) * blockDim.x)
+    y[i] = f32_to_act<BF16>(act_to_f32<BF16>(y[i]) + act_to_f32<BF16>(bias[i % N]));
 }
 
 // Host-side launcher for one bit width (defined per TU so the three widths compile in parallel).
 template <int BITS>
 hipError_t launch_gemv(const GemvArgs& a, int M, bool bf16, hipStream_t stream);
 
-template <int BITS, int P>
-static hipError_t launch_gemv_p(const GemvArgs& a, int M, bool bf16, hipStream_t stream) {
+constexpr int GEMV_MAX_ROWS_PER_BLOCK_KS4 = 1024;
+constexpr int GEMV_NOMINAL_BLOCKS = 256 * 4;   // 4 workgroups (16 waves) per CU on the 256 CUs
+
+template <int BITS, int P, int KS, int D>
+static hipError_t launch_gemv_d(const GemvArgs& a, int M, bool bf16, int rpw, hipStream_t stream) {
   GemvArgs args = a;
-  // rows per wave: aim for >= ~2 workgroups per CU (256 CUs) while keeping a few rows per wave so the
-  // lane-resident activations are amortised.
-  constexpr int R = (P == 1) ? 4 : (P <= 4 ? 2 : 1);
-  int rpw = R;
-  while (rpw < 64 && (a.N + 4 * rpw * 2 - 1) / (4 * rpw * 2) >= 1024) rpw *= 2;
   args.rows_per_wave = rpw;
-  const int blocks = (a.N + 4 * rpw - 1) / (4 * rpw);
-  const size_t shmem = Lds<BITS>::bytes(a.K);
+  size_t shmem = Lds<BITS>::bytes(a.K);
+  if (KS == 4) shmem += static_cast<size_t>(rpw) * 4 * sizeof(float);
+  const int rows_per_block = (KS == 1) ? 4 * rpw : rpw;
+  const int blocks = (a.N + rows_per_block - 1) / rows_per_block;
   dim3 grid(blocks, M), block(256);
-  if (bf16) hipLaunchKernelGGL((gemv_kernel<BITS, P, true>), grid, block, shmem, stream, args);
-  else hipLaunchKernelGGL((gemv_kernel<BITS, P, false>), grid, block, shmem, stream, args);
-  return hipGetLastError();
+  if (bf16) hipLaunchKernelGGL((gemv_kernel<BITS, P, KS, D, true>), grid, block, shmem, stream, args);
+  else hipLaunchKernelGGL((gemv_kernel<BITS, P, KS, D, false>), grid, block, shmem, stream, args);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && a.bias) {
+    const size_t total = static_cast<size_t>(M) * a.N;
+    const int bb = static_cast<int>(std::min<size_t>((total + 255) / 256, 2048));
+    auto Y = static_cast<unsigned short*>(a.y);
+    auto B = static_cast<const unsigned short*>(a.bias);
+    if (bf16) hipLaunchKernelGGL((add_bias_kernel<true>), dim3(bb), dim3(256), 0, stream, Y, B, a.N, total);
+    else hipLaunchKernelGGL((add_bias_kernel<false>), dim3(bb), dim3(256), 0, stream, Y, B, a.N, total);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+template <int BITS, int P, int KS>
+static hipError_t launch_gemv_p(const GemvArgs& a, int M, bool bf16, hipStream_t stream) {
+  // batches each row owner must take so that ~GEMV_NOMINAL_BLOCKS workgroups cover N; ring depth follows
+  const int owners = (KS == 1) ? GEMV_NOMINAL_BLOCKS * 4 : GEMV_NOMINAL_BLOCKS;
+  const int nb = (a.N + owners * GEMV_R - 1) / (owners * GEMV_R);
+  if (nb <= 1) return launch_gemv_d<BITS, P, KS, 1>(a, M, bf16, GEMV_R, stream);
+  if (nb <= 2) return launch_gemv_d<BITS, P, KS, 2>(a, M, bf16, 2 * GEMV_R, stream);
+  int rpw = ((nb + 3) / 4) * 4 * GEMV_R;
+  if (KS == 4 && rpw > GEMV_MAX_ROWS_PER_BLOCK_KS4) rpw = GEMV_MAX_ROWS_PER_BLOCK_KS4;
+  return launch_gemv_d<BITS, P, KS, 4>(a, M, bf16, rpw, stream);
 }
 
 // max K the lane-resident fast path covers for a bit width (beyond -> generic kernel)
-template <int BITS> constexpr int gemv_max_k() { return (BITS == 2 ? 4 : 8) * 64 * Fmt<BITS>::VPL; }
+template <int BITS> constexpr int gemv_max_k() { return 512 * Fmt<BITS>::VPL; }
 
 template <int BITS>
 static hipError_t dispatch_gemv(const GemvArgs& a, int M, bool bf16, hipStream_t s) {
   const int nslots = a.K / Fmt<BITS>::VPL;
-  if (nslots <= 64) return launch_gemv_p<BITS, 1>(a, M, bf16, s);
-  if (nslots <= 128) return launch_gemv_p<BITS, 2>(a, M, bf16, s);
-  if (nslots <= 256) return launch_gemv_p<BITS, 4>(a, M, bf16, s);
-  if constexpr (BITS != 2) {
-    if (nslots <= 512) return launch_gemv_p<BITS, 8>(a, M, bf16, s);
-  }
+  if (nslots <= 64) return launch_gemv_p<BITS, 1, 1>(a, M, bf16, s);
+  if (nslots <= 128) return launch_gemv_p<BITS, 2, 1>(a, M, bf16, s);
+  if (nslots <= 256) return launch_gemv_p<BITS, 1, 4>(a, M, bf16, s);
+  if (nslots <= 512) return launch_gemv_p<BITS, 2, 4>(a, M, bf16, s);
   return hipErrorInvalidValue;
 }
 
