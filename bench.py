@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Headline benchmark: greedy decode, batch 1, Llama-3-8B shapes with the synthetic layer-mix "S22" strategy
+(2/3/4-bit, g128, raw 2.22 bpw -- BASELINE.json configs[2]), synthetic packed weights.
+
+    python bench.py --gpus 1 --steps 64 --warmup 8
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W            # TP over N GPUs (RCCL all-reduce after o_proj / down_proj)
+
+One "step" = one decoded token = one pass of the hot path (224 QuantizedLinear GEMVs) plus its callers (norms, RoPE,
+attention over the KV cache, bf16 lm_head, argmax) with every tensor resident in HBM.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling ~6290 GB/s
+
+
+def qlinear_bytes(m, M=1):
+    """ALGORITHMIC bytes of one QuantizedLinear call: packed words + scales + zeros + x + y."""
+    n, k, b, g = m.output_dims, m.input_dims, m.bits, m.group_size
+    return n * k * b // 8 + 2 * n * (k // g) * 2 + M * k * 2 + M * n * 2 + (2 * n if m.bias is not None else 0)
+
+
+def token_bytes(model, context):
+    from gbx_lm_amd.models.quantized_linear_gba import QuantizedLinear
+    ql = sum(qlinear_bytes(m) for m in model.modules() if isinstance(m, QuantizedLinear))
+    hw = model.head_weight()
+    head = hw.numel() * hw.element_size()
+    at = model.model.layers[0].self_attn
+    kv = 2 * len(model.model.layers) * at.n_kv_heads * at.head_dim * context * 2
+    return ql, head, kv
+
+
+def cpu_baseline(model, cfg, timeout=240.0):
+    """Oracle port timed on this box's host cores, in a CHILD process (no torch / GPU context, its own OpenMP pool):
+    oracle/cpu_baseline.py.  Reported baseline, never the product path."""
+    import subprocess
+    at = model.model.layers[0].self_attn
+    spec = {"hidden": cfg["hidden_size"], "inter": cfg["intermediate_size"], "vocab": cfg["vocab_size"],
+            "kv_dim": at.n_kv_heads * at.head_dim, "group": model.model.layers[0].mlp.gate_proj.group_size,
+            "layer_bits": [blk.mlp.gate_proj.bits for blk in model.model.layers]}
+    env = dict(os.environ)
+    env["OMP_NUM_THREADS"] = str(os.cpu_count() or 1)
+    env["OMP_WAIT_POLICY"] = "passive"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), json.dumps(spec)],
+                         env=env, capture_output=True, text=True, timeout=timeout)
+    if out.returncode != 0:
+        raise RuntimeError(out.stderr[-400:])
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def kernel_leg(model, reps=20):
+    """Dominant hot-path kernel timed live with HIP events on the launch stream: the 2-bit gate/up_proj GEMV, cycled
+    over every 2-bit layer's own gate_proj and up_proj weights (>> 256 MiB, so the Infinity Cache cannot serve them)."""
+    from gbx_lm_amd import ops
+    mods = []
+    for blk in model.model.layers:
+        for p in (blk.mlp.gate_proj, blk.mlp.up_proj):
+            mods.append(p)
+    bits = min(m.bits for m in mods)
+    mods = [m for m in mods if m.bits == bits]
+    m0 = mods[0]
+    dev = m0.qweight.device
+    x = torch.randn(1, m0.input_dims, device=dev).to(torch.bfloat16)
+    y = torch.empty(1, m0.output_dims, device=dev, dtype=torch.bfloat16)
+
+    def sweep():
+        for m in mods:
+            ops.quantized_matmul(x, m.qweight, m.scales, m.zeros, group_size=m.group_size, bits=m.bits, out=y)
+
+    sweep()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        sweep()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (reps * len(mods))
+    nbytes = qlinear_bytes(m0)
+    achieved = nbytes / us / 1e3
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            "kernel": f"gbx::gemv_kernel<{bits},...> gate/up_proj N={m0.output_dims} K={m0.input_dims} g={m0.group_size}",
+            "bytes_per_launch": nbytes, "us_per_launch": us, "launches_timed": reps * len(mods),
+            "working_set_bytes": nbytes * len(mods)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--context", type=int, default=128, help="synthetic prompt length already in the KV cache")
+    ap.add_argument("--strategy", default="S22", choices=["S22", "S40", "S20", "S30"])
+    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama3.2-3b", "tiny"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-leg", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs MI355X GPUs (the QuantizedLinear path has no CPU fallback)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from gbx_lm_amd import synthetic as S, tp
+    from gbx_lm_amd.decode import DecodeRunner, FusedDecodeRunner, fused_eligible
+    from gbx_lm_amd.models.cache import KVCache
+
+    cfg = {"llama3-8b": S.LLAMA3_8B, "llama3.2-3b": S.LLAMA32_3B, "tiny": S.TINY}[args.model]
+    strat = S.make_strategy(args.strategy, cfg["num_hidden_layers"], 128)
+    model = S.build_model(cfg, strat, device=dev, seed=0)          # same seed on every rank -> identical weights
+    if world > 1:
+        tp.shard_llama(model, rank, world)
+    torch.cuda.synchronize()
+
+    at = model.model.layers[0].self_attn
+    total = args.context + args.warmup + args.steps + 2
+    cap = ((total + 255) // 256) * 256
+    caches = []
+    for _ in model.model.layers:
+        c = KVCache(step=cap)
+        like = torch.empty((1, at.n_kv_heads, 1, at.head_dim), dtype=torch.bfloat16, device=dev)
+        c.reserve(1, like, like)
+        caches.append(c)
+
+    # N > 1: RCCL inside graph capture is opt-in (GBX_TP_GRAPH=1) until it has run on a multi-GPU node
+    use_graph = not args.no_graph and (world == 1 or os.environ.get("GBX_TP_GRAPH") == "1")
+    graph_note = "hipGraph replay"
+    Runner = FusedDecodeRunner if fused_eligible(model) else DecodeRunner
+    try:
+        runner = Runner(model, caches, use_graph=use_graph)
+    except Exception as e:                                          # e.g. a collective that refuses capture
+        if not use_graph:
+            raise
+        runner = Runner(model, caches, use_graph=False)
+        graph_note = f"eager launches (graph capture failed: {type(e).__name__})"
+    if not use_graph:
+        graph_note = "eager launches"
+
+    vocab = cfg["vocab_size"]
+    # synthetic fixed-shape prompt: token ids arange(L) mod vocab, fed through the decode path to fill the KV cache
+    for t in range(args.context):
+        runner.step(torch.tensor([t % vocab], device=dev))
+    tok = torch.argmax(runner.logits, -1)
+
+    def decode(n):
+        nonlocal tok
+        for _ in range(n):
+            logits = runner.step(tok)
+            tok = torch.argmax(logits, -1)                          # greedy, stays on device
+
+    decode(args.warmup)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t_host0 = time.perf_counter()
+    e0.record()
+    decode(args.steps)
+    e1.record()
+    torch.cuda.synchronize()
+    t_host = time.perf_counter() - t_host0
+    if world > 1:
+        dist.barrier()
+    ms = max(e0.elapsed_time(e1), t_host * 1e3) if world > 1 else e0.elapsed_time(e1)   # HIP events on the launch stream
+    if world > 1:
+        tms = torch.tensor([ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(tms, op=dist.ReduceOp.MAX)
+        ms = float(tms.item())
+    ms_per_step = ms / args.steps
+    tok_s = 1e3 / ms_per_step
+
+    ql_b, head_b, kv_b = token_bytes(model, args.context + args.warmup + args.steps // 2)
+    per_gpu_bytes = ql_b + head_b + kv_b
+    e2e_gbps = per_gpu_bytes * tok_s / 1e9                          # per GPU (each rank streams its own shard)
+
+    roof = None
+    cpu = None
+    if rank == 0 and not args.no_kernel_leg:
+        roof = kernel_leg(model)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(model, cfg)
+        except Exception as e:                                      # never let the baseline leg sink the bench line
+            cpu = {"value": None, "unit": "tok/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        out = {
+            "metric": "decode_tok_per_s", "value": tok_s, "unit": "tok/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"{args.model} layer-mix {args.strategy} greedy decode batch=1 "
+                                   f"context={args.context} (BASELINE.json configs[2])",
+                       "global_batch": 1, "seq_len": args.context, "parallelism": f"tp{world}",
+                       "launch": graph_note, "decode_block": Runner.__name__, "bits_mix": args.strategy, "group_size": 128},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "e2e": {"bytes_per_token_per_gpu": per_gpu_bytes, "qlinear_bytes": ql_b, "lm_head_bytes": head_b,
+                    "kv_bytes": kv_b, "achieved_GBps_per_gpu": e2e_gbps, "frac_of_8TBps": e2e_gbps / HBM_PEAK_GBPS,
+                    "frac_of_measured_copy_6290": e2e_gbps / 6290.0},
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

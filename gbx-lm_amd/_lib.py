@@ -53,16 +53,24 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
+class FusedDesc(ctypes.Structure):
+    """Mirror of ``gbx_qlinear_fused`` (include/gbx_qlinear.h)."""
+    _fields_ = [("x", ctypes.c_void_p),
+                ("K", ctypes.c_int32), ("bits", ctypes.c_int32), ("group_size", ctypes.c_int32), ("act_dtype", ctypes.c_int32),
+                ("nseg", ctypes.c_int32),
+                ("qweight", ctypes.c_void_p * 3), ("scales", ctypes.c_void_p * 3), ("zeros", ctypes.c_void_p * 3),
+                ("y", ctypes.c_void_p * 3), ("N", ctypes.c_int32 * 3),
+                ("norm_weight", ctypes.c_void_p), ("norm_eps", ctypes.c_float),
+                ("residual", ctypes.c_void_p), ("swiglu", ctypes.c_int32)]
+
+
 def _declare_optional(L) -> None:
-    """argtypes of entry points added after ABI 1000 (present in the same .so)."""
+    """argtypes of the fused decode-block entry points."""
     i64, i32, p, f32 = ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_float
-    opt = {
-        "gbx_rmsnorm": [p, p, p, i64, i32, f32, i32, p],
-        "gbx_dense_gemv": [p, p, p, p, i64, i32, i32, i32, p],
-    }
-    for name, argt in opt.items():
-        if hasattr(L, name):
-            getattr(L, name).argtypes = argt
+    L.gbx_qlinear_fused_forward.argtypes = [ctypes.POINTER(FusedDesc), p]
+    L.gbx_attn_decode.argtypes = [p, p, p, p, p, p, p, p, i32, i32, i32, i32, f32, f32, i32, i32, p]
+    L.gbx_dense_gemv.argtypes = [p, p, p, p, f32, i32, i32, i32, p]
+    L.gbx_rmsnorm.argtypes = [p, p, p, i64, i32, f32, i32, p]
 
 
 def check(rc: int) -> None:

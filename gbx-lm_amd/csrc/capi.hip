@@ -75,7 +75,11 @@ int gbx_qlinear_forward(const void* x, const uint32_t* qweight, const void* scal
   const int max_k = bits == 2 ? gbx::gemv_max_k<2>() : bits == 3 ? gbx::gemv_max_k<3>() : gbx::gemv_max_k<4>();
   hipError_t e;
   if (!force_generic && (K % 128) == 0 && K <= max_k) {
-    gbx::GemvArgs a{x, qweight, scales, zeros, bias, y, N, K, log2g, 0};
+    gbx::GemvArgs a{};
+    a.x = x;
+    a.seg[0] = gbx::GemvSeg{qweight, static_cast<const unsigned short*>(scales), static_cast<const unsigned short*>(zeros),
+                            static_cast<unsigned short*>(y), N};
+    a.nseg = 1; a.N = N; a.K = K; a.log2g = log2g; a.bias = bias;
     switch (bits) {
       case 2: e = gbx::launch_gemv<2>(a, static_cast<int>(M), bf16, stream); break;
       case 3: e = gbx::launch_gemv<3>(a, static_cast<int>(M), bf16, stream); break;
@@ -85,6 +89,96 @@ int gbx_qlinear_forward(const void* x, const uint32_t* qweight, const void* scal
     e = gbx::launch_qlinear_generic(x, qweight, scales, zeros, bias, y, static_cast<int>(M), N, K, bits, log2g, bf16, stream);
   }
   if (e != hipSuccess) return hip_fail(e, "gbx_qlinear_forward launch");
+  return GBX_OK;
+}
+
+int gbx_qlinear_fused_forward(const gbx_qlinear_fused* d, void* hip_stream) {
+  if (!d) return fail(GBX_ERR_INVALID, "null descriptor");
+  if (d->nseg < 1 || d->nseg > 3) return fail(GBX_ERR_INVALID, "nseg must be 1..3 (got %d)", d->nseg);
+  if (d->act_dtype != GBX_F16 && d->act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  int ntot = 0;
+  for (int i = 0; i < d->nseg; ++i) {
+    int rc = check_shape(1, d->N[i], d->K, d->bits, d->group_size);
+    if (rc) return rc;
+    if (!d->qweight[i] || !d->scales[i] || !d->zeros[i]) return fail(GBX_ERR_INVALID, "null device pointer in segment %d", i);
+    if (!aligned(d->qweight[i], 16)) return fail(GBX_ERR_INVALID, "qweight must be 16-byte aligned");
+    ntot += d->N[i];
+  }
+  if (!d->x || !aligned(d->x, 16) || !d->y[0]) return fail(GBX_ERR_INVALID, "x / y missing or x not 16-byte aligned");
+  if (d->swiglu && (d->nseg != 2 || d->N[0] != d->N[1])) return fail(GBX_ERR_INVALID, "swiglu needs two equal-sized segments");
+  if (!d->swiglu) for (int i = 0; i < d->nseg; ++i) if (!d->y[i]) return fail(GBX_ERR_INVALID, "null y in segment %d", i);
+  if (d->residual && (d->nseg != 1 || d->swiglu)) return fail(GBX_ERR_INVALID, "residual needs a single plain segment");
+  if (d->norm_weight && !aligned(d->norm_weight, 16)) return fail(GBX_ERR_INVALID, "norm_weight must be 16-byte aligned");
+  const int K = d->K, bits = d->bits;
+  const int vpl = bits == 2 ? 64 : 32;
+  const int nslots = K / vpl;
+  if ((K % 128) != 0 || nslots > 512) return fail(GBX_ERR_UNSUPPORTED, "fused path needs K %% 128 == 0 and K <= %d (K = %d)", 512 * vpl, K);
+  if (d->norm_weight && nslots > 128)
+    return fail(GBX_ERR_UNSUPPORTED, "fused RMSNorm needs K <= %d at %d bits; call gbx_rmsnorm first", 128 * vpl, bits);
+  gbx::GemvArgs a{};
+  a.x = d->x;
+  for (int i = 0; i < d->nseg; ++i)
+    a.seg[i] = gbx::GemvSeg{d->qweight[i], static_cast<const unsigned short*>(d->scales[i]),
+                            static_cast<const unsigned short*>(d->zeros[i]), static_cast<unsigned short*>(d->y[i]), d->N[i]};
+  for (int i = d->nseg; i < 3; ++i) a.seg[i] = a.seg[0], a.seg[i].N = 0;     /* valid pointers, zero rows */
+  a.nseg = d->nseg;
+  a.N = d->swiglu ? d->N[0] : ntot;
+  a.K = K;
+  a.log2g = log2_group(d->group_size);
+  a.norm_w = static_cast<const unsigned short*>(d->norm_weight);
+  a.eps = d->norm_eps;
+  a.residual = static_cast<const unsigned short*>(d->residual);
+  a.swiglu = d->swiglu ? 1 : 0;
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  const bool bf16 = d->act_dtype == GBX_BF16;
+  hipError_t e;
+  switch (bits) {
+    case 2: e = gbx::launch_gemv<2>(a, 1, bf16, stream); break;
+    case 3: e = gbx::launch_gemv<3>(a, 1, bf16, stream); break;
+    default: e = gbx::launch_gemv<4>(a, 1, bf16, stream); break;
+  }
+  if (e != hipSuccess) return hip_fail(e, "gbx_qlinear_fused_forward launch");
+  return GBX_OK;
+}
+
+int gbx_attn_decode(const void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
+                    const int64_t* pos, void* out, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim,
+                    int32_t capacity, float rope_scale, float sm_scale, int32_t traditional, int32_t act_dtype,
+                    void* hip_stream) {
+  if (!q || !k || !v || !kcache || !vcache || !inv_freq || !pos || !out) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (head_dim != 64 && head_dim != 128) return fail(GBX_ERR_UNSUPPORTED, "head_dim must be 64 or 128 (got %d)", head_dim);
+  if (n_heads <= 0 || n_kv_heads <= 0 || n_heads % n_kv_heads) return fail(GBX_ERR_INVALID, "n_heads must be a multiple of n_kv_heads");
+  if (capacity <= 0) return fail(GBX_ERR_INVALID, "capacity must be positive");
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  if (!aligned(kcache, 16) || !aligned(vcache, 16)) return fail(GBX_ERR_INVALID, "KV cache must be 16-byte aligned");
+  hipError_t e = gbx::launch_attn_decode(q, k, v, kcache, vcache, inv_freq, reinterpret_cast<const long long*>(pos), out,
+                                         n_heads, n_kv_heads, head_dim, capacity, rope_scale, sm_scale, traditional,
+                                         act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_attn_decode launch");
+  return GBX_OK;
+}
+
+int gbx_dense_gemv(const void* x, const void* w, void* y, const void* norm_weight, float norm_eps, int32_t N, int32_t K,
+                   int32_t act_dtype, void* hip_stream) {
+  if (!x || !w || !y) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (N <= 0 || K <= 0 || (K % 8)) return fail(GBX_ERR_INVALID, "need N > 0 and K %% 8 == 0 (N=%d K=%d)", N, K);
+  if (K > 8192) return fail(GBX_ERR_UNSUPPORTED, "K = %d exceeds the dense GEMV limit of 8192", K);
+  if (!aligned(x, 16) || !aligned(w, 16) || (norm_weight && !aligned(norm_weight, 16)))
+    return fail(GBX_ERR_INVALID, "x, w and norm_weight must be 16-byte aligned");
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  hipError_t e = gbx::launch_dense_gemv(x, w, y, norm_weight, norm_eps, N, K, act_dtype == GBX_BF16,
+                                        static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_dense_gemv launch");
+  return GBX_OK;
+}
+
+int gbx_rmsnorm(const void* x, const void* w, void* y, int64_t M, int32_t K, float eps, int32_t act_dtype, void* hip_stream) {
+  if (M == 0) return GBX_OK;
+  if (!x || !w || !y) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (M < 0 || M > 65535 * 32768LL || K <= 0) return fail(GBX_ERR_INVALID, "bad shape M=%lld K=%d", (long long)M, K);
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  hipError_t e = gbx::launch_rmsnorm(x, w, y, static_cast<int>(M), K, eps, act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_rmsnorm launch");
   return GBX_OK;
 }
 

@@ -1,0 +1,341 @@
+// Callers of the QuantizedLinear hot path inside one decode step, as gfx950 kernels (batch 1, one new token):
+//   * attn_decode : RoPE(q, k) + KV-cache append + softmax(q k^T) v for one layer  (gbx_lm/models/qllama.py:76-95)
+//   * dense_gemv  : unquantised lm_head / tied embed_tokens.as_linear, optional fused final RMSNorm
+//                   (gbx_lm/models/qllama.py:174,194-198)
+//   * rmsnorm     : standalone RMSNorm for shapes the GEMV prologue does not fuse
+// All read the decode position from DEVICE memory so one captured HIP graph serves every token.
+#include "gbx_device.h"
+#include "kernels.h"
+
+namespace gbx {
+
+// ------------------------------------------------------------------------------------------------ attention (decode)
+struct AttnArgs {
+  const unsigned short* q;      // [n_heads * HD]    (projection outputs, un-rotated)
+  const unsigned short* k;      // [n_kv * HD]
+  const unsigned short* v;      // [n_kv * HD]
+  unsigned short* kcache;       // [n_kv, capacity, HD]
+  unsigned short* vcache;       // [n_kv, capacity, HD]
+  const float* inv_freq;        // [HD/2] (rope dims == HD)
+  const long long* pos;         // device scalar: index of the new token
+  unsigned short* out;          // [n_heads * HD]
+  int n_heads, n_kv, capacity;
+  float rope_scale, sm_scale;
+  int traditional;
+};
+
+template <bool BF16, int HD>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
+  constexpr int LP = HD / 8;          // lanes that share one cached position (8 features = one 16-byte load each)
+  constexpr int PPW = 64 / LP;        // positions per wave per iteration
+  constexpr int NG = 4 * PPW;         // (wave, sub) groups that carry partial softmax state
+  constexpr float NEG = -1e30f;
+  __shared__ float q_s[HD], kn_s[HD], vn_s[HD];
+  __shared__ float gm[NG], gl[NG];
+  __shared__ float gacc[NG][HD + 8];
+
+  const int h = blockIdx.x;
+  const int rep = a.n_heads / a.n_kv;
+  const int kvh = h / rep;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pos = static_cast<int>(*a.pos);
+
+  // ---- RoPE on this head's q and on its kv head's k (fp32 math, one rounding to the activation dtype like
+  //      mx.fast.rope); the first q head of a kv group appends k, v to the cache ----
+  if (tid < HD) {
+    const bool isk = tid >= HD / 2;
+    const int i = isk ? tid - HD / 2 : tid;
+    const unsigned short* src = isk ? a.k + static_cast<size_t>(kvh) * HD : a.q + static_cast<size_t>(h) * HD;
+    const int i1 = a.traditional ? 2 * i : i;
+    const int i2 = a.traditional ? 2 * i + 1 : i + HD / 2;
+    const float x1 = act_to_f32<BF16>(src[i1]), x2 = act_to_f32<BF16>(src[i2]);
+    float sn, cs;
+    sincosf(static_cast<float>(pos) * a.rope_scale * a.inv_freq[i], &sn, &cs);
+    const unsigned short r1 = f32_to_act<BF16>(x1 * cs - x2 * sn), r2 = f32_to_act<BF16>(x1 * sn + x2 * cs);
+    if (isk) {
+      kn_s[i1] = act_to_f32<BF16>(r1);
+      kn_s[i2] = act_to_f32<BF16>(r2);
+      if (h % rep == 0) {
+        unsigned short* dst = a.kcache + (static_cast<size_t>(kvh) * a.capacity + pos) * HD;
+        dst[i1] = r1;
+        dst[i2] = r2;
+      }
+    } else {
+      q_s[i1] = act_to_f32<BF16>(r1) * a.sm_scale;
+      q_s[i2] = act_to_f32<BF16>(r2) * a.sm_scale;
+    }
+  } else if (tid < 2 * HD) {
+    const int j = tid - HD;
+    const unsigned short vb = a.v[static_cast<size_t>(kvh) * HD + j];
+    vn_s[j] = act_to_f32<BF16>(vb);
+    if (h % rep == 0) a.vcache[(static_cast<size_t>(kvh) * a.capacity + pos) * HD + j] = vb;
+  }
+  __syncthreads();
+
+  // ---- cached positions [0, pos): LP lanes per position, online softmax per (wave, sub) group ----
+  const int d0 = (lane % LP) * 8, sub = lane / LP;
+  float qr[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) qr[j] = q_s[d0 + j];
+  float m = NEG, l = 0.f, acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  const unsigned short* kbase = a.kcache + static_cast<size_t>(kvh) * a.capacity * HD;
+  const unsigned short* vbase = a.vcache + static_cast<size_t>(kvh) * a.capacity * HD;
+  for (int t0 = wave * PPW; t0 < pos; t0 += 4 * PPW) {
+    const int t = t0 + sub;
+    const bool valid = t < pos;
+    const int tc = valid ? t : pos - 1;
+    const u32x4 kv4 = *reinterpret_cast<const u32x4*>(kbase + static_cast<size_t>(tc) * HD + d0);
+    const u32x4 vv4 = *reinterpret_cast<const u32x4*>(vbase + static_cast<size_t>(tc) * HD + d0);
+    const unsigned kw[4] = {kv4.x, kv4.y, kv4.z, kv4.w};
+    const unsigned vw[4] = {vv4.x, vv4.y, vv4.z, vv4.w};
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s = fmaf(qr[2 * j], act_lo<BF16>(kw[j]), s);
+      s = fmaf(qr[2 * j + 1], act_hi<BF16>(kw[j]), s);
+    }
+    // sum over the LP lanes of this position (LP = 16: one DPP row; LP = 8: half a row)
+    s += dpp_f32<0xB1>(s);
+    s += dpp_f32<0x4E>(s);
+    s += dpp_f32<0x141>(s);
+    if constexpr (LP == 16) s += dpp_f32<0x140>(s);
+    const float mn = valid ? fmaxf(m, s) : m;
+    const float corr = __expf(m - mn);
+    const float p = valid ? __expf(s - mn) : 0.f;
+    l = l * corr + p;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[2 * j] = acc[2 * j] * corr + p * act_lo<BF16>(vw[j]);
+      acc[2 * j + 1] = acc[2 * j + 1] * corr + p * act_hi<BF16>(vw[j]);
+    }
+    m = mn;
+  }
+  // ---- the new token itself (its k, v are in LDS, not yet visible through the cache to other blocks) ----
+  if (wave == 0 && sub == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s = fmaf(qr[j], kn_s[d0 + j], s);
+    s += dpp_f32<0xB1>(s);
+    s += dpp_f32<0x4E>(s);
+    s += dpp_f32<0x141>(s);
+    if constexpr (LP == 16) s += dpp_f32<0x140>(s);
+    const float mn = fmaxf(m, s);
+    const float corr = __expf(m - mn), p = __expf(s - mn);
+    l = l * corr + p;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = acc[j] * corr + p * vn_s[d0 + j];
+    m = mn;
+  }
+  const int g = wave * PPW + sub;
+  if (lane % LP == 0) { gm[g] = m; gl[g] = l; }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) gacc[g][d0 + j] = acc[j];
+  __syncthreads();
+  // ---- merge the NG partial states; one output feature per thread ----
+  if (tid < HD) {
+    float M = NEG;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) M = fmaxf(M, gm[i]);
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const float w = __expf(gm[i] - M);
+      num = fmaf(w, gacc[i][tid], num);
+      den = fmaf(w, gl[i], den);
+    }
+    a.out[static_cast<size_t>(h) * HD + tid] = f32_to_act<BF16>(num / den);
+  }
+}
+
+hipError_t launch_attn_decode(const void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
+                              const long long* pos, void* out, int n_heads, int n_kv, int head_dim, int capacity,
+                              float rope_scale, float sm_scale, int traditional, bool bf16, hipStream_t s) {
+  AttnArgs a{static_cast<const unsigned short*>(q), static_cast<const unsigned short*>(k), static_cast<const unsigned short*>(v),
+             static_cast<unsigned short*>(kcache), static_cast<unsigned short*>(vcache), inv_freq, pos,
+             static_cast<unsigned short*>(out), n_heads, n_kv, capacity, rope_scale, sm_scale, traditional};
+  dim3 grid(n_heads), block(256);
+  if (head_dim == 128) {
+    if (bf16) hipLaunchKernelGGL((attn_decode_kernel<true, 128>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((attn_decode_kernel<false, 128>), grid, block, 0, s, a);
+  } else if (head_dim == 64) {
+    if (bf16) hipLaunchKernelGGL((attn_decode_kernel<true, 64>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((attn_decode_kernel<false, 64>), grid, block, 0, s, a);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ dense GEMV (lm_head)
+// y[n] = sum_k W[n,k] * x'[k], W row-major 16-bit, x' = x or RMSNorm(x).  One wave per row, lane l owns the 8 features
+// [p*512 + 8l, +8) of pass p (one 16-byte non-temporal load per pass); activations stay in VGPRs as packed pairs and
+// meet the weights in v_dot2_f32_bf16 / v_dot2_f32_f16 (fp32 accumulate).  HBM-bound: 2 bytes per weight.
+struct DenseArgs {
+  const unsigned short* x;       // [K]
+  const unsigned short* w;       // [N, K]
+  unsigned short* y;             // [N]
+  const unsigned short* norm_w;  // [K] or null
+  float eps;
+  int N, K, rows_per_wave;
+};
+
+template <bool BF16>
+__device__ __forceinline__ float dot2_act(unsigned wbits, unsigned xbits, float acc) {
+  if constexpr (BF16) {
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(s2, wbits), __builtin_bit_cast(s2, xbits), acc, false);
+  } else {
+    return __builtin_amdgcn_fdot2(as_h2(wbits), as_h2(xbits), acc, false);
+  }
+}
+
+template <bool BF16, int P>
+__global__ __launch_bounds__(256) void dense_gemv_kernel(const DenseArgs a) {
+  constexpr int D = 2;                  // rows in flight per wave (ring)
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K = a.K, N = a.N;
+  const int nchunks = K / 8;            // 16-byte chunks per row
+  const int rpw = a.rows_per_wave;
+  const int row_begin = (blockIdx.x * 4 + wave) * rpw;
+
+  // activations (and norm weights) for this lane's chunks
+  u32x4 xv[P];
+  const unsigned short* nw = a.norm_w ? a.norm_w : a.x;
+  u32x4 wv[P];
+  float ssq = 0.f;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int c = p * 64 + lane;
+    const int cc = min(c, nchunks - 1);
+    xv[p] = *reinterpret_cast<const u32x4*>(a.x + static_cast<size_t>(cc) * 8);
+    wv[p] = *reinterpret_cast<const u32x4*>(nw + static_cast<size_t>(cc) * 8);
+  }
+  auto issue = [&](u32x4 (&buf)[P], int row) {
+    const unsigned short* wr = a.w + static_cast<size_t>(min(row, N - 1)) * K;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int cc = min(p * 64 + lane, nchunks - 1);
+      buf[p] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wr + static_cast<size_t>(cc) * 8));
+    }
+  };
+  u32x4 ring[D][P];
+#pragma unroll
+  for (int d = 0; d < D; ++d) issue(ring[d], row_begin + d);
+
+  if (a.norm_w) {      // fused final RMSNorm: every workgroup recomputes the statistics of the (tiny) vector
+    if (wave == 0) {
+      for (int c = lane; c < nchunks; c += 64) {
+        const u32x4 t = *reinterpret_cast<const u32x4*>(a.x + static_cast<size_t>(c) * 8);
+        const unsigned tw[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = act_lo<BF16>(tw[j]), hi = act_hi<BF16>(tw[j]);
+          ssq += lo * lo + hi * hi;
+        }
+      }
+      ssq = wave_sum(ssq);
+      if (lane == 0) red[0] = ssq;
+    }
+    __syncthreads();
+    const float rstd = rsqrtf(red[0] / static_cast<float>(K) + a.eps);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      unsigned xw[4] = {xv[p].x, xv[p].y, xv[p].z, xv[p].w};
+      const unsigned ww[4] = {wv[p].x, wv[p].y, wv[p].z, wv[p].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned lo = f32_to_act<BF16>(act_lo<BF16>(xw[j]) * rstd * act_lo<BF16>(ww[j]));
+        const unsigned hi = f32_to_act<BF16>(act_hi<BF16>(xw[j]) * rstd * act_hi<BF16>(ww[j]));
+        xw[j] = lo | (hi << 16);
+      }
+      xv[p] = u32x4{xw[0], xw[1], xw[2], xw[3]};
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < P; ++p)      // chunks past the end of the row contribute nothing
+    if (p * 64 + lane >= nchunks) xv[p] = u32x4{0, 0, 0, 0};
+
+  auto consume = [&](const u32x4 (&buf)[P], int row) {
+    float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      acc0 = dot2_act<BF16>(buf[p].x, xv[p].x, acc0);
+      acc1 = dot2_act<BF16>(buf[p].y, xv[p].y, acc1);
+      acc0 = dot2_act<BF16>(buf[p].z, xv[p].z, acc0);
+      acc1 = dot2_act<BF16>(buf[p].w, xv[p].w, acc1);
+    }
+    const float tot = wave_sum(acc0 + acc1);
+    if (lane == 0 && row < N) a.y[row] = f32_to_act<BF16>(tot);
+  };
+  const int steps = rpw / D;
+  int base = row_begin;
+  for (int st = 1; st < steps; ++st) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      consume(ring[d], base + d);
+      issue(ring[d], base + D + d);
+    }
+    base += D;
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) consume(ring[d], base + d);
+}
+
+hipError_t launch_dense_gemv(const void* x, const void* w, void* y, const void* norm_w, float eps, int N, int K, bool bf16,
+                             hipStream_t s) {
+  DenseArgs a{static_cast<const unsigned short*>(x), static_cast<const unsigned short*>(w), static_cast<unsigned short*>(y),
+              static_cast<const unsigned short*>(norm_w), eps, N, K, 0};
+  const int owners = 256 * 8 * 4;                       // waves when every workgroup is resident (8 per CU)
+  int rpw = (N + owners - 1) / owners;
+  rpw = ((rpw + 1) / 2) * 2;
+  if (rpw < 2) rpw = 2;
+  a.rows_per_wave = rpw;
+  const int blocks = (N + 4 * rpw - 1) / (4 * rpw);
+  const int P = (K / 8 + 63) / 64;
+  dim3 grid(blocks), block(256);
+#define GBX_DENSE(PP)                                                                                  \
+  if (bf16) hipLaunchKernelGGL((dense_gemv_kernel<true, PP>), grid, block, 0, s, a);                   \
+  else hipLaunchKernelGGL((dense_gemv_kernel<false, PP>), grid, block, 0, s, a);
+  if (P <= 1) { GBX_DENSE(1) }
+  else if (P <= 2) { GBX_DENSE(2) }
+  else if (P <= 4) { GBX_DENSE(4) }
+  else if (P <= 6) { GBX_DENSE(6) }
+  else if (P <= 8) { GBX_DENSE(8) }
+  else if (P <= 16) { GBX_DENSE(16) }
+  else return hipErrorInvalidValue;
+#undef GBX_DENSE
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ RMSNorm (standalone)
+template <bool BF16>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
+                                                      unsigned short* __restrict__ y, int K, float eps) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned short* xr = x + static_cast<size_t>(blockIdx.x) * K;
+  unsigned short* yr = y + static_cast<size_t>(blockIdx.x) * K;
+  float ssq = 0.f;
+  for (int i = tid; i < K; i += 256) { const float v = act_to_f32<BF16>(xr[i]); ssq += v * v; }
+  ssq = wave_sum(ssq);
+  if (lane == 0) red[wave] = ssq;
+  __syncthreads();
+  const float rstd = rsqrtf(((red[0] + red[1]) + (red[2] + red[3])) / static_cast<float>(K) + eps);
+  for (int i = tid; i < K; i += 256) yr[i] = f32_to_act<BF16>(act_to_f32<BF16>(xr[i]) * rstd * act_to_f32<BF16>(w[i]));
+}
+
+hipError_t launch_rmsnorm(const void* x, const void* w, void* y, int M, int K, float eps, bool bf16, hipStream_t s) {
+  auto X = static_cast<const unsigned short*>(x);
+  auto W = static_cast<const unsigned short*>(w);
+  auto Y = static_cast<unsigned short*>(y);
+  if (bf16) hipLaunchKernelGGL((rmsnorm_kernel<true>), dim3(M), dim3(256), 0, s, X, W, Y, K, eps);
+  else hipLaunchKernelGGL((rmsnorm_kernel<false>), dim3(M), dim3(256), 0, s, X, W, Y, K, eps);
+  return hipGetLastError();
+}
+
+}  // namespace gbx

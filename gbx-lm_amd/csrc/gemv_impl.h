@@ -22,16 +22,30 @@
 
 namespace gbx {
 
+// One packed matrix of a launch.  A launch streams up to three matrices that share the activation vector, K, bits
+// and group size (q/k/v, or gate/up), so the seven projections of a decoder block take four launches.
+struct GemvSeg {
+  const uint32_t* qweight;        // [N, K*bits/32]
+  const unsigned short* scales;   // [N, K/g] (act dtype)
+  const unsigned short* zeros;    // [N, K/g]
+  unsigned short* y;              // [M, N]
+  int N;
+};
+
 struct GemvArgs {
   const void* x;            // [M, K] activations (act dtype)
-  const uint32_t* qweight;  // [N, K*bits/32]
-  const void* scales;       // [N, K/g] (act dtype)
-  const void* zeros;        // [N, K/g]
-  const void* bias;         // [N] or null
-  void* y;                  // [M, N]
-  int N, K;
+  GemvSeg seg[3];
+  int nseg;
+  int N;                    // total output rows over the segments (SwiGLU mode: rows of ONE segment)
+  int K;
   int log2g;                // 5,6,7
-  int rows_per_wave;
+  int batches_per_owner;    // multiple of the ring depth D
+  const void* bias;         // [N] or null (single-segment launches; added by a second tiny kernel)
+  // ---- fused decode-block options (all optional) ----
+  const unsigned short* norm_w;    // RMSNorm weight [K]: x <- bf16(x * rsqrt(mean(x^2) + eps) * w)  (qllama.py:138-139)
+  float eps;
+  const unsigned short* residual;  // [N]: y <- residual + bf16(result)                              (qllama.py:138,140)
+  int swiglu;                      // seg[0] = gate, seg[1] = up: y0[n] = silu(gate[n]) * up[n]       (qllama.py:115)
 };
 
 // Per bit width: slot geometry and the pair table.  Pair i of a unit holds fields (ka(i), kb(i)) sitting at bit
@@ -150,7 +164,7 @@ template <int BITS> struct Lds {
   static constexpr int SSTR = PAIRS + 4;
   __host__ __device__ static constexpr size_t bytes(int K) {
     const int nslots = K / Fmt<BITS>::VPL;
-    return static_cast<size_t>(nslots) * SSTR * 4 + static_cast<size_t>(nslots) * Fmt<BITS>::NSUB * 8;
+    return static_cast<size_t>(nslots) * SSTR * 4 + static_cast<size_t>(nslots) * Fmt<BITS>::NSUB * 8 + 16;
   }
 };
 
@@ -160,13 +174,18 @@ template <int BITS, int P>
 struct RowBatch {
   typename SlotWords<BITS>::type w[GEMV_R][P];
   unsigned short s[GEMV_R][P][Fmt<BITS>::NSUB], z[GEMV_R][P][Fmt<BITS>::NSUB];
+  unsigned short res[GEMV_R];
 };
+
+__device__ __forceinline__ float round_bf16_or_f16(float v, bool bf16) {
+  return bf16 ? bf16_to_f32(f32_to_act<true>(v)) : f16_to_f32(f32_to_act<false>(v));
+}
 
 // P  = 64-slot passes one lane makes over its part of a row.
 // KS = wavefronts that share one row (1: a wave owns whole rows; 4: the workgroup's four waves each own a quarter of
 //      K and their partial sums meet in LDS once, after the last row) -- long rows (down_proj) stay at P = 1 and
 //      a small register footprint this way.
-// D  = batches in flight per wave (ring of register buffers).  Every row owner gets a multiple of D*R rows and every
+// D  = batches in flight per wave (ring of register buffers).  Every row owner gets a multiple of D batches and every
 //      issue is unconditional, so hipcc can count vmcnt exactly: activations are waited for with the whole first
 //      ring still in flight, and batch b+D is requested the moment batch b has been consumed.
 template <int BITS, int P, int KS, int D, bool BF16>
@@ -186,33 +205,61 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   const int nslots = K / F::VPL;
   h2* xp_lds = reinterpret_cast<h2*>(smem);
   float2* xs_lds = reinterpret_cast<float2*>(smem + static_cast<size_t>(nslots) * SSTR * 4);
-  float* part_lds = reinterpret_cast<float*>(xs_lds + nslots * NSUB);   // KS == 4: [rows of the block][4]
+  float* red_lds = reinterpret_cast<float*>(xs_lds + nslots * NSUB);    // 4 floats (RMSNorm block reduction)
+  float* part_lds = red_lds + 4;                                        // KS == 4: [batches of the block][R][4]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: row/segment math stays on the SALU
   const int W = K / 32 * BITS;                    // words per packed row
   const int G = K >> a.log2g;                     // groups per row
   const int m = blockIdx.y;                       // activation row (M > 1 re-streams the weights)
   const unsigned short* __restrict__ xg = static_cast<const unsigned short*>(a.x) + static_cast<size_t>(m) * K;
-  const unsigned short* __restrict__ sg = static_cast<const unsigned short*>(a.scales);
-  const unsigned short* __restrict__ zg = static_cast<const unsigned short*>(a.zeros);
   const int gshift = a.log2g - 5;                 // 32-value sub-slot index -> group index
   const int split1 = ((NSUB == 2) && (gshift == 0)) ? 1 : 0;
-  const int rpw = a.rows_per_wave;                // rows per owner (wave, or workgroup when KS == 4); multiple of D*R
-  const int row_begin = (KS == 1 ? (blockIdx.x * 4 + wave) : blockIdx.x) * rpw;
+  const bool swiglu = a.swiglu != 0;
+  const int rowstep = swiglu ? 1 : R;             // output rows covered by one batch
+  const int bpo = a.batches_per_owner;
+  const int batch_begin = (KS == 1 ? (blockIdx.x * 4 + wave) : blockIdx.x) * bpo;
   const int slot0 = (KS == 1 ? 0 : wave * 64) + lane;      // this lane's slot in pass 0
   constexpr int PSTRIDE = 64 * KS;                          // slot stride between passes
+  const int n0 = a.seg[0].N, n01 = n0 + a.seg[1].N;
 
-  // ---------------- 1. activation loads first (vmcnt retires in order: they must not queue behind weights) ------
+  // Segment tables in scalar registers; selection by compare/select only (indexing the kernel-argument struct with a
+  // computed index makes hipcc fetch it with VECTOR loads and drain vmcnt on every row).
+  const uint32_t* const q0 = a.seg[0].qweight; const uint32_t* const q1 = a.seg[1].qweight; const uint32_t* const q2 = a.seg[2].qweight;
+  const unsigned short* const s0 = a.seg[0].scales; const unsigned short* const s1 = a.seg[1].scales; const unsigned short* const s2 = a.seg[2].scales;
+  const unsigned short* const z0 = a.seg[0].zeros; const unsigned short* const z1 = a.seg[1].zeros; const unsigned short* const z2 = a.seg[2].zeros;
+  unsigned short* const y0 = a.seg[0].y; unsigned short* const y1 = a.seg[1].y; unsigned short* const y2 = a.seg[2].y;
+  const int n1 = a.seg[1].N, n2 = a.seg[2].N;
+  // row of batch element i -> (segment, local row); wave-uniform
+  auto locate = [&](int r0, int i, int& sg, int& row) {
+    if (swiglu) { sg = i; row = min(r0, N - 1); }
+    else {
+      const int r = min(r0 + i, N - 1);
+      sg = (r >= n0) + (r >= n01);
+      row = r - (sg == 0 ? 0 : (sg == 1 ? n0 : n01));
+    }
+  };
+  // ---------------- 1. activation (and norm weight) loads first: vmcnt retires in order -------------------------
   const int nunits = K / F::UNIT_VALS;
-  unsigned xr[UPT][UW];
+  // fused RMSNorm only where a wave owns whole rows (KS == 1: K = hidden size); the launcher rejects it otherwise
+  const bool norm = (KS == 1) && a.norm_w != nullptr;
+  const unsigned short* __restrict__ wg = norm ? a.norm_w : xg;       // dummy source keeps the loads unconditional
+  constexpr int WPT = (KS == 1) ? UPT : 1;
+  unsigned xr[UPT][UW], wr[WPT][UW];
 #pragma unroll
   for (int j = 0; j < UPT; ++j) {
     const int u = min(tid + 256 * j, nunits - 1);
     const unsigned* src = reinterpret_cast<const unsigned*>(xg + static_cast<size_t>(u) * F::UNIT_VALS);
+    const unsigned* wsrc = reinterpret_cast<const unsigned*>(wg + static_cast<size_t>(u) * F::UNIT_VALS);
 #pragma unroll
     for (int q = 0; q < UW; q += 4) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(src + q);
       xr[j][q] = v.x; xr[j][q + 1] = v.y; xr[j][q + 2] = v.z; xr[j][q + 3] = v.w;
+      if constexpr (KS == 1) {
+        const u32x4 t = *reinterpret_cast<const u32x4*>(wsrc + q);
+        wr[j][q] = t.x; wr[j][q + 1] = t.y; wr[j][q + 2] = t.z; wr[j][q + 3] = t.w;
+      }
     }
   }
 
@@ -220,30 +267,56 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   // Branch-free on purpose: a load in one arm and a register write in the other makes hipcc drain vmcnt at the join
   // (write-after-pending-load), which serialises the whole stream.  Out-of-range lanes / rows re-read the last valid
   // slot / row and are nulled through their zero activations or the store guard.
+  const unsigned short* __restrict__ resg = a.residual ? a.residual : y0;   // dummy source when unused
   auto issue = [&](RowBatch<BITS, P>& b, int r0) {
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-      const int row = min(r0 + i, N - 1);
-      const uint32_t* wrow = a.qweight + static_cast<size_t>(row) * W;
+      int sgi, row;
+      locate(r0, i, sgi, row);
+      const uint32_t* qsel = sgi == 0 ? q0 : (sgi == 1 ? q1 : q2);
+      const unsigned short* ssel = sgi == 0 ? s0 : (sgi == 1 ? s1 : s2);
+      const unsigned short* zsel = sgi == 0 ? z0 : (sgi == 1 ? z1 : z2);
+      const uint32_t* wrow = qsel + static_cast<size_t>(row) * W;
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const int slot = min(p * PSTRIDE + slot0, nslots - 1);
         b.w[i][p] = __builtin_nontemporal_load(reinterpret_cast<const WT*>(wrow + static_cast<size_t>(slot) * F::SLOT_WORDS));
         const size_t gi = static_cast<size_t>(row) * G + ((slot * NSUB) >> gshift);
-        b.s[i][p][0] = sg[gi];
-        b.z[i][p][0] = zg[gi];
+        b.s[i][p][0] = ssel[gi];
+        b.z[i][p][0] = zsel[gi];
         if constexpr (NSUB == 2) {   // second 32-value half: its own group only when g == 32
-          b.s[i][p][1] = sg[gi + split1];
-          b.z[i][p][1] = zg[gi + split1];
+          b.s[i][p][1] = ssel[gi + split1];
+          b.z[i][p][1] = zsel[gi + split1];
         }
       }
+      b.res[i] = resg[static_cast<size_t>(m) * n0 + min(row, n0 - 1)];
     }
   };
   RowBatch<BITS, P> ring[D];
 #pragma unroll
-  for (int d = 0; d < D; ++d) issue(ring[d], row_begin + d * R);
+  for (int d = 0; d < D; ++d) issue(ring[d], (batch_begin + d) * rowstep);
 
-  // ---------------- 3. activations -> pre-shifted fp16 pairs, one block exponent per 32-value sub-slot ----------
+  // ---------------- 3a. optional fused RMSNorm: block-wide mean of squares ---------------------------------------
+  float rstd = 1.f;
+  if (norm) {
+    float ssq = 0.f;
+#pragma unroll
+    for (int j = 0; j < UPT; ++j) {
+      const bool live = (tid + 256 * j) < nunits;
+#pragma unroll
+      for (int q = 0; q < UW; ++q) {
+        const float lo = act_lo<BF16>(xr[j][q]), hi = act_hi<BF16>(xr[j][q]);
+        ssq += live ? (lo * lo + hi * hi) : 0.f;
+      }
+    }
+    ssq = wave_sum(ssq);
+    if (lane == 0) red_lds[wave] = ssq;
+    __syncthreads();
+    const float tot = (red_lds[0] + red_lds[1]) + (red_lds[2] + red_lds[3]);
+    rstd = rsqrtf(tot / static_cast<float>(K) + a.eps);
+  }
+
+  // ---------------- 3b. activations -> pre-shifted fp16 pairs, one block exponent per 32-value sub-slot ----------
 #pragma unroll
   for (int j = 0; j < UPT; ++j) {
     const int u = tid + 256 * j;
@@ -251,9 +324,16 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
     unsigned amax = 0;
 #pragma unroll
     for (int q = 0; q < UW; ++q) {
-      xf[2 * q] = act_lo<BF16>(xr[j][q]);
-      xf[2 * q + 1] = act_hi<BF16>(xr[j][q]);
-      amax = max(amax, max(__float_as_uint(xf[2 * q]) & 0x7FFFFFFFu, __float_as_uint(xf[2 * q + 1]) & 0x7FFFFFFFu));
+      float lo = act_lo<BF16>(xr[j][q]), hi = act_hi<BF16>(xr[j][q]);
+      if constexpr (KS == 1) {
+        if (norm) {   // one rounding to the activation dtype, like the reference's RMSNorm output
+          lo = round_bf16_or_f16(lo * rstd * act_lo<BF16>(wr[j][q]), BF16);
+          hi = round_bf16_or_f16(hi * rstd * act_hi<BF16>(wr[j][q]), BF16);
+        }
+      }
+      xf[2 * q] = lo;
+      xf[2 * q + 1] = hi;
+      amax = max(amax, max(__float_as_uint(lo) & 0x7FFFFFFFu, __float_as_uint(hi) & 0x7FFFFFFFu));
     }
     float usum = 0.f;
 #pragma unroll
@@ -310,8 +390,34 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
     }
   }
 
-  // ---------------- 5. stream the rows: consume ring slot d, refill it D batches ahead ----------------------------
-  auto consume = [&](const RowBatch<BITS, P>& cur, int r0) {
+  // ---------------- 5. epilogue of one batch: the two row totals are wave-uniform here ---------------------------
+  auto finish = [&](int r0, float t0, float t1, unsigned short res0, unsigned short res1) {
+    if (swiglu) {
+      if (r0 < N) {     // bf16 gate, bf16 up, bf16 silu(gate), bf16 product: the reference's op-by-op roundings
+        const float g = round_bf16_or_f16(t0, BF16), up = round_bf16_or_f16(t1, BF16);
+        const float sl = round_bf16_or_f16(g / (1.f + __expf(-g)), BF16);
+        y0[static_cast<size_t>(m) * n0 + r0] = f32_to_act<BF16>(sl * up);
+      }
+      return;
+    }
+    const float tv[2] = {t0, t1};
+    const unsigned short rv[2] = {res0, res1};
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      if (r0 + i < N) {
+        int sgi, row;
+        locate(r0, i, sgi, row);
+        float v = tv[i];
+        if (a.residual) v = act_to_f32<BF16>(rv[i]) + round_bf16_or_f16(v, BF16);
+        unsigned short* ysel = sgi == 0 ? y0 : (sgi == 1 ? y1 : y2);
+        const int nsel = sgi == 0 ? n0 : (sgi == 1 ? n1 : n2);
+        ysel[static_cast<size_t>(m) * nsel + row] = f32_to_act<BF16>(v);
+      }
+    }
+  };
+
+  // ---------------- 6. stream the rows: consume ring slot d, refill it D batches ahead ----------------------------
+  auto consume = [&](const RowBatch<BITS, P>& cur, int b) {
     float acc[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) {
@@ -329,33 +435,44 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
         }
       }
     }
-    const float tot = wave_sum2(acc[0], acc[1]);            // row r0 in lane 31, row r0+1 in lane 63
-    const int row = r0 + (lane >> 5);
-    if ((lane & 31) == 31 && row < N) {
-      if constexpr (KS == 1) static_cast<unsigned short*>(a.y)[static_cast<size_t>(m) * N + row] = f32_to_act<BF16>(tot);
-      else part_lds[(row - row_begin) * 4 + wave] = tot;
+    const float tot = wave_sum2(acc[0], acc[1]);            // batch row 0 total in lane 31, row 1 total in lane 63
+    const float t0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tot), 31));
+    const float t1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tot), 63));
+    if constexpr (KS == 1) {
+      if (lane == 0) finish(b * rowstep, t0, t1, cur.res[0], cur.res[1]);
+    } else {
+      if (lane == 0) {
+        float* pp = part_lds + static_cast<size_t>(b - batch_begin) * (R * 4) + wave;
+        pp[0] = t0;
+        pp[4] = t1;
+      }
     }
   };
-  const int steps = rpw / (D * R);
-  int base = row_begin;
+  const int steps = bpo / D;
+  int base = batch_begin;
   for (int st = 1; st < steps; ++st) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      consume(ring[d], base + d * R);
-      issue(ring[d], base + (D + d) * R);
+      consume(ring[d], base + d);
+      issue(ring[d], (base + D + d) * rowstep);
     }
-    base += D * R;
+    base += D;
   }
 #pragma unroll
-  for (int d = 0; d < D; ++d) consume(ring[d], base + d * R);
+  for (int d = 0; d < D; ++d) consume(ring[d], base + d);
 
   if constexpr (KS == 4) {
     __syncthreads();
-    const int nrows = min(rpw, N - row_begin);
-    for (int r = tid; r < nrows; r += 256) {
-      const float4 pv = *reinterpret_cast<const float4*>(part_lds + r * 4);
-      const float v = (pv.x + pv.y) + (pv.z + pv.w);
-      static_cast<unsigned short*>(a.y)[static_cast<size_t>(m) * N + row_begin + r] = f32_to_act<BF16>(v);
+    for (int bl = tid; bl < bpo; bl += 256) {
+      const float4 p0 = *reinterpret_cast<const float4*>(part_lds + static_cast<size_t>(bl) * (R * 4));
+      const float4 p1 = *reinterpret_cast<const float4*>(part_lds + static_cast<size_t>(bl) * (R * 4) + 4);
+      const int r0 = (batch_begin + bl) * rowstep;
+      unsigned short res0 = 0, res1 = 0;
+      if (a.residual && !swiglu) {
+        if (r0 < N) res0 = a.residual[static_cast<size_t>(m) * n0 + r0];
+        if (r0 + 1 < N) res1 = a.residual[static_cast<size_t>(m) * n0 + r0 + 1];
+      }
+      finish(r0, (p0.x + p0.y) + (p0.z + p0.w), (p1.x + p1.y) + (p1.z + p1.w), res0, res1);
     }
   }
 }
@@ -373,17 +490,17 @@ __global__ __launch_bounds__(256) void add_bias_kernel(unsigned short* __restric
 template <int BITS>
 hipError_t launch_gemv(const GemvArgs& a, int M, bool bf16, hipStream_t stream);
 
-constexpr int GEMV_MAX_ROWS_PER_BLOCK_KS4 = 1024;
-constexpr int GEMV_NOMINAL_BLOCKS = 256 * 4;   // 4 workgroups (16 waves) per CU on the 256 CUs
+constexpr int GEMV_MAX_BATCHES_PER_BLOCK_KS4 = 512;
+constexpr int GEMV_NOMINAL_BLOCKS = 256 * 8;   // 8 workgroups (32 waves) per CU on the 256 CUs
 
 template <int BITS, int P, int KS, int D>
-static hipError_t launch_gemv_d(const GemvArgs& a, int M, bool bf16, int rpw, hipStream_t stream) {
+static hipError_t launch_gemv_d(const GemvArgs& a, int M, bool bf16, int bpo, int nbatches, hipStream_t stream) {
   GemvArgs args = a;
-  args.rows_per_wave = rpw;
-  size_t shmem = Lds<BITS>::bytes(a.K);
-  if (KS == 4) shmem += static_cast<size_t>(rpw) * 4 * sizeof(float);
-  const int rows_per_block = (KS == 1) ? 4 * rpw : rpw;
-  const int blocks = (a.N + rows_per_block - 1) / rows_per_block;
+  args.batches_per_owner = bpo;
+  size_t shmem = Lds<BITS>::bytes(a.K) + 16;
+  if (KS == 4) shmem += static_cast<size_t>(bpo) * GEMV_R * 4 * sizeof(float);
+  const int batches_per_block = (KS == 1) ? 4 * bpo : bpo;
+  const int blocks = (nbatches + batches_per_block - 1) / batches_per_block;
   dim3 grid(blocks, M), block(256);
   if (bf16) hipLaunchKernelGGL((gemv_kernel<BITS, P, KS, D, true>), grid, block, shmem, stream, args);
   else hipLaunchKernelGGL((gemv_kernel<BITS, P, KS, D, false>), grid, block, shmem, stream, args);
@@ -391,10 +508,9 @@ static hipError_t launch_gemv_d(const GemvArgs& a, int M, bool bf16, int rpw, hi
   if (e == hipSuccess && a.bias) {
     const size_t total = static_cast<size_t>(M) * a.N;
     const int bb = static_cast<int>(std::min<size_t>((total + 255) / 256, 2048));
-    auto Y = static_cast<unsigned short*>(a.y);
     auto B = static_cast<const unsigned short*>(a.bias);
-    if (bf16) hipLaunchKernelGGL((add_bias_kernel<true>), dim3(bb), dim3(256), 0, stream, Y, B, a.N, total);
-    else hipLaunchKernelGGL((add_bias_kernel<false>), dim3(bb), dim3(256), 0, stream, Y, B, a.N, total);
+    if (bf16) hipLaunchKernelGGL((add_bias_kernel<true>), dim3(bb), dim3(256), 0, stream, a.seg[0].y, B, a.N, total);
+    else hipLaunchKernelGGL((add_bias_kernel<false>), dim3(bb), dim3(256), 0, stream, a.seg[0].y, B, a.N, total);
     e = hipGetLastError();
   }
   return e;
@@ -402,14 +518,16 @@ static hipError_t launch_gemv_d(const GemvArgs& a, int M, bool bf16, int rpw, hi
 
 template <int BITS, int P, int KS>
 static hipError_t launch_gemv_p(const GemvArgs& a, int M, bool bf16, hipStream_t stream) {
-  // batches each row owner must take so that ~GEMV_NOMINAL_BLOCKS workgroups cover N; ring depth follows
+  // batches each row owner must take so that ~GEMV_NOMINAL_BLOCKS workgroups cover the rows; ring depth follows
+  const int rowstep = a.swiglu ? 1 : GEMV_R;
+  const int nbatches = (a.N + rowstep - 1) / rowstep;
   const int owners = (KS == 1) ? GEMV_NOMINAL_BLOCKS * 4 : GEMV_NOMINAL_BLOCKS;
-  const int nb = (a.N + owners * GEMV_R - 1) / (owners * GEMV_R);
-  if (nb <= 1) return launch_gemv_d<BITS, P, KS, 1>(a, M, bf16, GEMV_R, stream);
-  if (nb <= 2) return launch_gemv_d<BITS, P, KS, 2>(a, M, bf16, 2 * GEMV_R, stream);
-  int rpw = ((nb + 3) / 4) * 4 * GEMV_R;
-  if (KS == 4 && rpw > GEMV_MAX_ROWS_PER_BLOCK_KS4) rpw = GEMV_MAX_ROWS_PER_BLOCK_KS4;
-  return launch_gemv_d<BITS, P, KS, 4>(a, M, bf16, rpw, stream);
+  const int nb = (nbatches + owners - 1) / owners;
+  if (nb <= 1) return launch_gemv_d<BITS, P, KS, 1>(a, M, bf16, 1, nbatches, stream);
+  if (nb <= 2) return launch_gemv_d<BITS, P, KS, 2>(a, M, bf16, 2, nbatches, stream);
+  int bpo = ((nb + 3) / 4) * 4;
+  if (KS == 4 && bpo > GEMV_MAX_BATCHES_PER_BLOCK_KS4) bpo = GEMV_MAX_BATCHES_PER_BLOCK_KS4;
+  return launch_gemv_d<BITS, P, KS, 4>(a, M, bf16, bpo, nbatches, stream);
 }
 
 // max K the lane-resident fast path covers for a bit width (beyond -> generic kernel)

@@ -1,0 +1,208 @@
+"""Batch-1 decode runner: the whole per-token launch sequence captured once in a HIP graph and replayed.
+
+Counterpart of the reference's decode hot loop (gbx_lm/utils.py:325-338: ``_step`` -> ``model(y[None], cache)`` ->
+last-position logits), restructured for MI355X: ~230 tiny launches per token are launch-bound from Python, so the
+sequence is recorded once per KV-cache capacity with static buffers and a device-resident position, then replayed
+(graph replay costs ~10-16 us per token instead of ~3-4 us per launch).  Numerics follow the eager graph in
+``models/qllama.py`` op for op; tests compare the two.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .models.cache import KVCache
+from .tp import all_reduce_
+
+
+class DecodeRunner:
+    """Owns the captured graph for one model and one KV-cache capacity (B = 1, one new token per replay)."""
+
+    def __init__(self, model, caches: List[KVCache], use_graph: bool = True):
+        self.model = model
+        self.args = model.args
+        self.dev = next(model.parameters()).device
+        self.caches = caches
+        self.capacity = caches[0].capacity
+        self.dtype = model.model.embed_tokens.weight.dtype
+        self.tok = torch.zeros((1,), dtype=torch.long, device=self.dev)
+        self.pos = torch.zeros((1,), dtype=torch.long, device=self.dev)
+        self.logits = None
+        self.graph = None
+        a0 = model.model.layers[0].self_attn
+        self.n_heads, self.n_kv, self.hd = a0.n_heads, a0.n_kv_heads, a0.head_dim
+        self.ar = torch.arange(self.capacity, device=self.dev)
+        self.tp_world = getattr(model, "tp_world", 1)
+        self.use_graph = use_graph
+        if use_graph:
+            self._capture()
+
+    # one decode token, all shapes static, position read from device memory
+    def _forward(self):
+        m = self.model.model
+        pos = self.pos
+        h = m.embed_tokens(self.tok)[None]                       # [1, 1, D]
+        mask = torch.where(self.ar[None, None, None, :] <= pos, 0.0, float("-inf")).to(self.dtype)
+        for layer, c in zip(m.layers, self.caches):
+            at = layer.self_attn
+            x = layer.input_layernorm(h)
+            q = at.q_proj(x).reshape(1, 1, self.n_heads, self.hd).transpose(1, 2)
+            k = at.k_proj(x).reshape(1, 1, self.n_kv, self.hd).transpose(1, 2)
+            v = at.v_proj(x).reshape(1, 1, self.n_kv, self.hd).transpose(1, 2)
+            q = _rope_at(q, at.rope, pos)
+            k = _rope_at(k, at.rope, pos)
+            c.keys.index_copy_(2, pos, k)
+            c.values.index_copy_(2, pos, v)
+            rep = self.n_heads // self.n_kv
+            kk = c.keys.repeat_interleave(rep, dim=1) if rep > 1 else c.keys
+            vv = c.values.repeat_interleave(rep, dim=1) if rep > 1 else c.values
+            o = F.scaled_dot_product_attention(q, kk, vv, attn_mask=mask, scale=at.scale)
+            o = at.o_proj(o.transpose(1, 2).reshape(1, 1, -1))
+            if self.tp_world > 1:
+                all_reduce_(o, at.tp_group)
+            h = h + o
+            x = layer.post_attention_layernorm(h)
+            h = h + layer.mlp(x)
+        out = m.norm(h)
+        return F.linear(out, self.model.head_weight())[:, -1, :]   # [1, V]
+
+    def _capture(self):
+        torch.cuda.synchronize(self.dev)
+        s = torch.cuda.Stream(device=self.dev)
+        s.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(s), torch.no_grad():
+            self.pos.fill_(min(max(self.caches[0].offset, 0), self.capacity - 1))
+            for _ in range(2):                                   # warm-up outside capture (lazy inits)
+                self._forward()
+        torch.cuda.current_stream(self.dev).wait_stream(s)
+        torch.cuda.synchronize(self.dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.logits = self._forward()
+
+    def step(self, token: torch.Tensor) -> torch.Tensor:
+        """Consumes one token id (device tensor, shape [1]); returns logits [1, V] (a static buffer)."""
+        off = self.caches[0].offset
+        self.tok.copy_(token.reshape(1))
+        self.pos.fill_(off)
+        if self.use_graph:
+            self.graph.replay()
+        else:
+            with torch.no_grad():
+                self.logits = self._forward()
+        for c in self.caches:
+            c.offset = off + 1
+        return self.logits
+
+
+def fused_eligible(model) -> bool:
+    """The fused HIP decode block needs: no TP, no biases, q/k/v (and gate/up) packed alike, head_dim 64/128,
+    full-width RoPE, 16-bit activations and every K a multiple of 128."""
+    if getattr(model, "tp_world", 1) != 1:
+        return False
+    dt = model.model.embed_tokens.weight.dtype
+    if dt not in (torch.bfloat16, torch.float16):
+        return False
+    for blk in model.model.layers:
+        at, mlp = blk.self_attn, blk.mlp
+        mods = (at.q_proj, at.k_proj, at.v_proj, at.o_proj, mlp.gate_proj, mlp.up_proj, mlp.down_proj)
+        if any(m.bias is not None or m.input_dims % 128 or m.scales is None or m.scales.dtype != dt for m in mods):
+            return False
+        sig = lambda m: (m.bits, m.group_size)
+        if not (sig(at.q_proj) == sig(at.k_proj) == sig(at.v_proj)) or sig(mlp.gate_proj) != sig(mlp.up_proj):
+            return False
+        if at.head_dim not in (64, 128) or at.rope.inv_freq.numel() * 2 != at.head_dim:
+            return False
+        vpl = lambda m: 64 if m.bits == 2 else 32
+        if at.q_proj.input_dims // vpl(at.q_proj) > 128 or mlp.gate_proj.input_dims // vpl(mlp.gate_proj) > 128:
+            return False
+        if any(m.input_dims // vpl(m) > 512 for m in mods):
+            return False
+    hw = model.head_weight()
+    return hw.shape[1] % 8 == 0 and hw.shape[1] <= 8192 and hw.dtype == dt
+
+
+class FusedDecodeRunner(DecodeRunner):
+    """Same contract as DecodeRunner, but the block is 5 HIP launches per layer through the C-ABI fused entry points:
+    [RMSNorm + q/k/v GEMV] -> [RoPE + cache append + attention] -> [o_proj GEMV + residual] ->
+    [RMSNorm + gate/up GEMV + SwiGLU] -> [down_proj GEMV + residual], then [final RMSNorm + lm_head GEMV]."""
+
+    def __init__(self, model, caches: List[KVCache], use_graph: bool = True):
+        dev = next(model.parameters()).device
+        dt = model.model.embed_tokens.weight.dtype
+        a0 = model.model.layers[0].self_attn
+        D = model.args.hidden_size
+        I = model.model.layers[0].mlp.gate_proj.output_dims
+        mk = lambda n: torch.zeros((n,), dtype=dt, device=dev)
+        self.hb, self.qb, self.kb, self.vb = mk(D), mk(a0.n_heads * a0.head_dim), mk(a0.n_kv_heads * a0.head_dim), mk(a0.n_kv_heads * a0.head_dim)
+        self.ab, self.actb = mk(a0.n_heads * a0.head_dim), mk(I)
+        self.logits_buf = torch.zeros((1, model.head_weight().shape[0]), dtype=dt, device=dev)
+        self.descs = []
+        for blk in model.model.layers:
+            at, mlp = blk.self_attn, blk.mlp
+            eps = blk.input_layernorm.eps
+            self.descs.append((
+                ops.make_fused_desc(self.hb, (at.q_proj, at.k_proj, at.v_proj), (self.qb, self.kb, self.vb),
+                                    norm_weight=blk.input_layernorm.weight, eps=eps),
+                ops.make_fused_desc(self.ab, (at.o_proj,), (self.hb,), residual=self.hb),
+                ops.make_fused_desc(self.hb, (mlp.gate_proj, mlp.up_proj), (self.actb,),
+                                    norm_weight=blk.post_attention_layernorm.weight, eps=blk.post_attention_layernorm.eps,
+                                    swiglu=True),
+                ops.make_fused_desc(self.actb, (mlp.down_proj,), (self.hb,), residual=self.hb),
+            ))
+        super().__init__(model, caches, use_graph=use_graph)
+
+    def _forward(self):
+        m = self.model.model
+        dev = self.dev
+        torch.index_select(m.embed_tokens.weight, 0, self.tok, out=self.hb.view(1, -1))
+        for blk, c, (d_qkv, d_o, d_gu, d_dn) in zip(m.layers, self.caches, self.descs):
+            at = blk.self_attn
+            ops.qlinear_fused(d_qkv, dev)
+            ops.attn_decode(self.qb, self.kb, self.vb, c.keys, c.values, at.rope.inv_freq, self.pos, self.ab,
+                            at.n_heads, at.n_kv_heads, at.head_dim, c.capacity, getattr(at.rope, "scale", 1.0), at.scale,
+                            at.rope.traditional)
+            ops.qlinear_fused(d_o, dev)
+            ops.qlinear_fused(d_gu, dev)
+            ops.qlinear_fused(d_dn, dev)
+        ops.dense_gemv(self.hb, self.model.head_weight(), out=self.logits_buf.view(-1), norm_weight=m.norm.weight, eps=m.norm.eps)
+        return self.logits_buf
+
+
+def _rope_at(x: torch.Tensor, rope, pos: torch.Tensor) -> torch.Tensor:
+    """RoPE at a device-resident position (graph-safe twin of rope_utils.apply_rope)."""
+    inv = rope.inv_freq
+    dims = inv.numel() * 2
+    ang = (pos.to(torch.float32) * getattr(rope, "scale", 1.0))[:, None] * inv[None, :]
+    cos, sin = torch.cos(ang), torch.sin(ang)
+    xf = x[..., :dims].to(torch.float32)
+    if rope.traditional:
+        x1, x2 = xf[..., 0::2], xf[..., 1::2]
+        out = torch.stack([x1 * cos - x2 * sin, x1 * sin + x2 * cos], dim=-1).flatten(-2)
+    else:
+        x1, x2 = xf[..., : dims // 2], xf[..., dims // 2:]
+        out = torch.cat([x1 * cos - x2 * sin, x1 * sin + x2 * cos], dim=-1)
+    out = out.to(x.dtype)
+    if dims < x.shape[-1]:
+        out = torch.cat([out, x[..., dims:]], dim=-1)
+    return out
+
+
+def decode_step(model, y: torch.Tensor, prompt_cache: List[KVCache]) -> torch.Tensor:
+    """``model.decode_step`` hook used by generate_step for single-token steps: graph replay when possible."""
+    c0 = prompt_cache[0]
+    if not isinstance(c0, KVCache) or c0.keys is None or c0.keys.shape[0] != 1 or not c0.keys.is_cuda:
+        return model(y[None], cache=prompt_cache)[:, -1, :]
+    if c0.offset + 1 > c0.capacity:                               # grow every layer before (re)capturing
+        for c in prompt_cache:
+            c.reserve(1, c.keys[:, :, :1], c.values[:, :, :1])
+    runner: Optional[DecodeRunner] = getattr(model, "_decode_runner", None)
+    if runner is None or runner.caches is not prompt_cache or runner.capacity != c0.capacity \
+            or runner.caches[0].keys.data_ptr() != getattr(runner, "_kptr", None):
+        runner = (FusedDecodeRunner if fused_eligible(model) else DecodeRunner)(model, prompt_cache)
+        runner._kptr = prompt_cache[0].keys.data_ptr()
+        model._decode_runner = runner
+    return runner.step(y)

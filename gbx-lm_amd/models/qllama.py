@@ -85,7 +85,11 @@ class Attention(nn.Module):
             keys = self.rope(keys)
         output = scaled_dot_product_attention(queries, keys, values, cache=cache, scale=self.scale, mask=mask)
         output = output.transpose(1, 2).reshape(B, L, -1)
-        return self.o_proj(output)
+        out = self.o_proj(output)
+        if getattr(self, "tp_world", 1) > 1:       # K-split layer: partial sums meet here (gbx_lm_amd/tp.py)
+            from ..tp import all_reduce_
+            all_reduce_(out, self.tp_group)
+        return out
 
 
 class MLP(nn.Module):
@@ -98,7 +102,11 @@ class MLP(nn.Module):
         self.up_proj = QuantizedLinear(dim, hidden_dim, bias=mlp_bias)
 
     def forward(self, x):
-        return self.down_proj(nn.functional.silu(self.gate_proj(x)) * self.up_proj(x))
+        out = self.down_proj(nn.functional.silu(self.gate_proj(x)) * self.up_proj(x))
+        if getattr(self, "tp_world", 1) > 1:
+            from ..tp import all_reduce_
+            all_reduce_(out, self.tp_group)
+        return out
 
 
 class TransformerBlock(nn.Module):
@@ -159,6 +167,11 @@ class Model(nn.Module):
         out = self.model(inputs, mask, cache)
         logits = nn.functional.linear(out, self.head_weight())
         return (logits, out) if hidden_states else logits
+
+    def decode_step(self, y, prompt_cache):
+        """Single-token fast path (HIP-graph replay); see gbx_lm_amd/decode.py."""
+        from ..decode import decode_step
+        return decode_step(self, y, prompt_cache)
 
     def sanitize(self, weights):
         return {k: v for k, v in weights.items() if "self_attn.rotary_emb.inv_freq" not in k}

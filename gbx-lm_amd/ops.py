@@ -108,3 +108,71 @@ def dequantize(w: torch.Tensor, scales: torch.Tensor, biases: torch.Tensor, grou
                                    _DT[scales.dtype], _DT[dtype], _stream_ptr(w.device))
     _lib.check(rc)
     return out
+
+
+# ------------------------------------------------------------------------------------------------ fused decode block
+def make_fused_desc(x: torch.Tensor, mods, ys, norm_weight: Optional[torch.Tensor] = None, eps: float = 0.0,
+                    residual: Optional[torch.Tensor] = None, swiglu: bool = False) -> "_lib.FusedDesc":
+    """Descriptor for one launch over 1-3 QuantizedLinear modules sharing ``x`` (q/k/v, gate/up, or a single one).
+    All tensors must stay alive and in place while the descriptor is used (the decode runner owns static buffers)."""
+    m0 = mods[0]
+    for m in mods:
+        if (m.bits, m.group_size, m.input_dims) != (m0.bits, m0.group_size, m0.input_dims):
+            raise ValueError("fused segments must share bits, group_size and input_dims")
+        if m.bias is not None:
+            raise NotImplementedError("fused decode path does not carry a bias")
+        for t in (m.qweight, m.scales, m.zeros):
+            _require_cuda(t, "QuantizedLinear tensor")
+        if m.scales.dtype != x.dtype or m.zeros.dtype != x.dtype:
+            raise ValueError("scales/zeros must already be in the activation dtype")
+    d = _lib.FusedDesc()
+    d.x = x.data_ptr()
+    d.K, d.bits, d.group_size, d.act_dtype = m0.input_dims, m0.bits, m0.group_size, _DT[x.dtype]
+    d.nseg = len(mods)
+    for i, m in enumerate(mods):
+        d.qweight[i], d.scales[i], d.zeros[i], d.N[i] = m.qweight.data_ptr(), m.scales.data_ptr(), m.zeros.data_ptr(), m.output_dims
+    for i, y in enumerate(ys):
+        d.y[i] = y.data_ptr()
+    d.norm_weight = norm_weight.data_ptr() if norm_weight is not None else None
+    d.norm_eps = float(eps)
+    d.residual = residual.data_ptr() if residual is not None else None
+    d.swiglu = 1 if swiglu else 0
+    return d
+
+
+def qlinear_fused(desc, device) -> None:
+    import ctypes
+    _lib.check(_lib.lib().gbx_qlinear_fused_forward(ctypes.byref(desc), _stream_ptr(device)))
+
+
+def attn_decode(q, k, v, kcache, vcache, inv_freq, pos, out, n_heads: int, n_kv: int, head_dim: int, capacity: int,
+                rope_scale: float, sm_scale: float, traditional: bool) -> None:
+    _lib.check(_lib.lib().gbx_attn_decode(q.data_ptr(), k.data_ptr(), v.data_ptr(), kcache.data_ptr(), vcache.data_ptr(),
+                                          inv_freq.data_ptr(), pos.data_ptr(), out.data_ptr(), n_heads, n_kv, head_dim,
+                                          capacity, float(rope_scale), float(sm_scale), int(bool(traditional)),
+                                          _DT[q.dtype], _stream_ptr(q.device)))
+
+
+def dense_gemv(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None,
+               norm_weight: Optional[torch.Tensor] = None, eps: float = 0.0) -> torch.Tensor:
+    """logits[N] = W[N,K] @ (x or RMSNorm(x)) for the unquantised head (qllama.py:194-198)."""
+    for t, nm in ((x, "x"), (w, "w")):
+        _require_cuda(t, nm)
+    n, k = w.shape
+    if out is None:
+        out = torch.empty((n,), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().gbx_dense_gemv(x.data_ptr(), w.data_ptr(), out.data_ptr(),
+                                         norm_weight.data_ptr() if norm_weight is not None else None, float(eps),
+                                         n, k, _DT[x.dtype], _stream_ptr(x.device)))
+    return out
+
+
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _require_cuda(x, "x")
+    k = x.shape[-1]
+    x2 = x.reshape(-1, k).contiguous()
+    if out is None:
+        out = torch.empty_like(x2)
+    _lib.check(_lib.lib().gbx_rmsnorm(x2.data_ptr(), w.data_ptr(), out.data_ptr(), x2.shape[0], k, float(eps),
+                                      _DT[x.dtype], _stream_ptr(x.device)))
+    return out.reshape(x.shape)

@@ -1,0 +1,75 @@
+"""Tensor-parallel sharding of the QuantizedLinear layers over the GPUs of one node (RCCL over xGMI).
+
+Build-side extension: the reference has no tensor parallelism.  The packed format shards naturally:
+
+  * q/k/v/gate/up  -- split OUTPUT rows N (whole packed rows + their scales/zeros move together): no communication.
+  * o_proj/down    -- consume those sharded activations, so split INPUT columns K at multiples of 128 values
+                      (a whole number of 32-value periods, groups and 16-byte slots for every bits/group in scope);
+                      each rank produces a full-N partial sum -> ONE all-reduce(sum) after each.
+
+One process per GPU; ``torch.distributed`` backend "nccl" (= RCCL) on GPUs, "gloo" in the CPU tests.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from .models.quantized_linear_gba import QuantizedLinear
+
+
+def shard_rows(m: QuantizedLinear, rank: int, world: int) -> None:
+    """Keep output rows [rank*N/world, (rank+1)*N/world)."""
+    n = m.output_dims
+    if n % world:
+        raise ValueError(f"output_dims {n} not divisible by TP degree {world}")
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    for nm in ("qweight", "scales", "zeros"):
+        m._buffers[nm] = m._buffers[nm][lo:hi].contiguous()
+    if m.bias is not None:
+        m._buffers["bias"] = m._buffers["bias"][lo:hi].contiguous()
+    m.output_dims = hi - lo
+
+
+def shard_cols(m: QuantizedLinear, rank: int, world: int) -> None:
+    """Keep input columns [rank*K/world, (rank+1)*K/world); bias stays on rank 0 only (added once by the sum)."""
+    k = m.input_dims
+    if k % world or (k // world) % 128:
+        raise ValueError(f"input_dims {k} / TP {world} must be a multiple of 128 values")
+    kl = k // world
+    w_lo, w_hi = rank * kl * m.bits // 32, (rank + 1) * kl * m.bits // 32
+    g_lo, g_hi = rank * kl // m.group_size, (rank + 1) * kl // m.group_size
+    m._buffers["qweight"] = m._buffers["qweight"][:, w_lo:w_hi].contiguous()
+    m._buffers["scales"] = m._buffers["scales"][:, g_lo:g_hi].contiguous()
+    m._buffers["zeros"] = m._buffers["zeros"][:, g_lo:g_hi].contiguous()
+    m._buffers["channel_scale"] = m._buffers["channel_scale"][..., rank * kl:(rank + 1) * kl].contiguous()
+    if m.bias is not None and rank != 0:
+        m._buffers["bias"] = torch.zeros_like(m._buffers["bias"])
+    m.input_dims = kl
+
+
+def shard_llama(model, rank: int, world: int, group: Optional[dist.ProcessGroup] = None):
+    """In-place TP sharding of a qllama.Model; attention heads and KV heads are split with their projections."""
+    if world == 1:
+        return model
+    for blk in model.model.layers:
+        at, mlp = blk.self_attn, blk.mlp
+        if at.n_heads % world or at.n_kv_heads % world:
+            raise ValueError(f"heads {at.n_heads}/{at.n_kv_heads} not divisible by TP degree {world}")
+        for p in (at.q_proj, at.k_proj, at.v_proj, mlp.gate_proj, mlp.up_proj):
+            shard_rows(p, rank, world)
+        for p in (at.o_proj, mlp.down_proj):
+            shard_cols(p, rank, world)
+        at.n_heads //= world
+        at.n_kv_heads //= world
+        at.tp_group, mlp.tp_group = group, group
+        at.tp_world, mlp.tp_world = world, world
+    model.tp_world, model.tp_rank = world, rank
+    return model
+
+
+def all_reduce_(t: torch.Tensor, group=None) -> torch.Tensor:
+    """Sum of the per-rank partial outputs of a K-split layer (the path's only exchange step)."""
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t

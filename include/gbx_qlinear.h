@@ -83,6 +83,56 @@ int gbx_dequantize(const uint32_t* qweight, const void* scales, const void* zero
                    int32_t N, int32_t K, int32_t bits, int32_t group_size, int32_t sz_dtype,
                    int32_t out_dtype, void* hip_stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused decode-block entry points (batch 1, one new token).  Same conventions as above.  They replace the
+ * reference's per-op call sequence inside one transformer block so that a decoded token is ~5 launches per
+ * layer instead of ~40:   gbx_lm/models/qllama.py:68-96 (Attention), :114-115 (MLP), :131-141 (block).
+ * ------------------------------------------------------------------------------------------------ */
+
+/* Up to three packed matrices that share the activation vector x[K], bits and group_size, streamed by ONE
+ * launch (q/k/v or gate/up), with optional prologue / epilogue fusions:
+ *   norm_weight != NULL : x <- RMSNorm(x) * norm_weight, rounded once to act_dtype   (qllama.py:138-139)
+ *   residual    != NULL : y[0][n] <- residual[n] + round(result[n])   (nseg == 1)     (qllama.py:138,140)
+ *   swiglu      != 0    : nseg == 2, y[0][n] <- silu(seg0[n]) * seg1[n]               (qllama.py:115)
+ * Unused segment slots must be zeroed. */
+typedef struct gbx_qlinear_fused {
+  const void* x;
+  int32_t K, bits, group_size, act_dtype;
+  int32_t nseg;
+  const uint32_t* qweight[3];
+  const void* scales[3];
+  const void* zeros[3];
+  void* y[3];
+  int32_t N[3];
+  const void* norm_weight;
+  float norm_eps;
+  const void* residual;
+  int32_t swiglu;
+} gbx_qlinear_fused;
+
+int gbx_qlinear_fused_forward(const gbx_qlinear_fused* desc, void* hip_stream);
+
+/* One layer of single-token attention: RoPE on q and k at position *pos, append k, v to the caller's KV cache
+ * ([n_kv, capacity, head_dim], the layout of gbx_lm/models/cache.py:222-244 with B = 1), softmax(q k^T * sm_scale) v
+ * over positions 0..*pos.  Replaces qllama.py:78-95 (reshape/rope/cache.update_and_fetch/SDPA).  `pos` is a DEVICE
+ * int64 so that one captured graph serves every token.  head_dim in {64, 128}; rope over the full head_dim with
+ * inverse frequencies inv_freq[head_dim/2] (fp32; already Llama-3-scaled if the model asks for it,
+ * gbx_lm/models/rope_utils.py:70-122). */
+int gbx_attn_decode(const void* q, const void* k, const void* v, void* kcache, void* vcache,
+                    const float* inv_freq, const int64_t* pos, void* out,
+                    int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int32_t capacity,
+                    float rope_scale, float sm_scale, int32_t traditional, int32_t act_dtype, void* hip_stream);
+
+/* y[N] = W[N,K] x'[K] for an UNQUANTISED 16-bit weight (lm_head / tied embed_tokens.as_linear,
+ * qllama.py:194-198), x' = x or RMSNorm(x)*norm_weight (the final model.norm, qllama.py:174) when
+ * norm_weight != NULL.  K % 8 == 0, K <= 8192. */
+int gbx_dense_gemv(const void* x, const void* w, void* y, const void* norm_weight, float norm_eps,
+                   int32_t N, int32_t K, int32_t act_dtype, void* hip_stream);
+
+/* y[M,K] = RMSNorm(x[M,K]) * w[K] (fp32 statistics, one rounding).  mx.nn.RMSNorm as used at qllama.py:125-128,155. */
+int gbx_rmsnorm(const void* x, const void* w, void* y, int64_t M, int32_t K, float eps, int32_t act_dtype,
+                void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,10 +104,11 @@ int gba_oracle_qlinear(const uint16_t* x, const uint32_t* qweight, const uint16_
 #pragma omp for schedule(static)
             for (int64_t r = 0; r < n; ++r) {
                 const uint32_t* row = qweight + r * w;
-                for (int64_t c = 0; c < k; ++c) {
-                    float s = h_to_f32(scales[r * g + c / group], sz_dtype);
-                    float z = h_to_f32(zeros[r * g + c / group], sz_dtype);
-                    wr[c] = (float)field(row, c, bits) * s + z;
+                for (int64_t gi = 0; gi < g; ++gi) {          /* one (scale, zero) pair per group of `group` fields */
+                    const float s = h_to_f32(scales[r * g + gi], sz_dtype);
+                    const float z = h_to_f32(zeros[r * g + gi], sz_dtype);
+                    for (int64_t c = gi * group; c < (gi + 1) * group; ++c)
+                        wr[c] = (float)field(row, c, bits) * s + z;
                 }
                 float b = bias ? h_to_f32(bias[r], act_dtype) : 0.f;
                 for (int64_t i = 0; i < m; ++i) {

@@ -64,11 +64,43 @@ def double_quant_case():
                 scales=scales.numpy(), zeros=zeros.numpy(), K=K, N=N, g=g)
 
 
+TINY_PROMPT = [5, 17, 42, 7, 99]
+TINY_STEPS = 48
+
+
+def tiny_strategy():
+    from gbx_lm_amd import synthetic as S
+    strat = S.make_strategy("S22", 2)                       # layer 0 and 1 -> 4-bit g128 (n_layers = 2)
+    strat["model.layers.0"]["q_proj"] = {"bits": [3], "group_size": {"3": 32}}
+    strat["model.layers.0"]["k_proj"] = {"bits": [2], "group_size": {"2": 64}}
+    strat["model.layers.0"]["gate_proj"] = {"bits": [2], "group_size": {"2": 32}}
+    strat["model.layers.1"]["down_proj"] = {"bits": [3], "group_size": {"3": 128}}
+    strat["model.layers.1"]["o_proj"] = {"bits": [2], "group_size": {"2": 128}}
+    return strat
+
+
+def tiny_llama_case():
+    """(iv) 2-layer hidden-256 synthetic Llama with a mixed 2/3/4-bit strategy: greedy ids + first-step logits,
+    computed by the host graph with the QuantizedLinear op routed through the oracle on CPU."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import oracle_matmul
+    from gbx_lm_amd import ops, synthetic as S, utils as U
+    ops.quantized_matmul = oracle_matmul
+    model = S.build_model(S.TINY, tiny_strategy(), device="cpu", seed=7)
+    steps = list(U.generate_step(torch.tensor(TINY_PROMPT), model, max_tokens=TINY_STEPS))
+    ids = [t for t, _, _ in steps]
+    lps = torch.stack([lp.float() for _, lp, _ in steps]).numpy()
+    top2 = np.sort(lps, axis=1)[:, -2:]
+    return dict(prompt=np.array(TINY_PROMPT), ids=np.array(ids), logprobs=lps.astype(np.float32),
+                gap=(top2[:, 1] - top2[:, 0]).astype(np.float32))
+
+
 def main():
     with open(os.path.join(HERE, "known_answer.json"), "w") as f:
         json.dump(known_answer(), f, indent=1)
     np.savez_compressed(os.path.join(HERE, "qlinear_small.npz"), **small_cases())
     np.savez_compressed(os.path.join(HERE, "double_quant.npz"), **double_quant_case())
+    np.savez_compressed(os.path.join(HERE, "tiny_llama.npz"), **tiny_llama_case())
     print("wrote", sorted(os.listdir(HERE)))
 
 

@@ -1,0 +1,173 @@
+"""GPU: the fused decode-block entry points (C-ABI) against the oracle / a plain PyTorch fp32 restatement of the same
+ops, then the whole fused graph-replayed decode against the unfused host graph and the CPU-oracle model."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _mk(oracle, n, k, bits, g, seed):
+    from gbx_lm_amd.models.quantized_linear_gba import QuantizedLinear
+    d = oracle.synth_layer(n, k, bits, g, seed=seed)
+    m = QuantizedLinear(k, n, False, g, bits)
+    m._buffers["qweight"] = torch.from_numpy(d["qweight"].view(np.int32)).view(torch.uint32).to(DEV)
+    m._buffers["scales"], m._buffers["zeros"] = d["scales"].to(DEV), d["zeros"].to(DEV)
+    return m, d
+
+
+def _rms(x, w, eps):
+    xf = x.float()
+    return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps) * w.float()).to(x.dtype)
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("k", [256, 4096])
+def test_fused_norm_qkv(oracle, bits, k):
+    from gbx_lm_amd import ops
+    g = 128 if bits != 3 else 32
+    mods, ds = zip(*[_mk(oracle, n, k, bits, g, seed=10 * bits + i) for i, n in enumerate((512, 128, 130))])
+    x = (torch.randn(k) * 3).to(torch.bfloat16).to(DEV)
+    nw = (1 + 0.1 * torch.randn(k)).to(torch.bfloat16).to(DEV)
+    ys = [torch.zeros(m.output_dims, dtype=torch.bfloat16, device=DEV) for m in mods]
+    desc = ops.make_fused_desc(x, mods, ys, norm_weight=nw, eps=1e-5)
+    ops.qlinear_fused(desc, x.device)
+    xn = _rms(x, nw, 1e-5).cpu()                              # bf16-rounded norm output, like the reference graph
+    for m, d, y in zip(mods, ds, ys):
+        y64 = oracle.qlinear_ref(xn[None], d["qweight"], d["scales"], d["zeros"], bits, g, acc=np.float64)
+        oracle.assert_close(y[None], y64, "bf16", f"fused qkv b{bits} K{k}")
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("n,k", [(256, 512), (4096, 14336), (130, 4096)])
+def test_fused_residual(oracle, bits, n, k):
+    from gbx_lm_amd import ops
+    m, d = _mk(oracle, n, k, bits, 128, seed=bits + n)
+    x = d["x"].to(DEV).reshape(-1)
+    h = torch.randn(n).to(torch.bfloat16).to(DEV)
+    h0 = h.clone()
+    desc = ops.make_fused_desc(x, (m,), (h,), residual=h)     # in place: h <- h + W x
+    ops.qlinear_fused(desc, x.device)
+    y64 = oracle.qlinear_ref(d["x"], d["qweight"], d["scales"], d["zeros"], bits, 128, acc=np.float64)
+    want = h0.cpu().double().numpy()[None] + y64
+    oracle.assert_close(h[None], want, "bf16", "residual")
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+def test_fused_norm_swiglu(oracle, bits):
+    from gbx_lm_amd import ops
+    k, n, g = 4096, 1030, 64
+    gate, dg = _mk(oracle, n, k, bits, g, seed=1)
+    up, du = _mk(oracle, n, k, bits, g, seed=2)
+    x = (torch.randn(k) * 2).to(torch.bfloat16).to(DEV)
+    nw = torch.ones(k, dtype=torch.bfloat16, device=DEV)
+    act = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+    ops.qlinear_fused(ops.make_fused_desc(x, (gate, up), (act,), norm_weight=nw, eps=1e-5, swiglu=True), x.device)
+    xn = _rms(x, nw, 1e-5).cpu()
+    g64 = oracle.qlinear_ref(xn[None], dg["qweight"], dg["scales"], dg["zeros"], bits, g, acc=np.float64)
+    u64 = oracle.qlinear_ref(xn[None], du["qweight"], du["scales"], du["zeros"], bits, g, acc=np.float64)
+    want = (g64 / (1 + np.exp(-g64))) * u64
+    oracle.assert_close(act[None], want, "bf16", "swiglu")
+
+
+@pytest.mark.parametrize("hd,nh,nkv", [(128, 8, 2), (64, 4, 2), (128, 4, 4)])
+@pytest.mark.parametrize("pos", [0, 1, 5, 63, 200])
+def test_attn_decode_matches_torch(hd, nh, nkv, pos):
+    from gbx_lm_amd import ops
+    from gbx_lm_amd.models.rope_utils import RoPE, apply_rope
+    torch.manual_seed(pos + hd)
+    cap = 256
+    q = torch.randn(nh * hd).to(torch.bfloat16).to(DEV)
+    k = torch.randn(nkv * hd).to(torch.bfloat16).to(DEV)
+    v = torch.randn(nkv * hd).to(torch.bfloat16).to(DEV)
+    kc = torch.randn(1, nkv, cap, hd).to(torch.bfloat16).to(DEV)
+    vc = torch.randn(1, nkv, cap, hd).to(torch.bfloat16).to(DEV)
+    rope = RoPE(hd, base=500000.0).to(DEV)
+    kc0, vc0 = kc.clone(), vc.clone()
+    out = torch.zeros(nh * hd, dtype=torch.bfloat16, device=DEV)
+    p = torch.tensor([pos], dtype=torch.long, device=DEV)
+    ops.attn_decode(q, k, v, kc, vc, rope.inv_freq, p, out, nh, nkv, hd, cap, 1.0, hd ** -0.5, False)
+    # reference: torch fp32
+    qr = apply_rope(q.view(1, nh, 1, hd), rope.inv_freq, pos, 1.0, False)
+    kr = apply_rope(k.view(1, nkv, 1, hd), rope.inv_freq, pos, 1.0, False)
+    kc0[:, :, pos:pos + 1] = kr
+    vc0[:, :, pos:pos + 1] = v.view(1, nkv, 1, hd)
+    assert torch.equal(kc, kc0) or torch.allclose(kc.float(), kc0.float(), atol=2e-2), "cache append (k)"
+    assert torch.equal(vc, vc0), "cache append (v)"
+    rep = nh // nkv
+    K = kc0[:, :, :pos + 1].repeat_interleave(rep, 1).float()
+    V = vc0[:, :, :pos + 1].repeat_interleave(rep, 1).float()
+    s = (qr.float() @ K.transpose(-1, -2)) * hd ** -0.5
+    want = (torch.softmax(s, -1) @ V).reshape(-1)
+    assert torch.allclose(out.float(), want, atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("n,k", [(1000, 256), (128256, 4096), (513, 3072)])
+@pytest.mark.parametrize("norm", [False, True])
+def test_dense_gemv(n, k, norm):
+    from gbx_lm_amd import ops
+    torch.manual_seed(n)
+    w = (torch.randn(n, k) * 0.02).to(torch.bfloat16).to(DEV)
+    x = torch.randn(k).to(torch.bfloat16).to(DEV)
+    nw = (1 + 0.1 * torch.randn(k)).to(torch.bfloat16).to(DEV)
+    y = ops.dense_gemv(x, w, norm_weight=nw if norm else None, eps=1e-5)
+    xin = _rms(x, nw, 1e-5) if norm else x
+    want = w.double() @ xin.double()
+    rms = want.pow(2).mean().sqrt().item()
+    assert torch.allclose(y.double(), want, atol=2e-2 * rms, rtol=2e-2)
+
+
+def test_rmsnorm_kernel():
+    from gbx_lm_amd import ops
+    x = torch.randn(5, 3072).to(torch.bfloat16).to(DEV)
+    w = (1 + 0.1 * torch.randn(3072)).to(torch.bfloat16).to(DEV)
+    y = ops.rmsnorm(x, w, 1e-5)
+    assert torch.allclose(y.float(), _rms(x, w, 1e-5).float(), atol=1e-2, rtol=1e-2)
+
+
+def test_fused_runner_matches_unfused_and_oracle():
+    """6-layer mixed 2/3/4-bit tiny Llama: fused graph decode vs unfused graph decode (same GPU) vs the CPU-oracle
+    model, teacher-forced."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__)))
+    from conftest import oracle_matmul
+    from gbx_lm_amd import ops, synthetic as S
+    from gbx_lm_amd.decode import DecodeRunner, FusedDecodeRunner, fused_eligible
+    from gbx_lm_amd.models.cache import KVCache, make_prompt_cache
+    cfg = dict(S.TINY, num_hidden_layers=6, hidden_size=512, intermediate_size=1024, num_attention_heads=4,
+               num_key_value_heads=2)      # head_dim 128
+    strat = S.make_strategy("S22", 6, 64)
+    cpu = S.build_model(cfg, strat, device="cpu", seed=4)
+    gpu = S.build_model(cfg, strat, device="cpu", seed=4).to(DEV)
+    for blk in gpu.model.layers:
+        blk.self_attn.rope.to(DEV)
+    assert fused_eligible(gpu)
+    prompt = [7, 3, 200, 41]
+    ids = [9, 100, 37, 250, 6, 77, 300, 12, 5, 5, 480, 2]
+    # CPU oracle model (op monkeypatched for this block only)
+    real = ops.quantized_matmul
+    try:
+        ops.quantized_matmul = oracle_matmul
+        c = make_prompt_cache(cpu)
+        with torch.no_grad():
+            ref = [cpu(torch.tensor([prompt]), cache=c)[:, -1, :].float()]
+            for t in ids:
+                ref.append(cpu(torch.tensor([[t]]), cache=c)[:, -1, :].float())
+    finally:
+        ops.quantized_matmul = real
+    outs = {}
+    for name, cls in (("fused", FusedDecodeRunner), ("unfused", DecodeRunner)):
+        caches = [KVCache() for _ in gpu.model.layers]
+        with torch.no_grad():
+            first = gpu(torch.tensor([prompt], device=DEV), cache=caches)[:, -1, :].float().cpu()
+            r = cls(gpu, caches)
+            got = [first]
+            for t in ids:
+                got.append(r.step(torch.tensor([t], device=DEV)).float().cpu().clone())
+        outs[name] = got
+    for i in range(len(ref)):
+        scale = ref[i].abs().max().item()
+        for name in outs:
+            err = (outs[name][i] - ref[i]).abs().max().item()
+            assert err < 0.05 * scale + 0.05, f"{name} step {i}: {err} vs scale {scale}"

@@ -1,0 +1,150 @@
+"""Host-side mirror of the reference interface, on CPU: module shapes, strategy dispatch, loader contract and the
+generate loop semantics.  The QuantizedLinear op itself is routed through the oracle here (fixture cpu_oracle_op),
+which is test-only plumbing -- the product path has no CPU fallback (test_abi.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gbx_lm_amd import synthetic as S
+from gbx_lm_amd import utils as U
+from gbx_lm_amd.models import qllama
+from gbx_lm_amd.models.quantized_linear_gba import QuantizedLinear
+
+
+def test_module_signature_and_shapes():
+    m = QuantizedLinear(4096, 1024, True, 128, 3)           # (input_dims, output_dims, bias, group_size, bits)
+    assert (m.input_dims, m.output_dims, m.group_size, m.bits) == (4096, 1024, 128, 3)
+    assert m.qweight.shape == (1024, 4096 // 32 * 3) and m.qweight.dtype == torch.uint32
+    assert m.scales.shape == m.zeros.shape == (1024, 32) and m.scales.dtype == torch.float16
+    assert m.channel_scale.shape == (1, 1, 4096) and m.bias.shape == (1024,)
+    assert all(not p.requires_grad for p in m.parameters())  # frozen (reference :57-58)
+    d = QuantizedLinear(256, 8)                              # defaults: bias False, g64, 4-bit
+    assert (d.bias, d.group_size, d.bits) == (None, 64, 4)
+    m.init_params(True, True)                                # double-quant + q_perm allocation (:74-108)
+    assert m.qstatistic.shape == (32, 32, 32) and m.qstatistic.dtype == torch.uint8
+    assert m.qzeros_scales.shape == (32, 32, 1) and m.q_perm.dtype == torch.int16 and m.scales is None
+
+
+def test_reinit_module_strategy_table():
+    """Expected {module: (bits, g, qweight.shape, scales.shape)} for a hand-written strategy."""
+    model = S.build_model(S.TINY)
+    strat = S.make_strategy("S22", 2)
+    strat["model.layers.1"]["q_proj"] = {"bits": [3], "group_size": {"3": 32}}
+    strat["model.layers.1"]["down_proj"] = {"bits": [2], "group_size": {"2": 64}}
+    QuantizedLinear.reinit_module(model, group_size=64, bits=4, strategy=strat)
+    got = {n: (m.bits, m.group_size, tuple(m.qweight.shape), tuple(m.scales.shape))
+           for n, m in model.named_modules() if isinstance(m, QuantizedLinear)}
+    assert got["model.layers.0.self_attn.q_proj"] == (4, 128, (256, 32), (256, 2))
+    assert got["model.layers.1.self_attn.q_proj"] == (3, 32, (256, 24), (256, 8))
+    assert got["model.layers.1.mlp.down_proj"] == (2, 64, (256, 32), (256, 8))
+    assert got["model.layers.1.mlp.gate_proj"] == (4, 128, (512, 32), (512, 2))
+    # uniform path (strategy None) applies to every module
+    QuantizedLinear.reinit_module(model, group_size=32, bits=2, strategy=None)
+    assert all((m.bits, m.group_size) == (2, 32) for m in model.modules() if isinstance(m, QuantizedLinear))
+    bad = S.make_strategy("S40", 2)
+    bad["model.layers.0"]["q_proj"]["group_size"]["4"] = 256
+    with pytest.raises(AssertionError, match="must be 32, 64 or 128"):
+        QuantizedLinear.reinit_module(model, strategy=bad)
+
+
+def test_strategy_lookup_matches_oracle(oracle):
+    model = S.build_model(S.TINY)
+    strat = S.make_strategy("S22", 2)
+    strat["model.layers.0"]["v_proj"] = {"bits": [2], "group_size": {"2": 32}}
+    QuantizedLinear.reinit_module(model, strategy=strat)
+    for n, m in model.named_modules():
+        if isinstance(m, QuantizedLinear):
+            assert (m.bits, m.group_size) == oracle.strategy_lookup(n, strat)
+
+
+def test_double_quant_module_matches_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, "double_quant.npz"))
+    K, N, g = int(z["K"]), int(z["N"]), int(z["g"])
+    m = QuantizedLinear(K, N, False, g, 4)
+    m.init_params(True, False)
+    for nm in ("qstatistic", "qzeros_zeros", "qzeros_scales", "qscales_zeros", "qscales_scales"):
+        m._buffers[nm] = torch.from_numpy(z[nm])
+    m.create_scales_zeros()
+    np.testing.assert_array_equal(m.scales.numpy(), z["scales"])
+    np.testing.assert_array_equal(m.zeros.numpy(), z["zeros"])
+    assert m.qstatistic is None
+    before = m.zeros.clone()
+    m.set_bias_and_weight()                                   # GBA-native sign -> runtime sign (:151-155)
+    assert torch.equal(m.zeros, -before)
+
+
+def test_load_contract(tmp_path):
+    strat = S.make_strategy("S22", 2)
+    extra = {"model.layers.0.self_attn.rotary_emb.inv_freq": torch.ones(4),     # dropped by sanitize()
+             "model.layers.0.self_attn.q_proj.q_perm": torch.zeros((1, 1, 256), dtype=torch.int16),
+             "some.unknown.tensor": torch.zeros(3)}                              # strict=False: ignored
+    src = S.write_checkpoint(str(tmp_path), S.TINY, strat, seed=5, extra_tensors=extra)
+    model, cfg = U.load_model(tmp_path, device="cpu")
+    assert cfg["quantization"] == {"group_size": 64, "bits": 4}
+    a, b = S.state_dict_for_disk(src), S.state_dict_for_disk(model)
+    assert set(k for k in a if "q_perm" not in k) <= set(b)
+    for k in a:
+        ta, tb = a[k], b[k]
+        if ta.dtype == torch.uint32:
+            ta, tb = ta.view(torch.int32), tb.view(torch.int32)
+        assert torch.equal(ta, tb), k
+    ql = model.model.layers[0].self_attn.q_proj
+    assert ql.scales.dtype == torch.bfloat16 and ql.zeros.dtype == torch.bfloat16   # utils.py:841-843
+    assert ql.channel_scale.dtype == torch.bfloat16                                  # "scale" in key -> bf16 too
+    assert (ql.bits, ql.group_size) == (4, 128)
+    # missing safetensors / config raise like the reference
+    with pytest.raises(FileNotFoundError):
+        U.load_model(tmp_path / "nope", device="cpu")
+    os.remove(tmp_path / "model.safetensors")
+    with pytest.raises(FileNotFoundError):
+        U.load_model(tmp_path, device="cpu")
+
+
+def test_load_rejects_bad_group_and_shape(tmp_path):
+    S.write_checkpoint(str(tmp_path), S.TINY, None, seed=1, quantization={"group_size": 64, "bits": 4})
+    cfg = json.load(open(tmp_path / "config.json"))
+    cfg["quantization"]["group_size"] = 48
+    json.dump(cfg, open(tmp_path / "config.json", "w"))
+    with pytest.raises(AssertionError, match="must be 32, 64 or 128"):
+        U.load_model(tmp_path, device="cpu")
+    cfg["quantization"] = {"group_size": 64, "bits": 2}      # checkpoint tensors are 4-bit shaped
+    json.dump(cfg, open(tmp_path / "config.json", "w"))
+    with pytest.raises(ValueError, match="shape mismatch"):
+        U.load_model(tmp_path, device="cpu")
+
+
+def test_generate_loop_semantics(tmp_path, cpu_oracle_op):
+    strat = S.make_strategy("S22", 2)
+    S.write_checkpoint(str(tmp_path), S.TINY, strat, seed=3)
+    model, tok = U.load(str(tmp_path))
+    assert isinstance(model, qllama.Model) and tok.eos_token_ids == {511}
+    prompt = [5, 17, 42, 7, 99]
+    steps = list(U.generate_step(torch.tensor(prompt), model, max_tokens=6))
+    assert len(steps) == 6
+    t0, lp0, hs0 = steps[0]
+    assert isinstance(t0, int) and lp0.shape == (512,) and hs0 is None
+    assert abs(torch.logsumexp(lp0.float(), -1).item()) < 2e-2           # logprobs = logits - logsumexp
+    assert t0 == int(torch.argmax(lp0))                                   # greedy default sampler
+    # chunked prefill gives the same first token as one-shot prefill
+    s2 = list(U.generate_step(torch.tensor(prompt), model, max_tokens=2, prefill_step_size=2))
+    assert s2[0][0] == t0
+    # incremental decode == full re-forward (KV cache append + causal mask with offset)
+    ids = [s[0] for s in steps]
+    full = model(torch.tensor([prompt + ids[:3]]))[0, -1]
+    assert int(torch.argmax(full)) == ids[3]
+    with pytest.raises(ValueError, match="Wrong number of layers"):
+        next(U.generate_step(torch.tensor(prompt), model, prompt_cache=[None]))
+    with pytest.raises(NotImplementedError):
+        next(U.generate_step(torch.tensor(prompt), model, kv_bits=4))
+    # stream_generate / generate: response fields, finish reasons, EOS stop
+    rs = list(U.stream_generate(model, tok, prompt, max_tokens=4))
+    assert rs[-1].finish_reason == "length" and rs[-1].generation_tokens == 4 and rs[-1].prompt_tokens == 5
+    assert [r.token for r in rs[:-1]] == ids[:4] and all(r.finish_reason is None for r in rs[:-1])
+    tok.add_eos_token(ids[2])
+    rs = list(U.stream_generate(model, tok, prompt, max_tokens=6))
+    assert rs[-1].finish_reason == "stop" and rs[-1].token == ids[2] and len(rs) == 3
+    text = U.generate(model, tok, "hello world", max_tokens=3)
+    assert isinstance(text, str)

@@ -1,0 +1,85 @@
+"""GPU: the callers of the hot path (model graph, generate loop, graph-replayed decode) against the committed
+tiny-Llama fixture that the CPU oracle produced (tests/golden/make_golden.py, case iv)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def tiny(golden_dir):
+    assert torch.cuda.is_available()
+    sys.path.insert(0, golden_dir)
+    from make_golden import tiny_strategy
+    from gbx_lm_amd import synthetic as S
+    z = np.load(os.path.join(golden_dir, "tiny_llama.npz"))
+    model = S.build_model(S.TINY, tiny_strategy(), device="cpu", seed=7).to(DEV)   # same CPU RNG stream as the fixture
+    for blk in model.model.layers:
+        blk.self_attn.rope.to(DEV)
+    return model, z
+
+
+def _check_logprobs(got, want, what):
+    # bf16 logits of magnitude ~6 carry ~0.03 of rounding; accumulated bf16 activations add a little more
+    err = np.abs(got - want).max()
+    assert err < 0.12, f"{what}: max |dlogprob| = {err}"
+
+
+def test_prefill_logprobs_match_fixture(tiny):
+    from gbx_lm_amd import utils as U
+    model, z = tiny
+    step = next(U.generate_step(torch.tensor(z["prompt"]), model, max_tokens=1))
+    _check_logprobs(step[1].float().cpu().numpy(), z["logprobs"][0], "prefill")
+    if z["gap"][0] > 0.15:
+        assert step[0] == int(z["ids"][0])
+
+
+def test_teacher_forced_decode_graph_path(tiny):
+    """Feed the fixture's ids one at a time through model.decode_step (HIP-graph replay) and compare every step."""
+    from gbx_lm_amd.models.cache import make_prompt_cache
+    model, z = tiny
+    cache = make_prompt_cache(model)
+    with torch.no_grad():
+        logits = model(torch.tensor(z["prompt"], device=DEV)[None], cache=cache)[:, -1, :]
+        ids = z["ids"]
+        for t in range(len(ids) - 1):
+            lp = (logits - torch.logsumexp(logits.float(), -1, keepdim=True).to(logits.dtype)).float().cpu().numpy()[0]
+            _check_logprobs(lp, z["logprobs"][t], f"step {t}")
+            if z["gap"][t] > 0.25:
+                assert int(np.argmax(lp)) == int(ids[t]), f"argmax differs at step {t} (gap {z['gap'][t]})"
+            logits = model.decode_step(torch.tensor([ids[t]], device=DEV), cache)
+    assert getattr(model, "_decode_runner", None) is not None and model._decode_runner.graph is not None
+    assert cache[0].offset == len(z["prompt"]) + len(ids) - 1
+
+
+def test_graph_decode_equals_eager_and_survives_cache_growth(tiny):
+    from gbx_lm_amd.models.cache import make_prompt_cache, KVCache
+    model, z = tiny
+    prompt = torch.tensor(z["prompt"], device=DEV)
+    c1 = [KVCache(step=8) for _ in model.layers]             # tiny growth step: forces re-capture at 8, 16, 24
+    c2 = [KVCache(step=8) for _ in model.layers]
+    with torch.no_grad():
+        l1 = model(prompt[None], cache=c1)[:, -1, :]
+        l2 = model(prompt[None], cache=c2)[:, -1, :]
+        for t in range(22):
+            tok = torch.argmax(l2, -1)
+            l1 = model(tok[None], cache=c1)[:, -1, :]         # eager single-token forward
+            l2 = model.decode_step(tok, c2).clone()           # graph replay
+            assert torch.allclose(l1.float(), l2.float(), atol=0.08, rtol=0.05), f"step {t}"
+    assert c1[0].offset == c2[0].offset == len(prompt) + 22 and c2[0].capacity == 32
+
+
+def test_load_and_generate_text(tmp_path):
+    from gbx_lm_amd import synthetic as S, load, generate, stream_generate
+    S.write_checkpoint(str(tmp_path), S.TINY, S.make_strategy("S22", 2), seed=11)
+    model, tok = load(str(tmp_path))
+    assert next(model.parameters()).is_cuda
+    text = generate(model, tok, "hello world", max_tokens=12)
+    assert isinstance(text, str)
+    rs = list(stream_generate(model, tok, [3, 4, 5], max_tokens=5))
+    assert rs[-1].finish_reason in ("length", "stop") and rs[-1].generation_tps > 0 and rs[-1].peak_memory > 0
