@@ -173,7 +173,7 @@ constexpr int GEMV_R = 2;
 template <int BITS, int P>
 struct RowBatch {
   typename SlotWords<BITS>::type w[GEMV_R][P];
-  unsigned short s[GEMV_R][P][Fmt<BITS>::NSUB], z[GEMV_R][P][Fmt<BITS>::NSUB];
+  unsigned short s[GEMV_R][P][2], z[GEMV_R][P][2];
   unsigned short res[GEMV_R];
 };
 
@@ -188,15 +188,24 @@ __device__ __forceinline__ float round_bf16_or_f16(float v, bool bf16) {
 // D  = batches in flight per wave (ring of register buffers).  Every row owner gets a multiple of D batches and every
 //      issue is unconditional, so hipcc can count vmcnt exactly: activations are waited for with the whole first
 //      ring still in flight, and batch b+D is requested the moment batch b has been consumed.
-template <int BITS, int P, int KS, int D, bool BF16>
-__global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
+// NW = wavefronts per workgroup.  The activation vector is converted ONCE per workgroup (through LDS), so fat
+// workgroups (16 waves = one per CU-slot) make that prologue a small fraction of the row work even when every wave
+// owns only one or two rows.
+template <int P> struct WavesPerBlock { static constexpr int value = (P == 1) ? 16 : 8; };
+
+// SPLIT (2-bit only): group_size 32, i.e. the two 32-value halves of a lane's slot carry different scales.
+template <int BITS, int P, int KS, int D, bool BF16, bool SPLIT>
+__global__ __launch_bounds__(WavesPerBlock<P>::value * 64) void gemv_kernel(const GemvArgs a) {
+  constexpr int NW = WavesPerBlock<P>::value;
+  constexpr int NT = NW * 64;
+  constexpr int GPB = NW / 4;                                 // KS == 4: row groups (of four K-quarter waves) per workgroup
   using F = Fmt<BITS>;
   using L = Lds<BITS>;
   using WT = typename SlotWords<BITS>::type;
   constexpr int PAIRS = L::PAIRS, SSTR = L::SSTR, NSUB = F::NSUB;
   constexpr int R = GEMV_R;
   constexpr int UPS = F::VPL / F::UNIT_VALS;                 // units per slot
-  constexpr int UPT = (P * KS * 64 * UPS + 255) / 256;       // units per thread in the prologue
+  constexpr int UPT = (P * KS * 64 * UPS + NT - 1) / NT;     // units per thread in the prologue
   constexpr int UW = F::UNIT_VALS / 2;                       // 32-bit words of activations per unit
   constexpr int UPSUB = (32 / F::UNIT_VALS) ? (32 / F::UNIT_VALS) : 1;   // units per 32-value sub-slot
 
@@ -205,8 +214,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   const int nslots = K / F::VPL;
   h2* xp_lds = reinterpret_cast<h2*>(smem);
   float2* xs_lds = reinterpret_cast<float2*>(smem + static_cast<size_t>(nslots) * SSTR * 4);
-  float* red_lds = reinterpret_cast<float*>(xs_lds + nslots * NSUB);    // 4 floats (RMSNorm block reduction)
-  float* part_lds = red_lds + 4;                                        // KS == 4: [batches of the block][R][4]
+  float* red_lds = reinterpret_cast<float*>(xs_lds + nslots * NSUB);    // NW floats (RMSNorm block reduction)
+  float* part_lds = red_lds + NW;                                        // KS == 4: [batches of the block][R][4]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: row/segment math stays on the SALU
@@ -215,20 +224,24 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   const int m = blockIdx.y;                       // activation row (M > 1 re-streams the weights)
   const unsigned short* __restrict__ xg = static_cast<const unsigned short*>(a.x) + static_cast<size_t>(m) * K;
   const int gshift = a.log2g - 5;                 // 32-value sub-slot index -> group index
-  const int split1 = ((NSUB == 2) && (gshift == 0)) ? 1 : 0;
   const bool swiglu = a.swiglu != 0;
   const int rowstep = swiglu ? 1 : R;             // output rows covered by one batch
   const int bpo = a.batches_per_owner;
-  const int batch_begin = (KS == 1 ? (blockIdx.x * 4 + wave) : blockIdx.x) * bpo;
-  const int slot0 = (KS == 1 ? 0 : wave * 64) + lane;      // this lane's slot in pass 0
+  const int kq = wave & 3, rg = wave >> 2;        // KS == 4: K-quarter of this wave, row group inside the workgroup
+  const int batch_begin = (KS == 1 ? (blockIdx.x * NW + wave) : (blockIdx.x * GPB + rg)) * bpo;
+  const int slot0 = (KS == 1 ? 0 : kq * 64) + lane;        // this lane's slot in pass 0
   constexpr int PSTRIDE = 64 * KS;                          // slot stride between passes
   const int n0 = a.seg[0].N, n01 = n0 + a.seg[1].N;
 
-  // Segment tables in scalar registers; selection by compare/select only (indexing the kernel-argument struct with a
-  // computed index makes hipcc fetch it with VECTOR loads and drain vmcnt on every row).
-  const uint32_t* const q0 = a.seg[0].qweight; const uint32_t* const q1 = a.seg[1].qweight; const uint32_t* const q2 = a.seg[2].qweight;
-  const unsigned short* const s0 = a.seg[0].scales; const unsigned short* const s1 = a.seg[1].scales; const unsigned short* const s2 = a.seg[2].scales;
-  const unsigned short* const z0 = a.seg[0].zeros; const unsigned short* const z1 = a.seg[1].zeros; const unsigned short* const z2 = a.seg[2].zeros;
+  // One buffer descriptor per segment tensor, held in SGPRs; a row is then addressed as
+  //   descriptor (s_cselect by segment) + SGPR byte offset of the row + a per-lane VGPR offset that never changes,
+  // so streaming a row costs no vector address arithmetic at all.  (Indexing the kernel-argument struct with a
+  // computed index instead makes hipcc fetch it with VECTOR loads and drain vmcnt on every row.)
+  constexpr int RS_FLAGS = 0x00020000, RS_ALL = 0x7FFFFFFF;
+  auto rsrc = [](const void* ptr) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, RS_ALL, RS_FLAGS); };
+  const __amdgpu_buffer_rsrc_t q0 = rsrc(a.seg[0].qweight), q1 = rsrc(a.seg[1].qweight), q2 = rsrc(a.seg[2].qweight);
+  const __amdgpu_buffer_rsrc_t s0 = rsrc(a.seg[0].scales), s1 = rsrc(a.seg[1].scales), s2 = rsrc(a.seg[2].scales);
+  const __amdgpu_buffer_rsrc_t z0 = rsrc(a.seg[0].zeros), z1 = rsrc(a.seg[1].zeros), z2 = rsrc(a.seg[2].zeros);
   unsigned short* const y0 = a.seg[0].y; unsigned short* const y1 = a.seg[1].y; unsigned short* const y2 = a.seg[2].y;
   const int n1 = a.seg[1].N, n2 = a.seg[2].N;
   // row of batch element i -> (segment, local row); wave-uniform
@@ -249,7 +262,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   unsigned xr[UPT][UW], wr[WPT][UW];
 #pragma unroll
   for (int j = 0; j < UPT; ++j) {
-    const int u = min(tid + 256 * j, nunits - 1);
+    const int u = min(tid + NT * j, nunits - 1);
     const unsigned* src = reinterpret_cast<const unsigned*>(xg + static_cast<size_t>(u) * F::UNIT_VALS);
     const unsigned* wsrc = reinterpret_cast<const unsigned*>(wg + static_cast<size_t>(u) * F::UNIT_VALS);
 #pragma unroll
@@ -267,29 +280,35 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   // Branch-free on purpose: a load in one arm and a register write in the other makes hipcc drain vmcnt at the join
   // (write-after-pending-load), which serialises the whole stream.  Out-of-range lanes / rows re-read the last valid
   // slot / row and are nulled through their zero activations or the store guard.
-  const unsigned short* __restrict__ resg = a.residual ? a.residual : y0;   // dummy source when unused
+  const __amdgpu_buffer_rsrc_t resd = rsrc(a.residual ? static_cast<const void*>(a.residual) : static_cast<const void*>(y0));
+  int voff_w[P], voff_s[P];                        // per-lane byte offsets inside a row: packed words / scales
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int slot = min(p * PSTRIDE + slot0, nslots - 1);
+    voff_w[p] = slot * (F::SLOT_WORDS * 4);
+    voff_s[p] = ((slot * NSUB) >> gshift) * 2;
+  }
   auto issue = [&](RowBatch<BITS, P>& b, int r0) {
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       int sgi, row;
       locate(r0, i, sgi, row);
-      const uint32_t* qsel = sgi == 0 ? q0 : (sgi == 1 ? q1 : q2);
-      const unsigned short* ssel = sgi == 0 ? s0 : (sgi == 1 ? s1 : s2);
-      const unsigned short* zsel = sgi == 0 ? z0 : (sgi == 1 ? z1 : z2);
-      const uint32_t* wrow = qsel + static_cast<size_t>(row) * W;
+      const __amdgpu_buffer_rsrc_t qd = sgi == 0 ? q0 : (sgi == 1 ? q1 : q2);
+      const __amdgpu_buffer_rsrc_t sd = sgi == 0 ? s0 : (sgi == 1 ? s1 : s2);
+      const __amdgpu_buffer_rsrc_t zd = sgi == 0 ? z0 : (sgi == 1 ? z1 : z2);
+      const int woff = row * (W * 4), goff = row * (G * 2);
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        const int slot = min(p * PSTRIDE + slot0, nslots - 1);
-        b.w[i][p] = __builtin_nontemporal_load(reinterpret_cast<const WT*>(wrow + static_cast<size_t>(slot) * F::SLOT_WORDS));
-        const size_t gi = static_cast<size_t>(row) * G + ((slot * NSUB) >> gshift);
-        b.s[i][p][0] = ssel[gi];
-        b.z[i][p][0] = zsel[gi];
-        if constexpr (NSUB == 2) {   // second 32-value half: its own group only when g == 32
-          b.s[i][p][1] = ssel[gi + split1];
-          b.z[i][p][1] = zsel[gi + split1];
+        if constexpr (BITS == 3) b.w[i][p] = __builtin_amdgcn_raw_buffer_load_b96(qd, voff_w[p], woff, 2);   // nt
+        else b.w[i][p] = __builtin_amdgcn_raw_buffer_load_b128(qd, voff_w[p], woff, 2);
+        b.s[i][p][0] = __builtin_amdgcn_raw_buffer_load_b16(sd, voff_s[p], goff, 0);
+        b.z[i][p][0] = __builtin_amdgcn_raw_buffer_load_b16(zd, voff_s[p], goff, 0);
+        if constexpr (SPLIT) {       // second 32-value half has its own group only when g == 32 (2-bit)
+          b.s[i][p][1] = __builtin_amdgcn_raw_buffer_load_b16(sd, voff_s[p] + 2, goff, 0);
+          b.z[i][p][1] = __builtin_amdgcn_raw_buffer_load_b16(zd, voff_s[p] + 2, goff, 0);
         }
       }
-      b.res[i] = resg[static_cast<size_t>(m) * n0 + min(row, n0 - 1)];
+      b.res[i] = __builtin_amdgcn_raw_buffer_load_b16(resd, 0, (m * n0 + min(row, n0 - 1)) * 2, 0);
     }
   };
   RowBatch<BITS, P> ring[D];
@@ -302,7 +321,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
     float ssq = 0.f;
 #pragma unroll
     for (int j = 0; j < UPT; ++j) {
-      const bool live = (tid + 256 * j) < nunits;
+      const bool live = (tid + NT * j) < nunits;
 #pragma unroll
       for (int q = 0; q < UW; ++q) {
         const float lo = act_lo<BF16>(xr[j][q]), hi = act_hi<BF16>(xr[j][q]);
@@ -312,14 +331,16 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
     ssq = wave_sum(ssq);
     if (lane == 0) red_lds[wave] = ssq;
     __syncthreads();
-    const float tot = (red_lds[0] + red_lds[1]) + (red_lds[2] + red_lds[3]);
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) tot += red_lds[i];
     rstd = rsqrtf(tot / static_cast<float>(K) + a.eps);
   }
 
   // ---------------- 3b. activations -> pre-shifted fp16 pairs, one block exponent per 32-value sub-slot ----------
 #pragma unroll
   for (int j = 0; j < UPT; ++j) {
-    const int u = tid + 256 * j;
+    const int u = tid + NT * j;
     float xf[F::UNIT_VALS];
     unsigned amax = 0;
 #pragma unroll
@@ -426,12 +447,18 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
       for (int p = 0; p < P; ++p) {
         float d[NSUB];
         dot_slot<BITS>(cur.w[i][p], xv[p], d);
+        if constexpr (NSUB == 2 && !SPLIT) {     // both halves share one (scale, zero): s*(c0*d0 + c1*d1) + z*(xs0 + xs1)
+          const float t = fmaf(cf[p][1], d[1], cf[p][0] * d[0]);
+          acc[i] = fmaf(act_to_f32<BF16>(cur.s[i][p][0]), t, acc[i]);
+          acc[i] = fmaf(act_to_f32<BF16>(cur.z[i][p][0]), xs[p][0] + xs[p][1], acc[i]);
+        } else {
 #pragma unroll
-        for (int s = 0; s < NSUB; ++s) {
-          const float sc = act_to_f32<BF16>(cur.s[i][p][s]) * cf[p][s];
-          const float ze = act_to_f32<BF16>(cur.z[i][p][s]);
-          acc[i] = fmaf(sc, d[s], acc[i]);
-          acc[i] = fmaf(ze, xs[p][s], acc[i]);
+          for (int s = 0; s < NSUB; ++s) {
+            const float sc = act_to_f32<BF16>(cur.s[i][p][s]) * cf[p][s];
+            const float ze = act_to_f32<BF16>(cur.z[i][p][s]);
+            acc[i] = fmaf(sc, d[s], acc[i]);
+            acc[i] = fmaf(ze, xs[p][s], acc[i]);
+          }
         }
       }
     }
@@ -442,7 +469,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
       if (lane == 0) finish(b * rowstep, t0, t1, cur.res[0], cur.res[1]);
     } else {
       if (lane == 0) {
-        float* pp = part_lds + static_cast<size_t>(b - batch_begin) * (R * 4) + wave;
+        float* pp = part_lds + static_cast<size_t>(rg * bpo + (b - batch_begin)) * (R * 4) + kq;
         pp[0] = t0;
         pp[4] = t1;
       }
@@ -463,10 +490,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
 
   if constexpr (KS == 4) {
     __syncthreads();
-    for (int bl = tid; bl < bpo; bl += 256) {
+    for (int bl = tid; bl < GPB * bpo; bl += NT) {
       const float4 p0 = *reinterpret_cast<const float4*>(part_lds + static_cast<size_t>(bl) * (R * 4));
       const float4 p1 = *reinterpret_cast<const float4*>(part_lds + static_cast<size_t>(bl) * (R * 4) + 4);
-      const int r0 = (batch_begin + bl) * rowstep;
+      const int r0 = ((blockIdx.x * GPB + bl / bpo) * bpo + bl % bpo) * rowstep;
       unsigned short res0 = 0, res1 = 0;
       if (a.residual && !swiglu) {
         if (r0 < N) res0 = a.residual[static_cast<size_t>(m) * n0 + r0];
@@ -490,20 +517,45 @@ __global__ __launch_bounds__(256) void add_bias_kernel(unsigned short* __restric
 template <int BITS>
 hipError_t launch_gemv(const GemvArgs& a, int M, bool bf16, hipStream_t stream);
 
-constexpr int GEMV_MAX_BATCHES_PER_BLOCK_KS4 = 512;
-constexpr int GEMV_NOMINAL_BLOCKS = 256 * 8;   // 8 workgroups (32 waves) per CU on the 256 CUs
+constexpr int GEMV_MAX_BATCHES_PER_GROUP_KS4 = 256;
+constexpr int GEMV_CUS = 256;                  // MI355X
 
-template <int BITS, int P, int KS, int D>
+// Workgroups of this kernel variant that are resident at once on the whole chip (asked once, then cached).
+template <int BITS, int P, int KS, int D, bool SPLIT>
+static int resident_blocks(bool bf16, size_t shmem) {
+  static int cached[2] = {0, 0};
+  int& c = cached[bf16 ? 1 : 0];
+  if (c == 0) {
+    constexpr int NT = WavesPerBlock<P>::value * 64;
+    int per_cu = 0;
+    hipError_t e = bf16 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemv_kernel<BITS, P, KS, D, true, SPLIT>, NT, shmem)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemv_kernel<BITS, P, KS, D, false, SPLIT>, NT, shmem);
+    if (e != hipSuccess || per_cu < 1) per_cu = 1;
+    if (per_cu > 4) per_cu = 4;
+    c = per_cu * GEMV_CUS;
+  }
+  return c;
+}
+
+template <int BITS, int P, int KS>
+static size_t gemv_shmem(int K, int bpo) {
+  constexpr int NW = WavesPerBlock<P>::value;
+  size_t b = Lds<BITS>::bytes(K) + NW * sizeof(float) + 16;
+  if (KS == 4) b += static_cast<size_t>(NW / 4) * bpo * GEMV_R * 4 * sizeof(float);
+  return b;
+}
+
+template <int BITS, int P, int KS, int D, bool SPLIT>
 static hipError_t launch_gemv_d(const GemvArgs& a, int M, bool bf16, int bpo, int nbatches, hipStream_t stream) {
+  constexpr int NW = WavesPerBlock<P>::value;
   GemvArgs args = a;
   args.batches_per_owner = bpo;
-  size_t shmem = Lds<BITS>::bytes(a.K) + 16;
-  if (KS == 4) shmem += static_cast<size_t>(bpo) * GEMV_R * 4 * sizeof(float);
-  const int batches_per_block = (KS == 1) ? 4 * bpo : bpo;
+  const size_t shmem = gemv_shmem<BITS, P, KS>(a.K, bpo);
+  const int batches_per_block = (KS == 1 ? NW : NW / 4) * bpo;
   const int blocks = (nbatches + batches_per_block - 1) / batches_per_block;
-  dim3 grid(blocks, M), block(256);
-  if (bf16) hipLaunchKernelGGL((gemv_kernel<BITS, P, KS, D, true>), grid, block, shmem, stream, args);
-  else hipLaunchKernelGGL((gemv_kernel<BITS, P, KS, D, false>), grid, block, shmem, stream, args);
+  dim3 grid(blocks, M), block(NW * 64);
+  if (bf16) hipLaunchKernelGGL((gemv_kernel<BITS, P, KS, D, true, SPLIT>), grid, block, shmem, stream, args);
+  else hipLaunchKernelGGL((gemv_kernel<BITS, P, KS, D, false, SPLIT>), grid, block, shmem, stream, args);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess && a.bias) {
     const size_t total = static_cast<size_t>(M) * a.N;
@@ -516,31 +568,44 @@ static hipError_t launch_gemv_d(const GemvArgs& a, int M, bool bf16, int bpo, in
   return e;
 }
 
-template <int BITS, int P, int KS>
+// One round of co-resident workgroups covers all rows: pick the shallowest ring whose resident owners can hold the
+// batches, else split the batches evenly over the resident owners of the deepest ring (multiples of D per owner).
+template <int BITS, int P, int KS, bool SPLIT>
 static hipError_t launch_gemv_p(const GemvArgs& a, int M, bool bf16, hipStream_t stream) {
-  // batches each row owner must take so that ~GEMV_NOMINAL_BLOCKS workgroups cover the rows; ring depth follows
+  constexpr int NW = WavesPerBlock<P>::value;
   const int rowstep = a.swiglu ? 1 : GEMV_R;
   const int nbatches = (a.N + rowstep - 1) / rowstep;
-  const int owners = (KS == 1) ? GEMV_NOMINAL_BLOCKS * 4 : GEMV_NOMINAL_BLOCKS;
-  const int nb = (nbatches + owners - 1) / owners;
-  if (nb <= 1) return launch_gemv_d<BITS, P, KS, 1>(a, M, bf16, 1, nbatches, stream);
-  if (nb <= 2) return launch_gemv_d<BITS, P, KS, 2>(a, M, bf16, 2, nbatches, stream);
-  int bpo = ((nb + 3) / 4) * 4;
-  if (KS == 4 && bpo > GEMV_MAX_BATCHES_PER_BLOCK_KS4) bpo = GEMV_MAX_BATCHES_PER_BLOCK_KS4;
-  return launch_gemv_d<BITS, P, KS, 4>(a, M, bf16, bpo, nbatches, stream);
+  const int opb = (KS == 1) ? NW : NW / 4;                 // row owners per workgroup
+  const int own1 = resident_blocks<BITS, P, KS, 1, SPLIT>(bf16, gemv_shmem<BITS, P, KS>(a.K, 1)) * opb;
+  if (nbatches <= own1) return launch_gemv_d<BITS, P, KS, 1, SPLIT>(a, M, bf16, 1, nbatches, stream);
+  const int own2 = resident_blocks<BITS, P, KS, 2, SPLIT>(bf16, gemv_shmem<BITS, P, KS>(a.K, 2)) * opb;
+  if (nbatches <= 2 * own2) return launch_gemv_d<BITS, P, KS, 2, SPLIT>(a, M, bf16, 2, nbatches, stream);
+  const int own4 = resident_blocks<BITS, P, KS, 4, SPLIT>(bf16, gemv_shmem<BITS, P, KS>(a.K, 4)) * opb;
+  int bpo = (nbatches + own4 - 1) / own4;
+  bpo = ((bpo + 3) / 4) * 4;
+  if (KS == 4 && bpo > GEMV_MAX_BATCHES_PER_GROUP_KS4) bpo = GEMV_MAX_BATCHES_PER_GROUP_KS4;
+  return launch_gemv_d<BITS, P, KS, 4, SPLIT>(a, M, bf16, bpo, nbatches, stream);
 }
 
 // max K the lane-resident fast path covers for a bit width (beyond -> generic kernel)
 template <int BITS> constexpr int gemv_max_k() { return 512 * Fmt<BITS>::VPL; }
 
+template <int BITS, bool SPLIT>
+static hipError_t dispatch_gemv_s(const GemvArgs& a, int M, bool bf16, hipStream_t s) {
+  const int nslots = a.K / Fmt<BITS>::VPL;
+  if (nslots <= 64) return launch_gemv_p<BITS, 1, 1, SPLIT>(a, M, bf16, s);
+  if (nslots <= 128) return launch_gemv_p<BITS, 2, 1, SPLIT>(a, M, bf16, s);
+  if (nslots <= 256) return launch_gemv_p<BITS, 1, 4, SPLIT>(a, M, bf16, s);
+  if (nslots <= 512) return launch_gemv_p<BITS, 2, 4, SPLIT>(a, M, bf16, s);
+  return hipErrorInvalidValue;
+}
+
 template <int BITS>
 static hipError_t dispatch_gemv(const GemvArgs& a, int M, bool bf16, hipStream_t s) {
-  const int nslots = a.K / Fmt<BITS>::VPL;
-  if (nslots <= 64) return launch_gemv_p<BITS, 1, 1>(a, M, bf16, s);
-  if (nslots <= 128) return launch_gemv_p<BITS, 2, 1>(a, M, bf16, s);
-  if (nslots <= 256) return launch_gemv_p<BITS, 1, 4>(a, M, bf16, s);
-  if (nslots <= 512) return launch_gemv_p<BITS, 2, 4>(a, M, bf16, s);
-  return hipErrorInvalidValue;
+  if constexpr (BITS == 2) {
+    if (a.log2g == 5) return dispatch_gemv_s<2, true>(a, M, bf16, s);
+  }
+  return dispatch_gemv_s<BITS, false>(a, M, bf16, s);
 }
 
 #define GBX_DEFINE_LAUNCH_GEMV(BITS)                                                              \
