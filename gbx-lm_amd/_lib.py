@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-_SO = os.path.join(_CSRC, "libgbx_qlinear.so")
+_SO = os.environ.get("GBX_QLINEAR_LIB") or os.path.join(_CSRC, "libgbx_qlinear.so")   # override: experiment builds only
 
 GBX_OK, GBX_ERR_INVALID, GBX_ERR_HIP, GBX_ERR_UNSUPPORTED = 0, 1, 2, 3
 GBX_F16, GBX_BF16, GBX_F32 = 0, 1, 2

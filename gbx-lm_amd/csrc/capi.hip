@@ -80,6 +80,9 @@ int gbx_qlinear_forward(const void* x, const uint32_t* qweight, const void* scal
     a.seg[0] = gbx::GemvSeg{qweight, static_cast<const unsigned short*>(scales), static_cast<const unsigned short*>(zeros),
                             static_cast<unsigned short*>(y), N};
     a.nseg = 1; a.N = N; a.K = K; a.log2g = log2g; a.bias = bias;
+#ifdef GBX_STAMPS
+    a.stamps = reinterpret_cast<unsigned long long*>(strtoull(getenv("GBX_STAMP_PTR") ? getenv("GBX_STAMP_PTR") : "0", nullptr, 0));
+#endif
     switch (bits) {
       case 2: e = gbx::launch_gemv<2>(a, static_cast<int>(M), bf16, stream); break;
       case 3: e = gbx::launch_gemv<3>(a, static_cast<int>(M), bf16, stream); break;
@@ -129,6 +132,9 @@ int gbx_qlinear_fused_forward(const gbx_qlinear_fused* d, void* hip_stream) {
   a.eps = d->norm_eps;
   a.residual = static_cast<const unsigned short*>(d->residual);
   a.swiglu = d->swiglu ? 1 : 0;
+#ifdef GBX_STAMPS
+  a.stamps = reinterpret_cast<unsigned long long*>(strtoull(getenv("GBX_STAMP_PTR") ? getenv("GBX_STAMP_PTR") : "0", nullptr, 0));
+#endif
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   const bool bf16 = d->act_dtype == GBX_BF16;
   hipError_t e;

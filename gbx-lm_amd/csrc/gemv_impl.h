@@ -46,6 +46,9 @@ struct GemvArgs {
   float eps;
   const unsigned short* residual;  // [N]: y <- residual + bf16(result)                              (qllama.py:138,140)
   int swiglu;                      // seg[0] = gate, seg[1] = up: y0[n] = silu(gate[n]) * up[n]       (qllama.py:115)
+#ifdef GBX_STAMPS
+  unsigned long long* stamps;      // diagnostic build only: [workgroup][wave][8] s_memrealtime stamps
+#endif
 };
 
 // Per bit width: slot geometry and the pair table.  Pair i of a unit holds fields (ka(i), kb(i)) sitting at bit
@@ -239,9 +242,9 @@ __global__ __launch_bounds__(WavesPerBlock<P>::value * 64) void gemv_kernel(cons
   // computed index instead makes hipcc fetch it with VECTOR loads and drain vmcnt on every row.)
   constexpr int RS_FLAGS = 0x00020000, RS_ALL = 0x7FFFFFFF;
   auto rsrc = [](const void* ptr) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, RS_ALL, RS_FLAGS); };
-  const __amdgpu_buffer_rsrc_t q0 = rsrc(a.seg[0].qweight), q1 = rsrc(a.seg[1].qweight), q2 = rsrc(a.seg[2].qweight);
-  const __amdgpu_buffer_rsrc_t s0 = rsrc(a.seg[0].scales), s1 = rsrc(a.seg[1].scales), s2 = rsrc(a.seg[2].scales);
-  const __amdgpu_buffer_rsrc_t z0 = rsrc(a.seg[0].zeros), z1 = rsrc(a.seg[1].zeros), z2 = rsrc(a.seg[2].zeros);
+  const uint32_t* const q0 = a.seg[0].qweight; const uint32_t* const q1 = a.seg[1].qweight; const uint32_t* const q2 = a.seg[2].qweight;
+  const unsigned short* const s0 = a.seg[0].scales; const unsigned short* const s1 = a.seg[1].scales; const unsigned short* const s2 = a.seg[2].scales;
+  const unsigned short* const z0 = a.seg[0].zeros; const unsigned short* const z1 = a.seg[1].zeros; const unsigned short* const z2 = a.seg[2].zeros;
   unsigned short* const y0 = a.seg[0].y; unsigned short* const y1 = a.seg[1].y; unsigned short* const y2 = a.seg[2].y;
   const int n1 = a.seg[1].N, n2 = a.seg[2].N;
   // row of batch element i -> (segment, local row); wave-uniform
@@ -253,6 +256,12 @@ __global__ __launch_bounds__(WavesPerBlock<P>::value * 64) void gemv_kernel(cons
       row = r - (sg == 0 ? 0 : (sg == 1 ? n0 : n01));
     }
   };
+#ifdef GBX_STAMPS
+#define GBX_STAMP(i) do { if (lane == 0) a.stamps[(static_cast<size_t>(blockIdx.x) * NW + wave) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GBX_STAMP(i) do {} while (0)
+#endif
+  GBX_STAMP(0);
   // ---------------- 1. activation (and norm weight) loads first: vmcnt retires in order -------------------------
   const int nunits = K / F::UNIT_VALS;
   // fused RMSNorm only where a wave owns whole rows (KS == 1: K = hidden size); the launcher rejects it otherwise
@@ -293,9 +302,10 @@ __global__ __launch_bounds__(WavesPerBlock<P>::value * 64) void gemv_kernel(cons
     for (int i = 0; i < R; ++i) {
       int sgi, row;
       locate(r0, i, sgi, row);
-      const __amdgpu_buffer_rsrc_t qd = sgi == 0 ? q0 : (sgi == 1 ? q1 : q2);
-      const __amdgpu_buffer_rsrc_t sd = sgi == 0 ? s0 : (sgi == 1 ? s1 : s2);
-      const __amdgpu_buffer_rsrc_t zd = sgi == 0 ? z0 : (sgi == 1 ? z1 : z2);
+      // pointer selects stay on the SALU; only descriptor words 0-1 differ between segments
+      const __amdgpu_buffer_rsrc_t qd = rsrc(sgi == 0 ? q0 : (sgi == 1 ? q1 : q2));
+      const __amdgpu_buffer_rsrc_t sd = rsrc(sgi == 0 ? s0 : (sgi == 1 ? s1 : s2));
+      const __amdgpu_buffer_rsrc_t zd = rsrc(sgi == 0 ? z0 : (sgi == 1 ? z1 : z2));
       const int woff = row * (W * 4), goff = row * (G * 2);
 #pragma unroll
       for (int p = 0; p < P; ++p) {
@@ -311,10 +321,13 @@ __global__ __launch_bounds__(WavesPerBlock<P>::value * 64) void gemv_kernel(cons
       b.res[i] = __builtin_amdgcn_raw_buffer_load_b16(resd, 0, (m * n0 + min(row, n0 - 1)) * 2, 0);
     }
   };
+  // Only the FIRST batch is requested ahead of the activation prologue: a wave issues in order, and a deep burst of
+  // row loads here would hold the wave (TA back-pressure) for microseconds before it could even start converting x --
+  // the whole chip would then stream first and compute afterwards instead of overlapping the two.
   RowBatch<BITS, P> ring[D];
-#pragma unroll
-  for (int d = 0; d < D; ++d) issue(ring[d], (batch_begin + d) * rowstep);
+  issue(ring[0], batch_begin * rowstep);
 
+  GBX_STAMP(1);
   // ---------------- 3a. optional fused RMSNorm: block-wide mean of squares ---------------------------------------
   float rstd = 1.f;
   if (norm) {
@@ -386,6 +399,7 @@ __global__ __launch_bounds__(WavesPerBlock<P>::value * 64) void gemv_kernel(cons
   }
   __syncthreads();
 
+  GBX_STAMP(2);
   // ---------------- 4. lane-resident activations (zeros for lanes past the end of the row) ------------------------
   h2 xv[P][PAIRS];
   float xs[P][NSUB], cf[P][NSUB];
@@ -475,6 +489,9 @@ __global__ __launch_bounds__(WavesPerBlock<P>::value * 64) void gemv_kernel(cons
       }
     }
   };
+#pragma unroll
+  for (int d = 1; d < D; ++d) issue(ring[d], (batch_begin + d) * rowstep);
+  GBX_STAMP(3);
   const int steps = bpo / D;
   int base = batch_begin;
   for (int st = 1; st < steps; ++st) {
@@ -485,8 +502,13 @@ __global__ __launch_bounds__(WavesPerBlock<P>::value * 64) void gemv_kernel(cons
     }
     base += D;
   }
+  GBX_STAMP(4);
 #pragma unroll
-  for (int d = 0; d < D; ++d) consume(ring[d], base + d);
+  for (int d = 0; d < D; ++d) {
+    consume(ring[d], base + d);
+    if (d == 0) GBX_STAMP(5);
+  }
+  GBX_STAMP(6);
 
   if constexpr (KS == 4) {
     __syncthreads();
@@ -579,12 +601,10 @@ static hipError_t launch_gemv_p(const GemvArgs& a, int M, bool bf16, hipStream_t
   const int own1 = resident_blocks<BITS, P, KS, 1, SPLIT>(bf16, gemv_shmem<BITS, P, KS>(a.K, 1)) * opb;
   if (nbatches <= own1) return launch_gemv_d<BITS, P, KS, 1, SPLIT>(a, M, bf16, 1, nbatches, stream);
   const int own2 = resident_blocks<BITS, P, KS, 2, SPLIT>(bf16, gemv_shmem<BITS, P, KS>(a.K, 2)) * opb;
-  if (nbatches <= 2 * own2) return launch_gemv_d<BITS, P, KS, 2, SPLIT>(a, M, bf16, 2, nbatches, stream);
-  const int own4 = resident_blocks<BITS, P, KS, 4, SPLIT>(bf16, gemv_shmem<BITS, P, KS>(a.K, 4)) * opb;
-  int bpo = (nbatches + own4 - 1) / own4;
-  bpo = ((bpo + 3) / 4) * 4;
+  int bpo = (nbatches + own2 - 1) / own2;
+  bpo = ((bpo + 1) / 2) * 2;
   if (KS == 4 && bpo > GEMV_MAX_BATCHES_PER_GROUP_KS4) bpo = GEMV_MAX_BATCHES_PER_GROUP_KS4;
-  return launch_gemv_d<BITS, P, KS, 4, SPLIT>(a, M, bf16, bpo, nbatches, stream);
+  return launch_gemv_d<BITS, P, KS, 2, SPLIT>(a, M, bf16, bpo, nbatches, stream);
 }
 
 // max K the lane-resident fast path covers for a bit width (beyond -> generic kernel)
