@@ -50,8 +50,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     const int i1 = a.traditional ? 2 * i : i;
     const int i2 = a.traditional ? 2 * i + 1 : i + HD / 2;
     const float x1 = act_to_f32<BF16>(src[i1]), x2 = act_to_f32<BF16>(src[i2]);
-    float sn, cs;
-    sincosf(static_cast<float>(pos) * a.rope_scale * a.inv_freq[i], &sn, &cs);
+    // angle in revolutions, reduced to [0,1): v_sin/v_cos take revolutions and are accurate to ~1e-6 there
+    const float rev = static_cast<float>(pos) * a.rope_scale * a.inv_freq[i] * 0.15915494309189535f;
+    const float fr = rev - floorf(rev);
+    const float sn = __builtin_amdgcn_sinf(fr), cs = __builtin_amdgcn_cosf(fr);
     const unsigned short r1 = f32_to_act<BF16>(x1 * cs - x2 * sn), r2 = f32_to_act<BF16>(x1 * sn + x2 * cs);
     if (isk) {
       kn_s[i1] = act_to_f32<BF16>(r1);
@@ -83,35 +85,44 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
   const unsigned short* kbase = a.kcache + static_cast<size_t>(kvh) * a.capacity * HD;
   const unsigned short* vbase = a.vcache + static_cast<size_t>(kvh) * a.capacity * HD;
-  for (int t0 = wave * PPW; t0 < pos; t0 += 4 * PPW) {
-    const int t = t0 + sub;
-    const bool valid = t < pos;
-    const int tc = valid ? t : pos - 1;
-    const u32x4 kv4 = *reinterpret_cast<const u32x4*>(kbase + static_cast<size_t>(tc) * HD + d0);
-    const u32x4 vv4 = *reinterpret_cast<const u32x4*>(vbase + static_cast<size_t>(tc) * HD + d0);
-    const unsigned kw[4] = {kv4.x, kv4.y, kv4.z, kv4.w};
-    const unsigned vw[4] = {vv4.x, vv4.y, vv4.z, vv4.w};
-    float s = 0.f;
+  constexpr int UB = 4;                 // iterations whose K/V loads are in flight together
+  for (int t0 = wave * PPW; t0 < pos; t0 += 4 * PPW * UB) {
+    u32x4 kv4[UB], vv4[UB];
+    bool valid[UB];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      s = fmaf(qr[2 * j], act_lo<BF16>(kw[j]), s);
-      s = fmaf(qr[2 * j + 1], act_hi<BF16>(kw[j]), s);
+    for (int u = 0; u < UB; ++u) {
+      const int t = t0 + u * 4 * PPW + sub;
+      valid[u] = t < pos;
+      const int tc = valid[u] ? t : pos - 1;
+      kv4[u] = *reinterpret_cast<const u32x4*>(kbase + static_cast<size_t>(tc) * HD + d0);
+      vv4[u] = *reinterpret_cast<const u32x4*>(vbase + static_cast<size_t>(tc) * HD + d0);
     }
-    // sum over the LP lanes of this position (LP = 16: one DPP row; LP = 8: half a row)
-    s += dpp_f32<0xB1>(s);
-    s += dpp_f32<0x4E>(s);
-    s += dpp_f32<0x141>(s);
-    if constexpr (LP == 16) s += dpp_f32<0x140>(s);
-    const float mn = valid ? fmaxf(m, s) : m;
-    const float corr = __expf(m - mn);
-    const float p = valid ? __expf(s - mn) : 0.f;
-    l = l * corr + p;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      acc[2 * j] = acc[2 * j] * corr + p * act_lo<BF16>(vw[j]);
-      acc[2 * j + 1] = acc[2 * j + 1] * corr + p * act_hi<BF16>(vw[j]);
+    for (int u = 0; u < UB; ++u) {
+      const unsigned kw[4] = {kv4[u].x, kv4[u].y, kv4[u].z, kv4[u].w};
+      const unsigned vw[4] = {vv4[u].x, vv4[u].y, vv4[u].z, vv4[u].w};
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s = fmaf(qr[2 * j], act_lo<BF16>(kw[j]), s);
+        s = fmaf(qr[2 * j + 1], act_hi<BF16>(kw[j]), s);
+      }
+      // sum over the LP lanes of this position (LP = 16: one DPP row; LP = 8: half a row)
+      s += dpp_f32<0xB1>(s);
+      s += dpp_f32<0x4E>(s);
+      s += dpp_f32<0x141>(s);
+      if constexpr (LP == 16) s += dpp_f32<0x140>(s);
+      const float mn = valid[u] ? fmaxf(m, s) : m;
+      const float corr = __expf(m - mn);
+      const float p = valid[u] ? __expf(s - mn) : 0.f;
+      l = l * corr + p;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[2 * j] = acc[2 * j] * corr + p * act_lo<BF16>(vw[j]);
+        acc[2 * j + 1] = acc[2 * j + 1] * corr + p * act_hi<BF16>(vw[j]);
+      }
+      m = mn;
     }
-    m = mn;
   }
   // ---- the new token itself (its k, v are in LDS, not yet visible through the cache to other blocks) ----
   if (wave == 0 && sub == 0) {
