@@ -194,12 +194,11 @@ __device__ __forceinline__ float round_bf16_or_f16(float v, bool bf16) {
 // NW = wavefronts per workgroup.  The activation vector is converted ONCE per workgroup (through LDS), so fat
 // workgroups (16 waves = one per CU-slot) make that prologue a small fraction of the row work even when every wave
 // owns only one or two rows.
-template <int P> struct WavesPerBlock { static constexpr int value = (P == 1) ? 16 : 8; };
+template <int P> struct WavesPerBlock { static constexpr int value = (P == 1) ? 16 : 8; };   // "fat" geometry
 
 // SPLIT (2-bit only): group_size 32, i.e. the two 32-value halves of a lane's slot carry different scales.
-template <int BITS, int P, int KS, int D, bool BF16, bool SPLIT>
-__global__ __launch_bounds__(WavesPerBlock<P>::value * 64) void gemv_kernel(const GemvArgs a) {
-  constexpr int NW = WavesPerBlock<P>::value;
+template <int BITS, int P, int KS, int D, bool BF16, bool SPLIT, int NW>
+__global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
   constexpr int NT = NW * 64;
   constexpr int GPB = NW / 4;                                 // KS == 4: row groups (of four K-quarter waves) per workgroup
   using F = Fmt<BITS>;
@@ -543,41 +542,39 @@ constexpr int GEMV_MAX_BATCHES_PER_GROUP_KS4 = 256;
 constexpr int GEMV_CUS = 256;                  // MI355X
 
 // Workgroups of this kernel variant that are resident at once on the whole chip (asked once, then cached).
-template <int BITS, int P, int KS, int D, bool SPLIT>
+template <int BITS, int P, int KS, int D, bool SPLIT, int NW>
 static int resident_blocks(bool bf16, size_t shmem) {
   static int cached[2] = {0, 0};
   int& c = cached[bf16 ? 1 : 0];
   if (c == 0) {
-    constexpr int NT = WavesPerBlock<P>::value * 64;
+    constexpr int NT = NW * 64;
     int per_cu = 0;
-    hipError_t e = bf16 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemv_kernel<BITS, P, KS, D, true, SPLIT>, NT, shmem)
-                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemv_kernel<BITS, P, KS, D, false, SPLIT>, NT, shmem);
+    hipError_t e = bf16 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemv_kernel<BITS, P, KS, D, true, SPLIT, NW>, NT, shmem)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemv_kernel<BITS, P, KS, D, false, SPLIT, NW>, NT, shmem);
     if (e != hipSuccess || per_cu < 1) per_cu = 1;
-    if (per_cu > 4) per_cu = 4;
+    if (per_cu * NW > 32) per_cu = 32 / NW;
     c = per_cu * GEMV_CUS;
   }
   return c;
 }
 
-template <int BITS, int P, int KS>
+template <int BITS, int P, int KS, int NW>
 static size_t gemv_shmem(int K, int bpo) {
-  constexpr int NW = WavesPerBlock<P>::value;
   size_t b = Lds<BITS>::bytes(K) + NW * sizeof(float) + 16;
   if (KS == 4) b += static_cast<size_t>(NW / 4) * bpo * GEMV_R * 4 * sizeof(float);
   return b;
 }
 
-template <int BITS, int P, int KS, int D, bool SPLIT>
+template <int BITS, int P, int KS, int D, bool SPLIT, int NW>
 static hipError_t launch_gemv_d(const GemvArgs& a, int M, bool bf16, int bpo, int nbatches, hipStream_t stream) {
-  constexpr int NW = WavesPerBlock<P>::value;
   GemvArgs args = a;
   args.batches_per_owner = bpo;
-  const size_t shmem = gemv_shmem<BITS, P, KS>(a.K, bpo);
+  const size_t shmem = gemv_shmem<BITS, P, KS, NW>(a.K, bpo);
   const int batches_per_block = (KS == 1 ? NW : NW / 4) * bpo;
   const int blocks = (nbatches + batches_per_block - 1) / batches_per_block;
   dim3 grid(blocks, M), block(NW * 64);
-  if (bf16) hipLaunchKernelGGL((gemv_kernel<BITS, P, KS, D, true, SPLIT>), grid, block, shmem, stream, args);
-  else hipLaunchKernelGGL((gemv_kernel<BITS, P, KS, D, false, SPLIT>), grid, block, shmem, stream, args);
+  if (bf16) hipLaunchKernelGGL((gemv_kernel<BITS, P, KS, D, true, SPLIT, NW>), grid, block, shmem, stream, args);
+  else hipLaunchKernelGGL((gemv_kernel<BITS, P, KS, D, false, SPLIT, NW>), grid, block, shmem, stream, args);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess && a.bias) {
     const size_t total = static_cast<size_t>(M) * a.N;
@@ -592,19 +589,26 @@ static hipError_t launch_gemv_d(const GemvArgs& a, int M, bool bf16, int bpo, in
 
 // One round of co-resident workgroups covers all rows: pick the shallowest ring whose resident owners can hold the
 // batches, else split the batches evenly over the resident owners of the deepest ring (multiples of D per owner).
-template <int BITS, int P, int KS, bool SPLIT>
-static hipError_t launch_gemv_p(const GemvArgs& a, int M, bool bf16, hipStream_t stream) {
-  constexpr int NW = WavesPerBlock<P>::value;
-  const int rowstep = a.swiglu ? 1 : GEMV_R;
-  const int nbatches = (a.N + rowstep - 1) / rowstep;
+template <int BITS, int P, int KS, bool SPLIT, int NW>
+static hipError_t launch_gemv_nw(const GemvArgs& a, int M, bool bf16, int nbatches, hipStream_t stream) {
   const int opb = (KS == 1) ? NW : NW / 4;                 // row owners per workgroup
-  const int own1 = resident_blocks<BITS, P, KS, 1, SPLIT>(bf16, gemv_shmem<BITS, P, KS>(a.K, 1)) * opb;
-  if (nbatches <= own1) return launch_gemv_d<BITS, P, KS, 1, SPLIT>(a, M, bf16, 1, nbatches, stream);
-  const int own2 = resident_blocks<BITS, P, KS, 2, SPLIT>(bf16, gemv_shmem<BITS, P, KS>(a.K, 2)) * opb;
+  const int own1 = resident_blocks<BITS, P, KS, 1, SPLIT, NW>(bf16, gemv_shmem<BITS, P, KS, NW>(a.K, 1)) * opb;
+  if (nbatches <= own1) return launch_gemv_d<BITS, P, KS, 1, SPLIT, NW>(a, M, bf16, 1, nbatches, stream);
+  const int own2 = resident_blocks<BITS, P, KS, 2, SPLIT, NW>(bf16, gemv_shmem<BITS, P, KS, NW>(a.K, 2)) * opb;
   int bpo = (nbatches + own2 - 1) / own2;
   bpo = ((bpo + 1) / 2) * 2;
   if (KS == 4 && bpo > GEMV_MAX_BATCHES_PER_GROUP_KS4) bpo = GEMV_MAX_BATCHES_PER_GROUP_KS4;
-  return launch_gemv_d<BITS, P, KS, 2, SPLIT>(a, M, bf16, bpo, nbatches, stream);
+  return launch_gemv_d<BITS, P, KS, 2, SPLIT, NW>(a, M, bf16, bpo, nbatches, stream);
+}
+
+// Geometry: small matrices (a few rows per wave) launch as 4-wave workgroups (fast launch ramp, the duplicated
+// activation prologue is cheap in absolute terms); large ones as fat workgroups (prologue amortised 16x).
+template <int BITS, int P, int KS, bool SPLIT>
+static hipError_t launch_gemv_p(const GemvArgs& a, int M, bool bf16, hipStream_t stream) {
+  const int rowstep = a.swiglu ? 1 : GEMV_R;
+  const int nbatches = (a.N + rowstep - 1) / rowstep;
+  if (KS == 1 && nbatches <= 4096) return launch_gemv_nw<BITS, P, KS, SPLIT, 4>(a, M, bf16, nbatches, stream);
+  return launch_gemv_nw<BITS, P, KS, SPLIT, WavesPerBlock<P>::value>(a, M, bf16, nbatches, stream);
 }
 
 // max K the lane-resident fast path covers for a bit width (beyond -> generic kernel)
