@@ -99,10 +99,8 @@ class DecodeRunner:
 
 
 def fused_eligible(model) -> bool:
-    """The fused HIP decode block needs: no TP, no biases, q/k/v (and gate/up) packed alike, head_dim 64/128,
-    full-width RoPE, 16-bit activations and every K a multiple of 128."""
-    if getattr(model, "tp_world", 1) != 1:
-        return False
+    """The fused HIP decode block needs: no biases, q/k/v (and gate/up) packed alike, head_dim 64/128, full-width RoPE,
+    16-bit activations and every (per-rank) K a multiple of 128.  Tensor-parallel shards qualify too."""
     dt = model.model.embed_tokens.weight.dtype
     if dt not in (torch.bfloat16, torch.float16):
         return False
@@ -139,6 +137,8 @@ class FusedDecodeRunner(DecodeRunner):
         mk = lambda n: torch.zeros((n,), dtype=dt, device=dev)
         self.hb, self.qb, self.kb, self.vb = mk(D), mk(a0.n_heads * a0.head_dim), mk(a0.n_kv_heads * a0.head_dim), mk(a0.n_kv_heads * a0.head_dim)
         self.ab, self.actb = mk(a0.n_heads * a0.head_dim), mk(I)
+        self.pb = mk(D)                    # TP: this rank's partial o_proj / down_proj output before the all-reduce
+        tp = getattr(model, "tp_world", 1) > 1
         self.logits_buf = torch.zeros((1, model.head_weight().shape[0]), dtype=dt, device=dev)
         self.descs = []
         for blk in model.model.layers:
@@ -147,10 +147,12 @@ class FusedDecodeRunner(DecodeRunner):
             self.descs.append((
                 ops.make_fused_desc(self.hb, (at.q_proj, at.k_proj, at.v_proj), (self.qb, self.kb, self.vb),
                                     norm_weight=blk.input_layernorm.weight, eps=eps),
+                ops.make_fused_desc(self.ab, (at.o_proj,), (self.pb,)) if tp else
                 ops.make_fused_desc(self.ab, (at.o_proj,), (self.hb,), residual=self.hb),
                 ops.make_fused_desc(self.hb, (mlp.gate_proj, mlp.up_proj), (self.actb,),
                                     norm_weight=blk.post_attention_layernorm.weight, eps=blk.post_attention_layernorm.eps,
                                     swiglu=True),
+                ops.make_fused_desc(self.actb, (mlp.down_proj,), (self.pb,)) if tp else
                 ops.make_fused_desc(self.actb, (mlp.down_proj,), (self.hb,), residual=self.hb),
             ))
         super().__init__(model, caches, use_graph=use_graph)
@@ -166,8 +168,14 @@ class FusedDecodeRunner(DecodeRunner):
                             at.n_heads, at.n_kv_heads, at.head_dim, c.capacity, getattr(at.rope, "scale", 1.0), at.scale,
                             at.rope.traditional)
             ops.qlinear_fused(d_o, dev)
+            if self.tp_world > 1:            # K-split layer: partial sums meet over RCCL, then join the residual stream
+                all_reduce_(self.pb, at.tp_group)
+                self.hb.add_(self.pb)
             ops.qlinear_fused(d_gu, dev)
             ops.qlinear_fused(d_dn, dev)
+            if self.tp_world > 1:
+                all_reduce_(self.pb, blk.mlp.tp_group)
+                self.hb.add_(self.pb)
         ops.dense_gemv(self.hb, self.model.head_weight(), out=self.logits_buf.view(-1), norm_weight=m.norm.weight, eps=m.norm.eps)
         return self.logits_buf
 
