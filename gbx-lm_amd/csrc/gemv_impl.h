@@ -230,7 +230,12 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
   const int rowstep = swiglu ? 1 : R;             // output rows covered by one batch
   const int bpo = a.batches_per_owner;
   const int kq = wave & 3, rg = wave >> 2;        // KS == 4: K-quarter of this wave, row group inside the workgroup
-  const int batch_begin = (KS == 1 ? (blockIdx.x * NW + wave) : (blockIdx.x * GPB + rg)) * bpo;
+  // Owner o takes batches o, o + owners, o + 2*owners, ...: at any moment the whole chip streams ONE contiguous
+  // region of the matrix (all HBM channels busy), instead of 4096 regions a fixed stride apart (channel hot spots
+  // and a multi-microsecond straggler tail).
+  const int owner = KS == 1 ? (blockIdx.x * NW + wave) : (blockIdx.x * GPB + rg);
+  const int owners = static_cast<int>(gridDim.x) * (KS == 1 ? NW : GPB);
+  auto batch_of = [&](int j) { return owner + j * owners; };
   const int slot0 = (KS == 1 ? 0 : kq * 64) + lane;        // this lane's slot in pass 0
   constexpr int PSTRIDE = 64 * KS;                          // slot stride between passes
   const int n0 = a.seg[0].N, n01 = n0 + a.seg[1].N;
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
   // row loads here would hold the wave (TA back-pressure) for microseconds before it could even start converting x --
   // the whole chip would then stream first and compute afterwards instead of overlapping the two.
   RowBatch<BITS, P> ring[D];
-  issue(ring[0], batch_begin * rowstep);
+  issue(ring[0], batch_of(0) * rowstep);
 
   GBX_STAMP(1);
   // ---------------- 3a. optional fused RMSNorm: block-wide mean of squares ---------------------------------------
@@ -451,7 +456,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
   };
 
   // ---------------- 6. stream the rows: consume ring slot d, refill it D batches ahead ----------------------------
-  auto consume = [&](const RowBatch<BITS, P>& cur, int b) {
+  auto consume = [&](const RowBatch<BITS, P>& cur, int j) {
+    const int b = batch_of(j);
     float acc[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) {
@@ -482,22 +488,22 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
       if (lane == 0) finish(b * rowstep, t0, t1, cur.res[0], cur.res[1]);
     } else {
       if (lane == 0) {
-        float* pp = part_lds + static_cast<size_t>(rg * bpo + (b - batch_begin)) * (R * 4) + kq;
+        float* pp = part_lds + static_cast<size_t>(rg * bpo + j) * (R * 4) + kq;
         pp[0] = t0;
         pp[4] = t1;
       }
     }
   };
 #pragma unroll
-  for (int d = 1; d < D; ++d) issue(ring[d], (batch_begin + d) * rowstep);
+  for (int d = 1; d < D; ++d) issue(ring[d], batch_of(d) * rowstep);
   GBX_STAMP(3);
   const int steps = bpo / D;
-  int base = batch_begin;
+  int base = 0;
   for (int st = 1; st < steps; ++st) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       consume(ring[d], base + d);
-      issue(ring[d], (base + D + d) * rowstep);
+      issue(ring[d], batch_of(base + D + d) * rowstep);
     }
     base += D;
   }
@@ -514,7 +520,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
     for (int bl = tid; bl < GPB * bpo; bl += NT) {
       const float4 p0 = *reinterpret_cast<const float4*>(part_lds + static_cast<size_t>(bl) * (R * 4));
       const float4 p1 = *reinterpret_cast<const float4*>(part_lds + static_cast<size_t>(bl) * (R * 4) + 4);
-      const int r0 = ((blockIdx.x * GPB + bl / bpo) * bpo + bl % bpo) * rowstep;
+      const int r0 = ((blockIdx.x * GPB + bl / bpo) + (bl % bpo) * owners) * rowstep;
       unsigned short res0 = 0, res1 = 0;
       if (a.residual && !swiglu) {
         if (r0 < N) res0 = a.residual[static_cast<size_t>(m) * n0 + r0];
