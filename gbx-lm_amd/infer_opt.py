@@ -1,0 +1,104 @@
+"""EMINF (entropy minimisation at inference) decode loop: second caller of the batch-1 QuantizedLinear path.
+
+Host-side counterpart of gbx_lm/infer_opt.py: ``eminf_optimize`` (:30-77, the logits-only normalised-gradient
+descent on entropy) and ``eminf_generate`` (:79-142, prefill, then per token: optimise logits, sample with numpy,
+single-token model call).  The logits-side math is a few [vocab] vector ops in fp32 torch; every model call goes through
+the same HIP kernels as ``generate`` (single-token steps use ``model.decode_step``).  The prompt-prefix cache of the
+reference (gbx_lm/prompt_cache.py) is outside the hot path: ``prompt_cache`` must be None.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from .models.cache import make_prompt_cache
+from .tokenizer_utils import TokenizerWrapper
+
+
+def _entropy(x: torch.Tensor) -> torch.Tensor:
+    probs = torch.softmax(x, dim=-1)
+    return -torch.sum(probs * torch.log(probs + 1e-10))
+
+
+def _step_allocation(h_init: float, h_target: float, min_step: int = 3, max_step: int = 15) -> int:
+    r = max(0.0, h_init - h_target) / h_target
+    s = r / (1.0 + r)
+    return int(min_step + max_step * s)
+
+
+def eminf_optimize(logits: torch.Tensor, alpha: float = 0.65, num_steps: Optional[int] = None, threshold: float = 0.05):
+    """infer_opt.py:30-77.  Returns (best_logits fp32, best_entropy 0-d tensor)."""
+    current_logits = logits.to(torch.float32)
+    initial_alpha = alpha
+    initial_entropy = _entropy(current_logits)
+    best_entropy = initial_entropy
+    best_logits = current_logits
+    target_entropy = max(threshold, 0.1 * float(initial_entropy))
+    if num_steps is None:
+        num_steps = _step_allocation(float(initial_entropy), threshold)
+    for _ in range(num_steps):
+        current_entropy = _entropy(current_logits)
+        if float(current_entropy) < target_entropy:
+            break
+        current_logp = torch.log_softmax(current_logits, dim=-1)
+        current_p = torch.exp(current_logp)
+        gradient = current_p * (torch.sum(current_p * (current_logp + 1.0)) - (current_logp + 1.0))
+        gradient_norm = torch.sqrt(torch.sum(gradient ** 2))
+        if float(gradient_norm) > 0:
+            gradient = gradient / gradient_norm
+            new_logits = current_logits - initial_alpha * gradient
+            new_entropy = _entropy(new_logits)
+            if float(new_entropy) < float(current_entropy):
+                current_logits = new_logits
+                if float(new_entropy) < float(best_entropy):
+                    best_logits = new_logits
+                    best_entropy = new_entropy
+            else:
+                initial_alpha *= 0.65
+                if initial_alpha < 1e-4:
+                    break
+        else:
+            break
+    return best_logits, best_entropy
+
+
+@torch.no_grad()
+def eminf_generate(model, tokenizer, input_ids: List[int], input_ids_no_gen: Optional[List[int]] = None,
+                   max_tokens: int = 256, num_steps: Optional[int] = None, alpha: float = 0.65, threshold: float = 0.05,
+                   max_kv_size=None, prompt_cache=None, use_cache: bool = True, rng: Optional[np.random.Generator] = None,
+                   verbose: bool = False) -> List[int]:
+    """infer_opt.py:79-142.  ``rng`` (numpy Generator) makes the sampling step reproducible; the reference draws from
+    the global numpy RNG (``np.random.choice``), which is what happens when ``rng`` is None."""
+    if prompt_cache is not None:
+        raise NotImplementedError("the prompt-prefix cache (gbx_lm/prompt_cache.py) is outside the QuantizedLinear hot path")
+    if max_kv_size is not None:
+        raise NotImplementedError("RotatingKVCache (max_kv_size) is outside the QuantizedLinear hot path")
+    dev = next(model.parameters()).device
+    cache = make_prompt_cache(model)
+    generated: List[int] = []
+    out = model(torch.tensor([list(input_ids)], dtype=torch.long, device=dev), cache=cache, hidden_states=False)
+    logits = out[:, -1, :].to(torch.float32)
+    if not isinstance(tokenizer, TokenizerWrapper):
+        tokenizer = TokenizerWrapper(tokenizer)
+    detok = tokenizer.detokenizer
+    detok.reset()
+    fast = getattr(model, "decode_step", None)
+    for _ in range(max_tokens):
+        best_logits, _ = eminf_optimize(logits.reshape(-1), alpha=alpha, num_steps=num_steps, threshold=threshold)
+        probs = torch.softmax(best_logits, dim=-1).double().cpu().numpy().ravel()
+        probs = probs / probs.sum()
+        tok = int(rng.choice(len(probs), p=probs)) if rng is not None else int(np.random.choice(len(probs), p=probs))
+        generated.append(tok)
+        if tok == getattr(tokenizer, "eos_token_id", None) or tok in tokenizer.eos_token_ids:
+            break
+        detok.add_token(tok)
+        seg = detok.last_segment
+        if verbose and seg:
+            print(seg, flush=True, end="")
+        y = torch.tensor([tok], dtype=torch.long, device=dev)
+        nxt = fast(y, cache) if fast is not None else model(y[None], cache=cache)[:, -1, :]
+        logits = nxt.to(torch.float32)
+    detok.finalize()
+    return generated

@@ -212,6 +212,54 @@ def strategy_lookup(name: str, strategy: dict):
 
 
 # --------------------------------------------------------------------------- #
+# EMINF logits optimiser (second caller of the path; pure function)            #
+# --------------------------------------------------------------------------- #
+def eminf_optimize(logits, alpha=0.65, num_steps=None, threshold=0.05):
+    """numpy fp32 restatement of gbx_lm/infer_opt.py:30-77 (same update rule, same stopping tests)."""
+    f32 = np.float32
+
+    def softmax(x):
+        e = np.exp(x - x.max(), dtype=f32)
+        return (e / e.sum(dtype=f32)).astype(f32)
+
+    def entropy(x):
+        p = softmax(x)
+        return f32(-np.sum(p * np.log(p + f32(1e-10), dtype=f32), dtype=f32))
+
+    cur = np.asarray(logits, dtype=f32)
+    a = alpha
+    h0 = entropy(cur)
+    best_h, best = h0, cur
+    target = max(threshold, 0.1 * float(h0))
+    if num_steps is None:
+        r = max(0.0, float(h0) - threshold) / threshold
+        num_steps = int(3 + 15 * (r / (1.0 + r)))
+    for _ in range(num_steps):
+        h = entropy(cur)
+        if float(h) < target:
+            break
+        z = cur - cur.max()
+        logp = (z - np.log(np.sum(np.exp(z, dtype=f32), dtype=f32), dtype=f32)).astype(f32)
+        p = np.exp(logp, dtype=f32)
+        grad = p * (np.sum(p * (logp + f32(1.0)), dtype=f32) - (logp + f32(1.0)))
+        gn = np.sqrt(np.sum(grad * grad, dtype=f32), dtype=f32)
+        if float(gn) > 0:
+            new = (cur - f32(a) * (grad / gn)).astype(f32)
+            hn = entropy(new)
+            if float(hn) < float(h):
+                cur = new
+                if float(hn) < float(best_h):
+                    best, best_h = new, hn
+            else:
+                a *= 0.65
+                if a < 1e-4:
+                    break
+        else:
+            break
+    return best, best_h
+
+
+# --------------------------------------------------------------------------- #
 # synthetic inputs (SURVEY.md 8d)                                              #
 # --------------------------------------------------------------------------- #
 def synth_layer(n: int, k: int, bits: int, group_size: int, seed: int = 0, act_dtype: str = "bf16",

@@ -95,12 +95,23 @@ def tiny_llama_case():
                 gap=(top2[:, 1] - top2[:, 0]).astype(np.float32))
 
 
+def eminf_case():
+    """(v) EMINF: a fixed [512] logits vector -> best_logits, best_entropy (oracle numpy restatement)."""
+    rng = np.random.default_rng(123)
+    logits = (rng.standard_normal(512) * 2.5).astype(np.float32)
+    best, h = O.eminf_optimize(logits)
+    sharp = logits.copy(); sharp[7] += 30.0                         # already below the entropy target: returns input
+    b2, h2 = O.eminf_optimize(sharp)
+    return dict(logits=logits, best=best, entropy=np.float32(h), sharp=sharp, sharp_best=b2, sharp_entropy=np.float32(h2))
+
+
 def main():
     with open(os.path.join(HERE, "known_answer.json"), "w") as f:
         json.dump(known_answer(), f, indent=1)
     np.savez_compressed(os.path.join(HERE, "qlinear_small.npz"), **small_cases())
     np.savez_compressed(os.path.join(HERE, "double_quant.npz"), **double_quant_case())
     np.savez_compressed(os.path.join(HERE, "tiny_llama.npz"), **tiny_llama_case())
+    np.savez_compressed(os.path.join(HERE, "eminf.npz"), **eminf_case())
     print("wrote", sorted(os.listdir(HERE)))
 
 

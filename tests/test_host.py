@@ -148,3 +148,88 @@ def test_generate_loop_semantics(tmp_path, cpu_oracle_op):
     assert rs[-1].finish_reason == "stop" and rs[-1].token == ids[2] and len(rs) == 3
     text = U.generate(model, tok, "hello world", max_tokens=3)
     assert isinstance(text, str)
+
+
+def test_eminf_optimize_matches_oracle(golden_dir, oracle):
+    from gbx_lm_amd.infer_opt import eminf_optimize
+    z = np.load(os.path.join(golden_dir, "eminf.npz"))
+    best, h = eminf_optimize(torch.from_numpy(z["logits"]))
+    np.testing.assert_allclose(best.numpy(), z["best"], rtol=0, atol=2e-4)
+    assert abs(float(h) - float(z["entropy"])) < 2e-4
+    assert float(h) < float(oracle.eminf_optimize(z["logits"], num_steps=0)[1])      # entropy went down
+    b2, h2 = eminf_optimize(torch.from_numpy(z["sharp"]))
+    np.testing.assert_array_equal(b2.numpy(), z["sharp_best"])                        # below target: untouched
+    assert abs(float(h2) - float(z["sharp_entropy"])) < 1e-6
+
+
+def test_eminf_generate_loop(tmp_path, cpu_oracle_op):
+    from gbx_lm_amd.infer_opt import eminf_generate
+    S.write_checkpoint(str(tmp_path), S.TINY, S.make_strategy("S22", 2), seed=3)
+    model, tok = U.load(str(tmp_path))
+    ids = eminf_generate(model, tok, [5, 17, 42], max_tokens=5, rng=np.random.default_rng(0))
+    assert 1 <= len(ids) <= 5 and all(0 <= t < 512 for t in ids)
+    ids2 = eminf_generate(model, tok, [5, 17, 42], max_tokens=5, rng=np.random.default_rng(0))
+    assert ids == ids2                                                                # seeded numpy sampling
+    with pytest.raises(NotImplementedError):
+        eminf_generate(model, tok, [1], max_tokens=1, prompt_cache=object())
+
+
+def test_load_gba_native_conversion_and_double_quant(tmp_path):
+    """GBA-native checkpoints (utils.py:828-838,864-873): qweight/scales/zeros stored transposed, zeros with the
+    GBA sign (w = q*s - z), optionally double-quantised statistics instead of scales/zeros."""
+    from safetensors.torch import save_file
+    strat = S.make_strategy("S40", 2, 64)
+    src = S.write_checkpoint(str(tmp_path / "mlx"), S.TINY, strat, seed=8)
+    ref, _ = U.load_model(tmp_path / "mlx", device="cpu")
+    # --- plain GBA-native layout ---
+    sd = {}
+    for k, v in S.state_dict_for_disk(src).items():
+        if k.endswith("qweight"):
+            sd[k] = v.view(torch.int32).t().contiguous()
+        elif k.endswith("scales"):
+            sd[k] = v.to(torch.float16).t().contiguous()
+        elif k.endswith("zeros"):
+            sd[k] = (-v.to(torch.float32)).to(torch.float16).t().contiguous()
+        else:
+            sd[k] = v
+    nat = tmp_path / "native"
+    os.makedirs(nat)
+    save_file(sd, str(nat / "model.safetensors"))
+    for f in ("config.json", "quant_strategy.json"):
+        open(nat / f, "w").write(open(tmp_path / "mlx" / f).read())
+    conv, _ = U.load_model(nat, device="cpu", is_conversion=True)
+    a, b = S.state_dict_for_disk(ref), S.state_dict_for_disk(conv)
+    for k in a:
+        if k.endswith("qweight"):
+            assert torch.equal(a[k].view(torch.int32), b[k].view(torch.int32)), k
+        elif k.endswith(("scales", "zeros")):
+            # fp16 round trip of bf16 values is exact for these magnitudes; sign restored by post_processing_and_release
+            assert torch.allclose(a[k].float(), b[k].float(), rtol=1e-2, atol=1e-6), k
+            assert (torch.sign(a[k].float()) == torch.sign(b[k].float())).all(), k
+    # --- double-quantised statistics: scales/zeros replaced by qstatistic + 4 side tensors ---
+    q = ref.model.layers[0].mlp.gate_proj
+    K, N, g = q.input_dims, q.output_dims, q.group_size
+    kg, ng = K // g, N // 32
+    gen = torch.Generator().manual_seed(0)
+    dq = {k: v for k, v in sd.items() if not (k.endswith("scales") or k.endswith("zeros"))}
+    for name, m in ref.named_modules():
+        if isinstance(m, QuantizedLinear):
+            kgm, ngm = m.input_dims // m.group_size, -(-m.output_dims // 32)
+            dq[name + ".qstatistic"] = torch.randint(0, 256, (kgm, ngm, 32), dtype=torch.uint8, generator=gen)
+            dq[name + ".qzeros_zeros"] = torch.full((kgm, ngm, 1), 7.5, dtype=torch.float16)
+            dq[name + ".qzeros_scales"] = torch.full((kgm, ngm, 1), 0.01, dtype=torch.float16)
+            dq[name + ".qscales_zeros"] = torch.full((kgm, ngm, 1), -1.0, dtype=torch.float16)
+            dq[name + ".qscales_scales"] = torch.full((kgm, ngm, 1), 0.002, dtype=torch.float16)
+    dqd = tmp_path / "dq"
+    os.makedirs(dqd)
+    save_file(dq, str(dqd / "model.safetensors"))
+    for f in ("config.json", "quant_strategy.json"):
+        open(dqd / f, "w").write(open(tmp_path / "mlx" / f).read())
+    m2, _ = U.load_model(dqd, device="cpu", is_conversion=True)
+    g2 = m2.model.layers[0].mlp.gate_proj
+    assert g2.qstatistic is None and g2.scales.shape == (N, kg) and g2.zeros.shape == (N, kg)
+    st = dq["model.layers.0.mlp.gate_proj.qstatistic"]
+    want_s = ((((st & 0xF0) >> 4).to(torch.float16) + 1.0) * 0.002).view(kg, N).t()
+    want_z = -(((st & 0x0F).to(torch.float16) - 7.5) * 0.01).view(kg, N).t()          # negated by set_bias_and_weight
+    assert torch.allclose(g2.scales.float(), want_s.float(), rtol=1e-2, atol=1e-6)
+    assert torch.allclose(g2.zeros.float(), want_z.float(), rtol=1e-2, atol=1e-6)
