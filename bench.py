@@ -92,8 +92,15 @@ def kernel_leg(model, reps=20):
     us = e0.elapsed_time(e1) * 1e3 / (reps * len(mods))
     nbytes = qlinear_bytes(m0)
     achieved = nbytes / us / 1e3
+    traffic = None            # PMC-derived HBM bytes per launch for this exact kernel/shape, if a profile run recorded it
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            rec = json.load(f).get(f"b{bits}_N{m0.output_dims}_K{m0.input_dims}_g{m0.group_size}")
+            traffic = rec["traffic_bytes_per_launch"] if rec else None
+    except (OSError, ValueError, KeyError):
+        traffic = None
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
             "kernel": f"gbx::gemv_kernel<{bits},...> gate/up_proj N={m0.output_dims} K={m0.input_dims} g={m0.group_size}",
             "bytes_per_launch": nbytes, "us_per_launch": us, "launches_timed": reps * len(mods),
             "working_set_bytes": nbytes * len(mods)}
