@@ -172,12 +172,11 @@ def main():
     for t in range(args.context):
         runner.step(torch.tensor([t % vocab], device=dev))
     tok = torch.argmax(runner.logits, -1)
+    runner.start_greedy(tok)                                        # greedy chain: argmax + next-token feed stay on the device
 
     def decode(n):
-        nonlocal tok
         for _ in range(n):
-            logits = runner.step(tok)
-            tok = torch.argmax(logits, -1)                          # greedy, stays on device
+            runner.step_greedy()
 
     decode(args.warmup)
     if world > 1:

@@ -71,6 +71,8 @@ def _declare_optional(L) -> None:
     L.gbx_attn_decode.argtypes = [p, p, p, p, p, p, p, p, i32, i32, i32, i32, f32, f32, i32, i32, p]
     L.gbx_dense_gemv.argtypes = [p, p, p, p, f32, i32, i32, i32, p]
     L.gbx_rmsnorm.argtypes = [p, p, p, i64, i32, f32, i32, p]
+    L.gbx_dense_gemv_argmax.argtypes = [p, p, p, p, f32, i32, i32, p, i32, p]
+    L.gbx_embed_next_token.argtypes = [p, p, p, p, p, i32, i32, i32, i32, i32, p]
 
 
 def check(rc: int) -> None:

@@ -191,7 +191,18 @@ struct DenseArgs {
   const unsigned short* norm_w;  // [K] or null
   float eps;
   int N, K, rows_per_wave;
+  unsigned long long* best;      // optional [GBX_ARGMAX_SLOTS] packed (value, index) maxima: fused greedy argmax
 };
+
+// Greedy sampling fused into the head: every workgroup folds its rows' rounded logits into one of 64 sharded 64-bit
+// keys (orderable value bits << 32 | ~index, so the LOWEST index wins ties like argmax does); the next token's embed
+// kernel reduces the 64 keys.  No separate 128K-wide reduction launch, no host round trip.
+constexpr int GBX_ARGMAX_SLOTS = 64;
+__device__ __forceinline__ unsigned long long argmax_key(float v, int idx) {
+  unsigned u = __float_as_uint(v);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return (static_cast<unsigned long long>(u) << 32) | static_cast<unsigned long long>(0xFFFFFFFFu - static_cast<unsigned>(idx));
+}
 
 template <bool BF16>
 __device__ __forceinline__ float dot2_act(unsigned wbits, unsigned xbits, float acc) {
@@ -271,6 +282,7 @@ __global__ __launch_bounds__(256) void dense_gemv_kernel(const DenseArgs a) {
   for (int p = 0; p < P; ++p)      // chunks past the end of the row contribute nothing
     if (p * 64 + lane >= nchunks) xv[p] = u32x4{0, 0, 0, 0};
 
+  unsigned long long wbest = 0;
   auto consume = [&](const u32x4 (&buf)[P], int row) {
     float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
@@ -281,7 +293,12 @@ __global__ __launch_bounds__(256) void dense_gemv_kernel(const DenseArgs a) {
       acc1 = dot2_act<BF16>(buf[p].w, xv[p].w, acc1);
     }
     const float tot = wave_sum(acc0 + acc1);
-    if (lane == 0 && row < N) a.y[row] = f32_to_act<BF16>(tot);
+    if (lane == 0 && row < N) {
+      const unsigned short o = f32_to_act<BF16>(tot);
+      a.y[row] = o;
+      const unsigned long long key = argmax_key(act_to_f32<BF16>(o), row);
+      wbest = key > wbest ? key : wbest;
+    }
   };
   const int steps = rpw / D;
   int base = row_begin;
@@ -295,12 +312,68 @@ __global__ __launch_bounds__(256) void dense_gemv_kernel(const DenseArgs a) {
   }
 #pragma unroll
   for (int d = 0; d < D; ++d) consume(ring[d], base + d);
+  if (a.best) {                                  // one atomic per workgroup, spread over the sharded slots
+    __shared__ unsigned long long bw[4];
+    if (lane == 0) bw[wave] = wbest;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long b = bw[0];
+#pragma unroll
+      for (int i = 1; i < 4; ++i) b = bw[i] > b ? bw[i] : b;
+      atomicMax(a.best + (blockIdx.x % GBX_ARGMAX_SLOTS), b);
+    }
+  }
 }
 
-hipError_t launch_dense_gemv(const void* x, const void* w, void* y, const void* norm_w, float eps, int N, int K, bool bf16,
-                             hipStream_t s) {
+// Start of a decode step on the device: reduce the previous step's argmax keys to the next token id, publish it,
+// advance the position, clear the keys, and copy that token's embedding row into the residual stream
+// (embed_tokens lookup, gbx_lm/models/qllama.py:164).  `mode` 0: token comes from *tok_io (teacher forcing / sampled on
+// host), 1: token comes from the keys (greedy chain, no host involvement).
+template <bool BF16>
+__global__ __launch_bounds__(256) void embed_next_kernel(unsigned long long* best, long long* tok_io, long long* pos,
+                                                         const unsigned short* __restrict__ table, unsigned short* __restrict__ h,
+                                                         int D, int vocab, int mode, int advance) {
+  __shared__ long long tok_s;
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    unsigned long long k = best[tid];
+    // 64-lane max of a 64-bit key via two 32-bit stages (hi word, then lo word among the winners)
+    const unsigned hi = static_cast<unsigned>(k >> 32);
+    const unsigned mhi = wave_max_u32(hi);
+    const unsigned lo = (hi == mhi) ? static_cast<unsigned>(k & 0xFFFFFFFFu) : 0u;
+    const unsigned mlo = wave_max_u32(lo);
+    if (tid == 0) {
+      long long t = (mode == 1) ? static_cast<long long>(0xFFFFFFFFu - mlo) : *tok_io;
+      t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
+      tok_s = t;
+      *tok_io = t;
+      if (advance) *pos = *pos + 1;
+    }
+    best[tid] = 0ull;
+  }
+  __syncthreads();
+  const long long t = tok_s;
+  const u32x4* src = reinterpret_cast<const u32x4*>(table + static_cast<size_t>(t) * D);
+  u32x4* dst = reinterpret_cast<u32x4*>(h);
+  for (int i = tid; i < D / 8; i += 256) dst[i] = src[i];
+}
+
+hipError_t launch_embed_next(void* best, void* tok_io, void* pos, const void* table, void* h, int D, int vocab, int mode,
+                             int advance, bool bf16, hipStream_t s) {
+  auto B = static_cast<unsigned long long*>(best);
+  auto T = static_cast<long long*>(tok_io);
+  auto P = static_cast<long long*>(pos);
+  auto E = static_cast<const unsigned short*>(table);
+  auto H = static_cast<unsigned short*>(h);
+  if (bf16) hipLaunchKernelGGL((embed_next_kernel<true>), dim3(1), dim3(256), 0, s, B, T, P, E, H, D, vocab, mode, advance);
+  else hipLaunchKernelGGL((embed_next_kernel<false>), dim3(1), dim3(256), 0, s, B, T, P, E, H, D, vocab, mode, advance);
+  return hipGetLastError();
+}
+
+hipError_t launch_dense_gemv(const void* x, const void* w, void* y, const void* norm_w, float eps, int N, int K, void* best,
+                             bool bf16, hipStream_t s) {
   DenseArgs a{static_cast<const unsigned short*>(x), static_cast<const unsigned short*>(w), static_cast<unsigned short*>(y),
-              static_cast<const unsigned short*>(norm_w), eps, N, K, 0};
+              static_cast<const unsigned short*>(norm_w), eps, N, K, 0, static_cast<unsigned long long*>(best)};
   const int owners = 256 * 8 * 4;                       // waves when every workgroup is resident (8 per CU)
   int rpw = (N + owners - 1) / owners;
   rpw = ((rpw + 1) / 2) * 2;

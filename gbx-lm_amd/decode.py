@@ -70,18 +70,30 @@ class DecodeRunner:
         return F.linear(out, self.model.head_weight())[:, -1, :]   # [1, V]
 
     def _capture(self):
+        chain = getattr(self, "chain", False)
+        safe = min(max(self.caches[0].offset, 0), self.capacity - 1)
         torch.cuda.synchronize(self.dev)
         s = torch.cuda.Stream(device=self.dev)
         s.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(s), torch.no_grad():
-            self.pos.fill_(min(max(self.caches[0].offset, 0), self.capacity - 1))
-            for _ in range(2):                                   # warm-up outside capture (lazy inits)
+            for _ in range(2):                                   # warm-up outside capture (lazy inits, RCCL communicators)
+                self.pos.fill_(safe - 1 if chain else safe)      # a chained step advances the position itself
                 self._forward()
         torch.cuda.current_stream(self.dev).wait_stream(s)
         torch.cuda.synchronize(self.dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.logits = self._forward()
+
+    def start_greedy(self, token: torch.Tensor) -> None:
+        """Begin an on-device greedy chain whose first input token is ``token``."""
+        self._next = token.reshape(1).clone()
+
+    def step_greedy(self) -> torch.Tensor:
+        """One greedy token: feeds the previous argmax back in.  Generic version (argmax by torch)."""
+        logits = self.step(self._next)
+        self._next = torch.argmax(logits, -1)
+        return logits
 
     def step(self, token: torch.Tensor) -> torch.Tensor:
         """Consumes one token id (device tensor, shape [1]); returns logits [1, V] (a static buffer)."""
@@ -140,6 +152,9 @@ class FusedDecodeRunner(DecodeRunner):
         self.pb = mk(D)                    # TP: this rank's partial o_proj / down_proj output before the all-reduce
         tp = getattr(model, "tp_world", 1) > 1
         self.logits_buf = torch.zeros((1, model.head_weight().shape[0]), dtype=dt, device=dev)
+        self.keys = torch.zeros((64,), dtype=torch.int64, device=dev)      # sharded (value, index) argmax keys (uint64 bits)
+        self.chain = False                  # True while capturing / replaying the on-device greedy chain
+        self.graph_chain = None
         self.descs = []
         for blk in model.model.layers:
             at, mlp = blk.self_attn, blk.mlp
@@ -160,7 +175,10 @@ class FusedDecodeRunner(DecodeRunner):
     def _forward(self):
         m = self.model.model
         dev = self.dev
-        torch.index_select(m.embed_tokens.weight, 0, self.tok, out=self.hb.view(1, -1))
+        # token -> residual stream on the device (also clears the argmax keys and, in a greedy chain, takes the token
+        # from them and advances the position: no host involvement between tokens)
+        ops.embed_next_token(self.keys, self.tok, self.pos, m.embed_tokens.weight, self.hb, from_keys=self.chain,
+                             advance_pos=self.chain)
         for blk, c, (d_qkv, d_o, d_gu, d_dn) in zip(m.layers, self.caches, self.descs):
             at = blk.self_attn
             ops.qlinear_fused(d_qkv, dev)
@@ -176,7 +194,44 @@ class FusedDecodeRunner(DecodeRunner):
             if self.tp_world > 1:
                 all_reduce_(self.pb, blk.mlp.tp_group)
                 self.hb.add_(self.pb)
-        ops.dense_gemv(self.hb, self.model.head_weight(), out=self.logits_buf.view(-1), norm_weight=m.norm.weight, eps=m.norm.eps)
+        ops.dense_gemv(self.hb, self.model.head_weight(), out=self.logits_buf.view(-1), norm_weight=m.norm.weight,
+                       eps=m.norm.eps, argmax_keys=self.keys)
+        return self.logits_buf
+
+    # ---- on-device greedy chain: replay after replay with nothing in between ------------------------------------
+    def start_greedy(self, token: torch.Tensor) -> None:
+        off = self.caches[0].offset
+        tok = int(token.reshape(-1)[0].item())
+        key = (0x80000000 << 32) | (0xFFFFFFFF - tok)                 # key of (value 0.0, index tok)
+        if key >= 1 << 63:
+            key -= 1 << 64                                            # same bits as a signed int64
+        self.keys.zero_()
+        self.keys[0] = key
+        self.pos.fill_(off - 1)                                       # the embed kernel advances it to `off`
+        if self.use_graph and self.graph_chain is None:
+            self.chain = True
+            saved = (self.graph, self.logits)
+            keys0, pos0 = self.keys.clone(), self.pos.clone()
+            self._capture()                                           # captures _forward with from_keys / advance_pos set
+            self.graph_chain = self.graph
+            self.graph, self.logits = saved
+            self.chain = False
+            for c in self.caches:                                     # warm-up passes of the capture wrote positions >= off only
+                c.offset = off
+            self.keys.copy_(keys0)
+            self.pos.copy_(pos0)
+
+    def step_greedy(self) -> torch.Tensor:
+        off = self.caches[0].offset
+        if self.use_graph:
+            self.graph_chain.replay()
+        else:
+            self.chain = True
+            with torch.no_grad():
+                self._forward()
+            self.chain = False
+        for c in self.caches:
+            c.offset = off + 1
         return self.logits_buf
 
 

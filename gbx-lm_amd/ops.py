@@ -153,17 +153,27 @@ def attn_decode(q, k, v, kcache, vcache, inv_freq, pos, out, n_heads: int, n_kv:
                                           _DT[q.dtype], _stream_ptr(q.device)))
 
 
+def embed_next_token(keys: torch.Tensor, token_io: torch.Tensor, pos: torch.Tensor, table: torch.Tensor, h: torch.Tensor,
+                     from_keys: bool, advance_pos: bool) -> None:
+    """Device-side start of a decode step (see gbx_embed_next_token)."""
+    _lib.check(_lib.lib().gbx_embed_next_token(keys.data_ptr(), token_io.data_ptr(), pos.data_ptr(), table.data_ptr(),
+                                               h.data_ptr(), table.shape[1], table.shape[0], int(from_keys), int(advance_pos),
+                                               _DT[h.dtype], _stream_ptr(h.device)))
+
+
 def dense_gemv(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None,
-               norm_weight: Optional[torch.Tensor] = None, eps: float = 0.0) -> torch.Tensor:
+               norm_weight: Optional[torch.Tensor] = None, eps: float = 0.0,
+               argmax_keys: Optional[torch.Tensor] = None) -> torch.Tensor:
     """logits[N] = W[N,K] @ (x or RMSNorm(x)) for the unquantised head (qllama.py:194-198)."""
     for t, nm in ((x, "x"), (w, "w")):
         _require_cuda(t, nm)
     n, k = w.shape
     if out is None:
         out = torch.empty((n,), dtype=x.dtype, device=x.device)
-    _lib.check(_lib.lib().gbx_dense_gemv(x.data_ptr(), w.data_ptr(), out.data_ptr(),
-                                         norm_weight.data_ptr() if norm_weight is not None else None, float(eps),
-                                         n, k, _DT[x.dtype], _stream_ptr(x.device)))
+    _lib.check(_lib.lib().gbx_dense_gemv_argmax(x.data_ptr(), w.data_ptr(), out.data_ptr(),
+                                                norm_weight.data_ptr() if norm_weight is not None else None, float(eps),
+                                                n, k, argmax_keys.data_ptr() if argmax_keys is not None else None,
+                                                _DT[x.dtype], _stream_ptr(x.device)))
     return out
 
 

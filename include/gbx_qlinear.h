@@ -129,6 +129,22 @@ int gbx_attn_decode(const void* q, const void* k, const void* v, void* kcache, v
 int gbx_dense_gemv(const void* x, const void* w, void* y, const void* norm_weight, float norm_eps,
                    int32_t N, int32_t K, int32_t act_dtype, void* hip_stream);
 
+/* Same, plus greedy sampling fused into the head (the reference's `sampler = argmax(logprobs)`, gbx_lm/utils.py:285,
+ * applied to the rounded logits; logsumexp does not change the argmax): every workgroup folds its rows into one of
+ * GBX_ARGMAX_SLOTS (= 64) 64-bit keys in `argmax_keys` (uint64[64], must be zero before the call; lowest index wins
+ * ties).  gbx_embed_next_token consumes and clears them. */
+#define GBX_ARGMAX_SLOTS 64
+int gbx_dense_gemv_argmax(const void* x, const void* w, void* y, const void* norm_weight, float norm_eps,
+                          int32_t N, int32_t K, void* argmax_keys, int32_t act_dtype, void* hip_stream);
+
+/* Start of the next decode step, entirely on the device: token <- argmax keys (from_keys != 0) or *token_io;
+ * *token_io <- token; keys <- 0; *pos += 1 (advance_pos != 0); h[D] <- embed_table[token, :]
+ * (embed_tokens lookup, gbx_lm/models/qllama.py:164; feeding y back as the next input, gbx_lm/utils.py:325-338).
+ * With from_keys the greedy loop needs no host round trip between tokens. */
+int gbx_embed_next_token(void* argmax_keys, int64_t* token_io, int64_t* pos, const void* embed_table, void* h,
+                         int32_t D, int32_t vocab, int32_t from_keys, int32_t advance_pos, int32_t act_dtype,
+                         void* hip_stream);
+
 /* y[M,K] = RMSNorm(x[M,K]) * w[K] (fp32 statistics, one rounding).  mx.nn.RMSNorm as used at qllama.py:125-128,155. */
 int gbx_rmsnorm(const void* x, const void* w, void* y, int64_t M, int32_t K, float eps, int32_t act_dtype,
                 void* hip_stream);

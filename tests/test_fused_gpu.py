@@ -171,3 +171,57 @@ def test_fused_runner_matches_unfused_and_oracle():
         for name in outs:
             err = (outs[name][i] - ref[i]).abs().max().item()
             assert err < 0.05 * scale + 0.05, f"{name} step {i}: {err} vs scale {scale}"
+
+
+def test_fused_argmax_and_device_greedy_chain():
+    """lm_head with fused argmax keys + embed_next_token: the on-device greedy chain must produce the same tokens as
+    host-driven greedy decoding (argmax by torch, token fed back through step())."""
+    from gbx_lm_amd import ops, synthetic as S
+    from gbx_lm_amd.decode import FusedDecodeRunner
+    from gbx_lm_amd.models.cache import KVCache
+    # 1) keys decode to torch.argmax (lowest index on ties)
+    torch.manual_seed(0)
+    n, k = 5000, 512
+    w = (torch.randn(n, k) * 0.05).to(torch.bfloat16).to(DEV)
+    w[777] = w[123]                                                   # exact tie between two rows
+    x = torch.randn(k).to(torch.bfloat16).to(DEV)
+    keys = torch.zeros(64, dtype=torch.int64, device=DEV)
+    y = ops.dense_gemv(x, w, argmax_keys=keys)
+    h = torch.zeros(k, dtype=torch.bfloat16, device=DEV)
+    tok = torch.zeros(1, dtype=torch.long, device=DEV)
+    pos = torch.tensor([41], dtype=torch.long, device=DEV)
+    table = torch.randn(n, k).to(torch.bfloat16).to(DEV)
+    ops.embed_next_token(keys, tok, pos, table, h, from_keys=True, advance_pos=True)
+    want = int(torch.argmax(y.float()).item())
+    assert int(tok.item()) == want and int(pos.item()) == 42
+    assert torch.equal(h, table[want]) and int(keys.abs().sum().item()) == 0
+    # 2) whole chain on a small model, graph and eager
+    cfg = dict(S.TINY, num_hidden_layers=3, hidden_size=512, intermediate_size=1024, num_attention_heads=4, num_key_value_heads=2)
+    model = S.build_model(cfg, S.make_strategy("S22", 3, 64), device=DEV, seed=5)
+    at = model.model.layers[0].self_attn
+
+    def mk():
+        caches = []
+        for _ in model.model.layers:
+            c = KVCache(step=64)
+            like = torch.empty((1, at.n_kv_heads, 1, at.head_dim), dtype=torch.bfloat16, device=DEV)
+            c.reserve(1, like, like)
+            caches.append(c)
+        return caches
+
+    first = torch.tensor([11], device=DEV)
+    ref_r = FusedDecodeRunner(model, mk(), use_graph=False)
+    t, ref_ids = first, []
+    for _ in range(12):
+        lg = ref_r.step(t)
+        t = torch.argmax(lg, -1)
+        ref_ids.append(int(t.item()))
+    for use_graph in (False, True):
+        r = FusedDecodeRunner(model, mk(), use_graph=use_graph)
+        r.start_greedy(first)
+        ids = []
+        for _ in range(12):
+            lg = r.step_greedy()
+            ids.append(int(torch.argmax(lg, -1).item()))
+        assert ids == ref_ids, (use_graph, ids, ref_ids)
+        assert r.caches[0].offset == 12
