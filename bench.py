@@ -59,23 +59,26 @@ def cpu_baseline(model, cfg, timeout=240.0):
 
 
 def kernel_leg(model, reps=20):
-    """Dominant hot-path kernel timed live with HIP events on the launch stream: the 2-bit gate/up_proj GEMV, cycled
-    over every 2-bit layer's own gate_proj and up_proj weights (>> 256 MiB, so the Infinity Cache cannot serve them)."""
+    """Dominant hot-path kernel timed live with HIP events on the launch stream: the fused
+    [RMSNorm + gate_proj + up_proj + SwiGLU] GEMV launch of the narrowest-bit layers -- exactly the launch the decode
+    graph replays (20 % of a token) -- cycled over every such layer's own weights (>> 256 MiB, so the Infinity Cache
+    cannot serve them).  Algorithmic bytes per launch = both packed matrices + their scales/zeros + x + norm weight + out."""
     from gbx_lm_amd import ops
-    mods = []
-    for blk in model.model.layers:
-        for p in (blk.mlp.gate_proj, blk.mlp.up_proj):
-            mods.append(p)
-    bits = min(m.bits for m in mods)
-    mods = [m for m in mods if m.bits == bits]
-    m0 = mods[0]
-    dev = m0.qweight.device
-    x = torch.randn(1, m0.input_dims, device=dev).to(torch.bfloat16)
-    y = torch.empty(1, m0.output_dims, device=dev, dtype=torch.bfloat16)
+    layers = list(model.model.layers)
+    bits = min(blk.mlp.gate_proj.bits for blk in layers)
+    layers = [blk for blk in layers if blk.mlp.gate_proj.bits == bits and blk.mlp.up_proj.bits == bits]
+    g0 = layers[0].mlp.gate_proj
+    dev = g0.qweight.device
+    dt = g0.scales.dtype
+    x = torch.randn(g0.input_dims, device=dev).to(dt)
+    act = torch.empty(g0.output_dims, device=dev, dtype=dt)
+    descs = [ops.make_fused_desc(x, (blk.mlp.gate_proj, blk.mlp.up_proj), (act,),
+                                 norm_weight=blk.post_attention_layernorm.weight.to(dt), eps=blk.post_attention_layernorm.eps,
+                                 swiglu=True) for blk in layers]
 
     def sweep():
-        for m in mods:
-            ops.quantized_matmul(x, m.qweight, m.scales, m.zeros, group_size=m.group_size, bits=m.bits, out=y)
+        for d in descs:
+            ops.qlinear_fused(d, dev)
 
     sweep()
     g = torch.cuda.CUDAGraph()
@@ -89,21 +92,22 @@ def kernel_leg(model, reps=20):
         g.replay()
     e1.record()
     torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / (reps * len(mods))
-    nbytes = qlinear_bytes(m0)
+    us = e0.elapsed_time(e1) * 1e3 / (reps * len(descs))
+    n, k, grp = g0.output_dims, g0.input_dims, g0.group_size
+    nbytes = 2 * (n * k * bits // 8 + 2 * n * (k // grp) * 2) + k * 2 + k * 2 + n * 2
     achieved = nbytes / us / 1e3
     traffic = None            # PMC-derived HBM bytes per launch for this exact kernel/shape, if a profile run recorded it
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            rec = json.load(f).get(f"b{bits}_N{m0.output_dims}_K{m0.input_dims}_g{m0.group_size}")
+            rec = json.load(f).get(f"gateup_b{bits}_N{n}_K{k}_g{grp}")
             traffic = rec["traffic_bytes_per_launch"] if rec else None
     except (OSError, ValueError, KeyError):
         traffic = None
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-            "kernel": f"gbx::gemv_kernel<{bits},...> gate/up_proj N={m0.output_dims} K={m0.input_dims} g={m0.group_size}",
-            "bytes_per_launch": nbytes, "us_per_launch": us, "launches_timed": reps * len(mods),
-            "working_set_bytes": nbytes * len(mods)}
+            "kernel": f"gbx::gemv_kernel<{bits},...> fused RMSNorm+gate_proj+up_proj+SwiGLU, 2 x [N={n}, K={k}] g={grp}",
+            "bytes_per_launch": nbytes, "us_per_launch": us, "launches_timed": reps * len(descs),
+            "working_set_bytes": nbytes * len(descs)}
 
 
 def main():
