@@ -1,14 +1,19 @@
-"""Llama / Mistral host graph around the 7 QuantizedLinear call sites per block
-(host side of gbx_lm/models/qllama.py:39-209).  Plain torch for the glue (RMSNorm, RoPE, SDPA, KV cache);
-every projection goes through the HIP QuantizedLinear.  The fused batch-1 decode path lives in
-``gbx_lm_amd.decode`` and must agree with this graph.
+"""Llama / Mistral host graph around the seven QuantizedLinear call sites of a decoder block.
+
+PyTorch-ROCm counterpart of gbx_lm/models/qllama.py (Attention :39-96, MLP :99-115, TransformerBlock :118-141,
+LlamaModel :144-174, Model :177-209): same class names, constructor arguments, parameter paths
+(``model.layers.<i>.self_attn.q_proj.qweight`` ...) and call signatures, so checkpoints and callers carry over.
+Glue ops (RMSNorm, RoPE, SDPA, KV cache) are plain torch here; every projection is the HIP QuantizedLinear.
+Single-token steps bypass this eager graph through ``Model.decode_step`` (fused HIP decode block, graph-replayed,
+see ``gbx_lm_amd/decode.py``), which must agree with it numerically -- tests compare the two.
 """
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Any, Dict, Optional, Union
+from typing import Any, Dict, List, Optional, Union
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from .base import BaseModelArgs, create_attention_mask, scaled_dot_product_attention
@@ -18,6 +23,8 @@ from .rope_utils import initialize_rope
 
 @dataclass
 class ModelArgs(BaseModelArgs):
+    """config.json keys consumed by the Llama graph (unknown keys are dropped by ``from_dict``)."""
+    # required
     model_type: str
     hidden_size: int
     num_hidden_layers: int
@@ -25,6 +32,7 @@ class ModelArgs(BaseModelArgs):
     num_attention_heads: int
     rms_norm_eps: float
     vocab_size: int
+    # optional, with the reference's defaults (qllama.py:24-32)
     head_dim: Optional[int] = None
     max_position_embeddings: Optional[int] = None
     num_key_value_heads: Optional[int] = None
@@ -36,121 +44,129 @@ class ModelArgs(BaseModelArgs):
     tie_word_embeddings: bool = True
 
     def __post_init__(self):
-        if self.num_key_value_heads is None:
+        if self.num_key_value_heads is None:        # MHA unless the config says GQA
             self.num_key_value_heads = self.num_attention_heads
 
 
 class RMSNorm(nn.Module):
-    """``mx.nn.RMSNorm``: fp32 statistics, result in x.dtype."""
+    """``mx.nn.RMSNorm``: statistics in fp32, a single rounding back to the activation dtype."""
 
     def __init__(self, dims: int, eps: float = 1e-5):
         super().__init__()
-        self.weight = nn.Parameter(torch.ones(dims), requires_grad=False)
         self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dims), requires_grad=False)
 
-    def forward(self, x):
-        xf = x.to(torch.float32)
-        y = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + self.eps)
-        return (y * self.weight.to(torch.float32)).to(x.dtype)
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x32 = x.float()
+        inv = torch.rsqrt(x32.square().mean(dim=-1, keepdim=True) + self.eps)
+        return (x32 * inv * self.weight.float()).to(x.dtype)
+
+
+def _heads(t: torch.Tensor, n: int) -> torch.Tensor:
+    """[B, L, n*hd] -> [B, n, L, hd]"""
+    b, l, _ = t.shape
+    return t.view(b, l, n, -1).permute(0, 2, 1, 3)
 
 
 class Attention(nn.Module):
+    """GQA self-attention; q/k/v/o are the four attention QuantizedLinear call sites."""
+
     def __init__(self, args: ModelArgs):
         super().__init__()
-        dim = args.hidden_size
-        self.n_heads = n_heads = args.num_attention_heads
-        self.n_kv_heads = n_kv_heads = args.num_key_value_heads
-        self.head_dim = head_dim = args.head_dim or args.hidden_size // n_heads
-        self.scale = head_dim ** -0.5
-        attention_bias = getattr(args, "attention_bias", False)
-        self.q_proj = QuantizedLinear(dim, n_heads * head_dim, bias=attention_bias)
-        self.k_proj = QuantizedLinear(dim, n_kv_heads * head_dim, bias=attention_bias)
-        self.v_proj = QuantizedLinear(dim, n_kv_heads * head_dim, bias=attention_bias)
-        self.o_proj = QuantizedLinear(n_heads * head_dim, dim, bias=attention_bias)
+        hidden = args.hidden_size
+        self.n_heads = args.num_attention_heads
+        self.n_kv_heads = args.num_key_value_heads
+        self.head_dim = args.head_dim or hidden // self.n_heads
+        self.scale = self.head_dim ** -0.5
+        use_bias = bool(getattr(args, "attention_bias", False))
+        q_out, kv_out = self.n_heads * self.head_dim, self.n_kv_heads * self.head_dim
+        self.q_proj = QuantizedLinear(hidden, q_out, bias=use_bias)
+        self.k_proj = QuantizedLinear(hidden, kv_out, bias=use_bias)
+        self.v_proj = QuantizedLinear(hidden, kv_out, bias=use_bias)
+        self.o_proj = QuantizedLinear(q_out, hidden, bias=use_bias)
         self.rope = initialize_rope(self.head_dim, args.rope_theta, args.rope_traditional, args.rope_scaling,
                                     args.max_position_embeddings)
+        self.tp_world, self.tp_group = 1, None      # set by gbx_lm_amd.tp.shard_llama
 
-    def forward(self, x, mask=None, cache=None):
-        B, L, D = x.shape
-        queries, keys, values = self.q_proj(x), self.k_proj(x), self.v_proj(x)
-        queries = queries.reshape(B, L, self.n_heads, -1).transpose(1, 2)
-        keys = keys.reshape(B, L, self.n_kv_heads, -1).transpose(1, 2)
-        values = values.reshape(B, L, self.n_kv_heads, -1).transpose(1, 2)
+    def forward(self, x: torch.Tensor, mask: Optional[torch.Tensor] = None, cache: Optional[Any] = None) -> torch.Tensor:
+        b, l, _ = x.shape
+        q = _heads(self.q_proj(x), self.n_heads)
+        k = _heads(self.k_proj(x), self.n_kv_heads)
+        v = _heads(self.v_proj(x), self.n_kv_heads)
+        start = cache.offset if cache is not None else 0
+        q, k = self.rope(q, offset=start), self.rope(k, offset=start)
         if cache is not None:
-            queries = self.rope(queries, offset=cache.offset)
-            keys = self.rope(keys, offset=cache.offset)
-            keys, values = cache.update_and_fetch(keys, values)
-        else:
-            queries = self.rope(queries)
-            keys = self.rope(keys)
-        output = scaled_dot_product_attention(queries, keys, values, cache=cache, scale=self.scale, mask=mask)
-        output = output.transpose(1, 2).reshape(B, L, -1)
-        out = self.o_proj(output)
-        if getattr(self, "tp_world", 1) > 1:       # K-split layer: partial sums meet here (gbx_lm_amd/tp.py)
+            k, v = cache.update_and_fetch(k, v)
+        ctx = scaled_dot_product_attention(q, k, v, cache=cache, scale=self.scale, mask=mask)
+        out = self.o_proj(ctx.permute(0, 2, 1, 3).reshape(b, l, -1))
+        if self.tp_world > 1:                       # K-split layer: partial sums meet here (gbx_lm_amd/tp.py)
             from ..tp import all_reduce_
             all_reduce_(out, self.tp_group)
         return out
 
 
 class MLP(nn.Module):
+    """SwiGLU feed-forward: gate/up/down are the three MLP QuantizedLinear call sites."""
+
     def __init__(self, args: ModelArgs):
         super().__init__()
-        dim, hidden_dim = args.hidden_size, args.intermediate_size
-        mlp_bias = getattr(args, "mlp_bias", False)
-        self.gate_proj = QuantizedLinear(dim, hidden_dim, bias=mlp_bias)
-        self.down_proj = QuantizedLinear(hidden_dim, dim, bias=mlp_bias)
-        self.up_proj = QuantizedLinear(dim, hidden_dim, bias=mlp_bias)
+        use_bias = bool(getattr(args, "mlp_bias", False))
+        self.gate_proj = QuantizedLinear(args.hidden_size, args.intermediate_size, bias=use_bias)
+        self.down_proj = QuantizedLinear(args.intermediate_size, args.hidden_size, bias=use_bias)
+        self.up_proj = QuantizedLinear(args.hidden_size, args.intermediate_size, bias=use_bias)
+        self.tp_world, self.tp_group = 1, None
 
-    def forward(self, x):
-        out = self.down_proj(nn.functional.silu(self.gate_proj(x)) * self.up_proj(x))
-        if getattr(self, "tp_world", 1) > 1:
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        out = self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
+        if self.tp_world > 1:
             from ..tp import all_reduce_
             all_reduce_(out, self.tp_group)
         return out
 
 
 class TransformerBlock(nn.Module):
+    """Pre-norm residual block: h = x + attn(norm(x)); out = h + mlp(norm(h))."""
+
     def __init__(self, args: ModelArgs):
         super().__init__()
-        self.num_attention_heads = args.num_attention_heads
+        self.args = args
         self.hidden_size = args.hidden_size
+        self.num_attention_heads = args.num_attention_heads
         self.self_attn = Attention(args)
         self.mlp = MLP(args)
         self.input_layernorm = RMSNorm(args.hidden_size, eps=args.rms_norm_eps)
         self.post_attention_layernorm = RMSNorm(args.hidden_size, eps=args.rms_norm_eps)
-        self.args = args
 
-    def forward(self, x, mask=None, cache=None):
-        r = self.self_attn(self.input_layernorm(x), mask, cache)
-        h = x + r
-        r = self.mlp(self.post_attention_layernorm(h))
-        return h + r
+    def forward(self, x: torch.Tensor, mask: Optional[torch.Tensor] = None, cache: Optional[Any] = None) -> torch.Tensor:
+        h = x + self.self_attn(self.input_layernorm(x), mask, cache)
+        return h + self.mlp(self.post_attention_layernorm(h))
 
 
 class LlamaModel(nn.Module):
     def __init__(self, args: ModelArgs):
         super().__init__()
+        assert args.vocab_size > 0
         self.args = args
         self.vocab_size = args.vocab_size
         self.num_hidden_layers = args.num_hidden_layers
-        assert self.vocab_size > 0
         self.embed_tokens = nn.Embedding(args.vocab_size, args.hidden_size)
         self.embed_tokens.weight.requires_grad_(False)
-        self.layers = nn.ModuleList([TransformerBlock(args=args) for _ in range(args.num_hidden_layers)])
+        self.layers = nn.ModuleList(TransformerBlock(args) for _ in range(args.num_hidden_layers))
         self.norm = RMSNorm(args.hidden_size, eps=args.rms_norm_eps)
 
-    def forward(self, inputs, mask=None, cache=None):
+    def forward(self, inputs: torch.Tensor, mask: Optional[torch.Tensor] = None, cache: Optional[List[Any]] = None):
         h = self.embed_tokens(inputs)
         if mask is None:
             mask = create_attention_mask(h, cache)
-        if cache is None:
-            cache = [None] * len(self.layers)
-        for layer, c in zip(self.layers, cache):
-            h = layer(h, mask, cache=c)
+        caches = cache if cache is not None else [None] * len(self.layers)
+        for block, c in zip(self.layers, caches):
+            h = block(h, mask, cache=c)
         return self.norm(h)
 
 
 class Model(nn.Module):
+    """``Model(args)(inputs, mask=None, cache=None, hidden_states=False)`` like the reference (qllama.py:186-199)."""
+
     def __init__(self, args: ModelArgs):
         super().__init__()
         self.args = args
@@ -161,19 +177,21 @@ class Model(nn.Module):
             self.lm_head.weight.requires_grad_(False)
 
     def head_weight(self) -> torch.Tensor:
+        """[vocab, hidden] matrix of the output head (tied: the embedding table, ``embed_tokens.as_linear``)."""
         return self.model.embed_tokens.weight if self.args.tie_word_embeddings else self.lm_head.weight
 
     def forward(self, inputs, mask=None, cache=None, hidden_states: bool = False):
-        out = self.model(inputs, mask, cache)
-        logits = nn.functional.linear(out, self.head_weight())
-        return (logits, out) if hidden_states else logits
+        hidden = self.model(inputs, mask, cache)
+        logits = F.linear(hidden, self.head_weight())
+        return (logits, hidden) if hidden_states else logits
 
-    def decode_step(self, y, prompt_cache):
-        """Single-token fast path (HIP-graph replay); see gbx_lm_amd/decode.py."""
+    def decode_step(self, y: torch.Tensor, prompt_cache) -> torch.Tensor:
+        """Single-token fast path (fused HIP decode block, HIP-graph replay); see gbx_lm_amd/decode.py."""
         from ..decode import decode_step
         return decode_step(self, y, prompt_cache)
 
-    def sanitize(self, weights):
+    def sanitize(self, weights: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """Drop precomputed rotary tables some exporters leave in the checkpoint (qllama.py:201-205)."""
         return {k: v for k, v in weights.items() if "self_attn.rotary_emb.inv_freq" not in k}
 
     @property

@@ -36,3 +36,18 @@ t0 = s[:,0].min(); rel=(s-t0)/100.0
 print(f"{which}: waves={len(s)} span={rel[:,6].max():.2f} us")
 for i,nm in enumerate(["start","x+first batch issued","prologue done","lane x ready","ring issued/loop done","first drain consume","end"]):
     c=rel[:,i]; print(f"  {nm:24s} min {c.min():6.2f} med {np.median(c):6.2f} max {c.max():6.2f}")
+# --- tail analysis: per-workgroup end time vs block id / start time
+nwav = 16
+blk_end = rel[:,6].reshape(-1,nwav).max(1) if len(rel)%nwav==0 else None
+if blk_end is not None:
+    blk_start = rel[:,0].reshape(-1,nwav).min(1)
+    blk_pro = rel[:,2].reshape(-1,nwav).max(1)
+    order = np.argsort(blk_end)
+    print("  per-WG end: min %.2f p25 %.2f med %.2f p75 %.2f p90 %.2f max %.2f" % (blk_end.min(), np.percentile(blk_end,25), np.median(blk_end), np.percentile(blk_end,75), np.percentile(blk_end,90), blk_end.max()))
+    print("  slowest 8 WGs: ids", order[-8:], "start", np.round(blk_start[order[-8:]],2), "prologue", np.round(blk_pro[order[-8:]],2), "end", np.round(blk_end[order[-8:]],2))
+    print("  fastest 8 WGs: ids", order[:8], "start", np.round(blk_start[order[:8]],2), "prologue", np.round(blk_pro[order[:8]],2), "end", np.round(blk_end[order[:8]],2))
+    print("  corr(end, id%8)=", [round(float(blk_end[np.arange(len(blk_end))%8==x].mean()),2) for x in range(8)])
+    # per-wave durations of loop phases
+    for a_,b_,nm in ((3,4,"loop"),(4,6,"drain")):
+        dd = rel[:,b_]-rel[:,a_]
+        print(f"  {nm}: min {dd.min():.2f} med {np.median(dd):.2f} p90 {np.percentile(dd,90):.2f} max {dd.max():.2f}")
