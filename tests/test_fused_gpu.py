@@ -225,3 +225,51 @@ def test_fused_argmax_and_device_greedy_chain():
             ids.append(int(torch.argmax(lg, -1).item()))
         assert ids == ref_ids, (use_graph, ids, ref_ids)
         assert r.caches[0].offset == 12
+
+
+def test_fused_block_fp16_activations(oracle):
+    """The fp16 instantiations of the fused launches (norm, residual, SwiGLU) and of attention / lm_head."""
+    from gbx_lm_amd import ops
+    from gbx_lm_amd.models.quantized_linear_gba import QuantizedLinear
+    from gbx_lm_amd.models.rope_utils import RoPE, apply_rope
+    k, n, bits, g = 1024, 320, 4, 64
+    def mod(seed):
+        d = oracle.synth_layer(n, k, bits, g, seed=seed, act_dtype="f16")
+        m = QuantizedLinear(k, n, False, g, bits)
+        m._buffers["qweight"] = torch.from_numpy(d["qweight"].view(np.int32)).view(torch.uint32).to(DEV)
+        m._buffers["scales"], m._buffers["zeros"] = d["scales"].to(DEV), d["zeros"].to(DEV)
+        return m, d
+    (gate, dg), (up, du) = mod(1), mod(2)
+    x = torch.randn(k).to(torch.float16).to(DEV)
+    nw = (1 + 0.1 * torch.randn(k)).to(torch.float16).to(DEV)
+    act = torch.zeros(n, dtype=torch.float16, device=DEV)
+    ops.qlinear_fused(ops.make_fused_desc(x, (gate, up), (act,), norm_weight=nw, eps=1e-5, swiglu=True), x.device)
+    xn = _rms(x, nw, 1e-5).cpu()
+    g64 = oracle.qlinear_ref(xn[None], dg["qweight"], dg["scales"], dg["zeros"], bits, g, acc=np.float64)
+    u64 = oracle.qlinear_ref(xn[None], du["qweight"], du["scales"], du["zeros"], bits, g, acc=np.float64)
+    oracle.assert_close(act[None], (g64 / (1 + np.exp(-g64))) * u64, "f16", "swiglu f16")
+    h = torch.randn(n).to(torch.float16).to(DEV)
+    h0 = h.clone()
+    xa = torch.randn(k).to(torch.float16).to(DEV)
+    ops.qlinear_fused(ops.make_fused_desc(xa, (gate,), (h,), residual=h), xa.device)
+    y64 = oracle.qlinear_ref(xa.cpu()[None], dg["qweight"], dg["scales"], dg["zeros"], bits, g, acc=np.float64)
+    oracle.assert_close(h[None], h0.cpu().double().numpy()[None] + y64, "f16", "residual f16")
+    # attention + lm_head in fp16
+    hd, nh, nkv, cap, pos = 128, 4, 2, 64, 9
+    q, kk, v = (torch.randn(c * hd).to(torch.float16).to(DEV) for c in (nh, nkv, nkv))
+    kc = torch.randn(1, nkv, cap, hd).to(torch.float16).to(DEV)
+    vc = torch.randn(1, nkv, cap, hd).to(torch.float16).to(DEV)
+    kc0, vc0 = kc.clone(), vc.clone()
+    rope = RoPE(hd).to(DEV)
+    out = torch.zeros(nh * hd, dtype=torch.float16, device=DEV)
+    ops.attn_decode(q, kk, v, kc, vc, rope.inv_freq, torch.tensor([pos], device=DEV), out, nh, nkv, hd, cap, 1.0, hd ** -0.5, False)
+    qr = apply_rope(q.view(1, nh, 1, hd), rope.inv_freq, pos, 1.0, False)
+    kc0[:, :, pos:pos + 1] = apply_rope(kk.view(1, nkv, 1, hd), rope.inv_freq, pos, 1.0, False)
+    vc0[:, :, pos:pos + 1] = v.view(1, nkv, 1, hd)
+    K = kc0[:, :, :pos + 1].repeat_interleave(nh // nkv, 1).float()
+    V = vc0[:, :, :pos + 1].repeat_interleave(nh // nkv, 1).float()
+    want = (torch.softmax((qr.float() @ K.transpose(-1, -2)) * hd ** -0.5, -1) @ V).reshape(-1)
+    assert torch.allclose(out.float(), want, atol=5e-3, rtol=5e-3)
+    w = (torch.randn(777, k) * 0.02).to(torch.float16).to(DEV)
+    y = ops.dense_gemv(x, w, norm_weight=nw, eps=1e-5)
+    assert torch.allclose(y.double(), w.double() @ _rms(x, nw, 1e-5).double(), atol=2e-3, rtol=5e-3)
