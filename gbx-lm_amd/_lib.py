@@ -61,7 +61,8 @@ class FusedDesc(ctypes.Structure):
                 ("qweight", ctypes.c_void_p * 3), ("scales", ctypes.c_void_p * 3), ("zeros", ctypes.c_void_p * 3),
                 ("y", ctypes.c_void_p * 3), ("N", ctypes.c_int32 * 3),
                 ("norm_weight", ctypes.c_void_p), ("norm_eps", ctypes.c_float),
-                ("residual", ctypes.c_void_p), ("swiglu", ctypes.c_int32)]
+                ("residual", ctypes.c_void_p), ("swiglu", ctypes.c_int32),
+                ("sz", ctypes.c_void_p)]
 
 
 def _declare_optional(L) -> None:
@@ -73,6 +74,7 @@ def _declare_optional(L) -> None:
     L.gbx_rmsnorm.argtypes = [p, p, p, i64, i32, f32, i32, p]
     L.gbx_dense_gemv_argmax.argtypes = [p, p, p, p, f32, i32, i32, p, i32, p]
     L.gbx_embed_next_token.argtypes = [p, p, p, p, p, i32, i32, i32, i32, i32, p]
+    L.gbx_pack_scales_zeros.argtypes = [p, p, p, p, p, i32, i32, p]
 
 
 def check(rc: int) -> None:

@@ -122,9 +122,13 @@ int gbx_qlinear_fused_forward(const gbx_qlinear_fused* d, void* hip_stream) {
     return fail(GBX_ERR_UNSUPPORTED, "fused RMSNorm needs K <= %d at %d bits; call gbx_rmsnorm first", 128 * vpl, bits);
   gbx::GemvArgs a{};
   a.x = d->x;
-  for (int i = 0; i < d->nseg; ++i)
+  if (d->sz && !aligned(d->sz, 8)) return fail(GBX_ERR_INVALID, "sz must be 8-byte aligned");
+  for (int i = 0; i < d->nseg; ++i) {
+    if (d->sz && (d->N[i] & 1)) return fail(GBX_ERR_INVALID, "packed scales/zeros need an even row count (segment %d has %d)", i, d->N[i]);
     a.seg[i] = gbx::GemvSeg{d->qweight[i], static_cast<const unsigned short*>(d->scales[i]),
                             static_cast<const unsigned short*>(d->zeros[i]), static_cast<unsigned short*>(d->y[i]), d->N[i]};
+  }
+  a.sz = d->sz;
   for (int i = d->nseg; i < 3; ++i) a.seg[i] = a.seg[0], a.seg[i].N = 0;     /* valid pointers, zero rows */
   a.nseg = d->nseg;
   a.N = d->swiglu ? d->N[0] : ntot;
@@ -146,6 +150,18 @@ int gbx_qlinear_fused_forward(const gbx_qlinear_fused* d, void* hip_stream) {
     default: e = gbx::launch_gemv<4>(a, 1, bf16, stream); break;
   }
   if (e != hipSuccess) return hip_fail(e, "gbx_qlinear_fused_forward launch");
+  return GBX_OK;
+}
+
+int gbx_pack_scales_zeros(const void* scales0, const void* zeros0, const void* scales1, const void* zeros1,
+                          uint32_t* out, int32_t N, int32_t G, void* hip_stream) {
+  if (N < 0 || G <= 0) return fail(GBX_ERR_INVALID, "bad shape N=%d G=%d", N, G);
+  if (N == 0) return GBX_OK;
+  if (!scales0 || !zeros0 || !out) return fail(GBX_ERR_INVALID, "null device pointer");
+  if ((scales1 == nullptr) != (zeros1 == nullptr)) return fail(GBX_ERR_INVALID, "scales1 and zeros1 go together");
+  if (!scales1 && (N & 1)) return fail(GBX_ERR_INVALID, "row-pair packing needs an even N (got %d)", N);
+  hipError_t e = gbx::launch_pack_sz(scales0, zeros0, scales1, zeros1, out, N, G, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_pack_scales_zeros launch");
   return GBX_OK;
 }
 

@@ -46,6 +46,11 @@ struct GemvArgs {
   float eps;
   const unsigned short* residual;  // [N]: y <- residual + bf16(result)                              (qllama.py:138,140)
   int swiglu;                      // seg[0] = gate, seg[1] = up: y0[n] = silu(gate[n]) * up[n]       (qllama.py:115)
+  // optional load-time companion of (scales, zeros) for the whole launch: one dword (scale bits | zero bits << 16) per
+  // (row, group), the two rows of a batch interleaved -- [N/2][K/g][2] over the concatenated rows of the segments
+  // (pairs (2p, 2p+1); every segment has an even N), or [N][K/g][2] = (gate row p, up row p) for a SwiGLU launch --
+  // so a lane fetches both rows' scale and zero with ONE 8-byte load (gbx_pack_scales_zeros)
+  const uint32_t* sz;
 #ifdef GBX_STAMPS
   unsigned long long* stamps;      // diagnostic build only: [workgroup][wave][8] s_memrealtime stamps
 #endif
@@ -178,7 +183,19 @@ struct RowBatch {
   typename SlotWords<BITS>::type w[GEMV_R][P];
   unsigned short s[GEMV_R][P][2], z[GEMV_R][P][2];
   unsigned short res[GEMV_R];
+  unsigned szp[P][2][GEMV_R];   // PK: [pass][sub-slot group][row] packed scale|zero dwords
+  unsigned res2;            // PK: residual of both rows in one dword
 };
+
+// packed (scale | zero << 16) dword -> fp32
+template <bool BF16> __device__ __forceinline__ float sz_scale(unsigned v) {
+  if constexpr (BF16) return __uint_as_float(v << 16);
+  else return act_to_f32<false>(static_cast<unsigned short>(v & 0xFFFFu));
+}
+template <bool BF16> __device__ __forceinline__ float sz_zero(unsigned v) {
+  if constexpr (BF16) return __uint_as_float(v & 0xFFFF0000u);
+  else return act_to_f32<false>(static_cast<unsigned short>(v >> 16));
+}
 
 __device__ __forceinline__ float round_bf16_or_f16(float v, bool bf16) {
   return bf16 ? bf16_to_f32(f32_to_act<true>(v)) : f16_to_f32(f32_to_act<false>(v));
@@ -197,7 +214,8 @@ __device__ __forceinline__ float round_bf16_or_f16(float v, bool bf16) {
 template <int P> struct WavesPerBlock { static constexpr int value = (P == 1) ? 16 : 8; };   // "fat" geometry
 
 // SPLIT (2-bit only): group_size 32, i.e. the two 32-value halves of a lane's slot carry different scales.
-template <int BITS, int P, int KS, int D, bool BF16, bool SPLIT, int NW>
+// PK: scales/zeros come from the packed companion GemvSeg::sz (N of every segment even).
+template <int BITS, int P, int KS, int D, bool BF16, bool SPLIT, int NW, bool PK>
 __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
   constexpr int NT = NW * 64;
   constexpr int GPB = NW / 4;                                 // KS == 4: row groups (of four K-quarter waves) per workgroup
@@ -265,6 +283,38 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
 #else
 #define GBX_STAMP(i) do {} while (0)
 #endif
+  // ---------------- 0. per-lane offsets and the small loads of a batch (scale|zero pairs, residual) ----------------
+  // (Requesting the first batch's small loads AHEAD of the activation loads was measured 0.3-0.4 us slower per launch:
+  // everything queued in front of x delays the prologue.)
+  // Branch-free on purpose: a load in one arm and a register write in the other makes hipcc drain vmcnt at the join
+  // (write-after-pending-load), which serialises the whole stream.  Out-of-range lanes / rows re-read the last valid
+  // slot / row and are nulled through their zero activations or the store guard.
+  const __amdgpu_buffer_rsrc_t resd = rsrc(a.residual ? static_cast<const void*>(a.residual) : static_cast<const void*>(y0));
+  const __amdgpu_buffer_rsrc_t pd = rsrc(PK ? static_cast<const void*>(a.sz) : static_cast<const void*>(y0));
+  int voff_w[P], voff_s[P];                        // per-lane byte offsets inside a row: packed words / scales
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int slot = min(p * PSTRIDE + slot0, nslots - 1);
+    voff_w[p] = slot * (F::SLOT_WORDS * 4);
+    voff_s[p] = ((slot * NSUB) >> gshift) * (PK ? 8 : 2);
+  }
+  auto issue_small = [&](RowBatch<BITS, P>& b, int r0) {     // PK: both rows' (scale|zero) and residual
+    if constexpr (PK) {
+      const int rc = min(r0, N - rowstep);                  // batches past the end re-read the last pair
+      const int poff = (swiglu ? rc : (rc >> 1)) * (G * 8);
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const u32x2 v0 = __builtin_amdgcn_raw_buffer_load_b64(pd, voff_s[p], poff, 0);
+        b.szp[p][0][0] = v0.x; b.szp[p][0][1] = v0.y;
+        if constexpr (SPLIT) {
+          const u32x2 v1 = __builtin_amdgcn_raw_buffer_load_b64(pd, voff_s[p] + 8, poff, 0);
+          b.szp[p][1][0] = v1.x; b.szp[p][1][1] = v1.y;
+        }
+      }
+      b.res2 = __builtin_amdgcn_raw_buffer_load_b32(resd, 0, (m * n0 + min(rc, n0 - 2)) * 2, 0);
+    }
+  };
+  RowBatch<BITS, P> ring[D];
   GBX_STAMP(0);
   // ---------------- 1. activation (and norm weight) loads first: vmcnt retires in order -------------------------
   const int nunits = K / F::UNIT_VALS;
@@ -289,19 +339,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
     }
   }
 
-  // ---------------- 2. the first D batches of packed rows go in flight before any activation math ---------------
-  // Branch-free on purpose: a load in one arm and a register write in the other makes hipcc drain vmcnt at the join
-  // (write-after-pending-load), which serialises the whole stream.  Out-of-range lanes / rows re-read the last valid
-  // slot / row and are nulled through their zero activations or the store guard.
-  const __amdgpu_buffer_rsrc_t resd = rsrc(a.residual ? static_cast<const void*>(a.residual) : static_cast<const void*>(y0));
-  int voff_w[P], voff_s[P];                        // per-lane byte offsets inside a row: packed words / scales
-#pragma unroll
-  for (int p = 0; p < P; ++p) {
-    const int slot = min(p * PSTRIDE + slot0, nslots - 1);
-    voff_w[p] = slot * (F::SLOT_WORDS * 4);
-    voff_s[p] = ((slot * NSUB) >> gshift) * 2;
-  }
-  auto issue = [&](RowBatch<BITS, P>& b, int r0) {
+  // ---------------- 2. the first batch of packed rows goes in flight before any activation math ---------------
+  auto issue_rows = [&](RowBatch<BITS, P>& b, int r0) {
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       int sgi, row;
@@ -315,20 +354,22 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
       for (int p = 0; p < P; ++p) {
         if constexpr (BITS == 3) b.w[i][p] = __builtin_amdgcn_raw_buffer_load_b96(qd, voff_w[p], woff, 2);   // nt
         else b.w[i][p] = __builtin_amdgcn_raw_buffer_load_b128(qd, voff_w[p], woff, 2);
-        b.s[i][p][0] = __builtin_amdgcn_raw_buffer_load_b16(sd, voff_s[p], goff, 0);
-        b.z[i][p][0] = __builtin_amdgcn_raw_buffer_load_b16(zd, voff_s[p], goff, 0);
-        if constexpr (SPLIT) {       // second 32-value half has its own group only when g == 32 (2-bit)
-          b.s[i][p][1] = __builtin_amdgcn_raw_buffer_load_b16(sd, voff_s[p] + 2, goff, 0);
-          b.z[i][p][1] = __builtin_amdgcn_raw_buffer_load_b16(zd, voff_s[p] + 2, goff, 0);
+        if constexpr (!PK) {
+          b.s[i][p][0] = __builtin_amdgcn_raw_buffer_load_b16(sd, voff_s[p], goff, 0);
+          b.z[i][p][0] = __builtin_amdgcn_raw_buffer_load_b16(zd, voff_s[p], goff, 0);
+          if constexpr (SPLIT) {       // second 32-value half has its own group only when g == 32 (2-bit)
+            b.s[i][p][1] = __builtin_amdgcn_raw_buffer_load_b16(sd, voff_s[p] + 2, goff, 0);
+            b.z[i][p][1] = __builtin_amdgcn_raw_buffer_load_b16(zd, voff_s[p] + 2, goff, 0);
+          }
         }
       }
-      b.res[i] = __builtin_amdgcn_raw_buffer_load_b16(resd, 0, (m * n0 + min(row, n0 - 1)) * 2, 0);
+      if constexpr (!PK) b.res[i] = __builtin_amdgcn_raw_buffer_load_b16(resd, 0, (m * n0 + min(row, n0 - 1)) * 2, 0);
     }
   };
   // Only the FIRST batch is requested ahead of the activation prologue: a wave issues in order, and a deep burst of
   // row loads here would hold the wave (TA back-pressure) for microseconds before it could even start converting x --
   // the whole chip would then stream first and compute afterwards instead of overlapping the two.
-  RowBatch<BITS, P> ring[D];
+  auto issue = [&](RowBatch<BITS, P>& b, int r0) { issue_rows(b, r0); issue_small(b, r0); };
   issue(ring[0], batch_of(0) * rowstep);
 
   GBX_STAMP(1);
@@ -466,15 +507,17 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
       for (int p = 0; p < P; ++p) {
         float d[NSUB];
         dot_slot<BITS>(cur.w[i][p], xv[p], d);
+        auto scale_of = [&](int s) { return PK ? sz_scale<BF16>(cur.szp[p][s][i]) : act_to_f32<BF16>(cur.s[i][p][s]); };
+        auto zero_of = [&](int s) { return PK ? sz_zero<BF16>(cur.szp[p][s][i]) : act_to_f32<BF16>(cur.z[i][p][s]); };
         if constexpr (NSUB == 2 && !SPLIT) {     // both halves share one (scale, zero): s*(c0*d0 + c1*d1) + z*(xs0 + xs1)
           const float t = fmaf(cf[p][1], d[1], cf[p][0] * d[0]);
-          acc[i] = fmaf(act_to_f32<BF16>(cur.s[i][p][0]), t, acc[i]);
-          acc[i] = fmaf(act_to_f32<BF16>(cur.z[i][p][0]), xs[p][0] + xs[p][1], acc[i]);
+          acc[i] = fmaf(scale_of(0), t, acc[i]);
+          acc[i] = fmaf(zero_of(0), xs[p][0] + xs[p][1], acc[i]);
         } else {
 #pragma unroll
           for (int s = 0; s < NSUB; ++s) {
-            const float sc = act_to_f32<BF16>(cur.s[i][p][s]) * cf[p][s];
-            const float ze = act_to_f32<BF16>(cur.z[i][p][s]);
+            const float sc = scale_of(s) * cf[p][s];
+            const float ze = zero_of(s);
             acc[i] = fmaf(sc, d[s], acc[i]);
             acc[i] = fmaf(ze, xs[p][s], acc[i]);
           }
@@ -485,7 +528,10 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
     const float t0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tot), 31));
     const float t1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tot), 63));
     if constexpr (KS == 1) {
-      if (lane == 0) finish(b * rowstep, t0, t1, cur.res[0], cur.res[1]);
+      if (lane == 0) {
+        if constexpr (PK) finish(b * rowstep, t0, t1, static_cast<unsigned short>(cur.res2 & 0xFFFFu), static_cast<unsigned short>(cur.res2 >> 16));
+        else finish(b * rowstep, t0, t1, cur.res[0], cur.res[1]);
+      }
     } else {
       if (lane == 0) {
         float* pp = part_lds + static_cast<size_t>(rg * bpo + j) * (R * 4) + kq;
@@ -548,15 +594,15 @@ constexpr int GEMV_MAX_BATCHES_PER_GROUP_KS4 = 256;
 constexpr int GEMV_CUS = 256;                  // MI355X
 
 // Workgroups of this kernel variant that are resident at once on the whole chip (asked once, then cached).
-template <int BITS, int P, int KS, int D, bool SPLIT, int NW>
+template <int BITS, int P, int KS, int D, bool SPLIT, int NW, bool PK>
 static int resident_blocks(bool bf16, size_t shmem) {
   static int cached[2] = {0, 0};
   int& c = cached[bf16 ? 1 : 0];
   if (c == 0) {
     constexpr int NT = NW * 64;
     int per_cu = 0;
-    hipError_t e = bf16 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemv_kernel<BITS, P, KS, D, true, SPLIT, NW>, NT, shmem)
-                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemv_kernel<BITS, P, KS, D, false, SPLIT, NW>, NT, shmem);
+    hipError_t e = bf16 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemv_kernel<BITS, P, KS, D, true, SPLIT, NW, PK>, NT, shmem)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemv_kernel<BITS, P, KS, D, false, SPLIT, NW, PK>, NT, shmem);
     if (e != hipSuccess || per_cu < 1) per_cu = 1;
     if (per_cu * NW > 32) per_cu = 32 / NW;
     c = per_cu * GEMV_CUS;
@@ -571,7 +617,7 @@ static size_t gemv_shmem(int K, int bpo) {
   return b;
 }
 
-template <int BITS, int P, int KS, int D, bool SPLIT, int NW>
+template <int BITS, int P, int KS, int D, bool SPLIT, int NW, bool PK>
 static hipError_t launch_gemv_d(const GemvArgs& a, int M, bool bf16, int bpo, int nbatches, hipStream_t stream) {
   GemvArgs args = a;
   args.batches_per_owner = bpo;
@@ -579,8 +625,8 @@ static hipError_t launch_gemv_d(const GemvArgs& a, int M, bool bf16, int bpo, in
   const int batches_per_block = (KS == 1 ? NW : NW / 4) * bpo;
   const int blocks = (nbatches + batches_per_block - 1) / batches_per_block;
   dim3 grid(blocks, M), block(NW * 64);
-  if (bf16) hipLaunchKernelGGL((gemv_kernel<BITS, P, KS, D, true, SPLIT, NW>), grid, block, shmem, stream, args);
-  else hipLaunchKernelGGL((gemv_kernel<BITS, P, KS, D, false, SPLIT, NW>), grid, block, shmem, stream, args);
+  if (bf16) hipLaunchKernelGGL((gemv_kernel<BITS, P, KS, D, true, SPLIT, NW, PK>), grid, block, shmem, stream, args);
+  else hipLaunchKernelGGL((gemv_kernel<BITS, P, KS, D, false, SPLIT, NW, PK>), grid, block, shmem, stream, args);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess && a.bias) {
     const size_t total = static_cast<size_t>(M) * a.N;
@@ -595,16 +641,16 @@ static hipError_t launch_gemv_d(const GemvArgs& a, int M, bool bf16, int bpo, in
 
 // One round of co-resident workgroups covers all rows: pick the shallowest ring whose resident owners can hold the
 // batches, else split the batches evenly over the resident owners of the deepest ring (multiples of D per owner).
-template <int BITS, int P, int KS, bool SPLIT, int NW>
+template <int BITS, int P, int KS, bool SPLIT, int NW, bool PK>
 static hipError_t launch_gemv_nw(const GemvArgs& a, int M, bool bf16, int nbatches, hipStream_t stream) {
   const int opb = (KS == 1) ? NW : NW / 4;                 // row owners per workgroup
-  const int own1 = resident_blocks<BITS, P, KS, 1, SPLIT, NW>(bf16, gemv_shmem<BITS, P, KS, NW>(a.K, 1)) * opb;
-  if (nbatches <= own1) return launch_gemv_d<BITS, P, KS, 1, SPLIT, NW>(a, M, bf16, 1, nbatches, stream);
-  const int own2 = resident_blocks<BITS, P, KS, 2, SPLIT, NW>(bf16, gemv_shmem<BITS, P, KS, NW>(a.K, 2)) * opb;
+  const int own1 = resident_blocks<BITS, P, KS, 1, SPLIT, NW, PK>(bf16, gemv_shmem<BITS, P, KS, NW>(a.K, 1)) * opb;
+  if (nbatches <= own1) return launch_gemv_d<BITS, P, KS, 1, SPLIT, NW, PK>(a, M, bf16, 1, nbatches, stream);
+  const int own2 = resident_blocks<BITS, P, KS, 2, SPLIT, NW, PK>(bf16, gemv_shmem<BITS, P, KS, NW>(a.K, 2)) * opb;
   int bpo = (nbatches + own2 - 1) / own2;
   bpo = ((bpo + 1) / 2) * 2;
   if (KS == 4 && bpo > GEMV_MAX_BATCHES_PER_GROUP_KS4) bpo = GEMV_MAX_BATCHES_PER_GROUP_KS4;
-  return launch_gemv_d<BITS, P, KS, 2, SPLIT, NW>(a, M, bf16, bpo, nbatches, stream);
+  return launch_gemv_d<BITS, P, KS, 2, SPLIT, NW, PK>(a, M, bf16, bpo, nbatches, stream);
 }
 
 // Geometry: small matrices (a few rows per wave) launch as 4-wave workgroups (fast launch ramp, the duplicated
@@ -613,8 +659,12 @@ template <int BITS, int P, int KS, bool SPLIT>
 static hipError_t launch_gemv_p(const GemvArgs& a, int M, bool bf16, hipStream_t stream) {
   const int rowstep = a.swiglu ? 1 : GEMV_R;
   const int nbatches = (a.N + rowstep - 1) / rowstep;
-  if (KS == 1 && nbatches <= 4096) return launch_gemv_nw<BITS, P, KS, SPLIT, 4>(a, M, bf16, nbatches, stream);
-  return launch_gemv_nw<BITS, P, KS, SPLIT, WavesPerBlock<P>::value>(a, M, bf16, nbatches, stream);
+  if (a.sz) {              // packed scale/zero companion of the launch (decode runner)
+    if (KS == 1 && nbatches <= 4096) return launch_gemv_nw<BITS, P, KS, SPLIT, 4, true>(a, M, bf16, nbatches, stream);
+    return launch_gemv_nw<BITS, P, KS, SPLIT, WavesPerBlock<P>::value, true>(a, M, bf16, nbatches, stream);
+  }
+  if (KS == 1 && nbatches <= 4096) return launch_gemv_nw<BITS, P, KS, SPLIT, 4, false>(a, M, bf16, nbatches, stream);
+  return launch_gemv_nw<BITS, P, KS, SPLIT, WavesPerBlock<P>::value, false>(a, M, bf16, nbatches, stream);
 }
 
 // max K the lane-resident fast path covers for a bit width (beyond -> generic kernel)

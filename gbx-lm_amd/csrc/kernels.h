@@ -26,6 +26,8 @@ hipError_t launch_dense_gemv(const void* x, const void* w, void* y, const void* 
                              bool bf16, hipStream_t s);
 hipError_t launch_embed_next(void* best, void* tok_io, void* pos, const void* table, void* h, int D, int vocab, int mode,
                              int advance, bool bf16, hipStream_t s);
+hipError_t launch_pack_sz(const void* s0, const void* z0, const void* s1, const void* z1, uint32_t* out, int N, int G,
+                          hipStream_t s);
 hipError_t launch_rmsnorm(const void* x, const void* w, void* y, int M, int K, float eps, bool bf16, hipStream_t s);
 
 }  // namespace gbx

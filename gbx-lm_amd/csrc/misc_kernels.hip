@@ -79,6 +79,36 @@ hipError_t launch_dequant(const uint32_t* qw, const void* sc, const void* ze, vo
   return hipGetLastError();
 }
 
+// ---- packed scale|zero companion (load time) ---------------------------------------------------
+// out[p][g][i]: i-th row of pair p; pair = rows (2p, 2p+1) of one tensor, or row p of tensor 0 / tensor 1.
+__global__ __launch_bounds__(256) void pack_sz_kernel(const unsigned short* __restrict__ s0, const unsigned short* __restrict__ z0,
+                                                      const unsigned short* __restrict__ s1, const unsigned short* __restrict__ z1,
+                                                      uint32_t* __restrict__ out, int npairs, int G) {
+  const size_t total = static_cast<size_t>(npairs) * G * 2;
+  for (size_t t = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; t < total;
+       t += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    const int i = static_cast<int>(t & 1);
+    const size_t pg = t >> 1;
+    const int g = static_cast<int>(pg % G);
+    const size_t p = pg / G;
+    const unsigned short* sc = s1 ? (i ? s1 : s0) : s0;
+    const unsigned short* ze = s1 ? (i ? z1 : z0) : z0;
+    const size_t row = s1 ? p : 2 * p + i;
+    out[t] = static_cast<uint32_t>(sc[row * G + g]) | (static_cast<uint32_t>(ze[row * G + g]) << 16);
+  }
+}
+
+hipError_t launch_pack_sz(const void* s0, const void* z0, const void* s1, const void* z1, uint32_t* out, int N, int G,
+                          hipStream_t s) {
+  const int npairs = s1 ? N : N / 2;
+  const size_t total = static_cast<size_t>(npairs) * G * 2;
+  const int blocks = static_cast<int>(std::min<size_t>((total + 255) / 256, 4096));
+  hipLaunchKernelGGL(pack_sz_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const unsigned short*>(s0),
+                     static_cast<const unsigned short*>(z0), static_cast<const unsigned short*>(s1),
+                     static_cast<const unsigned short*>(z1), out, npairs, G);
+  return hipGetLastError();
+}
+
 // ---- shape-generic qlinear (any K % 32 == 0, any M): one wave per (row n, activation row m) ----
 // Lanes stride over 32-value chunks (always a whole number of words); fp32 math throughout.
 template <int BITS, bool BF16>

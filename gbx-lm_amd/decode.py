@@ -156,19 +156,25 @@ class FusedDecodeRunner(DecodeRunner):
         self.chain = False                  # True while capturing / replaying the on-device greedy chain
         self.graph_chain = None
         self.descs = []
+        self.packed = []                    # load-time (scale | zero) companions, kept alive for the descriptors
         for blk in model.model.layers:
             at, mlp = blk.self_attn, blk.mlp
             eps = blk.input_layernorm.eps
+            even = all(m.output_dims % 2 == 0 for m in (at.q_proj, at.k_proj, at.v_proj, at.o_proj, mlp.gate_proj, mlp.down_proj))
+            pk = lambda *mods: torch.cat([ops.pack_scales_zeros(m) for m in mods]) if even else None
+            p_qkv, p_o, p_dn = pk(at.q_proj, at.k_proj, at.v_proj), pk(at.o_proj), pk(mlp.down_proj)
+            p_gu = ops.pack_scales_zeros(mlp.gate_proj, mlp.up_proj) if even else None
+            self.packed.append((p_qkv, p_o, p_gu, p_dn))
             self.descs.append((
                 ops.make_fused_desc(self.hb, (at.q_proj, at.k_proj, at.v_proj), (self.qb, self.kb, self.vb),
-                                    norm_weight=blk.input_layernorm.weight, eps=eps),
-                ops.make_fused_desc(self.ab, (at.o_proj,), (self.pb,)) if tp else
-                ops.make_fused_desc(self.ab, (at.o_proj,), (self.hb,), residual=self.hb),
+                                    norm_weight=blk.input_layernorm.weight, eps=eps, packed=p_qkv),
+                ops.make_fused_desc(self.ab, (at.o_proj,), (self.pb,), packed=p_o) if tp else
+                ops.make_fused_desc(self.ab, (at.o_proj,), (self.hb,), residual=self.hb, packed=p_o),
                 ops.make_fused_desc(self.hb, (mlp.gate_proj, mlp.up_proj), (self.actb,),
                                     norm_weight=blk.post_attention_layernorm.weight, eps=blk.post_attention_layernorm.eps,
-                                    swiglu=True),
-                ops.make_fused_desc(self.actb, (mlp.down_proj,), (self.pb,)) if tp else
-                ops.make_fused_desc(self.actb, (mlp.down_proj,), (self.hb,), residual=self.hb),
+                                    swiglu=True, packed=p_gu),
+                ops.make_fused_desc(self.actb, (mlp.down_proj,), (self.pb,), packed=p_dn) if tp else
+                ops.make_fused_desc(self.actb, (mlp.down_proj,), (self.hb,), residual=self.hb, packed=p_dn),
             ))
         super().__init__(model, caches, use_graph=use_graph)
 

@@ -111,9 +111,28 @@ def dequantize(w: torch.Tensor, scales: torch.Tensor, biases: torch.Tensor, grou
 
 
 # ------------------------------------------------------------------------------------------------ fused decode block
+def pack_scales_zeros(mod, mod2=None) -> torch.Tensor:
+    """Load-time packed companion of ``(scales, zeros)`` for the decode GEMV (gbx_pack_scales_zeros): uint32
+    ``[N/2, G, 2]`` for row pairs of one module, or ``[N, G, 2]`` interleaving ``mod`` / ``mod2`` (gate / up).
+    A q/k/v launch takes ``torch.cat`` of its modules' packs."""
+    n, g = mod.scales.shape
+    for t in (mod.scales, mod.zeros) + ((mod2.scales, mod2.zeros) if mod2 is not None else ()):
+        _require_cuda(t, "scales/zeros")
+        if t.shape != (n, g) or t.dtype != mod.scales.dtype or not t.is_contiguous():
+            raise ValueError("scales/zeros of the packed pair must be contiguous and agree in shape and dtype")
+    out = torch.empty((n if mod2 is not None else n // 2, g, 2), dtype=torch.int32, device=mod.scales.device)
+    _lib.check(_lib.lib().gbx_pack_scales_zeros(mod.scales.data_ptr(), mod.zeros.data_ptr(),
+                                                mod2.scales.data_ptr() if mod2 is not None else None,
+                                                mod2.zeros.data_ptr() if mod2 is not None else None,
+                                                out.data_ptr(), n, g, _stream_ptr(out.device)))
+    return out
+
+
 def make_fused_desc(x: torch.Tensor, mods, ys, norm_weight: Optional[torch.Tensor] = None, eps: float = 0.0,
-                    residual: Optional[torch.Tensor] = None, swiglu: bool = False) -> "_lib.FusedDesc":
+                    residual: Optional[torch.Tensor] = None, swiglu: bool = False, packed=None) -> "_lib.FusedDesc":
     """Descriptor for one launch over 1-3 QuantizedLinear modules sharing ``x`` (q/k/v, gate/up, or a single one).
+    ``packed``: ``pack_scales_zeros`` companion of the launch (per-module packs concatenated in order, or the one
+    gate/up-interleaved tensor with ``swiglu``).
     All tensors must stay alive and in place while the descriptor is used (the decode runner owns static buffers)."""
     m0 = mods[0]
     for m in mods:
@@ -137,6 +156,12 @@ def make_fused_desc(x: torch.Tensor, mods, ys, norm_weight: Optional[torch.Tenso
     d.norm_eps = float(eps)
     d.residual = residual.data_ptr() if residual is not None else None
     d.swiglu = 1 if swiglu else 0
+    if packed is not None:
+        _require_cuda(packed, "packed scales/zeros")
+        rows = sum(m.output_dims for m in mods)
+        if packed.dtype != torch.int32 or packed.numel() != rows * (m0.input_dims // m0.group_size):
+            raise ValueError("packed scales/zeros do not match the launch (int32, one dword per row and group)")
+        d.sz = packed.data_ptr()
     return d
 
 

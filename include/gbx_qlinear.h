@@ -108,9 +108,22 @@ typedef struct gbx_qlinear_fused {
   float norm_eps;
   const void* residual;
   int32_t swiglu;
+  /* optional: packed (scale | zero << 16) companion of the whole launch, built once at load time by
+   * gbx_pack_scales_zeros (segments concatenated in order, every N even; gate/up interleaved for swiglu) --
+   * one 8-byte load per lane and row pair instead of four 2-byte loads. */
+  const uint32_t* sz;
 } gbx_qlinear_fused;
 
 int gbx_qlinear_fused_forward(const gbx_qlinear_fused* desc, void* hip_stream);
+
+/* Load-time companion of the loader's scale/zero cast (gbx_lm/utils.py:841-843): out[p][g][i] = scale bits | zero bits << 16
+ * (16-bit act-dtype patterns, copied verbatim) for the two rows a GEMV batch streams together:
+ *   scales1 == NULL : rows (2p, 2p+1) of (scales0, zeros0), out = uint32[N/2][G][2], N even;
+ *   scales1 != NULL : row p of (scales0, zeros0) and row p of (scales1, zeros1) -- gate_proj / up_proj of a SwiGLU
+ *                     launch --, out = uint32[N][G][2].
+ * G = K / group_size. */
+int gbx_pack_scales_zeros(const void* scales0, const void* zeros0, const void* scales1, const void* zeros1,
+                          uint32_t* out, int32_t N, int32_t G, void* hip_stream);
 
 /* One layer of single-token attention: RoPE on q and k at position *pos, append k, v to the caller's KV cache
  * ([n_kv, capacity, head_dim], the layout of gbx_lm/models/cache.py:222-244 with B = 1), softmax(q k^T * sm_scale) v

@@ -273,3 +273,58 @@ def test_fused_block_fp16_activations(oracle):
     w = (torch.randn(777, k) * 0.02).to(torch.float16).to(DEV)
     y = ops.dense_gemv(x, w, norm_weight=nw, eps=1e-5)
     assert torch.allclose(y.double(), w.double() @ _rms(x, nw, 1e-5).double(), atol=2e-3, rtol=5e-3)
+
+
+@pytest.mark.parametrize("bits,g", [(2, 128), (2, 32), (3, 64), (4, 128)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_packed_scales_zeros_companion(oracle, bits, g, dt):
+    """gbx_pack_scales_zeros copies the 16-bit patterns verbatim, and a launch that reads the packed companion is
+    bit-identical to the one that reads scales/zeros (same arithmetic, fewer loads): q/k/v, residual (KS=1 and the
+    K-split long-row kernel) and SwiGLU."""
+    from gbx_lm_amd import ops
+    act = "bf16" if dt == torch.bfloat16 else "f16"
+    def mod(n, k, seed):
+        from gbx_lm_amd.models.quantized_linear_gba import QuantizedLinear
+        d = oracle.synth_layer(n, k, bits, g, seed=seed, act_dtype=act)
+        m = QuantizedLinear(k, n, False, g, bits)
+        m._buffers["qweight"] = torch.from_numpy(d["qweight"].view(np.int32)).view(torch.uint32).to(DEV)
+        m._buffers["scales"], m._buffers["zeros"] = d["scales"].to(DEV), d["zeros"].to(DEV)
+        return m
+    k = 4096
+    q, kk, v = mod(512, k, 1), mod(128, k, 2), mod(130, k, 3)
+    pq = ops.pack_scales_zeros(q)
+    s16, z16 = q.scales.view(torch.int16).int() & 0xFFFF, q.zeros.view(torch.int16).int() & 0xFFFF
+    want = (s16 | (z16 << 16)).view(256, 2, k // g).transpose(1, 2).contiguous()
+    assert torch.equal(pq, want)
+    gate, up = mod(1030, k, 4), mod(1030, k, 5)
+    pgu = ops.pack_scales_zeros(gate, up)
+    sg, zg = gate.scales.view(torch.int16).int() & 0xFFFF, gate.zeros.view(torch.int16).int() & 0xFFFF
+    su, zu = up.scales.view(torch.int16).int() & 0xFFFF, up.zeros.view(torch.int16).int() & 0xFFFF
+    assert torch.equal(pgu, torch.stack([sg | (zg << 16), su | (zu << 16)], dim=-1))
+
+    x = (torch.randn(k) * 2).to(dt).to(DEV)
+    nw = (1 + 0.1 * torch.randn(k)).to(dt).to(DEV)
+    def run_qkv(packed):
+        ys = [torch.zeros(m.output_dims, dtype=dt, device=DEV) for m in (q, kk, v)]
+        ops.qlinear_fused(ops.make_fused_desc(x, (q, kk, v), ys, norm_weight=nw, eps=1e-5, packed=packed), x.device)
+        return ys
+    for a, b in zip(run_qkv(None), run_qkv(torch.cat([ops.pack_scales_zeros(m) for m in (q, kk, v)]))):
+        assert torch.equal(a, b)
+    def run_gu(packed):
+        o = torch.zeros(1030, dtype=dt, device=DEV)
+        ops.qlinear_fused(ops.make_fused_desc(x, (gate, up), (o,), norm_weight=nw, eps=1e-5, swiglu=True, packed=packed), x.device)
+        return o
+    assert torch.equal(run_gu(None), run_gu(pgu))
+    for n, kd in ((4096, 14336), (130, 4096), (30000, 1024)):
+        dn = mod(n, kd, 6)
+        xd = torch.randn(kd).to(dt).to(DEV)
+        h0 = torch.randn(n).to(dt).to(DEV)
+        def run_dn(packed):
+            h = h0.clone()
+            ops.qlinear_fused(ops.make_fused_desc(xd, (dn,), (h,), residual=h, packed=packed), xd.device)
+            return h
+        assert torch.equal(run_dn(None), run_dn(ops.pack_scales_zeros(dn)))
+    with pytest.raises(ValueError):
+        odd = mod(129, k, 7)
+        y = torch.zeros(129, dtype=dt, device=DEV)
+        ops.qlinear_fused(ops.make_fused_desc(x, (odd,), (y,), packed=torch.zeros((129 * (k // g),), dtype=torch.int32, device=DEV)), x.device)
