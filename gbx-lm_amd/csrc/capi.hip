@@ -74,7 +74,9 @@ int gbx_qlinear_forward(const void* x, const uint32_t* qweight, const void* scal
   static const bool force_generic = getenv("GBX_FORCE_GENERIC") != nullptr;
   const int max_k = bits == 2 ? gbx::gemv_max_k<2>() : bits == 3 ? gbx::gemv_max_k<3>() : gbx::gemv_max_k<4>();
   hipError_t e;
-  if (!force_generic && M > 1 && (K % 128) == 0) {
+  if (!force_generic && M > 1 && M <= 64 && (K % 128) == 0 && K >= 512) {
+    e = gbx::launch_qgemm_skinny(x, qweight, scales, zeros, bias, y, static_cast<int>(M), N, K, bits, log2g, bf16, stream);
+  } else if (!force_generic && M > 1 && (K % 128) == 0) {
     e = gbx::launch_qgemm_mfma(x, qweight, scales, zeros, bias, y, static_cast<int>(M), N, K, bits, log2g, bf16, stream);
   } else if (!force_generic && (K % 128) == 0 && K <= max_k) {
     gbx::GemvArgs a{};

@@ -13,63 +13,10 @@
 //     conflict-free), double-buffered; next chunk's activations and packed words are in flight during the MFMAs.
 //   * wave tile (32*MT) x (32*NT), workgroup = WM x (4/WM) waves.
 // MFMA-bound for large M (2*M*N*K flop), HBM-bound for small M (weights read once per column tile).
-#include "gbx_device.h"
+#include "mfma_common.h"
 #include "kernels.h"
 
 namespace gbx {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct MfmaArgs {
-  const unsigned short* x;      // [M, K]
-  const uint32_t* qweight;      // [N, K*bits/32]
-  const unsigned short* scales; // [N, K/g]
-  const unsigned short* zeros;  // [N, K/g]
-  const unsigned short* bias;   // [N] or null
-  unsigned short* y;            // [M, N]
-  int M, N, K, log2g;
-};
-
-constexpr int KC = 128;                 // k-values per chunk (one LDS stage of activations)
-constexpr int XROW = KC * 2 + 16;       // LDS bytes per activation row: 256 B + 16 B pad (conflict-free ds_read_b128)
-
-template <bool BF16>
-__device__ __forceinline__ f32x16 mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
-  if constexpr (BF16) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-  else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-
-template <bool BF16>
-__device__ __forceinline__ unsigned pack2(float a, float b) {
-  return static_cast<unsigned>(f32_to_act<BF16>(a)) | (static_cast<unsigned>(f32_to_act<BF16>(b)) << 16);
-}
-
-// The 8 integer fields (natural k order) of weight row n for k-step t, lane half h, as fp32.
-template <int BITS>
-__device__ __forceinline__ void fields8(const unsigned* wv, int t, int h, float* q) {
-  if constexpr (BITS == 4) {
-    const unsigned w = h ? wv[2 * t + 1] : wv[2 * t];
-    const unsigned e = w & 0x0F0F0F0Fu, o = (w >> 4) & 0x0F0F0F0Fu;      // even / odd nibbles as bytes
-    q[0] = static_cast<float>(e & 0xFFu);         q[1] = static_cast<float>(o & 0xFFu);
-    q[2] = static_cast<float>((e >> 8) & 0xFFu);  q[3] = static_cast<float>((o >> 8) & 0xFFu);
-    q[4] = static_cast<float>((e >> 16) & 0xFFu); q[5] = static_cast<float>((o >> 16) & 0xFFu);
-    q[6] = static_cast<float>(e >> 24);           q[7] = static_cast<float>(o >> 24);
-  } else if constexpr (BITS == 2) {
-    const unsigned hw = (wv[t] >> (16 * h)) & 0xFFFFu;                   // 8 fields of 2 bits
-#pragma unroll
-    for (int j = 0; j < 8; ++j) q[j] = static_cast<float>((hw >> (2 * j)) & 3u);
-  } else {
-    // 24 bits starting at bit 48t + 24h of the chunk's 12-word bit-stream; compile-time word indices for both halves
-    const int b0 = 48 * t, b1 = 48 * t + 24;
-    const unsigned win0 = __builtin_amdgcn_alignbit(wv[(b0 >> 5) + 1 < 12 ? (b0 >> 5) + 1 : 11], wv[b0 >> 5], b0 & 31);
-    const unsigned win1 = __builtin_amdgcn_alignbit(wv[(b1 >> 5) + 1 < 12 ? (b1 >> 5) + 1 : 11], wv[b1 >> 5], b1 & 31);
-    const unsigned win = h ? win1 : win0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) q[j] = static_cast<float>((win >> (3 * j)) & 7u);
-  }
-}
 
 // WM waves along M, 4/WM along N; each wave owns a (32*MT) x (32*NT) output tile.
 template <int BITS, int WM, int MT, int NT, bool BF16>

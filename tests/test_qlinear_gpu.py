@@ -190,3 +190,15 @@ def test_module_forward_and_graph_capture(ops, oracle, c_oracle):
     gr.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, y)
+
+
+@pytest.mark.parametrize("bits,g", [(2, 128), (3, 32), (4, 64)])
+@pytest.mark.parametrize("m,n,k", [(20, 4128, 1024), (40, 4128, 512), (16, 200, 2048), (64, 96, 4096), (3, 4104, 4096)])
+def test_skinny_mfma_tiles(ops, oracle, c_oracle, bits, g, m, n, k):
+    """2 <= M <= 64: split-K MFMA kernel -- 32-row tiles (N > 4096) and 16-row tiles, 4- and 8-way K split, wide and
+    per-value scale loads, ragged N and M."""
+    d = oracle.synth_layer(n, k, bits, g, seed=m + bits, m=m)
+    dd = _dev(d)
+    y = ops.quantized_matmul(dd["x"], dd["qweight"], dd["scales"], dd["zeros"], group_size=g, bits=bits)
+    y64 = c_oracle.qlinear(d["x"], d["qweight"], d["scales"], d["zeros"], bits, g, acc64=True)
+    oracle.assert_close(y, y64, "bf16", f"skinny M={m} N={n} K={k} b{bits} g{g}")
