@@ -1,49 +1,65 @@
-// Batched GBA QuantizedLinear (M > 1): y[M,N] = x[M,K] . dequant(W[N,K])^T on the matrix cores (gfx950 MFMA).
+// Prefill GBA QuantizedLinear (M > 64): y[M,N] = x[M,K] . dequant(W[N,K])^T on the matrix cores (gfx950 MFMA).
 //
-// Replaces mx.quantized_matmul(..., transpose=True) for prefill / batched decode
-// (gbx_lm/models/quantized_linear_gba.py:195-203 when x is [B, L, K] with B*L > 1; e.g. the chunked prefill at
+// Replaces mx.quantized_matmul(..., transpose=True) for prompts / batched evaluation
+// (gbx_lm/models/quantized_linear_gba.py:195-203 when x is [B, L, K] with B*L > 64; e.g. the chunked prefill at
 // gbx_lm/utils.py:312-319 and the batched eval at gbx_lm/evaluate.py:144-185).
 //
-// Here the dequantised tile is a genuine dense contraction, so it runs on v_mfma_f32_32x32x16_{bf16,f16}:
-//   * B operand: lane (n = l&31, h = l>>5) owns 8 consecutive k of weight row n per k-step -- ONE packed word at 4 bits,
-//     half a word at 2 bits, 24 bits at 3 bits -- so a fragment is built from the lane's own registers: fields -> fp32
-//     (v_cvt_f32_ubyte*), w = s*q + z in fp32, one rounding to the activation dtype (v_cvt_pk).  That is the arithmetic
-//     of a dequantise-then-matmul (what MLX's qmm does too); the exact-integer algebraic form is kept for the M = 1 GEMV.
-//   * A operand: activations staged per 128-wide K chunk in LDS (natural order, rows padded by 16 B so ds_read_b128 is
-//     conflict-free), double-buffered; next chunk's activations and packed words are in flight during the MFMAs.
-//   * wave tile (32*MT) x (32*NT), workgroup = WM x (4/WM) waves.
-// MFMA-bound for large M (2*M*N*K flop), HBM-bound for small M (weights read once per column tile).
+// Here the dequantised tile is a genuine dense contraction, so it runs on v_mfma_f32_32x32x16_{bf16,f16}.  What limits a
+// dequant-GEMM is the VALU work of turning packed fields into 16-bit operands, so every weight is dequantised ONCE per
+// workgroup and shared through LDS by all of its (64*MT) activation rows:
+//   * workgroup tile (64*MT) x 128, K chunks of 64, 4 waves as 2 (M) x 2 (N); a wave owns a (32*MT) x 64 tile =
+//     MT x 2 accumulators of 32x32.
+//   * B tile: 128 weight rows x 64 k.  Thread (row = tid/2, half = tid%2) owns 32 consecutive values of one row per chunk
+//     -- 2 / 3 / 4 packed words, always inside one group -- and dequantises them as fields -> fp32, w = s*q + z (fp32 fma),
+//     ONE rounding to the activation dtype (v_cvt_pk), then four 16-byte LDS stores.  That is the arithmetic of a
+//     dequantise-then-matmul (what MLX's qmm does); the exact-integer algebraic form is kept for the M = 1 GEMV.
+//   * A tile: (64*MT) activation rows x 64 k, fetched coalesced (8 rows x 128 B per wave instruction) into registers
+//     while the previous chunk is on the matrix cores, then stored to LDS.
+//   * LDS rows are 128 B + 16 B pad, so the 16-byte fragment reads (lane = row, 8 consecutive k) are conflict-free;
+//     two buffers, one barrier per chunk.
+// MFMA-bound (2*M*N*K flop); the weights are re-read from L2/HBM once per (64*MT)-row tile.
 #include "mfma_common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 namespace gbx {
 
-// WM waves along M, 4/WM along N; each wave owns a (32*MT) x (32*NT) output tile.
-template <int BITS, int WM, int MT, int NT, bool BF16>
-__global__ __launch_bounds__(256) void qgemm_mfma_kernel(const MfmaArgs a) {
-  constexpr int WN = 4 / WM;
-  constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
-  constexpr int WPC = KC * BITS / 32;               // packed words per row per chunk (8 / 12 / 16)
-  constexpr int XPT = BM * KC * 2 / 16 / 256;       // 16-byte activation pieces per thread per chunk
-  static_assert(XPT >= 1, "tile too small for 256 threads");
-  __shared__ __attribute__((aligned(16))) unsigned char xs_lds[2][BM * XROW];
+constexpr int PKC = 64;                  // k-values per chunk
+constexpr int PROW = PKC * 2 + 16;       // LDS bytes per tile row (activations and dequantised weights alike)
+
+template <int BITS, int MT, int NT, bool BF16>
+__global__ __launch_bounds__(256) void qgemm_prefill_kernel(const MfmaArgs a) {
+  constexpr int BM = 64 * MT;                     // activation rows per workgroup
+  constexpr int PBN = 64 * NT;                    // weight rows (output columns) per workgroup
+  constexpr int NU = NT / 2;                      // 32-value units of the B tile per thread and chunk
+  constexpr int AP = BM * 8 / 256;                // 16-byte activation pieces per thread per chunk
+  constexpr int ABYTES = BM * PROW, BBYTES = PBN * PROW, STAGE = ABYTES + BBYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 stages of [A tile | B tile]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
+  const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
   const int K = a.K, N = a.N, M = a.M;
   const int W = K / 32 * BITS, G = K >> a.log2g;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int gpc = KC >> a.log2g;                     // groups per chunk: 1, 2 or 4
-  const int kshift = a.log2g - 4;                    // k-step index -> group-in-chunk index
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * PBN;
+  const int nchunks = K / PKC;
 
-  int nrow[NT];
-  const uint32_t* wrow[NT];
+  // B loader: unit u = tid*NU + j -> row u/2 of the tile, 32-value half u%2 of the chunk (NU = 2: the whole row chunk)
+  const int brow = (tid * NU) >> 1, bhalf = (tid * NU) & 1;
+  const int bn = min(n0 + brow, N - 1);
+  const uint32_t* wsrc = a.qweight + static_cast<size_t>(bn) * W + bhalf * BITS;
+  const unsigned short* ssrc = a.scales + static_cast<size_t>(bn) * G;
+  const unsigned short* zsrc = a.zeros + static_cast<size_t>(bn) * G;
+  const int bdst = ABYTES + brow * PROW + bhalf * 64;
+  // A loader: piece p = tid + 256*i -> row p/8, 16-byte column p%8
+  const unsigned short* asrc[AP];
+  int adst[AP];
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    nrow[j] = min(n0 + (wn * NT + j) * 32 + r, N - 1);
-    wrow[j] = a.qweight + static_cast<size_t>(nrow[j]) * W;
+  for (int i = 0; i < AP; ++i) {
+    const int p = tid + 256 * i, row = p >> 3, col = p & 7;
+    asrc[i] = a.x + static_cast<size_t>(min(m0 + row, M - 1)) * K + col * 8;
+    adst[i] = row * PROW + col * 16;
   }
 
   f32x16 acc[MT][NT];
@@ -52,98 +68,110 @@ __global__ __launch_bounds__(256) void qgemm_mfma_kernel(const MfmaArgs a) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x16{0};
 
-  // two register sets for the packed words / scales, used alternately (the chunk loop is unrolled by two so that no
-  // set is ever copied)
-  unsigned wA[NT][WPC], wB[NT][WPC];
-  unsigned short sA[NT][4], zA[NT][4], sB[NT][4], zB[NT][4];
-  u32x4 xstage[XPT];
+  // Two register sets: chunk c+2 is requested while chunk c is on the matrix cores and chunk c+1 moves from registers
+  // to LDS, so a global load has a whole iteration (>= 1000 MFMA cycles) before its first use.
+  u32x4 areg[2][AP];
+  unsigned wreg[2][NU * BITS];
+  unsigned short sreg[2][NU], zreg[2][NU];
 
-  auto load_w = [&](unsigned (&wv)[NT][WPC], unsigned short (&sv)[NT][4], unsigned short (&zv)[NT][4], int kc) {
+  auto load_chunk = [&](int set, int c) {         // global -> registers (clamped: late prefetches re-read the final chunk)
+    const int kc = min(c, nchunks - 1) * PKC;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const uint32_t* src = wrow[j] + (kc / 32) * BITS;
+    for (int i = 0; i < AP; ++i) areg[set][i] = *reinterpret_cast<const u32x4*>(asrc[i] + kc);
+    const uint32_t* src = wsrc + (kc / 32) * BITS;
+    if constexpr (NU * BITS % 4 == 0) {
 #pragma unroll
-      for (int q = 0; q < WPC; q += 4) {
+      for (int q = 0; q < NU * BITS; q += 4) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(src + q);
-        wv[j][q] = v.x; wv[j][q + 1] = v.y; wv[j][q + 2] = v.z; wv[j][q + 3] = v.w;
+        wreg[set][q] = v.x; wreg[set][q + 1] = v.y; wreg[set][q + 2] = v.z; wreg[set][q + 3] = v.w;
       }
-      const size_t g0 = static_cast<size_t>(nrow[j]) * G + (kc >> a.log2g);
+    } else if constexpr (NU * BITS % 2 == 0) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {                  // unconditional (clamped) so the waitcnt pass can count
-        const size_t gi = g0 + min(u, gpc - 1);
-        sv[j][u] = a.scales[gi];
-        zv[j][u] = a.zeros[gi];
+      for (int q = 0; q < NU * BITS; q += 2) {
+        const u32x2 v = *reinterpret_cast<const u32x2*>(src + q);
+        wreg[set][q] = v.x; wreg[set][q + 1] = v.y;
       }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NU * BITS; ++q) wreg[set][q] = src[q];
+    }
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      const int g = (kc + (bhalf + j) * 32) >> a.log2g;
+      sreg[set][j] = ssrc[g];
+      zreg[set][j] = zsrc[g];
     }
   };
-  // piece p of this thread: row = (tid + 256*p) / 16, 16-byte column = (tid + 256*p) % 16
-  auto load_x = [&](int kc) {
+  // quarter t (0..3) of: registers -> LDS stage, dequantising the weights on the way
+  auto store_quarter = [&](int set, int stage, int t) {
+    unsigned char* base = lds + stage * STAGE;
 #pragma unroll
-    for (int p = 0; p < XPT; ++p) {
-      const int idx = tid + 256 * p, row = idx >> 4, col = idx & 15;
-      const int mg = min(m0 + row, M - 1);
-      xstage[p] = *reinterpret_cast<const u32x4*>(a.x + static_cast<size_t>(mg) * K + kc + col * 8);
-    }
-  };
-  auto store_x = [&](int buf) {
+    for (int i = t * (AP / 4); i < (t + 1) * (AP / 4); ++i) *reinterpret_cast<u32x4*>(base + adst[i]) = areg[set][i];
 #pragma unroll
-    for (int p = 0; p < XPT; ++p) {
-      const int idx = tid + 256 * p, row = idx >> 4, col = idx & 15;
-      *reinterpret_cast<u32x4*>(xs_lds[buf] + row * XROW + col * 16) = xstage[p];
-    }
-  };
-  // all MFMAs of one chunk: B fragments dequantised from registers, A fragments from LDS buffer `buf`
-  auto compute = [&](const unsigned (&wv)[NT][WPC], const unsigned short (&sv)[NT][4], const unsigned short (&zv)[NT][4], int buf) {
-    float sf[NT][4], zf[NT][4];
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { sf[j][u] = act_to_f32<BF16>(sv[j][u]); zf[j][u] = act_to_f32<BF16>(zv[j][u]); }
-#pragma unroll
-    for (int t = 0; t < KC / 16; ++t) {
-      u32x4 bf[NT];
-      const int gi = t >> kshift;                    // group of this k-step inside the chunk (wave-uniform)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        float q[8];
-        fields8<BITS>(wv[j], t, h, q);
-        const float s = gi == 0 ? sf[j][0] : gi == 1 ? sf[j][1] : gi == 2 ? sf[j][2] : sf[j][3];
-        const float z = gi == 0 ? zf[j][0] : gi == 1 ? zf[j][1] : gi == 2 ? zf[j][2] : zf[j][3];
-        bf[j].x = pack2<BF16>(fmaf(s, q[0], z), fmaf(s, q[1], z));
-        bf[j].y = pack2<BF16>(fmaf(s, q[2], z), fmaf(s, q[3], z));
-        bf[j].z = pack2<BF16>(fmaf(s, q[4], z), fmaf(s, q[5], z));
-        bf[j].w = pack2<BF16>(fmaf(s, q[6], z), fmaf(s, q[7], z));
+    for (int j = 0; j < NU; ++j) {                // octet t of every unit this thread owns
+      const unsigned* wu = wreg[set] + j * BITS;
+      unsigned win;
+      if constexpr (BITS == 4) win = wu[t];
+      else if constexpr (BITS == 2) win = (t & 1) ? (wu[t >> 1] >> 16) : wu[t >> 1];
+      else {
+        const int b = 24 * t, w = b >> 5;         // 96-bit period: octet t starts at bit 24*t
+        win = __builtin_amdgcn_alignbit(wu[w + 1 <= 2 ? w + 1 : 2], wu[w], b & 31);
       }
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const u32x4 af = *reinterpret_cast<const u32x4*>(xs_lds[buf] + ((wm * MT + i) * 32 + r) * XROW + (2 * t + h) * 16);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = mfma<BF16>(af, bf[j], acc[i][j]);
-      }
+      float q[8];
+      decode8<BITS>(win, q);
+      const float s = act_to_f32<BF16>(sreg[set][j]), z = act_to_f32<BF16>(zreg[set][j]);
+      u32x4 v;
+      v.x = pack2<BF16>(fmaf(s, q[0], z), fmaf(s, q[1], z));
+      v.y = pack2<BF16>(fmaf(s, q[2], z), fmaf(s, q[3], z));
+      v.z = pack2<BF16>(fmaf(s, q[4], z), fmaf(s, q[5], z));
+      v.w = pack2<BF16>(fmaf(s, q[6], z), fmaf(s, q[7], z));
+      *reinterpret_cast<u32x4*>(base + bdst + j * 64 + t * 16) = v;
     }
   };
+  // Fragments are read one k-step ahead of the MFMAs that use them (two register sets), so the LDS latency of step t+1
+  // hides under the 2*MT MFMAs of step t; only the first step of a chunk (right after the barrier) waits for LDS.
+  u32x4 fa[2][MT], fb[2][NT];
+  auto read_frags = [&](int fs, int stage, int t) {
+    const unsigned char* abase = lds + stage * STAGE + (wm * 32 * MT + r) * PROW + h * 16;
+    const unsigned char* bbase = lds + stage * STAGE + ABYTES + (wn * 32 * NT + r) * PROW + h * 16;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) fb[fs][j] = *reinterpret_cast<const u32x4*>(bbase + j * 32 * PROW + t * 32);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) fa[fs][i] = *reinterpret_cast<const u32x4*>(abase + i * 32 * PROW + t * 32);
+  };
+  auto mfma_step = [&](int fs) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = mfma<BF16>(fa[fs][i], fb[fs][j], acc[i][j]);
+  };
+  // one chunk: LDS stage `stage` on the matrix cores while register set `set` (the next chunk) moves into the other stage
+  auto chunk = [&](int stage, int set) {
+    read_frags(0, stage, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t < 3) read_frags((t + 1) & 1, stage, t + 1);
+      mfma_step(t & 1);
+      store_quarter(set, stage ^ 1, t);
+    }
+  };
+  static_assert(AP % 4 == 0, "activation pieces are stored in four quarters");
 
-  load_x(0);
-  load_w(wA, sA, zA, 0);
-  store_x(0);
+  load_chunk(0, 0);
+  load_chunk(1, 1);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) store_quarter(0, 0, t);
   __syncthreads();
-
-  const int nchunks = K / KC;
   for (int c = 0; c < nchunks; c += 2) {
-    // even chunk: set A, LDS buffer 0; prefetch chunk c+1 into set B / buffer 1
-    int kn = min((c + 1) * KC, K - KC);              // clamped: a last prefetch re-reads the final chunk harmlessly
-    load_x(kn);
-    load_w(wB, sB, zB, kn);
-    compute(wA, sA, zA, 0);
-    store_x(1);
+    // even chunk c: LDS stage 0 on the matrix cores; registers set 1 (chunk c+1) -> stage 1; request chunk c+2 into set 0
+    load_chunk(0, c + 2);
+    __builtin_amdgcn_sched_barrier(0);            // keep the requests at the top: hipcc otherwise sinks them to the barrier
+    chunk(0, 1);
     __syncthreads();
-    if (c + 1 >= nchunks) break;
-    // odd chunk: set B, LDS buffer 1; prefetch chunk c+2 into set A / buffer 0
-    kn = min((c + 2) * KC, K - KC);
-    load_x(kn);
-    load_w(wA, sA, zA, kn);
-    compute(wB, sB, zB, 1);
-    store_x(0);
+    // odd chunk c+1 (K % 128 == 0: the chunk count is even): stage 1; set 0 (chunk c+2) -> stage 0; request chunk c+3
+    load_chunk(1, c + 3);
+    __builtin_amdgcn_sched_barrier(0);
+    chunk(1, 0);
     __syncthreads();
   }
 
@@ -168,19 +196,35 @@ __global__ __launch_bounds__(256) void qgemm_mfma_kernel(const MfmaArgs a) {
   }
 }
 
-template <int BITS, int WM, int MT, int NT>
-static void launch_cfg(const MfmaArgs& a, bool bf16, hipStream_t s) {
-  constexpr int BM = 32 * MT * WM, BN = 32 * NT * (4 / WM);
+template <int BITS, int MT, int NT>
+static hipError_t launch_prefill_cfg(const MfmaArgs& a, bool bf16, hipStream_t s) {
+  constexpr int BM = 64 * MT, BN = 64 * NT;
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM), block(256);
-  if (bf16) hipLaunchKernelGGL((qgemm_mfma_kernel<BITS, WM, MT, NT, true>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((qgemm_mfma_kernel<BITS, WM, MT, NT, false>), grid, block, 0, s, a);
+  const size_t shmem = 2 * static_cast<size_t>(BM + BN) * PROW;
+  if (shmem > 48 * 1024) {        // opt in to the large LDS carve-out once per instantiation
+    static bool done[2] = {false, false};
+    if (!done[bf16]) {
+      hipError_t e = bf16 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&qgemm_prefill_kernel<BITS, MT, NT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shmem))
+                          : hipFuncSetAttribute(reinterpret_cast<const void*>(&qgemm_prefill_kernel<BITS, MT, NT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shmem));
+      if (e != hipSuccess) return e;
+      done[bf16] = true;
+    }
+  }
+  if (bf16) hipLaunchKernelGGL((qgemm_prefill_kernel<BITS, MT, NT, true>), grid, block, shmem, s, a);
+  else hipLaunchKernelGGL((qgemm_prefill_kernel<BITS, MT, NT, false>), grid, block, shmem, s, a);
+  return hipGetLastError();
 }
 
 template <int BITS>
-static void launch_bits(const MfmaArgs& a, bool bf16, hipStream_t s) {
-  if (a.M <= 32) launch_cfg<BITS, 1, 1, 1>(a, bf16, s);        // 32 x 128 tile: batched decode, weights streamed once
-  else if (a.M <= 64) launch_cfg<BITS, 1, 2, 1>(a, bf16, s);   // 64 x 128
-  else launch_cfg<BITS, 2, 2, 2>(a, bf16, s);                  // 128 x 128: prefill
+static hipError_t launch_prefill_bits(const MfmaArgs& a, bool bf16, hipStream_t s) {
+  static const int force = getenv("GBX_PREFILL_TILE") ? atoi(getenv("GBX_PREFILL_TILE")) : 0;   // tuning aid: 1, 2 or 3
+  // the biggest tile that still gives every CU a workgroup: LDS bytes per flop fall with the tile (measured on
+  // 32768 x 4096 x 4096: 128x128 ~600, 256x128 ~800, 256x256 ~870-900 TFLOP/s)
+  const long t256 = static_cast<long>((a.M + 255) / 256) * ((a.N + 255) / 256);
+  const long t128 = static_cast<long>((a.M + 255) / 256) * ((a.N + 127) / 128);
+  if (force == 3 || (force == 0 && t256 >= 256)) return launch_prefill_cfg<BITS, 4, 4>(a, bf16, s);   // 256 x 256
+  if (force == 2 || (force == 0 && t128 >= 128 && a.M > 128)) return launch_prefill_cfg<BITS, 4, 2>(a, bf16, s);   // 256 x 128
+  return launch_prefill_cfg<BITS, 2, 2>(a, bf16, s);                                                  // 128 x 128
 }
 
 hipError_t launch_qgemm_mfma(const void* x, const uint32_t* qw, const void* sc, const void* ze, const void* bias, void* y,
@@ -189,12 +233,11 @@ hipError_t launch_qgemm_mfma(const void* x, const uint32_t* qw, const void* sc, 
              static_cast<const unsigned short*>(ze), static_cast<const unsigned short*>(bias),
              static_cast<unsigned short*>(y), M, N, K, log2g};
   switch (bits) {
-    case 2: launch_bits<2>(a, bf16, s); break;
-    case 3: launch_bits<3>(a, bf16, s); break;
-    case 4: launch_bits<4>(a, bf16, s); break;
+    case 2: return launch_prefill_bits<2>(a, bf16, s);
+    case 3: return launch_prefill_bits<3>(a, bf16, s);
+    case 4: return launch_prefill_bits<4>(a, bf16, s);
     default: return hipErrorInvalidValue;
   }
-  return hipGetLastError();
 }
 
 }  // namespace gbx

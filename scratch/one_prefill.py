@@ -1,0 +1,10 @@
+import sys, torch
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gbx_lm_amd import ops
+dev='cuda:0'
+m,n,k,b = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]); g=128
+qw = torch.randint(0, 2**32, (n, k//32*b), dtype=torch.int64, device=dev).to(torch.int32).view(torch.uint32)
+sc = (torch.rand((n,k//g),device=dev)*0.01).to(torch.bfloat16); ze=(-sc*1.5).to(torch.bfloat16)
+x = torch.randn(m,k,device=dev).to(torch.bfloat16); y = torch.empty(m,n,device=dev,dtype=torch.bfloat16)
+for _ in range(6): ops.quantized_matmul(x,qw,sc,ze,group_size=g,bits=b,out=y)
+torch.cuda.synchronize()
