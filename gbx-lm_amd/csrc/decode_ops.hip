@@ -39,6 +39,20 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   const int kvh = h / rep;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // ---- the first UB0 * 4 * PPW cached positions are requested before anything else: their addresses depend neither on
+  //      the position counter (clamped to the buffer; masked when consumed) nor on q, so the cache latency overlaps the
+  //      q/k/v loads, RoPE and the barrier instead of following them (one dependent memory round trip less) ----
+  constexpr int LP0 = HD / 8, PPW0 = 64 / LP0, UB0 = 8;
+  const int d0 = (lane % LP0) * 8, sub = lane / LP0;
+  const unsigned short* kbase = a.kcache + static_cast<size_t>(kvh) * a.capacity * HD;
+  const unsigned short* vbase = a.vcache + static_cast<size_t>(kvh) * a.capacity * HD;
+  u32x4 k0[UB0], v0[UB0];
+#pragma unroll
+  for (int u = 0; u < UB0; ++u) {
+    const int tc = min(wave * PPW0 + u * 4 * PPW0 + sub, a.capacity - 1);
+    k0[u] = *reinterpret_cast<const u32x4*>(kbase + static_cast<size_t>(tc) * HD + d0);
+    v0[u] = *reinterpret_cast<const u32x4*>(vbase + static_cast<size_t>(tc) * HD + d0);
+  }
   const int pos = static_cast<int>(*a.pos);
 
   // ---- RoPE on this head's q and on its kv head's k (fp32 math, one rounding to the activation dtype like
@@ -76,17 +90,41 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   __syncthreads();
 
   // ---- cached positions [0, pos): LP lanes per position, online softmax per (wave, sub) group ----
-  const int d0 = (lane % LP) * 8, sub = lane / LP;
   float qr[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) qr[j] = q_s[d0 + j];
   float m = NEG, l = 0.f, acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  const unsigned short* kbase = a.kcache + static_cast<size_t>(kvh) * a.capacity * HD;
-  const unsigned short* vbase = a.vcache + static_cast<size_t>(kvh) * a.capacity * HD;
+  auto consume = [&](const u32x4& kq, const u32x4& vq, bool valid) {
+    const unsigned kw[4] = {kq.x, kq.y, kq.z, kq.w};
+    const unsigned vw[4] = {vq.x, vq.y, vq.z, vq.w};
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s = fmaf(qr[2 * j], act_lo<BF16>(kw[j]), s);
+      s = fmaf(qr[2 * j + 1], act_hi<BF16>(kw[j]), s);
+    }
+    // sum over the LP lanes of this position (LP = 16: one DPP row; LP = 8: half a row)
+    s += dpp_f32<0xB1>(s);
+    s += dpp_f32<0x4E>(s);
+    s += dpp_f32<0x141>(s);
+    if constexpr (LP == 16) s += dpp_f32<0x140>(s);
+    const float mn = valid ? fmaxf(m, s) : m;
+    const float corr = __expf(m - mn);
+    const float p = valid ? __expf(s - mn) : 0.f;
+    l = l * corr + p;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[2 * j] = acc[2 * j] * corr + p * act_lo<BF16>(vw[j]);
+      acc[2 * j + 1] = acc[2 * j + 1] * corr + p * act_hi<BF16>(vw[j]);
+    }
+    m = mn;
+  };
+#pragma unroll
+  for (int u = 0; u < UB0; ++u) consume(k0[u], v0[u], wave * PPW + u * 4 * PPW + sub < pos);
   constexpr int UB = 4;                 // iterations whose K/V loads are in flight together
-  for (int t0 = wave * PPW; t0 < pos; t0 += 4 * PPW * UB) {
+  for (int t0 = UB0 * 4 * PPW + wave * PPW; t0 < pos; t0 += 4 * PPW * UB) {
     u32x4 kv4[UB], vv4[UB];
     bool valid[UB];
 #pragma unroll
@@ -98,31 +136,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
       vv4[u] = *reinterpret_cast<const u32x4*>(vbase + static_cast<size_t>(tc) * HD + d0);
     }
 #pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      const unsigned kw[4] = {kv4[u].x, kv4[u].y, kv4[u].z, kv4[u].w};
-      const unsigned vw[4] = {vv4[u].x, vv4[u].y, vv4[u].z, vv4[u].w};
-      float s = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        s = fmaf(qr[2 * j], act_lo<BF16>(kw[j]), s);
-        s = fmaf(qr[2 * j + 1], act_hi<BF16>(kw[j]), s);
-      }
-      // sum over the LP lanes of this position (LP = 16: one DPP row; LP = 8: half a row)
-      s += dpp_f32<0xB1>(s);
-      s += dpp_f32<0x4E>(s);
-      s += dpp_f32<0x141>(s);
-      if constexpr (LP == 16) s += dpp_f32<0x140>(s);
-      const float mn = valid[u] ? fmaxf(m, s) : m;
-      const float corr = __expf(m - mn);
-      const float p = valid[u] ? __expf(s - mn) : 0.f;
-      l = l * corr + p;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[2 * j] = acc[2 * j] * corr + p * act_lo<BF16>(vw[j]);
-        acc[2 * j + 1] = acc[2 * j + 1] * corr + p * act_hi<BF16>(vw[j]);
-      }
-      m = mn;
-    }
+    for (int u = 0; u < UB; ++u) consume(kv4[u], vv4[u], valid[u]);
   }
   // ---- the new token itself (its k, v are in LDS, not yet visible through the cache to other blocks) ----
   if (wave == 0 && sub == 0) {
