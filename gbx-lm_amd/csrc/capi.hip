@@ -167,6 +167,48 @@ int gbx_pack_scales_zeros(const void* scales0, const void* zeros0, const void* s
   return GBX_OK;
 }
 
+static int check_tiled(int32_t N, int32_t K, int32_t bits, int32_t group_size) {
+  int rc = check_shape(1, N, K, bits, group_size);
+  if (rc) return rc;
+  if (bits != 2 || group_size != 128 || (K % 1024) != 0 || K > 16384)
+    return fail(GBX_ERR_UNSUPPORTED, "tiled decode GEMV covers 2-bit, group_size 128, K %% 1024 == 0, K <= 16384 (got bits=%d g=%d K=%d)", bits, group_size, K);
+  return GBX_OK;
+}
+
+int gbx_qlinear_prepack_tiles(const uint32_t* qweight, const void* scales, const void* zeros,
+                              const uint32_t* qweight_up, const void* scales_up, const void* zeros_up,
+                              uint32_t* wt, uint32_t* szt, int32_t N, int32_t K, int32_t bits, int32_t group_size,
+                              void* hip_stream) {
+  int rc = check_tiled(N, K, bits, group_size);
+  if (rc) return rc;
+  if (N == 0) return GBX_OK;
+  if (!qweight || !scales || !zeros || !wt || !szt) return fail(GBX_ERR_INVALID, "null device pointer");
+  if ((qweight_up != nullptr) != (scales_up != nullptr) || (qweight_up != nullptr) != (zeros_up != nullptr))
+    return fail(GBX_ERR_INVALID, "qweight_up, scales_up and zeros_up go together");
+  if (!aligned(wt, 16) || !aligned(szt, 16)) return fail(GBX_ERR_INVALID, "tiled buffers must be 16-byte aligned");
+  hipError_t e = gbx::launch_prepack_tiles(qweight, scales, zeros, qweight_up, scales_up, zeros_up, wt, szt, N, K,
+                                           static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_qlinear_prepack_tiles launch");
+  return GBX_OK;
+}
+
+int gbx_gemv_tiled(const void* x, const uint32_t* wt, const uint32_t* szt, void* y, int32_t N, int32_t K, int32_t bits,
+                   int32_t group_size, const void* norm_weight, float norm_eps, const void* residual, int32_t swiglu,
+                   int32_t act_dtype, void* hip_stream) {
+  int rc = check_tiled(N, K, bits, group_size);
+  if (rc) return rc;
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  if (N == 0) return GBX_OK;
+  if (!x || !wt || !szt || !y) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (!aligned(x, 16) || !aligned(wt, 16) || !aligned(szt, 16)) return fail(GBX_ERR_INVALID, "x and the tiled buffers must be 16-byte aligned");
+  if (norm_weight && !aligned(norm_weight, 4)) return fail(GBX_ERR_INVALID, "norm_weight must be 4-byte aligned");
+  if (swiglu && residual) return fail(GBX_ERR_INVALID, "swiglu and residual exclude each other");
+  hipError_t e = gbx::launch_gemv_mfma(x, wt, szt, y, N, K, norm_weight, norm_eps, residual, swiglu ? 1 : 0,
+                                       act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_gemv_tiled launch");
+  return GBX_OK;
+}
+
 int gbx_attn_decode(const void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
                     const int64_t* pos, void* out, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim,
                     int32_t capacity, float rope_scale, float sm_scale, int32_t traditional, int32_t act_dtype,

@@ -110,4 +110,15 @@ __device__ __forceinline__ unsigned field_of_row(const uint32_t* __restrict__ ro
   return q;
 }
 
+// packed (scale | zero << 16) dword -> fp32
+template <bool BF16> __device__ __forceinline__ float sz_scale(unsigned v) {
+  if constexpr (BF16) return __uint_as_float(v << 16);
+  else return act_to_f32<false>(static_cast<unsigned short>(v & 0xFFFFu));
+}
+template <bool BF16> __device__ __forceinline__ float sz_zero(unsigned v) {
+  if constexpr (BF16) return __uint_as_float(v & 0xFFFF0000u);
+  else return act_to_f32<false>(static_cast<unsigned short>(v >> 16));
+}
+
+
 }  // namespace gbx

@@ -187,16 +187,6 @@ struct RowBatch {
   unsigned res2;            // PK: residual of both rows in one dword
 };
 
-// packed (scale | zero << 16) dword -> fp32
-template <bool BF16> __device__ __forceinline__ float sz_scale(unsigned v) {
-  if constexpr (BF16) return __uint_as_float(v << 16);
-  else return act_to_f32<false>(static_cast<unsigned short>(v & 0xFFFFu));
-}
-template <bool BF16> __device__ __forceinline__ float sz_zero(unsigned v) {
-  if constexpr (BF16) return __uint_as_float(v & 0xFFFF0000u);
-  else return act_to_f32<false>(static_cast<unsigned short>(v >> 16));
-}
-
 __device__ __forceinline__ float round_bf16_or_f16(float v, bool bf16) {
   return bf16 ? bf16_to_f32(f32_to_act<true>(v)) : f16_to_f32(f32_to_act<false>(v));
 }

@@ -128,6 +128,44 @@ def pack_scales_zeros(mod, mod2=None) -> torch.Tensor:
     return out
 
 
+def prepack_tiles(mod, mod_up=None):
+    """Load-time tiled form of a 2-bit / group-128 QuantizedLinear for the matrix-core decode GEMV
+    (gbx_qlinear_prepack_tiles): returns ``(wt, szt)`` int32 tensors.  With ``mod_up`` the pair (gate_proj, up_proj) is
+    interleaved 8 + 8 rows per tile for a SwiGLU launch."""
+    n, k = mod.output_dims, mod.input_dims
+    mods = (mod,) if mod_up is None else (mod, mod_up)
+    for m in mods:
+        if (m.output_dims, m.input_dims, m.bits, m.group_size) != (n, k, mod.bits, mod.group_size):
+            raise ValueError("the two matrices of a SwiGLU pair must agree in shape, bits and group_size")
+        for t in (m.qweight, m.scales, m.zeros):
+            _require_cuda(t, "QuantizedLinear tensor")
+    rows = ((n + 15) // 16 * 16) if mod_up is None else ((n + 7) // 8 * 16)
+    wt = torch.empty((rows * (k // 16),), dtype=torch.int32, device=mod.qweight.device)
+    szt = torch.empty((rows * (k // 128),), dtype=torch.int32, device=mod.qweight.device)
+    up = mod_up
+    _lib.check(_lib.lib().gbx_qlinear_prepack_tiles(
+        mod.qweight.data_ptr(), mod.scales.data_ptr(), mod.zeros.data_ptr(),
+        up.qweight.data_ptr() if up is not None else None, up.scales.data_ptr() if up is not None else None,
+        up.zeros.data_ptr() if up is not None else None,
+        wt.data_ptr(), szt.data_ptr(), n, k, mod.bits, mod.group_size, _stream_ptr(wt.device)))
+    return wt, szt
+
+
+def gemv_tiled(x: torch.Tensor, wt: torch.Tensor, szt: torch.Tensor, n: int, k: int, out: Optional[torch.Tensor] = None,
+               bits: int = 2, group_size: int = 128, norm_weight: Optional[torch.Tensor] = None, eps: float = 0.0,
+               residual: Optional[torch.Tensor] = None, swiglu: bool = False) -> torch.Tensor:
+    """y[n] = W x from the tiled form (gbx_gemv_tiled); x is one activation row; optional fused RMSNorm prologue,
+    residual epilogue or (pair tiles) SwiGLU epilogue."""
+    _require_cuda(x, "x")
+    if out is None:
+        out = torch.empty((n,), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().gbx_gemv_tiled(x.data_ptr(), wt.data_ptr(), szt.data_ptr(), out.data_ptr(), n, k, bits, group_size,
+                                         norm_weight.data_ptr() if norm_weight is not None else None, float(eps),
+                                         residual.data_ptr() if residual is not None else None, int(bool(swiglu)),
+                                         _DT[x.dtype], _stream_ptr(x.device)))
+    return out
+
+
 def make_fused_desc(x: torch.Tensor, mods, ys, norm_weight: Optional[torch.Tensor] = None, eps: float = 0.0,
                     residual: Optional[torch.Tensor] = None, swiglu: bool = False, packed=None) -> "_lib.FusedDesc":
     """Descriptor for one launch over 1-3 QuantizedLinear modules sharing ``x`` (q/k/v, gate/up, or a single one).

@@ -125,6 +125,25 @@ int gbx_qlinear_fused_forward(const gbx_qlinear_fused* desc, void* hip_stream);
 int gbx_pack_scales_zeros(const void* scales0, const void* zeros0, const void* scales1, const void* zeros1,
                           uint32_t* out, int32_t N, int32_t G, void* hip_stream);
 
+/* Load-time re-tiling for the matrix-core decode GEMV (2-bit, group_size 128, K % 1024 == 0): 16-row tiles, K-steps of
+ * 256 values, so that a wavefront load is one contiguous 1 KiB block that IS the int8 MFMA operand layout, plus the
+ * (scale | zero << 16) dwords as [tile][group][16 rows].  With a second matrix (qweight_up != NULL: gate_proj / up_proj
+ * of one SwiGLU launch, both [N, K]) a tile holds 8 gate rows followed by the 8 up rows of the same outputs.
+ * Sizes in uint32: wt = T*16 * K/16, szt = T*16 * K/128 with T = ceil(N/16) (single) or ceil(N/8) (pair); rows past N
+ * are zero-filled.  The originals stay valid for the other entry points. */
+int gbx_qlinear_prepack_tiles(const uint32_t* qweight, const void* scales, const void* zeros,
+                              const uint32_t* qweight_up, const void* scales_up, const void* zeros_up,
+                              uint32_t* wt, uint32_t* szt, int32_t N, int32_t K, int32_t bits, int32_t group_size,
+                              void* hip_stream);
+
+/* y[N] = W x' for ONE activation row from the tiled form above; same result contract and the same optional fusions as
+ * gbx_qlinear_fused_forward: x' = RMSNorm(x) * norm_weight (norm_weight != NULL), y <- residual + round(result)
+ * (residual != NULL), or -- pair tiles, swiglu != 0 -- y[n] = silu(gate[n]) * up[n] with the reference's op-by-op
+ * roundings.  Exact integer sums per group on the int8 matrix cores, fp32 scale/zero application. */
+int gbx_gemv_tiled(const void* x, const uint32_t* wt, const uint32_t* szt, void* y, int32_t N, int32_t K, int32_t bits,
+                   int32_t group_size, const void* norm_weight, float norm_eps, const void* residual, int32_t swiglu,
+                   int32_t act_dtype, void* hip_stream);
+
 /* One layer of single-token attention: RoPE on q and k at position *pos, append k, v to the caller's KV cache
  * ([n_kv, capacity, head_dim], the layout of gbx_lm/models/cache.py:222-244 with B = 1), softmax(q k^T * sm_scale) v
  * over positions 0..*pos.  Replaces qllama.py:78-95 (reshape/rope/cache.update_and_fetch/SDPA).  `pos` is a DEVICE

@@ -328,3 +328,41 @@ def test_packed_scales_zeros_companion(oracle, bits, g, dt):
         odd = mod(129, k, 7)
         y = torch.zeros(129, dtype=dt, device=DEV)
         ops.qlinear_fused(ops.make_fused_desc(x, (odd,), (y,), packed=torch.zeros((129 * (k // g),), dtype=torch.int32, device=DEV)), x.device)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_tiled_gemv_fused_variants(oracle, dt):
+    """Matrix-core GEMV with the decode-block fusions against the oracle and against the VALU fused launch:
+    RMSNorm prologue + SwiGLU pair tiles (gate/up), residual epilogue on a long-row matrix (down_proj shape)."""
+    from gbx_lm_amd import ops
+    from gbx_lm_amd.models.quantized_linear_gba import QuantizedLinear
+    act = "bf16" if dt == torch.bfloat16 else "f16"
+    def mod(n, k, seed):
+        d = oracle.synth_layer(n, k, 2, 128, seed=seed, act_dtype=act)
+        m = QuantizedLinear(k, n, False, 128, 2)
+        m._buffers["qweight"] = torch.from_numpy(d["qweight"].view(np.int32)).view(torch.uint32).to(DEV)
+        m._buffers["scales"], m._buffers["zeros"] = d["scales"].to(DEV), d["zeros"].to(DEV)
+        return m, d
+    k, n = 4096, 1032                       # n % 16 == 8: the last pair tile is full, the last plain tile is ragged
+    (gate, dg), (up, du) = mod(n, k, 1), mod(n, k, 2)
+    x = (torch.randn(k) * 2).to(dt).to(DEV)
+    nw = (1 + 0.1 * torch.randn(k)).to(dt).to(DEV)
+    wt, szt = ops.prepack_tiles(gate, up)
+    act_t = ops.gemv_tiled(x, wt, szt, n, k, norm_weight=nw, eps=1e-5, swiglu=True)
+    xn = _rms(x, nw, 1e-5).cpu()
+    g64 = oracle.qlinear_ref(xn[None], dg["qweight"], dg["scales"], dg["zeros"], 2, 128, acc=np.float64)
+    u64 = oracle.qlinear_ref(xn[None], du["qweight"], du["scales"], du["zeros"], 2, 128, acc=np.float64)
+    oracle.assert_close(act_t[None], (g64 / (1 + np.exp(-g64))) * u64, act, "tiled swiglu")
+    act_v = torch.zeros(n, dtype=dt, device=DEV)
+    ops.qlinear_fused(ops.make_fused_desc(x, (gate, up), (act_v,), norm_weight=nw, eps=1e-5, swiglu=True), x.device)
+    assert (act_t.float() - act_v.float()).abs().max().item() <= 0.02 * act_v.float().abs().max().item() + 1e-3
+    # residual, K = 14336
+    kd, nd = 14336, 520
+    dn, dd = mod(nd, kd, 3)
+    xd = torch.randn(kd).to(dt).to(DEV)
+    h0 = torch.randn(nd).to(dt).to(DEV)
+    wt2, szt2 = ops.prepack_tiles(dn)
+    h = h0.clone()
+    ops.gemv_tiled(xd, wt2, szt2, nd, kd, out=h, residual=h)
+    y64 = oracle.qlinear_ref(xd.cpu()[None], dd["qweight"], dd["scales"], dd["zeros"], 2, 128, acc=np.float64)
+    oracle.assert_close(h[None], h0.cpu().double().numpy()[None] + y64, act, "tiled residual")

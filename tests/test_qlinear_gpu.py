@@ -202,3 +202,31 @@ def test_skinny_mfma_tiles(ops, oracle, c_oracle, bits, g, m, n, k):
     y = ops.quantized_matmul(dd["x"], dd["qweight"], dd["scales"], dd["zeros"], group_size=g, bits=bits)
     y64 = c_oracle.qlinear(d["x"], d["qweight"], d["scales"], d["zeros"], bits, g, acc64=True)
     oracle.assert_close(y, y64, "bf16", f"skinny M={m} N={n} K={k} b{bits} g{g}")
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("n,k", [(4096, 4096), (130, 1024), (1000, 2048), (4096, 14336), (28672, 4096)])
+def test_tiled_matrix_core_gemv(ops, oracle, c_oracle, dt, n, k):
+    """Decode GEMV on the int8 matrix cores from the load-time tiled form: same contract as the M = 1 forward
+    (vs the fp64-accumulated oracle), ragged N, long rows, outlier activations (block fixed point must stay exact)."""
+    from gbx_lm_amd.models.quantized_linear_gba import QuantizedLinear
+    d = oracle.synth_layer(n, k, 2, 128, seed=n % 97 + k % 89, act_dtype=dt)
+    x = d["x"].clone()
+    x[0, 7] = 200.0                      # an outlier 2^7.6 above the rest of its group
+    x[0, 300] = 1e-4
+    d["x"] = x
+    dd = _dev(d)
+    m = QuantizedLinear(k, n, False, 128, 2)
+    m._buffers["qweight"], m._buffers["scales"], m._buffers["zeros"] = dd["qweight"], dd["scales"], dd["zeros"]
+    wt, szt = ops.prepack_tiles(m)
+    y = ops.gemv_tiled(dd["x"].reshape(-1), wt, szt, n, k)
+    y64 = c_oracle.qlinear(d["x"], d["qweight"], d["scales"], d["zeros"], 2, 128, acc64=True)
+    oracle.assert_close(y[None], y64, dt, f"tiled gemv N={n} K={k}")
+    yref = ops.quantized_matmul(dd["x"], dd["qweight"], dd["scales"], dd["zeros"], group_size=128, bits=2)
+    assert (y[None].float() - yref.float()).abs().max().item() <= 2e-2 * yref.float().abs().max().item()
+    with pytest.raises(NotImplementedError):
+        m4 = QuantizedLinear(k, 16, False, 128, 4)
+        m4._buffers["qweight"] = torch.zeros((16, k // 8), dtype=torch.int32, device=DEV).view(torch.uint32)
+        m4._buffers["scales"] = torch.zeros((16, k // 128), dtype=dd["scales"].dtype, device=DEV)
+        m4._buffers["zeros"] = torch.zeros((16, k // 128), dtype=dd["scales"].dtype, device=DEV)
+        ops.prepack_tiles(m4)
