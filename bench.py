@@ -72,9 +72,10 @@ def kernel_leg(model, reps=20):
     dt = g0.scales.dtype
     x = torch.randn(g0.input_dims, device=dev).to(dt)
     act = torch.empty(g0.output_dims, device=dev, dtype=dt)
+    packs = [ops.pack_scales_zeros(blk.mlp.gate_proj, blk.mlp.up_proj) for blk in layers]   # as the decode runner does
     descs = [ops.make_fused_desc(x, (blk.mlp.gate_proj, blk.mlp.up_proj), (act,),
                                  norm_weight=blk.post_attention_layernorm.weight.to(dt), eps=blk.post_attention_layernorm.eps,
-                                 swiglu=True) for blk in layers]
+                                 swiglu=True, packed=pk) for blk, pk in zip(layers, packs)]
 
     def sweep():
         for d in descs:

@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0,'.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gbx_lm_amd import ops
 from gbx_lm_amd.models.quantized_linear_gba import QuantizedLinear
 dev='cuda:0'
@@ -13,7 +13,7 @@ k=4096; x=torch.randn(k,device=dev).to(torch.bfloat16); nw=torch.ones(k,dtype=to
 sets=[]
 for _ in range(20):
     g_,u_=mod(14336,k,2,128),mod(14336,k,2,128); act=torch.zeros(14336,dtype=torch.bfloat16,device=dev)
-    sets.append((ops.make_fused_desc(x,(g_,u_),(act,),norm_weight=nw,eps=1e-5,swiglu=True),(g_,u_,act)))
+    pk=ops.pack_scales_zeros(g_,u_); sets.append((ops.make_fused_desc(x,(g_,u_),(act,),norm_weight=nw,eps=1e-5,swiglu=True,packed=pk),(g_,u_,act,pk)))
 for r in range(3):
     for d,_ in sets: ops.qlinear_fused(d, x.device)
 torch.cuda.synchronize()
