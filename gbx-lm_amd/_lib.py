@@ -74,6 +74,7 @@ def _declare_optional(L) -> None:
     L.gbx_rmsnorm.argtypes = [p, p, p, i64, i32, f32, i32, p]
     L.gbx_dense_gemv_argmax.argtypes = [p, p, p, p, f32, i32, i32, p, i32, p]
     L.gbx_embed_next_token.argtypes = [p, p, p, p, p, i32, i32, i32, i32, i32, p]
+    L.gbx_rope_append.argtypes = [p, p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, i32, i32, p]
     L.gbx_pack_scales_zeros.argtypes = [p, p, p, p, p, i32, i32, p]
     L.gbx_qlinear_prepack_tiles.argtypes = [p, p, p, p, p, p, p, p, i32, i32, i32, i32, p]
     L.gbx_gemv_tiled.argtypes = [p, p, p, p, i32, i32, i32, i32, p, f32, p, i32, i32, p]

@@ -258,6 +258,21 @@ int gbx_dense_gemv_argmax(const void* x, const void* w, void* y, const void* nor
   return GBX_OK;
 }
 
+int gbx_rope_append(void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
+                    const int64_t* pos, int32_t batch, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int32_t capacity,
+                    float rope_scale, int32_t traditional, int32_t act_dtype, void* hip_stream) {
+  if (batch == 0) return GBX_OK;
+  if (!q || !k || !v || !kcache || !vcache || !inv_freq || !pos) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (batch < 0 || batch > 65535 || n_heads <= 0 || n_kv_heads <= 0 || head_dim <= 0 || (head_dim & 1) || capacity <= 0)
+    return fail(GBX_ERR_INVALID, "bad shape batch=%d heads=%d/%d head_dim=%d capacity=%d", batch, n_heads, n_kv_heads, head_dim, capacity);
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  hipError_t e = gbx::launch_rope_append(q, k, v, kcache, vcache, inv_freq, reinterpret_cast<const long long*>(pos), batch, n_heads,
+                                         n_kv_heads, head_dim, capacity, rope_scale, traditional, act_dtype == GBX_BF16,
+                                         static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_rope_append launch");
+  return GBX_OK;
+}
+
 int gbx_rmsnorm(const void* x, const void* w, void* y, int64_t M, int32_t K, float eps, int32_t act_dtype, void* hip_stream) {
   if (M == 0) return GBX_OK;
   if (!x || !w || !y) return fail(GBX_ERR_INVALID, "null device pointer");

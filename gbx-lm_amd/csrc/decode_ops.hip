@@ -436,4 +436,51 @@ hipError_t launch_rmsnorm(const void* x, const void* w, void* y, int M, int K, f
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ batched RoPE + cache append
+// One launch for a synchronous batched decode step (every sequence at position *pos): q is rotated in place, k is rotated
+// into kcache[b, kvh, pos, :], v is copied into vcache[b, kvh, pos, :].  Replaces rope(q), rope(k) and
+// cache.update_and_fetch of qllama.py:84-91 for L = 1 (fp32 math, one rounding, like mx.fast.rope).
+template <bool BF16>
+__global__ __launch_bounds__(128) void rope_append_kernel(unsigned short* __restrict__ q, const unsigned short* __restrict__ k,
+                                                          const unsigned short* __restrict__ v, unsigned short* __restrict__ kcache,
+                                                          unsigned short* __restrict__ vcache, const float* __restrict__ inv_freq,
+                                                          const long long* __restrict__ posp, int n_heads, int n_kv, int hd,
+                                                          int capacity, float rope_scale, int traditional) {
+  const int b = blockIdx.y, hh = blockIdx.x;            // hh < n_heads: query head; else kv head hh - n_heads
+  const int pos = static_cast<int>(*posp);
+  const bool isk = hh >= n_heads;
+  const int kvh = hh - n_heads;
+  const unsigned short* src = isk ? k + (static_cast<size_t>(b) * n_kv + kvh) * hd : q + (static_cast<size_t>(b) * n_heads + hh) * hd;
+  unsigned short* dst = isk ? kcache + ((static_cast<size_t>(b) * n_kv + kvh) * capacity + pos) * hd
+                            : q + (static_cast<size_t>(b) * n_heads + hh) * hd;
+  for (int i = threadIdx.x; i < hd / 2; i += blockDim.x) {
+    const int i1 = traditional ? 2 * i : i, i2 = traditional ? 2 * i + 1 : i + hd / 2;
+    const float x1 = act_to_f32<BF16>(src[i1]), x2 = act_to_f32<BF16>(src[i2]);
+    const float rev = static_cast<float>(pos) * rope_scale * inv_freq[i] * 0.15915494309189535f;
+    const float fr = rev - floorf(rev);
+    const float sn = __builtin_amdgcn_sinf(fr), cs = __builtin_amdgcn_cosf(fr);
+    dst[i1] = f32_to_act<BF16>(x1 * cs - x2 * sn);
+    dst[i2] = f32_to_act<BF16>(x1 * sn + x2 * cs);
+  }
+  if (isk) {
+    const unsigned short* vs = v + (static_cast<size_t>(b) * n_kv + kvh) * hd;
+    unsigned short* vd = vcache + ((static_cast<size_t>(b) * n_kv + kvh) * capacity + pos) * hd;
+    for (int i = threadIdx.x; i < hd; i += blockDim.x) vd[i] = vs[i];
+  }
+}
+
+hipError_t launch_rope_append(void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
+                              const long long* pos, int batch, int n_heads, int n_kv, int hd, int capacity, float rope_scale,
+                              int traditional, bool bf16, hipStream_t s) {
+  dim3 grid(n_heads + n_kv, batch), block(128);
+  auto Q = static_cast<unsigned short*>(q);
+  auto K = static_cast<const unsigned short*>(k);
+  auto V = static_cast<const unsigned short*>(v);
+  auto KC = static_cast<unsigned short*>(kcache);
+  auto VC = static_cast<unsigned short*>(vcache);
+  if (bf16) hipLaunchKernelGGL((rope_append_kernel<true>), grid, block, 0, s, Q, K, V, KC, VC, inv_freq, pos, n_heads, n_kv, hd, capacity, rope_scale, traditional);
+  else hipLaunchKernelGGL((rope_append_kernel<false>), grid, block, 0, s, Q, K, V, KC, VC, inv_freq, pos, n_heads, n_kv, hd, capacity, rope_scale, traditional);
+  return hipGetLastError();
+}
+
 }  // namespace gbx

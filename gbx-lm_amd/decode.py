@@ -19,7 +19,9 @@ from .tp import all_reduce_
 
 
 class DecodeRunner:
-    """Owns the captured graph for one model and one KV-cache capacity (B = 1, one new token per replay)."""
+    """Owns the captured graph for one model and one KV-cache capacity: one new token per sequence and replay.  The
+    batch is whatever the KV cache holds (B = 1 for the reference's generate loop; B > 1 = synchronous batched decode,
+    every sequence at the same position, QuantizedLinear then runs the split-K MFMA kernel)."""
 
     def __init__(self, model, caches: List[KVCache], use_graph: bool = True):
         self.model = model
@@ -28,7 +30,8 @@ class DecodeRunner:
         self.caches = caches
         self.capacity = caches[0].capacity
         self.dtype = model.model.embed_tokens.weight.dtype
-        self.tok = torch.zeros((1,), dtype=torch.long, device=self.dev)
+        self.batch = caches[0].keys.shape[0] if caches[0].keys is not None else 1
+        self.tok = torch.zeros((self.batch,), dtype=torch.long, device=self.dev)
         self.pos = torch.zeros((1,), dtype=torch.long, device=self.dev)
         self.logits = None
         self.graph = None
@@ -44,30 +47,37 @@ class DecodeRunner:
     def _forward(self):
         m = self.model.model
         pos = self.pos
-        h = m.embed_tokens(self.tok)[None]                       # [1, 1, D]
+        B = self.batch
+        h = m.embed_tokens(self.tok)[:, None]                    # [B, 1, D]
         mask = torch.where(self.ar[None, None, None, :] <= pos, 0.0, float("-inf")).to(self.dtype)
         for layer, c in zip(m.layers, self.caches):
             at = layer.self_attn
-            x = layer.input_layernorm(h)
-            q = at.q_proj(x).reshape(1, 1, self.n_heads, self.hd).transpose(1, 2)
-            k = at.k_proj(x).reshape(1, 1, self.n_kv, self.hd).transpose(1, 2)
-            v = at.v_proj(x).reshape(1, 1, self.n_kv, self.hd).transpose(1, 2)
-            q = _rope_at(q, at.rope, pos)
-            k = _rope_at(k, at.rope, pos)
-            c.keys.index_copy_(2, pos, k)
-            c.values.index_copy_(2, pos, v)
+            x = ops.rmsnorm(h, layer.input_layernorm.weight, layer.input_layernorm.eps)     # one launch (gbx_rmsnorm)
+            q, k, v = at.q_proj(x).reshape(B, -1), at.k_proj(x).reshape(B, -1), at.v_proj(x).reshape(B, -1)
+            if at.rope.inv_freq.numel() * 2 == self.hd and c.keys.is_contiguous() and c.values.is_contiguous():
+                # one launch: rotate q in place, rotate k / copy v into the cache at the device-resident position
+                ops.rope_append(q, k, v, c.keys, c.values, at.rope.inv_freq, pos, self.n_heads, self.n_kv, self.hd,
+                                getattr(at.rope, "scale", 1.0), at.rope.traditional)
+            else:                                                    # partial-width RoPE: torch glue
+                q = _rope_at(q.reshape(B, 1, self.n_heads, self.hd).transpose(1, 2), at.rope, pos).transpose(1, 2)
+                kr = _rope_at(k.reshape(B, 1, self.n_kv, self.hd).transpose(1, 2), at.rope, pos)
+                c.keys.index_copy_(2, pos, kr)
+                c.values.index_copy_(2, pos, v.reshape(B, 1, self.n_kv, self.hd).transpose(1, 2))
+            # grouped-query attention over the whole (static) cache buffer without materialising repeated K/V:
+            # q [B, n_kv, rep, hd] x K^T [B, n_kv, hd, cap]; positions past `pos` are masked
             rep = self.n_heads // self.n_kv
-            kk = c.keys.repeat_interleave(rep, dim=1) if rep > 1 else c.keys
-            vv = c.values.repeat_interleave(rep, dim=1) if rep > 1 else c.values
-            o = F.scaled_dot_product_attention(q, kk, vv, attn_mask=mask, scale=at.scale)
-            o = at.o_proj(o.transpose(1, 2).reshape(1, 1, -1))
+            qg = q.reshape(B, self.n_kv, rep, self.hd)
+            sc = torch.matmul(qg, c.keys.transpose(-1, -2)).float() * at.scale + mask.float()
+            p = torch.softmax(sc, dim=-1).to(self.dtype)
+            o = torch.matmul(p, c.values)                            # [B, n_kv, rep, hd]
+            o = at.o_proj(o.reshape(B, 1, -1))
             if self.tp_world > 1:
                 all_reduce_(o, at.tp_group)
             h = h + o
-            x = layer.post_attention_layernorm(h)
+            x = ops.rmsnorm(h, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.eps)
             h = h + layer.mlp(x)
-        out = m.norm(h)
-        return F.linear(out, self.model.head_weight())[:, -1, :]   # [1, V]
+        out = ops.rmsnorm(h, m.norm.weight, m.norm.eps)
+        return F.linear(out, self.model.head_weight())[:, -1, :]   # [B, V]
 
     def _capture(self):
         chain = getattr(self, "chain", False)
@@ -87,7 +97,7 @@ class DecodeRunner:
 
     def start_greedy(self, token: torch.Tensor) -> None:
         """Begin an on-device greedy chain whose first input token is ``token``."""
-        self._next = token.reshape(1).clone()
+        self._next = token.reshape(-1).clone()
 
     def step_greedy(self) -> torch.Tensor:
         """One greedy token: feeds the previous argmax back in.  Generic version (argmax by torch)."""
@@ -96,9 +106,9 @@ class DecodeRunner:
         return logits
 
     def step(self, token: torch.Tensor) -> torch.Tensor:
-        """Consumes one token id (device tensor, shape [1]); returns logits [1, V] (a static buffer)."""
+        """Consumes one token id per sequence (device tensor, shape [B]); returns logits [B, V] (a static buffer)."""
         off = self.caches[0].offset
-        self.tok.copy_(token.reshape(1))
+        self.tok.copy_(token.reshape(-1))
         self.pos.fill_(off)
         if self.use_graph:
             self.graph.replay()

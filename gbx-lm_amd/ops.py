@@ -240,6 +240,21 @@ def dense_gemv(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = N
     return out
 
 
+def rope_append(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor,
+                inv_freq: torch.Tensor, pos: torch.Tensor, n_heads: int, n_kv: int, head_dim: int,
+                rope_scale: float, traditional: bool) -> None:
+    """Batched one-token RoPE + KV-cache append (gbx_rope_append): q [B, n_heads*hd] rotated in place, k/v [B, n_kv*hd]
+    written at the device-resident position ``pos`` of caches [B, n_kv, capacity, hd]."""
+    for t in (q, k, v, kcache, vcache):
+        _require_cuda(t, "rope_append tensor")
+        if not t.is_contiguous():
+            raise ValueError("rope_append needs contiguous tensors")
+    _lib.check(_lib.lib().gbx_rope_append(q.data_ptr(), k.data_ptr(), v.data_ptr(), kcache.data_ptr(), vcache.data_ptr(),
+                                          inv_freq.data_ptr(), pos.data_ptr(), q.shape[0], n_heads, n_kv, head_dim,
+                                          kcache.shape[2], float(rope_scale), int(bool(traditional)), _DT[q.dtype],
+                                          _stream_ptr(q.device)))
+
+
 def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _require_cuda(x, "x")
     k = x.shape[-1]

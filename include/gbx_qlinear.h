@@ -177,6 +177,14 @@ int gbx_embed_next_token(void* argmax_keys, int64_t* token_io, int64_t* pos, con
                          int32_t D, int32_t vocab, int32_t from_keys, int32_t advance_pos, int32_t act_dtype,
                          void* hip_stream);
 
+/* Synchronous batched decode step, every sequence at position *pos (device int64): q[batch, n_heads*head_dim] is rotated
+ * in place, k[batch, n_kv*head_dim] is rotated into kcache[b, kvh, *pos, :], v copied into vcache[b, kvh, *pos, :]
+ * (caches [batch, n_kv, capacity, head_dim]).  rope(q), rope(k), cache.update_and_fetch of qllama.py:84-91 for one new
+ * token per sequence; rope over the full head_dim like gbx_attn_decode. */
+int gbx_rope_append(void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
+                    const int64_t* pos, int32_t batch, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int32_t capacity,
+                    float rope_scale, int32_t traditional, int32_t act_dtype, void* hip_stream);
+
 /* y[M,K] = RMSNorm(x[M,K]) * w[K] (fp32 statistics, one rounding).  mx.nn.RMSNorm as used at qllama.py:125-128,155. */
 int gbx_rmsnorm(const void* x, const void* w, void* y, int64_t M, int32_t K, float eps, int32_t act_dtype,
                 void* hip_stream);

@@ -366,3 +366,24 @@ def test_tiled_gemv_fused_variants(oracle, dt):
     ops.gemv_tiled(xd, wt2, szt2, nd, kd, out=h, residual=h)
     y64 = oracle.qlinear_ref(xd.cpu()[None], dd["qweight"], dd["scales"], dd["zeros"], 2, 128, acc=np.float64)
     oracle.assert_close(h[None], h0.cpu().double().numpy()[None] + y64, act, "tiled residual")
+
+
+@pytest.mark.parametrize("traditional", [False, True])
+def test_rope_append_batched(traditional):
+    from gbx_lm_amd import ops
+    from gbx_lm_amd.models.rope_utils import RoPE, apply_rope
+    B, nh, nkv, hd, cap, pos = 5, 8, 2, 128, 64, 37
+    q = torch.randn(B, nh * hd).to(torch.bfloat16).to(DEV)
+    k = torch.randn(B, nkv * hd).to(torch.bfloat16).to(DEV)
+    v = torch.randn(B, nkv * hd).to(torch.bfloat16).to(DEV)
+    kc = torch.zeros(B, nkv, cap, hd, dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros_like(kc)
+    rope = RoPE(hd, traditional=traditional).to(DEV)
+    q0 = q.clone()
+    ops.rope_append(q, k, v, kc, vc, rope.inv_freq, torch.tensor([pos], device=DEV), nh, nkv, hd, 1.0, traditional)
+    qr = apply_rope(q0.view(B, 1, nh, hd).transpose(1, 2), rope.inv_freq, pos, 1.0, traditional).transpose(1, 2).reshape(B, -1)
+    kr = apply_rope(k.view(B, 1, nkv, hd).transpose(1, 2), rope.inv_freq, pos, 1.0, traditional)
+    assert torch.allclose(q.float(), qr.float(), atol=2e-2, rtol=2e-2)
+    assert torch.allclose(kc[:, :, pos].float(), kr[:, :, 0].float(), atol=2e-2, rtol=2e-2)
+    assert torch.equal(vc[:, :, pos], v.view(B, nkv, hd))
+    assert torch.count_nonzero(kc[:, :, :pos]) == 0 and torch.count_nonzero(kc[:, :, pos + 1:]) == 0
