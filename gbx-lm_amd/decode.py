@@ -159,8 +159,12 @@ class FusedDecodeRunner(DecodeRunner):
         mk = lambda n: torch.zeros((n,), dtype=dt, device=dev)
         self.hb, self.qb, self.kb, self.vb = mk(D), mk(a0.n_heads * a0.head_dim), mk(a0.n_kv_heads * a0.head_dim), mk(a0.n_kv_heads * a0.head_dim)
         self.ab, self.actb = mk(a0.n_heads * a0.head_dim), mk(I)
-        self.pb = mk(D)                    # TP: this rank's partial o_proj / down_proj output before the all-reduce
+        # TP: the residual stream ping-pongs between hb and pb.  Rank 0 folds the residual into its partial sum
+        # (y = stream + W_0 x), the other ranks write bare partials, and the all-reduce of that buffer IS the new stream --
+        # no separate residual-add launch between the collective and the next GEMV.
+        self.pb = mk(D)
         tp = getattr(model, "tp_world", 1) > 1
+        r0 = getattr(model, "tp_rank", 0) == 0
         self.logits_buf = torch.zeros((1, model.head_weight().shape[0]), dtype=dt, device=dev)
         self.keys = torch.zeros((64,), dtype=torch.int64, device=dev)      # sharded (value, index) argmax keys (uint64 bits)
         self.chain = False                  # True while capturing / replaying the on-device greedy chain
@@ -178,12 +182,12 @@ class FusedDecodeRunner(DecodeRunner):
             self.descs.append((
                 ops.make_fused_desc(self.hb, (at.q_proj, at.k_proj, at.v_proj), (self.qb, self.kb, self.vb),
                                     norm_weight=blk.input_layernorm.weight, eps=eps, packed=p_qkv),
-                ops.make_fused_desc(self.ab, (at.o_proj,), (self.pb,), packed=p_o) if tp else
+                ops.make_fused_desc(self.ab, (at.o_proj,), (self.pb,), residual=self.hb if r0 else None, packed=p_o) if tp else
                 ops.make_fused_desc(self.ab, (at.o_proj,), (self.hb,), residual=self.hb, packed=p_o),
-                ops.make_fused_desc(self.hb, (mlp.gate_proj, mlp.up_proj), (self.actb,),
+                ops.make_fused_desc(self.pb if tp else self.hb, (mlp.gate_proj, mlp.up_proj), (self.actb,),
                                     norm_weight=blk.post_attention_layernorm.weight, eps=blk.post_attention_layernorm.eps,
                                     swiglu=True, packed=p_gu),
-                ops.make_fused_desc(self.actb, (mlp.down_proj,), (self.pb,), packed=p_dn) if tp else
+                ops.make_fused_desc(self.actb, (mlp.down_proj,), (self.hb,), residual=self.pb if r0 else None, packed=p_dn) if tp else
                 ops.make_fused_desc(self.actb, (mlp.down_proj,), (self.hb,), residual=self.hb, packed=p_dn),
             ))
         super().__init__(model, caches, use_graph=use_graph)
@@ -202,14 +206,12 @@ class FusedDecodeRunner(DecodeRunner):
                             at.n_heads, at.n_kv_heads, at.head_dim, c.capacity, getattr(at.rope, "scale", 1.0), at.scale,
                             at.rope.traditional)
             ops.qlinear_fused(d_o, dev)
-            if self.tp_world > 1:            # K-split layer: partial sums meet over RCCL, then join the residual stream
+            if self.tp_world > 1:            # K-split layer: partial sums (+ rank 0's residual) meet over RCCL in pb
                 all_reduce_(self.pb, at.tp_group)
-                self.hb.add_(self.pb)
             ops.qlinear_fused(d_gu, dev)
             ops.qlinear_fused(d_dn, dev)
-            if self.tp_world > 1:
-                all_reduce_(self.pb, blk.mlp.tp_group)
-                self.hb.add_(self.pb)
+            if self.tp_world > 1:            # ... and the stream returns to hb
+                all_reduce_(self.hb, blk.mlp.tp_group)
         ops.dense_gemv(self.hb, self.model.head_weight(), out=self.logits_buf.view(-1), norm_weight=m.norm.weight,
                        eps=m.norm.eps, argmax_keys=self.keys)
         return self.logits_buf
