@@ -66,18 +66,26 @@ class FusedDesc(ctypes.Structure):
 
 
 def _declare_optional(L) -> None:
-    """argtypes of the fused decode-block entry points."""
+    """argtypes of the entry points beyond the core forward (declared one by one so that a diagnostic build that lacks
+    one of them -- GBX_QLINEAR_LIB -- still loads; calling a missing entry point raises AttributeError)."""
     i64, i32, p, f32 = ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_float
-    L.gbx_qlinear_fused_forward.argtypes = [ctypes.POINTER(FusedDesc), p]
-    L.gbx_attn_decode.argtypes = [p, p, p, p, p, p, p, p, i32, i32, i32, i32, f32, f32, i32, i32, p]
-    L.gbx_dense_gemv.argtypes = [p, p, p, p, f32, i32, i32, i32, p]
-    L.gbx_rmsnorm.argtypes = [p, p, p, i64, i32, f32, i32, p]
-    L.gbx_dense_gemv_argmax.argtypes = [p, p, p, p, f32, i32, i32, p, i32, p]
-    L.gbx_embed_next_token.argtypes = [p, p, p, p, p, i32, i32, i32, i32, i32, p]
-    L.gbx_rope_append.argtypes = [p, p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, i32, i32, p]
-    L.gbx_pack_scales_zeros.argtypes = [p, p, p, p, p, i32, i32, p]
-    L.gbx_qlinear_prepack_tiles.argtypes = [p, p, p, p, p, p, p, p, i32, i32, i32, i32, p]
-    L.gbx_gemv_tiled.argtypes = [p, p, p, p, i32, i32, i32, i32, p, f32, p, i32, i32, p]
+    table = {
+        "gbx_qlinear_fused_forward": [ctypes.POINTER(FusedDesc), p],
+        "gbx_attn_decode": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, f32, f32, i32, i32, p],
+        "gbx_dense_gemv": [p, p, p, p, f32, i32, i32, i32, p],
+        "gbx_rmsnorm": [p, p, p, i64, i32, f32, i32, p],
+        "gbx_dense_gemv_argmax": [p, p, p, p, f32, i32, i32, p, i32, p],
+        "gbx_embed_next_token": [p, p, p, p, p, i32, i32, i32, i32, i32, p],
+        "gbx_gather_qlinear_forward": [p, p, p, p, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, p],
+        "gbx_rope_append": [p, p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, i32, i32, p],
+        "gbx_pack_scales_zeros": [p, p, p, p, p, i32, i32, p],
+        "gbx_qlinear_prepack_tiles": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, p],
+        "gbx_gemv_tiled": [p, p, p, p, i32, i32, i32, i32, p, f32, p, i32, i32, p],
+    }
+    for name, argtypes in table.items():
+        fn = getattr(L, name, None)
+        if fn is not None:
+            fn.argtypes = argtypes
 
 
 def check(rc: int) -> None:

@@ -51,6 +51,12 @@ struct GemvArgs {
   // (pairs (2p, 2p+1); every segment has an even N), or [N][K/g][2] = (gate row p, up row p) for a SwiGLU launch --
   // so a lane fetches both rows' scale and zero with ONE 8-byte load (gbx_pack_scales_zeros)
   const uint32_t* sz;
+  // ---- expert-indexed launch (QuantizedSwitchLinear / mx.gather_qmm, switch_layers.py:78-92): blockIdx.y = (token, slot)
+  // pair p; its activation row is x[p / x_div], its matrix is expert expert_idx[p] of the stacked [E, N, ...] tensors
+  const int* expert_idx;           // [pairs] or null
+  int x_div;                       // pairs that share one activation row (k for up/gate, 1 for down); >= 1
+  int num_experts;
+  long long e_stride_w, e_stride_g;   // elements between experts: N*W words, N*G scales
 #ifdef GBX_STAMPS
   unsigned long long* stamps;      // diagnostic build only: [workgroup][wave][8] s_memrealtime stamps
 #endif
@@ -204,9 +210,12 @@ __device__ __forceinline__ float round_bf16_or_f16(float v, bool bf16) {
 template <int P> struct WavesPerBlock { static constexpr int value = (P == 1) ? 16 : 8; };   // "fat" geometry
 
 // SPLIT (2-bit only): group_size 32, i.e. the two 32-value halves of a lane's slot carry different scales.
-// PK: scales/zeros come from the packed companion GemvSeg::sz (N of every segment even).
-template <int BITS, int P, int KS, int D, bool BF16, bool SPLIT, int NW, bool PK>
+// MODE 1 (PK): scales/zeros come from the packed companion GemvArgs::sz (N of every segment even).
+// MODE 2 (GATHER): expert-indexed launch (GemvArgs::expert_idx).  Compile-time so that the plain decode launches carry
+// neither the expert-offset arithmetic nor its kernel arguments' loads (measured: 1.5-2 % of a token when done at run time).
+template <int BITS, int P, int KS, int D, bool BF16, bool SPLIT, int NW, int MODE>
 __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
+  constexpr bool PK = MODE == 1, GATHER = MODE == 2;
   constexpr int NT = NW * 64;
   constexpr int GPB = NW / 4;                                 // KS == 4: row groups (of four K-quarter waves) per workgroup
   using F = Fmt<BITS>;
@@ -232,7 +241,13 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
   const int W = K / 32 * BITS;                    // words per packed row
   const int G = K >> a.log2g;                     // groups per row
   const int m = blockIdx.y;                       // activation row (M > 1 re-streams the weights)
-  const unsigned short* __restrict__ xg = static_cast<const unsigned short*>(a.x) + static_cast<size_t>(m) * K;
+  int xrow = m;
+  long long eo = 0;       // expert of this pair (wave-uniform scalar load; clamped so that a bad index cannot leave the tensors)
+  if constexpr (GATHER) {
+    xrow = m / a.x_div;
+    eo = static_cast<long long>(min(max(a.expert_idx[m], 0), a.num_experts - 1));
+  }
+  const unsigned short* __restrict__ xg = static_cast<const unsigned short*>(a.x) + static_cast<size_t>(xrow) * K;
   const int gshift = a.log2g - 5;                 // 32-value sub-slot index -> group index
   const bool swiglu = a.swiglu != 0;
   const int rowstep = swiglu ? 1 : R;             // output rows covered by one batch
@@ -254,9 +269,9 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
   // computed index instead makes hipcc fetch it with VECTOR loads and drain vmcnt on every row.)
   constexpr int RS_FLAGS = 0x00020000, RS_ALL = 0x7FFFFFFF;
   auto rsrc = [](const void* ptr) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, RS_ALL, RS_FLAGS); };
-  const uint32_t* const q0 = a.seg[0].qweight; const uint32_t* const q1 = a.seg[1].qweight; const uint32_t* const q2 = a.seg[2].qweight;
-  const unsigned short* const s0 = a.seg[0].scales; const unsigned short* const s1 = a.seg[1].scales; const unsigned short* const s2 = a.seg[2].scales;
-  const unsigned short* const z0 = a.seg[0].zeros; const unsigned short* const z1 = a.seg[1].zeros; const unsigned short* const z2 = a.seg[2].zeros;
+  const uint32_t* const q0 = a.seg[0].qweight + (GATHER ? eo * a.e_stride_w : 0); const uint32_t* const q1 = a.seg[1].qweight; const uint32_t* const q2 = a.seg[2].qweight;
+  const unsigned short* const s0 = a.seg[0].scales + (GATHER ? eo * a.e_stride_g : 0); const unsigned short* const s1 = a.seg[1].scales; const unsigned short* const s2 = a.seg[2].scales;
+  const unsigned short* const z0 = a.seg[0].zeros + (GATHER ? eo * a.e_stride_g : 0); const unsigned short* const z1 = a.seg[1].zeros; const unsigned short* const z2 = a.seg[2].zeros;
   unsigned short* const y0 = a.seg[0].y; unsigned short* const y1 = a.seg[1].y; unsigned short* const y2 = a.seg[2].y;
   const int n1 = a.seg[1].N, n2 = a.seg[2].N;
   // row of batch element i -> (segment, local row); wave-uniform
@@ -570,10 +585,12 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
 // y[m, n] += bias[n] (second rounding, like the reference's separate `x + self.bias`, quantized_linear_gba.py:204-205)
 template <bool BF16>
 __global__ __launch_bounds__(256) void add_bias_kernel(unsigned short* __restrict__ y, const unsigned short* __restrict__ bias,
-                                                       int N, size_t total) {
+                                                       int N, size_t total, const int* __restrict__ expert_idx, int num_experts) {
   for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < total;
-       i += static_cast<size_t>(gridDim.x) * blockDim.x)
-    y[i] = f32_to_act<BF16>(act_to_f32<BF16>(y[i]) + act_to_f32<BF16>(bias[i % N]));
+       i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    const size_t e = expert_idx ? static_cast<size_t>(min(max(expert_idx[i / N], 0), num_experts - 1)) : 0;   // bias[indices] (switch_layers.py:90-91)
+    y[i] = f32_to_act<BF16>(act_to_f32<BF16>(y[i]) + act_to_f32<BF16>(bias[e * N + i % N]));
+  }
 }
 
 // Host-side launcher for one bit width (defined per TU so the three widths compile in parallel).
@@ -584,7 +601,7 @@ constexpr int GEMV_MAX_BATCHES_PER_GROUP_KS4 = 256;
 constexpr int GEMV_CUS = 256;                  // MI355X
 
 // Workgroups of this kernel variant that are resident at once on the whole chip (asked once, then cached).
-template <int BITS, int P, int KS, int D, bool SPLIT, int NW, bool PK>
+template <int BITS, int P, int KS, int D, bool SPLIT, int NW, int PK>
 static int resident_blocks(bool bf16, size_t shmem) {
   static int cached[2] = {0, 0};
   int& c = cached[bf16 ? 1 : 0];
@@ -607,7 +624,7 @@ static size_t gemv_shmem(int K, int bpo) {
   return b;
 }
 
-template <int BITS, int P, int KS, int D, bool SPLIT, int NW, bool PK>
+template <int BITS, int P, int KS, int D, bool SPLIT, int NW, int PK>
 static hipError_t launch_gemv_d(const GemvArgs& a, int M, bool bf16, int bpo, int nbatches, hipStream_t stream) {
   GemvArgs args = a;
   args.batches_per_owner = bpo;
@@ -622,8 +639,8 @@ static hipError_t launch_gemv_d(const GemvArgs& a, int M, bool bf16, int bpo, in
     const size_t total = static_cast<size_t>(M) * a.N;
     const int bb = static_cast<int>(std::min<size_t>((total + 255) / 256, 2048));
     auto B = static_cast<const unsigned short*>(a.bias);
-    if (bf16) hipLaunchKernelGGL((add_bias_kernel<true>), dim3(bb), dim3(256), 0, stream, a.seg[0].y, B, a.N, total);
-    else hipLaunchKernelGGL((add_bias_kernel<false>), dim3(bb), dim3(256), 0, stream, a.seg[0].y, B, a.N, total);
+    if (bf16) hipLaunchKernelGGL((add_bias_kernel<true>), dim3(bb), dim3(256), 0, stream, a.seg[0].y, B, a.N, total, a.expert_idx, a.num_experts);
+    else hipLaunchKernelGGL((add_bias_kernel<false>), dim3(bb), dim3(256), 0, stream, a.seg[0].y, B, a.N, total, a.expert_idx, a.num_experts);
     e = hipGetLastError();
   }
   return e;
@@ -631,7 +648,7 @@ static hipError_t launch_gemv_d(const GemvArgs& a, int M, bool bf16, int bpo, in
 
 // One round of co-resident workgroups covers all rows: pick the shallowest ring whose resident owners can hold the
 // batches, else split the batches evenly over the resident owners of the deepest ring (multiples of D per owner).
-template <int BITS, int P, int KS, bool SPLIT, int NW, bool PK>
+template <int BITS, int P, int KS, bool SPLIT, int NW, int PK>
 static hipError_t launch_gemv_nw(const GemvArgs& a, int M, bool bf16, int nbatches, hipStream_t stream) {
   const int opb = (KS == 1) ? NW : NW / 4;                 // row owners per workgroup
   const int own1 = resident_blocks<BITS, P, KS, 1, SPLIT, NW, PK>(bf16, gemv_shmem<BITS, P, KS, NW>(a.K, 1)) * opb;
@@ -650,11 +667,15 @@ static hipError_t launch_gemv_p(const GemvArgs& a, int M, bool bf16, hipStream_t
   const int rowstep = a.swiglu ? 1 : GEMV_R;
   const int nbatches = (a.N + rowstep - 1) / rowstep;
   if (a.sz) {              // packed scale/zero companion of the launch (decode runner)
-    if (KS == 1 && nbatches <= 4096) return launch_gemv_nw<BITS, P, KS, SPLIT, 4, true>(a, M, bf16, nbatches, stream);
-    return launch_gemv_nw<BITS, P, KS, SPLIT, WavesPerBlock<P>::value, true>(a, M, bf16, nbatches, stream);
+    if (KS == 1 && nbatches <= 4096) return launch_gemv_nw<BITS, P, KS, SPLIT, 4, 1>(a, M, bf16, nbatches, stream);
+    return launch_gemv_nw<BITS, P, KS, SPLIT, WavesPerBlock<P>::value, 1>(a, M, bf16, nbatches, stream);
   }
-  if (KS == 1 && nbatches <= 4096) return launch_gemv_nw<BITS, P, KS, SPLIT, 4, false>(a, M, bf16, nbatches, stream);
-  return launch_gemv_nw<BITS, P, KS, SPLIT, WavesPerBlock<P>::value, false>(a, M, bf16, nbatches, stream);
+  if (a.expert_idx) {      // expert-indexed pairs (QuantizedSwitchLinear)
+    if (KS == 1 && nbatches <= 4096) return launch_gemv_nw<BITS, P, KS, SPLIT, 4, 2>(a, M, bf16, nbatches, stream);
+    return launch_gemv_nw<BITS, P, KS, SPLIT, WavesPerBlock<P>::value, 2>(a, M, bf16, nbatches, stream);
+  }
+  if (KS == 1 && nbatches <= 4096) return launch_gemv_nw<BITS, P, KS, SPLIT, 4, 0>(a, M, bf16, nbatches, stream);
+  return launch_gemv_nw<BITS, P, KS, SPLIT, WavesPerBlock<P>::value, 0>(a, M, bf16, nbatches, stream);
 }
 
 // max K the lane-resident fast path covers for a bit width (beyond -> generic kernel)

@@ -32,6 +32,11 @@ def _is_gba_linear(m) -> bool:
     return isinstance(m, QuantizedLinear)
 
 
+def _is_gba_linear_or_switch(m) -> bool:
+    from .switch_layers import QuantizedSwitchLinear          # late import: switch_layers imports ops like this module
+    return isinstance(m, (QuantizedLinear, QuantizedSwitchLinear))
+
+
 class QuantizedLinear(nn.Module):
     """y = x @ dequant(qweight, scales, zeros)^T (+ bias), weights packed at 2/3/4 bits."""
 
@@ -129,7 +134,29 @@ class QuantizedLinear(nn.Module):
                     m.bits = bits
                     m.init_params(use_double_quantization, use_q_perm)
             return
+        from .switch_layers import QuantizedSwitchLinear
+        last_strg = None
         for name, child in model.named_modules():
+            if isinstance(child, QuantizedSwitchLinear):
+                # stacked experts: strategy["model.layers.<i>"]["moe_expert_<proj>"] over gate/up/down only (:236-252)
+                per_block = strategy["model.layers.{}".format(name.split('.')[2])]
+                strg = None
+                for key in ('gate_proj', 'up_proj', 'down_proj'):
+                    if key in name:
+                        try:
+                            strg = per_block['moe_expert_' + key]
+                            break
+                        except KeyError:
+                            pass
+                if strg is None:
+                    raise KeyError(f"quant strategy has no moe_expert entry for {name}")
+                child.bits = strg["bits"][0]
+                child.group_size = strg["group_size"][str(child.bits)]
+                assert child.group_size in [32, 64, 128], \
+                    f"The group size value ({child.group_size}) must be 32, 64 or 128."
+                child.init_params()
+                last_strg = strg
+                continue
             if not isinstance(child, QuantizedLinear):
                 continue
             layer_number = name.split('.')[2]
@@ -145,7 +172,13 @@ class QuantizedLinear(nn.Module):
                     except KeyError:
                         pass
             if strg is None:
+                # A name none of the keys matches -- the MoE router ``mlp.gate`` -- keeps the entry of the module visited
+                # just before it in the reference (its loop variable simply carries over, :256-272), i.e. o_proj's:
+                # checkpoints are laid out accordingly, so the carry-over is part of the format.
+                strg = last_strg
+            if strg is None:
                 raise KeyError(f"quant strategy has no entry for {name}")
+            last_strg = strg
             child.bits = strg["bits"][0]
             child.group_size = strg["group_size"][str(child.bits)]
             assert child.group_size in [32, 64, 128], \
@@ -161,7 +194,7 @@ class QuantizedLinear(nn.Module):
 
     @classmethod
     def post_processing_and_release(cls, model: nn.Module,
-                                    gba_linear_class_predicate: Callable = _is_gba_linear) -> None:
+                                    gba_linear_class_predicate: Callable = _is_gba_linear_or_switch) -> None:
         """zeros -> -zeros for GBA-native checkpoints (:303-324)."""
         for m in model.modules():
             if gba_linear_class_predicate(m):

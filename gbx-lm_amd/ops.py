@@ -128,6 +128,51 @@ def pack_scales_zeros(mod, mod2=None) -> torch.Tensor:
     return out
 
 
+def gather_quantized_matmul(x: torch.Tensor, w: torch.Tensor, scales: torch.Tensor, biases: torch.Tensor,
+                            rhs_indices: torch.Tensor, transpose: bool = True, group_size: int = 64, bits: int = 4,
+                            sorted_indices: bool = False, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``mx.gather_qmm(x, w[E,N,W], scales[E,N,G], biases[E,N,G], rhs_indices=indices, transpose=True, ...)`` as
+    QuantizedSwitchLinear calls it (gbx_lm/models/switch_layers.py:78-92), plus the optional ``bias[indices]``.
+
+    x: [..., 1, 1, K] or [..., k, 1, K]; rhs_indices: [..., k] -> [..., k, 1, N].  Few (token, slot) pairs run the
+    expert-indexed decode GEMV in ONE launch; many pairs are grouped by expert on the host (one batched GEMM per
+    expert present -- the reference's ``sorted_indices`` hint needs no special handling)."""
+    if not transpose:
+        raise NotImplementedError("gather_quantized_matmul supports transpose=True only (the reference's only use)")
+    for t, nm in ((x, "x"), (w, "w"), (scales, "scales"), (biases, "biases"), (rhs_indices, "rhs_indices")):
+        _require_cuda(t, nm)
+    E, N = w.shape[0], w.shape[1]
+    K = x.shape[-1]
+    if w.shape[2] * 32 != K * bits:
+        raise ValueError(f"packed width {w.shape[2]} does not match K={K} at {bits} bits")
+    if group_size not in (32, 64, 128):
+        raise ValueError(f"The group size value ({group_size}) must be 32, 64 or 128.")
+    k = rhs_indices.shape[-1]
+    lead = tuple(rhs_indices.shape[:-1])
+    if x.shape[-2] != 1 or x.shape[-3] not in (1, k) or tuple(x.shape[:-3]) != lead:
+        raise ValueError(f"x {tuple(x.shape)} does not broadcast against indices {tuple(rhs_indices.shape)}")
+    shared = x.shape[-3] == 1
+    pairs = rhs_indices.numel()
+    xr = x.reshape(-1, K).contiguous()                  # [tokens, K] (shared) or [pairs, K]
+    idx = rhs_indices.reshape(-1)
+    y = torch.empty((pairs, N), dtype=x.dtype, device=x.device)
+    max_k = 512 * (64 if bits == 2 else 32)
+    if pairs <= 64 and K % 128 == 0 and K <= max_k:
+        idx32 = idx if idx.dtype == torch.int32 else idx.to(torch.int32)
+        _lib.check(_lib.lib().gbx_gather_qlinear_forward(
+            xr.data_ptr(), w.data_ptr(), scales.data_ptr(), biases.data_ptr(), bias.data_ptr() if bias is not None else None,
+            idx32.data_ptr(), y.data_ptr(), pairs, k if shared else 1, E, N, K, bits, group_size, _DT[x.dtype],
+            _stream_ptr(x.device)))
+    else:                                               # grouped by expert (one host sync for the expert list)
+        ar = torch.arange(pairs, device=x.device)
+        rows = ar // k if shared else ar
+        for e in torch.unique(idx).tolist():
+            sel = (idx == e).nonzero(as_tuple=True)[0]
+            y[sel] = quantized_matmul(xr[rows[sel]], w[e], scales=scales[e], biases=biases[e], transpose=True,
+                                      group_size=group_size, bits=bits, bias=bias[e] if bias is not None else None)
+    return y.reshape(*lead, k, 1, N)
+
+
 def prepack_tiles(mod, mod_up=None):
     """Load-time tiled form of a 2-bit / group-128 QuantizedLinear for the matrix-core decode GEMV
     (gbx_qlinear_prepack_tiles): returns ``(wt, szt)`` int32 tensors.  With ``mod_up`` the pair (gate_proj, up_proj) is

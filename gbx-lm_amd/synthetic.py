@@ -13,7 +13,8 @@ from typing import Dict, Optional
 
 import torch
 
-from .models import qllama
+from .models import qllama, qqwen3_moe
+from .models.switch_layers import QuantizedSwitchLinear
 from .models.quantized_linear_gba import QuantizedLinear
 
 PROJ = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")
@@ -31,6 +32,13 @@ LLAMA32_3B = dict(model_type="llama", hidden_size=3072, intermediate_size=8192, 
 TINY = dict(model_type="llama", hidden_size=256, intermediate_size=512, num_hidden_layers=2,
             num_attention_heads=4, num_key_value_heads=2, rms_norm_eps=1e-5, vocab_size=512,
             rope_theta=10000.0, max_position_embeddings=512, tie_word_embeddings=False, eos_token_id=511)
+
+
+TINY_MOE = dict(model_type="qwen3_moe", hidden_size=256, intermediate_size=512, moe_intermediate_size=128,
+                num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, head_dim=64, num_experts=8,
+                num_experts_per_tok=2, decoder_sparse_step=1, mlp_only_layers=[], norm_topk_prob=True,
+                rms_norm_eps=1e-6, vocab_size=512, rope_theta=10000.0, max_position_embeddings=512,
+                tie_word_embeddings=False, eos_token_id=511)
 
 
 def strategy_bits(name: str, layer: int, n_layers: int) -> int:
@@ -56,6 +64,10 @@ def make_strategy(name: str, n_layers: int, group_size: int = 128) -> Dict:
     for i in range(n_layers):
         b = strategy_bits(name, i, n_layers)
         strat[f"model.layers.{i}"] = {p: {"bits": [b], "group_size": {str(b): group_size}} for p in PROJ}
+        # stacked experts (QuantizedSwitchLinear): 'moe_expert_<proj>', one step narrower than the dense projections
+        be = max(2, b - 1)
+        for p in ("gate_proj", "up_proj", "down_proj"):
+            strat[f"model.layers.{i}"]["moe_expert_" + p] = {"bits": [be], "group_size": {str(be): group_size}}
     return strat
 
 
@@ -74,13 +86,27 @@ def _fill_qlinear(m: QuantizedLinear, gen: torch.Generator, device, act_dtype) -
         m._buffers["bias"] = (torch.randn((n,), device=device, generator=gen) * 0.01).to(act_dtype)
 
 
+def _fill_switch(m: QuantizedSwitchLinear, gen: torch.Generator, device, act_dtype) -> None:
+    e, n, k, b, g = m.num_experts, m.output_dims, m.input_dims, m.bits, m.group_size
+    qw = torch.randint(0, 2**32, (e, n, k // 32 * b), dtype=torch.int64, device=device, generator=gen).to(torch.int32)
+    qmax = float((1 << b) - 1)
+    sc = (torch.rand((e, n, k // g), device=device, generator=gen) + 0.5) * (2.0 / qmax) * 0.02
+    ze = -sc * qmax / 2.0 + torch.randn((e, n, k // g), device=device, generator=gen) * 0.1 * sc
+    m._buffers["qweight"] = qw.view(torch.uint32)
+    m._buffers["scales"] = sc.to(act_dtype)
+    m._buffers["zeros"] = ze.to(act_dtype)
+    if m.bias is not None:
+        m._buffers["bias"] = (torch.randn((e, n), device=device, generator=gen) * 0.01).to(act_dtype)
+
+
 def build_model(config: Dict, strategy: Optional[Dict] = None, device="cpu", seed: int = 0,
                 act_dtype=torch.bfloat16, bits: int = 4, group_size: int = 64) -> qllama.Model:
     """Random-init model with real shapes, generated directly on ``device`` (no files)."""
     device = torch.device(device)
-    args = qllama.ModelArgs.from_dict(config)
+    arch = qqwen3_moe if config.get("model_type") == "qwen3_moe" else qllama
+    args = arch.ModelArgs.from_dict(config)
     with torch.device("meta"):
-        model = qllama.Model(args)
+        model = arch.Model(args)
     model = model.to_empty(device=device)
     QuantizedLinear.reinit_module(model, group_size=group_size, bits=bits, strategy=strategy)
     gen = torch.Generator(device=device)
@@ -91,6 +117,8 @@ def build_model(config: Dict, strategy: Optional[Dict] = None, device="cpu", see
                 if m._buffers[nm] is not None and m._buffers[nm].device != device:
                     m._buffers[nm] = torch.empty_like(m._buffers[nm], device=device)
             _fill_qlinear(m, gen, device, act_dtype)
+        elif isinstance(m, QuantizedSwitchLinear):
+            _fill_switch(m, gen, device, act_dtype)
         elif isinstance(m, qllama.RMSNorm):
             m.weight = torch.nn.Parameter(torch.ones(m.weight.shape, dtype=act_dtype, device=device), requires_grad=False)
         elif isinstance(m, torch.nn.Embedding):
@@ -105,7 +133,8 @@ def build_model(config: Dict, strategy: Optional[Dict] = None, device="cpu", see
     from .models.rope_utils import initialize_rope
     for blk in model.model.layers:
         at = blk.self_attn
-        at.rope = initialize_rope(at.head_dim, args.rope_theta, args.rope_traditional, args.rope_scaling,
+        at.rope = initialize_rope(at.head_dim, args.rope_theta, getattr(args, "rope_traditional", False),
+                                  getattr(args, "rope_scaling", None) if arch is qllama else None,
                                   args.max_position_embeddings).to(device)
     model.eval()
     return model
@@ -120,6 +149,12 @@ def state_dict_for_disk(model: qllama.Model) -> Dict[str, torch.Tensor]:
                 t = getattr(m, nm, None)
                 if t is not None:
                     out[f"{name}.{nm}"] = t.detach().cpu().contiguous()
+        elif isinstance(m, QuantizedSwitchLinear):
+            # on disk the experts are separate modules ``...mlp.experts.<e>.<proj>`` (Model.sanitize stacks them)
+            base, proj = name.rsplit(".switch_mlp.", 1)
+            for e in range(m.num_experts):
+                for nm in ("qweight", "scales", "zeros"):
+                    out[f"{base}.experts.{e}.{proj}.{nm}"] = getattr(m, nm)[e].detach().cpu().contiguous()
         elif isinstance(m, (qllama.RMSNorm, torch.nn.Embedding, torch.nn.Linear)):
             out[f"{name}.weight"] = m.weight.detach().cpu().contiguous()
     return out

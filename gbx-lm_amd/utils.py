@@ -18,7 +18,7 @@ from typing import Any, Callable, Generator, List, Optional, Tuple, Type, Union
 import torch
 from torch import nn
 
-from .models import qllama
+from .models import qllama, qqwen3_moe
 from .models import cache as cache_mod
 from .models.quantized_linear_gba import QuantizedLinear
 from .tokenizer_utils import TokenizerWrapper, load_tokenizer
@@ -26,6 +26,7 @@ from .tokenizer_utils import TokenizerWrapper, load_tokenizer
 MODEL_MAPPING = {
     "llama": qllama,
     "mistral": qllama,  # utils.py:52-61 maps mistral onto the llama graph
+    "qwen3_moe": qqwen3_moe,
 }
 
 _DQ_KEYS = ('qstatistic', 'qscales_scales', 'qzeros_scales', 'qscales_zeros', 'qzeros_zeros')
@@ -202,8 +203,9 @@ def load_model(model_path: Path, lazy: bool = False, model_config: dict = {}, bi
     # path never casts
     act_dtype = model.model.embed_tokens.weight.dtype if hasattr(model, "model") else torch.bfloat16
     if act_dtype in (torch.float16, torch.bfloat16):
+        from .models.switch_layers import QuantizedSwitchLinear
         for m in model.modules():
-            if isinstance(m, QuantizedLinear):
+            if isinstance(m, (QuantizedLinear, QuantizedSwitchLinear)):
                 for nm in ("scales", "zeros", "bias"):
                     t = getattr(m, nm, None)
                     if t is not None and t.dtype != act_dtype:

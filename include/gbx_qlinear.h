@@ -125,6 +125,18 @@ int gbx_qlinear_fused_forward(const gbx_qlinear_fused* desc, void* hip_stream);
 int gbx_pack_scales_zeros(const void* scales0, const void* zeros0, const void* scales1, const void* zeros1,
                           uint32_t* out, int32_t N, int32_t G, void* hip_stream);
 
+/* Expert-indexed QuantizedLinear for a few (token, expert-slot) pairs -- the decode case of
+ * mx.gather_qmm(x, qweight[E,N,W], scales[E,N,G], zeros[E,N,G], rhs_indices=indices, transpose=True) + bias[indices]
+ * (QuantizedSwitchLinear.__call__, gbx_lm/models/switch_layers.py:78-92):
+ *   y[p, :] = W[indices[p]] . x[p / x_div, :] (+ bias[indices[p], :]),  p = 0 .. pairs-1,
+ * x_div = pairs sharing one activation row (num_experts_per_tok when SwitchGLU feeds up/gate_proj, 1 for down_proj).
+ * indices: device int32[pairs] (out-of-range values are clamped); pairs <= 65535.  Each pair streams its expert's
+ * rows once through the decode GEMV; for many tokens sort by expert and call gbx_qlinear_forward per expert. */
+int gbx_gather_qlinear_forward(const void* x, const uint32_t* qweight, const void* scales, const void* zeros,
+                               const void* bias, const int32_t* indices, void* y, int32_t pairs, int32_t x_div,
+                               int32_t num_experts, int32_t N, int32_t K, int32_t bits, int32_t group_size,
+                               int32_t act_dtype, void* hip_stream);
+
 /* Load-time re-tiling for the matrix-core decode GEMV (2-bit, group_size 128, K % 1024 == 0): 16-row tiles, K-steps of
  * 256 values, so that a wavefront load is one contiguous 1 KiB block that IS the int8 MFMA operand layout, plus the
  * (scale | zero << 16) dwords as [tile][group][16 rows].  With a second matrix (qweight_up != NULL: gate_proj / up_proj

@@ -134,6 +134,35 @@ def qlinear_ref(x, qweight, scales, zeros, bits: int, group_size: int, bias=None
     return y
 
 
+def gather_qlinear_ref(x, qweight, scales, zeros, indices, bits: int, group_size: int, bias=None,
+                       acc=np.float32) -> np.ndarray:
+    """Expert-indexed QuantizedLinear (QuantizedSwitchLinear.__call__, gbx_lm/models/switch_layers.py:78-92):
+    ``mx.gather_qmm(x, qweight[E,N,W], scales[E,N,G], zeros, rhs_indices=indices, transpose=True)`` + ``bias[indices]``.
+
+    x: [..., 1, 1, K] (one row shared by the k expert slots, as SwitchGLU feeds up/gate, switch_layers.py:176) or
+    [..., k, 1, K] (one row per slot, as it feeds down_proj); indices: [..., k] -> y [..., k, 1, N] with
+    y[..., j, 0, :] = W[indices[..., j]] . x[..., j or 0, 0, :].  ``sorted_indices`` changes nothing numerically."""
+    idx = np.asarray(indices)
+    xf = _to_f32(x).astype(acc)
+    qw = np.asarray(qweight)
+    E, N = qw.shape[0], qw.shape[1]
+    K = xf.shape[-1]
+    k = idx.shape[-1]
+    lead = idx.shape[:-1]
+    xb = np.broadcast_to(xf, lead + (k, 1, K)).reshape(-1, K)
+    flat = idx.reshape(-1)
+    y = np.zeros((flat.shape[0], N), dtype=acc)
+    for e in np.unique(flat):
+        if not 0 <= int(e) < E:
+            raise IndexError(f"expert index {int(e)} out of range [0, {E})")
+        w = dequant(qw[e], _to_f32(scales)[e], _to_f32(zeros)[e], bits, group_size, dtype=np.float32).astype(acc)
+        rows = flat == e
+        y[rows] = xb[rows] @ w.T
+        if bias is not None:
+            y[rows] += _to_f32(bias)[e].astype(acc)
+    return y.reshape(lead + (k, 1, N))
+
+
 def round_to(y: np.ndarray, act_dtype: str):
     """Round an oracle result to the activation dtype ('bf16' | 'f16'); returns torch tensor."""
     t = torch.from_numpy(np.asarray(y, dtype=np.float32))
@@ -188,21 +217,30 @@ _STRATEGY_KEYS = ['kv_a_proj_with_mqa', 'kv_b_proj', 'q_a_proj', 'q_b_proj', 'q_
                   'v_proj', 'o_proj', 'gate_proj', 'up_proj', 'down_proj', 'qkv_proj', 'gate_up_proj']
 
 
-def strategy_lookup(name: str, strategy: dict):
+def strategy_lookup(name: str, strategy: dict, switch: bool = False):
     """(bits, group_size) for module ``name``; restates quantized_linear_gba.py:256-272
     including the substring-order quirk and the KeyError fall-through."""
     layer_number = name.split('.')[2]
     per_block = strategy["model.layers.{}".format(layer_number)]
     strg = None
-    for key in _STRATEGY_KEYS:
-        if key in name:
-            try:
-                if "shared_expert" in name:
-                    key = 'moe_shared_expert_' + key
-                strg = per_block[key]
-                break
-            except KeyError:
-                pass
+    if switch:                 # QuantizedSwitchLinear: 'moe_expert_' + key over gate/up/down only (:238-246)
+        for key in ['gate_proj', 'up_proj', 'down_proj']:
+            if key in name:
+                try:
+                    strg = per_block['moe_expert_' + key]
+                    break
+                except KeyError:
+                    pass
+    else:
+        for key in _STRATEGY_KEYS:
+            if key in name:
+                try:
+                    if "shared_expert" in name:
+                        key = 'moe_shared_expert_' + key
+                    strg = per_block[key]
+                    break
+                except KeyError:
+                    pass
     if strg is None:
         raise KeyError(f"no strategy entry matches {name}")
     bits = strg["bits"][0]

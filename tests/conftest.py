@@ -51,9 +51,22 @@ def oracle_matmul(x, w, scales, biases, transpose=True, group_size=64, bits=4, b
     return yt
 
 
+def oracle_gather_matmul(x, w, scales, biases, rhs_indices, transpose=True, group_size=64, bits=4,
+                         sorted_indices=False, bias=None):
+    """CPU stand-in for gbx_lm_amd.ops.gather_quantized_matmul backed by the oracle.  TEST USE ONLY."""
+    import numpy as np
+    import torch
+    from oracle import gba_oracle as O
+    qw = w.detach().cpu().view(torch.int32).numpy().view(np.uint32)
+    y = O.gather_qlinear_ref(x.detach().cpu(), qw, scales.cpu(), biases.cpu(), rhs_indices.cpu().numpy(), bits, group_size,
+                             bias=None if bias is None else bias.cpu())
+    return torch.from_numpy(y.astype(np.float32)).to(x.dtype)
+
+
 @pytest.fixture
 def cpu_oracle_op(monkeypatch):
-    """Route QuantizedLinear.forward through the oracle on CPU (host-logic tests only)."""
+    """Route QuantizedLinear / QuantizedSwitchLinear forward through the oracle on CPU (host-logic tests only)."""
     from gbx_lm_amd import ops
     monkeypatch.setattr(ops, "quantized_matmul", oracle_matmul)
+    monkeypatch.setattr(ops, "gather_quantized_matmul", oracle_gather_matmul)
     return oracle_matmul

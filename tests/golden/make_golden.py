@@ -95,6 +95,36 @@ def tiny_llama_case():
                 gap=(top2[:, 1] - top2[:, 0]).astype(np.float32))
 
 
+MOE_PROMPT = [3, 141, 59, 26, 5, 35]
+MOE_STEPS = 24
+
+
+def moe_strategy():
+    from gbx_lm_amd import synthetic as S
+    strat = S.make_strategy("S22", 2, 64)
+    strat["model.layers.0"]["moe_expert_up_proj"] = {"bits": [2], "group_size": {"2": 32}}
+    strat["model.layers.1"]["moe_expert_down_proj"] = {"bits": [4], "group_size": {"4": 128}}
+    strat["model.layers.1"]["o_proj"] = {"bits": [3], "group_size": {"3": 64}}      # the router of layer 1 inherits this
+    return strat
+
+
+def tiny_moe_case():
+    """(vi) 2-layer Qwen3-MoE (8 experts, top-2, stacked QuantizedSwitchLinear at 2/3/4 bits): greedy ids + logprobs
+    from the host graph with QuantizedLinear / gather_qmm routed through the oracle on CPU."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import oracle_matmul, oracle_gather_matmul
+    from gbx_lm_amd import ops, synthetic as S, utils as U
+    ops.quantized_matmul = oracle_matmul
+    ops.gather_quantized_matmul = oracle_gather_matmul
+    model = S.build_model(S.TINY_MOE, moe_strategy(), device="cpu", seed=11)
+    steps = list(U.generate_step(torch.tensor(MOE_PROMPT), model, max_tokens=MOE_STEPS))
+    ids = [t for t, _, _ in steps]
+    lps = torch.stack([lp.float() for _, lp, _ in steps]).numpy()
+    top2 = np.sort(lps, axis=1)[:, -2:]
+    return dict(prompt=np.array(MOE_PROMPT), ids=np.array(ids), logprobs=lps.astype(np.float32),
+                gap=(top2[:, 1] - top2[:, 0]).astype(np.float32))
+
+
 def eminf_case():
     """(v) EMINF: a fixed [512] logits vector -> best_logits, best_entropy (oracle numpy restatement)."""
     rng = np.random.default_rng(123)
@@ -112,6 +142,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "double_quant.npz"), **double_quant_case())
     np.savez_compressed(os.path.join(HERE, "tiny_llama.npz"), **tiny_llama_case())
     np.savez_compressed(os.path.join(HERE, "eminf.npz"), **eminf_case())
+    np.savez_compressed(os.path.join(HERE, "tiny_qwen3_moe.npz"), **tiny_moe_case())
     print("wrote", sorted(os.listdir(HERE)))
 
 
