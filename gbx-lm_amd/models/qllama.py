@@ -71,21 +71,23 @@ def _heads(t: torch.Tensor, n: int) -> torch.Tensor:
 class Attention(nn.Module):
     """GQA self-attention; q/k/v/o are the four attention QuantizedLinear call sites."""
 
-    def __init__(self, args: ModelArgs):
+    def __init__(self, args, qkv_bias: Optional[bool] = None, o_bias: Optional[bool] = None):
         super().__init__()
         hidden = args.hidden_size
         self.n_heads = args.num_attention_heads
         self.n_kv_heads = args.num_key_value_heads
-        self.head_dim = args.head_dim or hidden // self.n_heads
+        self.head_dim = getattr(args, "head_dim", None) or hidden // self.n_heads
         self.scale = self.head_dim ** -0.5
-        use_bias = bool(getattr(args, "attention_bias", False))
+        use_bias = bool(getattr(args, "attention_bias", False))       # Llama: one switch for all four (qllama.py:50-58)
+        qkv_bias = use_bias if qkv_bias is None else qkv_bias         # families derived from this graph override
+        o_bias = use_bias if o_bias is None else o_bias
         q_out, kv_out = self.n_heads * self.head_dim, self.n_kv_heads * self.head_dim
-        self.q_proj = QuantizedLinear(hidden, q_out, bias=use_bias)
-        self.k_proj = QuantizedLinear(hidden, kv_out, bias=use_bias)
-        self.v_proj = QuantizedLinear(hidden, kv_out, bias=use_bias)
-        self.o_proj = QuantizedLinear(q_out, hidden, bias=use_bias)
-        self.rope = initialize_rope(self.head_dim, args.rope_theta, args.rope_traditional, args.rope_scaling,
-                                    args.max_position_embeddings)
+        self.q_proj = QuantizedLinear(hidden, q_out, bias=qkv_bias)
+        self.k_proj = QuantizedLinear(hidden, kv_out, bias=qkv_bias)
+        self.v_proj = QuantizedLinear(hidden, kv_out, bias=qkv_bias)
+        self.o_proj = QuantizedLinear(q_out, hidden, bias=o_bias)
+        self.rope = initialize_rope(self.head_dim, args.rope_theta, getattr(args, "rope_traditional", False),
+                                    getattr(args, "rope_scaling", None), args.max_position_embeddings)
         self.tp_world, self.tp_group = 1, None      # set by gbx_lm_amd.tp.shard_llama
 
     def forward(self, x: torch.Tensor, mask: Optional[torch.Tensor] = None, cache: Optional[Any] = None) -> torch.Tensor:

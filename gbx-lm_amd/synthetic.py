@@ -13,7 +13,7 @@ from typing import Dict, Optional
 
 import torch
 
-from .models import qllama, qqwen3_moe
+from .models import qllama, qqwen2, qqwen3, qqwen3_moe
 from .models.switch_layers import QuantizedSwitchLinear
 from .models.quantized_linear_gba import QuantizedLinear
 
@@ -39,6 +39,14 @@ TINY_MOE = dict(model_type="qwen3_moe", hidden_size=256, intermediate_size=512, 
                 num_experts_per_tok=2, decoder_sparse_step=1, mlp_only_layers=[], norm_topk_prob=True,
                 rms_norm_eps=1e-6, vocab_size=512, rope_theta=10000.0, max_position_embeddings=512,
                 tie_word_embeddings=False, eos_token_id=511)
+
+
+TINY_QWEN2 = dict(model_type="qwen2", hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                  num_key_value_heads=2, rms_norm_eps=1e-6, vocab_size=512, rope_theta=1000000.0,
+                  max_position_embeddings=512, tie_word_embeddings=True, eos_token_id=511)
+TINY_QWEN3 = dict(model_type="qwen3", hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                  num_key_value_heads=2, head_dim=64, rms_norm_eps=1e-6, vocab_size=512, rope_theta=1000000.0,
+                  max_position_embeddings=512, tie_word_embeddings=False, eos_token_id=511)
 
 
 def strategy_bits(name: str, layer: int, n_layers: int) -> int:
@@ -103,7 +111,7 @@ def build_model(config: Dict, strategy: Optional[Dict] = None, device="cpu", see
                 act_dtype=torch.bfloat16, bits: int = 4, group_size: int = 64) -> qllama.Model:
     """Random-init model with real shapes, generated directly on ``device`` (no files)."""
     device = torch.device(device)
-    arch = qqwen3_moe if config.get("model_type") == "qwen3_moe" else qllama
+    arch = {"qwen3_moe": qqwen3_moe, "qwen3": qqwen3, "qwen2": qqwen2}.get(config.get("model_type"), qllama)
     args = arch.ModelArgs.from_dict(config)
     with torch.device("meta"):
         model = arch.Model(args)
@@ -134,7 +142,7 @@ def build_model(config: Dict, strategy: Optional[Dict] = None, device="cpu", see
     for blk in model.model.layers:
         at = blk.self_attn
         at.rope = initialize_rope(at.head_dim, args.rope_theta, getattr(args, "rope_traditional", False),
-                                  getattr(args, "rope_scaling", None) if arch is qllama else None,
+                                  getattr(args, "rope_scaling", None) if arch in (qllama, qqwen2) else None,
                                   args.max_position_embeddings).to(device)
     model.eval()
     return model
