@@ -13,7 +13,7 @@ from typing import Dict, Optional
 
 import torch
 
-from .models import qllama, qqwen2, qqwen3, qqwen3_moe
+from .models import qllama, qmixtral, qqwen2, qqwen3, qqwen3_moe
 from .models.switch_layers import QuantizedSwitchLinear
 from .models.quantized_linear_gba import QuantizedLinear
 
@@ -44,6 +44,9 @@ TINY_MOE = dict(model_type="qwen3_moe", hidden_size=256, intermediate_size=512, 
 TINY_QWEN2 = dict(model_type="qwen2", hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
                   num_key_value_heads=2, rms_norm_eps=1e-6, vocab_size=512, rope_theta=1000000.0,
                   max_position_embeddings=512, tie_word_embeddings=True, eos_token_id=511)
+TINY_MIXTRAL = dict(model_type="mixtral", hidden_size=256, intermediate_size=128, num_hidden_layers=2,
+                    num_attention_heads=4, num_key_value_heads=2, num_local_experts=4, num_experts_per_tok=2,
+                    rms_norm_eps=1e-5, vocab_size=512, rope_theta=1000000.0, max_position_embeddings=512, eos_token_id=511)
 TINY_QWEN3 = dict(model_type="qwen3", hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
                   num_key_value_heads=2, head_dim=64, rms_norm_eps=1e-6, vocab_size=512, rope_theta=1000000.0,
                   max_position_embeddings=512, tie_word_embeddings=False, eos_token_id=511)
@@ -111,7 +114,7 @@ def build_model(config: Dict, strategy: Optional[Dict] = None, device="cpu", see
                 act_dtype=torch.bfloat16, bits: int = 4, group_size: int = 64) -> qllama.Model:
     """Random-init model with real shapes, generated directly on ``device`` (no files)."""
     device = torch.device(device)
-    arch = {"qwen3_moe": qqwen3_moe, "qwen3": qqwen3, "qwen2": qqwen2}.get(config.get("model_type"), qllama)
+    arch = {"qwen3_moe": qqwen3_moe, "qwen3": qqwen3, "qwen2": qqwen2, "mixtral": qmixtral}.get(config.get("model_type"), qllama)
     args = arch.ModelArgs.from_dict(config)
     with torch.device("meta"):
         model = arch.Model(args)
@@ -160,6 +163,8 @@ def state_dict_for_disk(model: qllama.Model) -> Dict[str, torch.Tensor]:
         elif isinstance(m, QuantizedSwitchLinear):
             # on disk the experts are separate modules ``...mlp.experts.<e>.<proj>`` (Model.sanitize stacks them)
             base, proj = name.rsplit(".switch_mlp.", 1)
+            if base.endswith("block_sparse_moe"):                   # Mixtral checkpoints call the projections w1 / w2 / w3
+                proj = {"gate_proj": "w1", "down_proj": "w2", "up_proj": "w3"}[proj]
             for e in range(m.num_experts):
                 for nm in ("qweight", "scales", "zeros"):
                     out[f"{base}.experts.{e}.{proj}.{nm}"] = getattr(m, nm)[e].detach().cpu().contiguous()

@@ -1,5 +1,5 @@
 """CPU: the other dense families of the reference registry that reuse the path with small graph deltas:
-Qwen2 (biased q/k/v) and Qwen3 (per-head q/k RMSNorm) -- structure, loader contract, generate loop through the oracle."""
+Qwen2 (biased q/k/v), Qwen3 (per-head q/k RMSNorm) and Mixtral (unquantised router, stacked experts named w1/w2/w3) -- structure, loader contract, generate loop through the oracle."""
 import pytest
 import torch
 
@@ -18,14 +18,20 @@ def test_registry_and_structure():
     names = dict(m3.named_parameters()).keys()
     assert "model.layers.0.self_attn.q_norm.weight" in names and "model.layers.1.self_attn.k_norm.weight" in names
     assert m3.model.layers[0].self_attn.head_dim == 64 and hasattr(m3, "lm_head")
+    from gbx_lm_amd.models import qmixtral
+    from gbx_lm_amd.models.switch_layers import QuantizedSwitchLinear
+    mx_ = S.build_model(S.TINY_MIXTRAL, S.make_strategy("S22", 2, 64), device="cpu", seed=1)
+    moe = mx_.model.layers[0].block_sparse_moe
+    assert U.MODEL_MAPPING["mixtral"] is qmixtral and isinstance(moe.gate, torch.nn.Linear)        # qmixtral.py:108
+    assert isinstance(moe.switch_mlp.down_proj, QuantizedSwitchLinear) and moe.switch_mlp.down_proj.bias is None
     with pytest.raises(ValueError):
         U._get_classes({"model_type": "gpt_oss"})                  # not built: fails like the reference does (utils.py:153-156)
 
 
-@pytest.mark.parametrize("cfg", [S.TINY_QWEN2, S.TINY_QWEN3], ids=["qwen2", "qwen3"])
+@pytest.mark.parametrize("cfg", [S.TINY_QWEN2, S.TINY_QWEN3, S.TINY_MIXTRAL], ids=["qwen2", "qwen3", "mixtral"])
 def test_checkpoint_roundtrip_and_generate(tmp_path, cpu_oracle_op, cfg):
     strat = S.make_strategy("S22", 2, 64)
-    extra = {"lm_head.weight": torch.zeros((cfg["vocab_size"], cfg["hidden_size"]))} if cfg["tie_word_embeddings"] else None
+    extra = {"lm_head.weight": torch.zeros((cfg["vocab_size"], cfg["hidden_size"]))} if cfg.get("tie_word_embeddings") else None
     src = S.write_checkpoint(str(tmp_path), cfg, strat, seed=6, extra_tensors=extra)
     model, tok = U.load(str(tmp_path))
     model = model.to("cpu")
