@@ -73,6 +73,27 @@ class Llama3RoPE(nn.Module):
         return apply_rope(x, self.inv_freq, offset, 1.0, self.traditional)
 
 
+class SuScaledRotaryEmbedding(nn.Module):
+    """Phi-3 "su" / longrope embedding (gbx_lm/models/su_rope.py:11-65): per-frequency ``long_factor`` stretches the
+    rotary periods and the input is scaled by sqrt(1 + ln(max / original) / ln(original)) (or ``long_mscale``) before
+    the rotation.  ``short_factor`` / ``short_mscale`` are accepted and unused, like in the reference."""
+
+    def __init__(self, dims: int, base: float = 10000.0, max_position_embeddings: int = 131072,
+                 original_max_position_embeddings: int = 4096, short_factor=1.0, long_factor=1.0,
+                 short_mscale: Optional[float] = None, long_mscale: Optional[float] = None):
+        super().__init__()
+        self.dims, self.traditional = dims, False
+        periods = base ** (torch.arange(0, dims, 2, dtype=torch.float32) / dims)
+        periods = torch.as_tensor(long_factor, dtype=torch.float32) * periods
+        self.register_buffer("inv_freq", 1.0 / periods, persistent=False)
+        self.original_max_position_embeddings = original_max_position_embeddings
+        self.scale = long_mscale or math.sqrt(
+            1 + math.log(max_position_embeddings / original_max_position_embeddings) / math.log(original_max_position_embeddings))
+
+    def forward(self, x, offset: int = 0):
+        return apply_rope((self.scale * x.float()).to(x.dtype), self.inv_freq, offset, 1.0, False)
+
+
 def initialize_rope(dims, base, traditional, scaling_config: Optional[dict] = None,
                     max_position_embeddings: Optional[int] = None):
     """rope_utils.py:197-257 (dispatch on ``type`` / ``rope_type``)."""

@@ -13,7 +13,7 @@ from typing import Dict, Optional
 
 import torch
 
-from .models import qllama, qmixtral, qqwen2, qqwen3, qqwen3_moe
+from .models import qllama, qmixtral, qphi3, qqwen2, qqwen3, qqwen3_moe
 from .models.switch_layers import QuantizedSwitchLinear
 from .models.quantized_linear_gba import QuantizedLinear
 
@@ -47,6 +47,11 @@ TINY_QWEN2 = dict(model_type="qwen2", hidden_size=256, intermediate_size=512, nu
 TINY_MIXTRAL = dict(model_type="mixtral", hidden_size=256, intermediate_size=128, num_hidden_layers=2,
                     num_attention_heads=4, num_key_value_heads=2, num_local_experts=4, num_experts_per_tok=2,
                     rms_norm_eps=1e-5, vocab_size=512, rope_theta=1000000.0, max_position_embeddings=512, eos_token_id=511)
+TINY_PHI3 = dict(model_type="phi3", hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                 num_key_value_heads=2, rms_norm_eps=1e-5, vocab_size=512, rope_theta=10000.0,
+                 max_position_embeddings=4096, original_max_position_embeddings=512, eos_token_id=511,
+                 rope_scaling={"type": "su", "short_factor": [1.0] * 32,
+                               "long_factor": [1.0 + 0.05 * i for i in range(32)]})
 TINY_QWEN3 = dict(model_type="qwen3", hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
                   num_key_value_heads=2, head_dim=64, rms_norm_eps=1e-6, vocab_size=512, rope_theta=1000000.0,
                   max_position_embeddings=512, tie_word_embeddings=False, eos_token_id=511)
@@ -75,6 +80,8 @@ def make_strategy(name: str, n_layers: int, group_size: int = 128) -> Dict:
     for i in range(n_layers):
         b = strategy_bits(name, i, n_layers)
         strat[f"model.layers.{i}"] = {p: {"bits": [b], "group_size": {str(b): group_size}} for p in PROJ}
+        for p in ("qkv_proj", "gate_up_proj"):      # Phi-3 fused projections; the reference's substring scan reaches them only
+            strat[f"model.layers.{i}"][p] = {"bits": [b], "group_size": {str(b): group_size}}   # when v_proj / up_proj are absent
         # stacked experts (QuantizedSwitchLinear): 'moe_expert_<proj>', one step narrower than the dense projections
         be = max(2, b - 1)
         for p in ("gate_proj", "up_proj", "down_proj"):
@@ -114,7 +121,7 @@ def build_model(config: Dict, strategy: Optional[Dict] = None, device="cpu", see
                 act_dtype=torch.bfloat16, bits: int = 4, group_size: int = 64) -> qllama.Model:
     """Random-init model with real shapes, generated directly on ``device`` (no files)."""
     device = torch.device(device)
-    arch = {"qwen3_moe": qqwen3_moe, "qwen3": qqwen3, "qwen2": qqwen2, "mixtral": qmixtral}.get(config.get("model_type"), qllama)
+    arch = {"qwen3_moe": qqwen3_moe, "qwen3": qqwen3, "qwen2": qqwen2, "mixtral": qmixtral, "phi3": qphi3}.get(config.get("model_type"), qllama)
     args = arch.ModelArgs.from_dict(config)
     with torch.device("meta"):
         model = arch.Model(args)
@@ -144,6 +151,9 @@ def build_model(config: Dict, strategy: Optional[Dict] = None, device="cpu", see
     from .models.rope_utils import initialize_rope
     for blk in model.model.layers:
         at = blk.self_attn
+        if hasattr(at, "build_rope"):               # families with their own embedding (Phi-3 su / longrope)
+            at.rope = at.build_rope(args).to(device)
+            continue
         at.rope = initialize_rope(at.head_dim, args.rope_theta, getattr(args, "rope_traditional", False),
                                   getattr(args, "rope_scaling", None) if arch in (qllama, qqwen2) else None,
                                   args.max_position_embeddings).to(device)

@@ -18,7 +18,7 @@ from typing import Any, Callable, Generator, List, Optional, Tuple, Type, Union
 import torch
 from torch import nn
 
-from .models import qllama, qmixtral, qqwen2, qqwen3, qqwen3_moe
+from .models import qllama, qmixtral, qphi3, qqwen2, qqwen3, qqwen3_moe
 from .models import cache as cache_mod
 from .models.quantized_linear_gba import QuantizedLinear
 from .tokenizer_utils import TokenizerWrapper, load_tokenizer
@@ -27,6 +27,7 @@ MODEL_MAPPING = {
     "llama": qllama,
     "mistral": qllama,  # utils.py:52-61 maps mistral onto the llama graph
     "mixtral": qmixtral,
+    "phi3": qphi3,
     "qwen2": qqwen2,
     "qwen3": qqwen3,
     "qwen3_moe": qqwen3_moe,

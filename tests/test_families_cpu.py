@@ -1,5 +1,6 @@
 """CPU: the other dense families of the reference registry that reuse the path with small graph deltas:
-Qwen2 (biased q/k/v), Qwen3 (per-head q/k RMSNorm) and Mixtral (unquantised router, stacked experts named w1/w2/w3) -- structure, loader contract, generate loop through the oracle."""
+Qwen2 (biased q/k/v), Qwen3 (per-head q/k RMSNorm), Mixtral (unquantised router, stacked experts named w1/w2/w3)
+and Phi-3 (fused qkv / gate_up projections, su-scaled RoPE) -- structure, loader contract, generate loop through the oracle."""
 import pytest
 import torch
 
@@ -24,11 +25,26 @@ def test_registry_and_structure():
     moe = mx_.model.layers[0].block_sparse_moe
     assert U.MODEL_MAPPING["mixtral"] is qmixtral and isinstance(moe.gate, torch.nn.Linear)        # qmixtral.py:108
     assert isinstance(moe.switch_mlp.down_proj, QuantizedSwitchLinear) and moe.switch_mlp.down_proj.bias is None
+    from gbx_lm_amd.models import qphi3
+    from gbx_lm_amd.models.rope_utils import SuScaledRotaryEmbedding
+    strat = S.make_strategy("S22", 2, 64)
+    for blk in ("model.layers.0", "model.layers.1"):            # a Phi-3 strategy file has only the fused entries
+        for k in ("q_proj", "k_proj", "v_proj", "gate_proj", "up_proj"):
+            del strat[blk][k]
+    strat["model.layers.1"]["qkv_proj"] = {"bits": [2], "group_size": {"2": 32}}
+    p3 = S.build_model(S.TINY_PHI3, strat, device="cpu", seed=1)
+    at = p3.model.layers[1].self_attn
+    assert U.MODEL_MAPPING["phi3"] is qphi3 and isinstance(at.rope, SuScaledRotaryEmbedding)
+    assert at.qkv_proj.output_dims == 256 + 2 * 128 and (at.qkv_proj.bits, at.qkv_proj.group_size) == (2, 32)
+    assert p3.model.layers[0].mlp.gate_up_proj.output_dims == 1024
+    assert at.rope.scale == pytest.approx((1 + __import__("math").log(4096 / 512) / __import__("math").log(512)) ** 0.5)
+    with pytest.raises(ValueError):
+        qphi3.ModelArgs.from_dict(dict(S.TINY_PHI3, rope_scaling={"type": "su"}))          # long_factor missing (qphi3.py:34-37)
     with pytest.raises(ValueError):
         U._get_classes({"model_type": "gpt_oss"})                  # not built: fails like the reference does (utils.py:153-156)
 
 
-@pytest.mark.parametrize("cfg", [S.TINY_QWEN2, S.TINY_QWEN3, S.TINY_MIXTRAL], ids=["qwen2", "qwen3", "mixtral"])
+@pytest.mark.parametrize("cfg", [S.TINY_QWEN2, S.TINY_QWEN3, S.TINY_MIXTRAL, S.TINY_PHI3], ids=["qwen2", "qwen3", "mixtral", "phi3"])
 def test_checkpoint_roundtrip_and_generate(tmp_path, cpu_oracle_op, cfg):
     strat = S.make_strategy("S22", 2, 64)
     extra = {"lm_head.weight": torch.zeros((cfg["vocab_size"], cfg["hidden_size"]))} if cfg.get("tie_word_embeddings") else None
