@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--context", type=int, default=128, help="synthetic prompt length already in the KV cache")
     ap.add_argument("--strategy", default="S22", choices=["S22", "S40", "S20", "S30"])
     ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama3.2-3b", "tiny"])
+    ap.add_argument("--batch", type=int, default=1, help="sequences decoded synchronously (1 = the headline workload; "
+                    "32 = BASELINE.json configs[4], through the generic graph-replayed runner)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-leg", action="store_true")
@@ -153,7 +155,7 @@ def main():
     caches = []
     for _ in model.model.layers:
         c = KVCache(step=cap)
-        like = torch.empty((1, at.n_kv_heads, 1, at.head_dim), dtype=torch.bfloat16, device=dev)
+        like = torch.empty((args.batch, at.n_kv_heads, 1, at.head_dim), dtype=torch.bfloat16, device=dev)
         c.reserve(1, like, like)
         caches.append(c)
 
@@ -161,7 +163,7 @@ def main():
     # world_size 1); GBX_TP_GRAPH=0 forces eager launches, and a failed capture falls back to them
     use_graph = not args.no_graph and (world == 1 or os.environ.get("GBX_TP_GRAPH", "1") != "0")
     graph_note = "hipGraph replay"
-    Runner = FusedDecodeRunner if fused_eligible(model) else DecodeRunner
+    Runner = FusedDecodeRunner if (fused_eligible(model) and args.batch == 1) else DecodeRunner
     try:
         runner = Runner(model, caches, use_graph=use_graph)
     except Exception as e:                                          # e.g. a collective that refuses capture
@@ -175,7 +177,7 @@ def main():
     vocab = cfg["vocab_size"]
     # synthetic fixed-shape prompt: token ids arange(L) mod vocab, fed through the decode path to fill the KV cache
     for t in range(args.context):
-        runner.step(torch.tensor([t % vocab], device=dev))
+        runner.step(torch.full((args.batch,), t % vocab, device=dev, dtype=torch.long))
     tok = torch.argmax(runner.logits, -1)
     runner.start_greedy(tok)                                        # greedy chain: argmax + next-token feed stay on the device
 
@@ -202,11 +204,11 @@ def main():
         dist.all_reduce(tms, op=dist.ReduceOp.MAX)
         ms = float(tms.item())
     ms_per_step = ms / args.steps
-    tok_s = 1e3 / ms_per_step
+    tok_s = args.batch * 1e3 / ms_per_step
 
     ql_b, head_b, kv_b = token_bytes(model, args.context + args.warmup + args.steps // 2)
     per_gpu_bytes = ql_b + head_b + kv_b
-    e2e_gbps = per_gpu_bytes * tok_s / 1e9                          # per GPU (each rank streams its own shard)
+    e2e_gbps = per_gpu_bytes * (tok_s / args.batch) / 1e9           # per GPU and step (each rank streams its own shard once per step)
 
     roof = None
     cpu = None
@@ -226,9 +228,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": f"{args.model} layer-mix {args.strategy} greedy decode batch=1 "
-                                   f"context={args.context} (BASELINE.json configs[2])",
-                       "global_batch": 1, "seq_len": args.context, "parallelism": f"tp{world}",
+            "config": {"workload": f"{args.model} layer-mix {args.strategy} greedy decode batch={args.batch} "
+                                   f"context={args.context} (BASELINE.json configs[{2 if args.batch == 1 else 4}])",
+                       "global_batch": args.batch, "seq_len": args.context, "parallelism": f"tp{world}",
                        "launch": graph_note, "decode_block": Runner.__name__, "bits_mix": args.strategy, "group_size": 128},
             "roofline": roof,
             "cpu_baseline": cpu,
