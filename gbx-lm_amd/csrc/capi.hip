@@ -167,6 +167,29 @@ int gbx_pack_scales_zeros(const void* scales0, const void* zeros0, const void* s
   return GBX_OK;
 }
 
+int gbx_qlinear_forward_multi(const void* x, int32_t nseg, const uint32_t* const* qweight, const void* const* scales,
+                              const void* const* zeros, const void* const* bias, void* const* y, const int32_t* N,
+                              int64_t M, int32_t K, int32_t bits, int32_t group_size, int32_t act_dtype, void* hip_stream) {
+  if (nseg < 1 || nseg > 3 || !qweight || !scales || !zeros || !bias || !y || !N) return fail(GBX_ERR_INVALID, "nseg must be 1..3 and the tables non-null");
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  if (M < 2 || M > 64 || K < 512 || (K % 128) != 0)
+    return fail(GBX_ERR_UNSUPPORTED, "multi-matrix launch covers 2 <= M <= 64, K >= 512, K %% 128 == 0 (M=%lld K=%d)", (long long)M, K);
+  int n[3] = {0, 0, 0};
+  for (int i = 0; i < nseg; ++i) {
+    int rc = check_shape(M, N[i], K, bits, group_size);
+    if (rc) return rc;
+    if (N[i] % 32) return fail(GBX_ERR_UNSUPPORTED, "every N must be a multiple of 32 (segment %d has %d)", i, N[i]);
+    if (!qweight[i] || !scales[i] || !zeros[i] || !y[i]) return fail(GBX_ERR_INVALID, "null device pointer in segment %d", i);
+    if (!aligned(qweight[i], 16)) return fail(GBX_ERR_INVALID, "qweight must be 16-byte aligned");
+    n[i] = N[i];
+  }
+  if (!x || !aligned(x, 16)) return fail(GBX_ERR_INVALID, "x missing or not 16-byte aligned");
+  hipError_t e = gbx::launch_qgemm_skinny_multi(x, nseg, qweight, scales, zeros, bias, y, n, static_cast<int>(M), K, bits,
+                                                log2_group(group_size), act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_qlinear_forward_multi launch");
+  return GBX_OK;
+}
+
 int gbx_gather_qlinear_forward(const void* x, const uint32_t* qweight, const void* scales, const void* zeros,
                                const void* bias, const int32_t* indices, void* y, int32_t pairs, int32_t x_div,
                                int32_t num_experts, int32_t N, int32_t K, int32_t bits, int32_t group_size,

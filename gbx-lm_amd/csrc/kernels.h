@@ -21,6 +21,9 @@ hipError_t launch_qgemm_mfma(const void* x, const uint32_t* qw, const void* sc, 
                              int M, int N, int K, int bits, int log2g, bool bf16, hipStream_t s);
 hipError_t launch_qgemm_skinny(const void* x, const uint32_t* qw, const void* sc, const void* ze, const void* bias, void* y,
                                int M, int N, int K, int bits, int log2g, bool bf16, hipStream_t s);
+hipError_t launch_qgemm_skinny_multi(const void* x, int nseg, const uint32_t* const* qw, const void* const* sc, const void* const* ze,
+                                     const void* const* bias, void* const* y, const int* n, int M, int K, int bits, int log2g,
+                                     bool bf16, hipStream_t s);
 hipError_t launch_prepack_tiles(const uint32_t* qw, const void* sc, const void* ze, const uint32_t* qw2, const void* sc2,
                                 const void* ze2, uint32_t* wt, uint32_t* szt, int N, int K, hipStream_t s);
 hipError_t launch_gemv_mfma(const void* x, const uint32_t* wt, const uint32_t* szt, void* y, int N, int K, const void* norm_w,

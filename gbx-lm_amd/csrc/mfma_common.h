@@ -16,6 +16,15 @@ struct MfmaArgs {
   const unsigned short* bias;   // [N] or null
   unsigned short* y;            // [M, N]
   int M, N, K, log2g;
+  // split-K kernel only: up to two more matrices that share x, K, bits and group size (q/k/v, gate/up) in ONE launch;
+  // N is then the sum of the row counts, the segments are tiled in order (each row count a multiple of the tile)
+  int nseg;                     // 0 or 1: single matrix
+  int n_seg[3];                 // rows of segment 0..2 (segment 0 described by the fields above)
+  const uint32_t* qweight_x[2];
+  const unsigned short* scales_x[2];
+  const unsigned short* zeros_x[2];
+  const unsigned short* bias_x[2];
+  unsigned short* y_x[2];
 };
 
 constexpr int KC = 128;                 // k-values per chunk (one LDS stage of activations)

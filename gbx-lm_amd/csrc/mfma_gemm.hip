@@ -229,9 +229,10 @@ static hipError_t launch_prefill_bits(const MfmaArgs& a, bool bf16, hipStream_t 
 
 hipError_t launch_qgemm_mfma(const void* x, const uint32_t* qw, const void* sc, const void* ze, const void* bias, void* y,
                              int M, int N, int K, int bits, int log2g, bool bf16, hipStream_t s) {
-  MfmaArgs a{static_cast<const unsigned short*>(x), qw, static_cast<const unsigned short*>(sc),
-             static_cast<const unsigned short*>(ze), static_cast<const unsigned short*>(bias),
-             static_cast<unsigned short*>(y), M, N, K, log2g};
+  MfmaArgs a{};
+  a.x = static_cast<const unsigned short*>(x); a.qweight = qw; a.scales = static_cast<const unsigned short*>(sc);
+  a.zeros = static_cast<const unsigned short*>(ze); a.bias = static_cast<const unsigned short*>(bias);
+  a.y = static_cast<unsigned short*>(y); a.M = M; a.N = N; a.K = K; a.log2g = log2g;
   switch (bits) {
     case 2: return launch_prefill_bits<2>(a, bf16, s);
     case 3: return launch_prefill_bits<3>(a, bf16, s);

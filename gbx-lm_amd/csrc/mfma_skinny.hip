@@ -46,10 +46,25 @@ __global__ __launch_bounds__(KW * 64) void qgemm_skinny_kernel(const MfmaArgs a)
   const int c0 = wave * nchunks / KW, c1 = (wave + 1) * nchunks / KW;   // this wave's chunks
   unsigned char* slab = smem + wave * SLAB;
 
-  const int nrow = min(n0 + r, N - 1);
-  const uint32_t* wrow = a.qweight + static_cast<size_t>(nrow) * W;
-  const unsigned short* srow = a.scales + static_cast<size_t>(nrow) * G;
-  const unsigned short* zrow = a.zeros + static_cast<size_t>(nrow) * G;
+  // segment of this tile (wave-uniform): a tile never straddles two matrices (row counts are multiples of the tile)
+  const uint32_t* qw = a.qweight;
+  const unsigned short* sc = a.scales;
+  const unsigned short* ze = a.zeros;
+  const unsigned short* bs = a.bias;
+  unsigned short* yo = a.y;
+  int nl0 = n0, NL = N;                             // tile start and row count inside the segment
+  if (a.nseg > 1) {
+    const int sg = (n0 >= a.n_seg[0]) + (n0 >= a.n_seg[0] + a.n_seg[1]);
+    NL = a.n_seg[sg];
+    if (sg > 0) {
+      nl0 = n0 - a.n_seg[0] - (sg > 1 ? a.n_seg[1] : 0);
+      qw = a.qweight_x[sg - 1]; sc = a.scales_x[sg - 1]; ze = a.zeros_x[sg - 1]; bs = a.bias_x[sg - 1]; yo = a.y_x[sg - 1];
+    }
+  }
+  const int nrow = min(nl0 + r, NL - 1);
+  const uint32_t* wrow = qw + static_cast<size_t>(nrow) * W;
+  const unsigned short* srow = sc + static_cast<size_t>(nrow) * G;
+  const unsigned short* zrow = ze + static_cast<size_t>(nrow) * G;
   // coalesced activation fetch: piece p = it*64 + lane -> row p/16, 16-byte column p%16
   const unsigned short* xsrc[XP];
   int xdst[XP];
@@ -175,12 +190,12 @@ __global__ __launch_bounds__(KW * 64) void qgemm_skinny_kernel(const MfmaArgs a)
 #pragma unroll
     for (int w = 0; w < KW; ++w) v += red[(w * MT * AE + ie) * 64 + ln];
     const int i = ie / AE, e = ie % AE;
-    const int n = n0 + (ln & (TN - 1));
+    const int n = nl0 + (ln & (TN - 1));
     // C/D layouts: 32x32: row = (e&3) + 8*(e>>2) + 4*(lane>>5); 16x16: row = 4*(lane>>4) + e
     const int m = m0 + i * TN + (TN == 32 ? (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5) : 4 * (ln >> 4) + e);
-    if (n < N && m < M) {
-      if (a.bias) v = act_to_f32<BF16>(f32_to_act<BF16>(v)) + act_to_f32<BF16>(a.bias[n]);
-      a.y[static_cast<size_t>(m) * N + n] = f32_to_act<BF16>(v);
+    if (n < NL && m < M) {
+      if (bs) v = act_to_f32<BF16>(f32_to_act<BF16>(v)) + act_to_f32<BF16>(bs[n]);
+      yo[static_cast<size_t>(m) * NL + n] = f32_to_act<BF16>(v);
     }
   }
 }
@@ -226,11 +241,34 @@ static hipError_t launch_skinny_bits(const MfmaArgs& a, bool bf16, hipStream_t s
   return a.M <= 32 ? launch_skinny_mt<BITS, 32, 1>(a, bf16, s) : launch_skinny_mt<BITS, 32, 2>(a, bf16, s);
 }
 
+hipError_t launch_qgemm_skinny_multi(const void* x, int nseg, const uint32_t* const* qw, const void* const* sc, const void* const* ze,
+                                     const void* const* bias, void* const* y, const int* n, int M, int K, int bits, int log2g,
+                                     bool bf16, hipStream_t s) {
+  MfmaArgs a{};
+  a.x = static_cast<const unsigned short*>(x);
+  a.qweight = qw[0]; a.scales = static_cast<const unsigned short*>(sc[0]); a.zeros = static_cast<const unsigned short*>(ze[0]);
+  a.bias = static_cast<const unsigned short*>(bias[0]); a.y = static_cast<unsigned short*>(y[0]);
+  a.M = M; a.K = K; a.log2g = log2g; a.nseg = nseg; a.N = 0;
+  for (int i = 0; i < nseg; ++i) { a.n_seg[i] = n[i]; a.N += n[i]; }
+  for (int i = 1; i < nseg; ++i) {
+    a.qweight_x[i - 1] = qw[i]; a.scales_x[i - 1] = static_cast<const unsigned short*>(sc[i]);
+    a.zeros_x[i - 1] = static_cast<const unsigned short*>(ze[i]); a.bias_x[i - 1] = static_cast<const unsigned short*>(bias[i]);
+    a.y_x[i - 1] = static_cast<unsigned short*>(y[i]);
+  }
+  switch (bits) {
+    case 2: return launch_skinny_bits<2>(a, bf16, s);
+    case 3: return launch_skinny_bits<3>(a, bf16, s);
+    case 4: return launch_skinny_bits<4>(a, bf16, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 hipError_t launch_qgemm_skinny(const void* x, const uint32_t* qw, const void* sc, const void* ze, const void* bias, void* y,
                                int M, int N, int K, int bits, int log2g, bool bf16, hipStream_t s) {
-  MfmaArgs a{static_cast<const unsigned short*>(x), qw, static_cast<const unsigned short*>(sc),
-             static_cast<const unsigned short*>(ze), static_cast<const unsigned short*>(bias),
-             static_cast<unsigned short*>(y), M, N, K, log2g};
+  MfmaArgs a{};
+  a.x = static_cast<const unsigned short*>(x); a.qweight = qw; a.scales = static_cast<const unsigned short*>(sc);
+  a.zeros = static_cast<const unsigned short*>(ze); a.bias = static_cast<const unsigned short*>(bias);
+  a.y = static_cast<unsigned short*>(y); a.M = M; a.N = N; a.K = K; a.log2g = log2g;
   switch (bits) {
     case 2: return launch_skinny_bits<2>(a, bf16, s);
     case 3: return launch_skinny_bits<3>(a, bf16, s);

@@ -53,7 +53,7 @@ class DecodeRunner:
         for layer, c in zip(m.layers, self.caches):
             at = layer.self_attn
             x = ops.rmsnorm(h, layer.input_layernorm.weight, layer.input_layernorm.eps)     # one launch (gbx_rmsnorm)
-            q, k, v = at.q_proj(x).reshape(B, -1), at.k_proj(x).reshape(B, -1), at.v_proj(x).reshape(B, -1)
+            q, k, v = (t.reshape(B, -1) for t in ops.quantized_matmul_multi(x, (at.q_proj, at.k_proj, at.v_proj)))
             if at.rope.inv_freq.numel() * 2 == self.hd and c.keys.is_contiguous() and c.values.is_contiguous():
                 # one launch: rotate q in place, rotate k / copy v into the cache at the device-resident position
                 ops.rope_append(q, k, v, c.keys, c.values, at.rope.inv_freq, pos, self.n_heads, self.n_kv, self.hd,
@@ -75,7 +75,12 @@ class DecodeRunner:
                 all_reduce_(o, at.tp_group)
             h = h + o
             x = ops.rmsnorm(h, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.eps)
-            h = h + layer.mlp(x)
+            mlp = layer.mlp
+            if B > 1 and getattr(mlp, "tp_world", 1) == 1 and hasattr(mlp, "gate_proj"):
+                g, u = ops.quantized_matmul_multi(x, (mlp.gate_proj, mlp.up_proj))     # one launch for gate and up
+                h = h + mlp.down_proj(F.silu(g) * u)
+            else:
+                h = h + mlp(x)
         out = ops.rmsnorm(h, m.norm.weight, m.norm.eps)
         return F.linear(out, self.model.head_weight())[:, -1, :]   # [B, V]
 

@@ -128,6 +128,30 @@ def pack_scales_zeros(mod, mod2=None) -> torch.Tensor:
     return out
 
 
+def quantized_matmul_multi(x: torch.Tensor, mods) -> list:
+    """[m(x) for m in mods] for 2-3 QuantizedLinear modules that share ``x`` (q/k/v, gate/up) -- ONE launch of the
+    split-K matrix-core kernel when the batch is decode-sized (gbx_qlinear_forward_multi), else one call per module."""
+    import ctypes
+    m0 = mods[0]
+    k = m0.input_dims
+    x2 = x.reshape(-1, k)
+    rows = x2.shape[0]
+    same = all((m.bits, m.group_size, m.input_dims) == (m0.bits, m0.group_size, k) for m in mods)
+    if not (same and x.is_cuda and 2 <= rows <= 64 and k >= 512 and k % 128 == 0 and 1 < len(mods) <= 3
+            and all(m.output_dims % 32 == 0 and m.scales is not None and m.scales.dtype == x.dtype for m in mods)):
+        return [m(x) for m in mods]
+    x2 = x2.contiguous()
+    ys = [torch.empty((rows, m.output_dims), dtype=x.dtype, device=x.device) for m in mods]
+    n = len(mods)
+    VP, I32 = ctypes.c_void_p * n, ctypes.c_int32 * n
+    _lib.check(_lib.lib().gbx_qlinear_forward_multi(
+        x2.data_ptr(), n, VP(*[m.qweight.data_ptr() for m in mods]), VP(*[m.scales.data_ptr() for m in mods]),
+        VP(*[m.zeros.data_ptr() for m in mods]), VP(*[(m.bias.data_ptr() if m.bias is not None else None) for m in mods]),
+        VP(*[y.data_ptr() for y in ys]), I32(*[m.output_dims for m in mods]), rows, k, m0.bits, m0.group_size,
+        _DT[x.dtype], _stream_ptr(x.device)))
+    return [y.reshape(*x.shape[:-1], m.output_dims) for y, m in zip(ys, mods)]
+
+
 def gather_quantized_matmul(x: torch.Tensor, w: torch.Tensor, scales: torch.Tensor, biases: torch.Tensor,
                             rhs_indices: torch.Tensor, transpose: bool = True, group_size: int = 64, bits: int = 4,
                             sorted_indices: bool = False, bias: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -125,6 +125,14 @@ int gbx_qlinear_fused_forward(const gbx_qlinear_fused* desc, void* hip_stream);
 int gbx_pack_scales_zeros(const void* scales0, const void* zeros0, const void* scales1, const void* zeros1,
                           uint32_t* out, int32_t N, int32_t G, void* hip_stream);
 
+/* Up to three QuantizedLinear calls that share the activation rows, K, bits and group size (q/k/v, gate/up of one block:
+ * qllama.py:76, :115) in ONE launch of the split-K matrix-core kernel, for batched decode: 2 <= M <= 64, K >= 512,
+ * K % 128 == 0, every N[i] a multiple of 32.  y[i] is [M, N[i]]; bias[i] may be NULL.  Same arithmetic and result
+ * contract as gbx_qlinear_forward per matrix. */
+int gbx_qlinear_forward_multi(const void* x, int32_t nseg, const uint32_t* const* qweight, const void* const* scales,
+                              const void* const* zeros, const void* const* bias, void* const* y, const int32_t* N,
+                              int64_t M, int32_t K, int32_t bits, int32_t group_size, int32_t act_dtype, void* hip_stream);
+
 /* Expert-indexed QuantizedLinear for a few (token, expert-slot) pairs -- the decode case of
  * mx.gather_qmm(x, qweight[E,N,W], scales[E,N,G], zeros[E,N,G], rhs_indices=indices, transpose=True) + bias[indices]
  * (QuantizedSwitchLinear.__call__, gbx_lm/models/switch_layers.py:78-92):

@@ -230,3 +230,26 @@ def test_tiled_matrix_core_gemv(ops, oracle, c_oracle, dt, n, k):
         m4._buffers["scales"] = torch.zeros((16, k // 128), dtype=dd["scales"].dtype, device=DEV)
         m4._buffers["zeros"] = torch.zeros((16, k // 128), dtype=dd["scales"].dtype, device=DEV)
         ops.prepack_tiles(m4)
+
+
+@pytest.mark.parametrize("bits,g", [(2, 128), (3, 64), (4, 32)])
+@pytest.mark.parametrize("m", [2, 32, 50])
+def test_multi_matrix_launch_equals_separate_calls(ops, oracle, bits, g, m):
+    """gbx_qlinear_forward_multi (q/k/v or gate/up in one split-K launch) is bit-identical to one call per matrix."""
+    from gbx_lm_amd.models.quantized_linear_gba import QuantizedLinear
+    k = 1024
+    mods = []
+    for i, n in enumerate((2048, 512, 4128 if m == 2 else 96)):       # total N > 4096 (32-row tiles) or <= 4096 (16-row)
+        d = oracle.synth_layer(n, k, bits, g, seed=10 * i + bits, bias=(i == 1))
+        q = QuantizedLinear(k, n, i == 1, g, bits)
+        q._buffers["qweight"] = torch.from_numpy(d["qweight"].view(np.int32)).view(torch.uint32).to(DEV)
+        q._buffers["scales"], q._buffers["zeros"] = d["scales"].to(DEV), d["zeros"].to(DEV)
+        if i == 1:
+            q._buffers["bias"] = d["bias"].to(DEV)
+        mods.append(q)
+    x = torch.randn(m, k).to(torch.bfloat16).to(DEV)
+    fused = ops.quantized_matmul_multi(x, mods)
+    for y, q in zip(fused, mods):
+        assert torch.equal(y, q(x))
+    two = ops.quantized_matmul_multi(x.reshape(1, m, k), mods[:2])
+    assert two[0].shape == (1, m, 2048) and torch.equal(two[1].reshape(m, -1), mods[1](x))
