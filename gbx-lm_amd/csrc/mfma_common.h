@@ -25,6 +25,9 @@ struct MfmaArgs {
   const unsigned short* zeros_x[2];
   const unsigned short* bias_x[2];
   unsigned short* y_x[2];
+#ifdef GBX_PSTAMPS
+  long long* stamps;            // diagnostic build only: [workgroup][wave][4] s_memtime totals
+#endif
 };
 
 constexpr int KC = 128;                 // k-values per chunk (one LDS stage of activations)

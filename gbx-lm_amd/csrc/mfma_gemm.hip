@@ -27,22 +27,38 @@ namespace gbx {
 constexpr int PKC = 64;                  // k-values per chunk
 constexpr int PROW = PKC * 2 + 16;       // LDS bytes per tile row (activations and dequantised weights alike)
 
-template <int BITS, int MT, int NT, bool BF16>
-__global__ __launch_bounds__(256) void qgemm_prefill_kernel(const MfmaArgs a) {
+// WV waves per workgroup as 2 (M) x WV/2 (N); a wave owns a (32*MT) x (32*NT) tile.  WV = 8 puts two waves on every
+// SIMD, so one wave's staging (global loads: 64 B/clk per CU, LDS stores, dequantise VALU) issues under the other's MFMAs
+// -- with one wave per SIMD those issue costs add to the MFMA time (stamps: 1.2k cycles of load issue + 3.3k of body per
+// 2k-cycle chunk of MFMAs).
+template <int BITS, int MT, int NT, int WV, bool BF16>
+__global__ __launch_bounds__(WV * 64) void qgemm_prefill_kernel(const MfmaArgs a) {
+  constexpr int NTH = WV * 64, WN = WV / 2;
   constexpr int BM = 64 * MT;                     // activation rows per workgroup
-  constexpr int PBN = 64 * NT;                    // weight rows (output columns) per workgroup
-  constexpr int NU = NT / 2;                      // 32-value units of the B tile per thread and chunk
-  constexpr int AP = BM * 8 / 256;                // 16-byte activation pieces per thread per chunk
+  constexpr int PBN = 32 * NT * WN;               // weight rows (output columns) per workgroup
+  constexpr int NU = PBN * 2 / NTH;               // 32-value units of the B tile per thread and chunk
+  constexpr int AP = BM * 8 / NTH;                // 16-byte activation pieces per thread per chunk
+  static_assert(NU >= 1 && AP >= 4, "tile too small for the thread count");
   constexpr int ABYTES = BM * PROW, BBYTES = PBN * PROW, STAGE = ABYTES + BBYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 stages of [A tile | B tile]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
   const int K = a.K, N = a.N, M = a.M;
   const int W = K / 32 * BITS, G = K >> a.log2g;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * PBN;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so workgroup b runs on
+  // XCD b % 8.  Give every XCD a CONTIGUOUS run of tiles in (M-tile major, N-tile minor) order: the ~32 workgroups an XCD
+  // holds at a time then share one or two activation tiles, which are fetched into that L2 once and hit by the others
+  // (with the plain 2-D grid the column tiles of one activation tile were spread over all eight L2s: 8x the misses, and
+  // the activation requests -- 32 KB per chunk and workgroup -- queued behind the per-CU miss capacity).
+  const int tiles_n = (N + PBN - 1) / PBN, tiles_m = (M + BM - 1) / BM;
+  const int tiles = tiles_m * tiles_n;
+  const int per_xcd = (tiles + 7) / 8;
+  const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (tile >= tiles) return;
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * PBN;
   const int nchunks = K / PKC;
 
   // B loader: unit u = tid*NU + j -> row u/2 of the tile, 32-value half u%2 of the chunk (NU = 2: the whole row chunk)
@@ -52,12 +68,12 @@ __global__ __launch_bounds__(256) void qgemm_prefill_kernel(const MfmaArgs a) {
   const unsigned short* ssrc = a.scales + static_cast<size_t>(bn) * G;
   const unsigned short* zsrc = a.zeros + static_cast<size_t>(bn) * G;
   const int bdst = ABYTES + brow * PROW + bhalf * 64;
-  // A loader: piece p = tid + 256*i -> row p/8, 16-byte column p%8
+  // A loader: piece p = tid + NTH*i -> row p/8, 16-byte column p%8
   const unsigned short* asrc[AP];
   int adst[AP];
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
-    const int p = tid + 256 * i, row = p >> 3, col = p & 7;
+    const int p = tid + NTH * i, row = p >> 3, col = p & 7;
     asrc[i] = a.x + static_cast<size_t>(min(m0 + row, M - 1)) * K + col * 8;
     adst[i] = row * PROW + col * 16;
   }
@@ -74,33 +90,43 @@ __global__ __launch_bounds__(256) void qgemm_prefill_kernel(const MfmaArgs a) {
   unsigned wreg[2][NU * BITS];
   unsigned short sreg[2][NU], zreg[2][NU];
 
-  auto load_chunk = [&](int set, int c) {         // global -> registers (clamped: late prefetches re-read the final chunk)
+  // global -> registers, in four parts so that the requests of a chunk spread over the k-steps of the chunk before it
+  // (the vector-memory path moves 64 B/clk per CU: a burst of 10-14 requests per thread at the top of a chunk holds
+  // every wave for ~1k cycles).  Part 0 carries the scales / zeros and packed words, every part a quarter of the
+  // activation pieces.  Clamped: late prefetches re-read the final chunk.
+  auto load_part = [&](int set, int c, int t) {
     const int kc = min(c, nchunks - 1) * PKC;
+    if (t == 0) {
 #pragma unroll
-    for (int i = 0; i < AP; ++i) areg[set][i] = *reinterpret_cast<const u32x4*>(asrc[i] + kc);
-    const uint32_t* src = wsrc + (kc / 32) * BITS;
-    if constexpr (NU * BITS % 4 == 0) {
-#pragma unroll
-      for (int q = 0; q < NU * BITS; q += 4) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(src + q);
-        wreg[set][q] = v.x; wreg[set][q + 1] = v.y; wreg[set][q + 2] = v.z; wreg[set][q + 3] = v.w;
+      for (int j = 0; j < NU; ++j) {
+        const int g = (kc + (bhalf + j) * 32) >> a.log2g;
+        sreg[set][j] = ssrc[g];
+        zreg[set][j] = zsrc[g];
       }
-    } else if constexpr (NU * BITS % 2 == 0) {
+      const uint32_t* src = wsrc + (kc / 32) * BITS;
+      if constexpr (NU * BITS % 4 == 0) {
 #pragma unroll
-      for (int q = 0; q < NU * BITS; q += 2) {
-        const u32x2 v = *reinterpret_cast<const u32x2*>(src + q);
-        wreg[set][q] = v.x; wreg[set][q + 1] = v.y;
+        for (int q = 0; q < NU * BITS; q += 4) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(src + q);
+          wreg[set][q] = v.x; wreg[set][q + 1] = v.y; wreg[set][q + 2] = v.z; wreg[set][q + 3] = v.w;
+        }
+      } else if constexpr (NU * BITS % 2 == 0) {
+#pragma unroll
+        for (int q = 0; q < NU * BITS; q += 2) {
+          const u32x2 v = *reinterpret_cast<const u32x2*>(src + q);
+          wreg[set][q] = v.x; wreg[set][q + 1] = v.y;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < NU * BITS; ++q) wreg[set][q] = src[q];
       }
-    } else {
-#pragma unroll
-      for (int q = 0; q < NU * BITS; ++q) wreg[set][q] = src[q];
     }
 #pragma unroll
-    for (int j = 0; j < NU; ++j) {
-      const int g = (kc + (bhalf + j) * 32) >> a.log2g;
-      sreg[set][j] = ssrc[g];
-      zreg[set][j] = zsrc[g];
-    }
+    for (int i = t * (AP / 4); i < (t + 1) * (AP / 4); ++i) areg[set][i] = *reinterpret_cast<const u32x4*>(asrc[i] + kc);
+  };
+  auto load_chunk = [&](int set, int c) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) load_part(set, c, t);
   };
   // quarter t (0..3) of: registers -> LDS stage, dequantising the weights on the way
   auto store_quarter = [&](int set, int stage, int t) {
@@ -145,14 +171,16 @@ __global__ __launch_bounds__(256) void qgemm_prefill_kernel(const MfmaArgs a) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] = mfma<BF16>(fa[fs][i], fb[fs][j], acc[i][j]);
   };
-  // one chunk: LDS stage `stage` on the matrix cores while register set `set` (the next chunk) moves into the other stage
-  auto chunk = [&](int stage, int set) {
+  // one chunk: LDS stage `stage` on the matrix cores while register set `set` (chunk c+1) moves into the other stage and
+  // the set just emptied quarter by quarter is refilled with chunk c+2
+  auto chunk = [&](int stage, int set, int cnext) {
     read_frags(0, stage, 0);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       if (t < 3) read_frags((t + 1) & 1, stage, t + 1);
       mfma_step(t & 1);
       store_quarter(set, stage ^ 1, t);
+      load_part(set ^ 1, cnext, t);
     }
   };
   static_assert(AP % 4 == 0, "activation pieces are stored in four quarters");
@@ -162,18 +190,27 @@ __global__ __launch_bounds__(256) void qgemm_prefill_kernel(const MfmaArgs a) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) store_quarter(0, 0, t);
   __syncthreads();
+#ifdef GBX_PSTAMPS
+  long long t_bar = 0, t_issue = 0, t_body = 0;
+  const long long t_start = __builtin_amdgcn_s_memtime();
+#define PST(var, code) { const long long _t0 = __builtin_amdgcn_s_memtime(); code; var += __builtin_amdgcn_s_memtime() - _t0; }
+#else
+#define PST(var, code) { code; }
+#endif
   for (int c = 0; c < nchunks; c += 2) {
     // even chunk c: LDS stage 0 on the matrix cores; registers set 1 (chunk c+1) -> stage 1; request chunk c+2 into set 0
-    load_chunk(0, c + 2);
-    __builtin_amdgcn_sched_barrier(0);            // keep the requests at the top: hipcc otherwise sinks them to the barrier
-    chunk(0, 1);
-    __syncthreads();
+    PST(t_body, chunk(0, 1, c + 2); __builtin_amdgcn_sched_barrier(0));
+    PST(t_bar, __syncthreads());
     // odd chunk c+1 (K % 128 == 0: the chunk count is even): stage 1; set 0 (chunk c+2) -> stage 0; request chunk c+3
-    load_chunk(1, c + 3);
-    __builtin_amdgcn_sched_barrier(0);
-    chunk(1, 0);
-    __syncthreads();
+    PST(t_body, chunk(1, 0, c + 3); __builtin_amdgcn_sched_barrier(0));
+    PST(t_bar, __syncthreads());
   }
+#ifdef GBX_PSTAMPS
+  if (lane == 0 && a.stamps) {
+    long long* o = a.stamps + (static_cast<size_t>(blockIdx.x) * 4 + wave) * 4;
+    o[0] = __builtin_amdgcn_s_memtime() - t_start; o[1] = t_issue; o[2] = t_body; o[3] = t_bar;
+  }
+#endif
 
   // ---- epilogue: one rounding to the activation dtype (+ bias as a second rounding, like the reference's x + bias) ----
 #pragma unroll
@@ -196,35 +233,36 @@ __global__ __launch_bounds__(256) void qgemm_prefill_kernel(const MfmaArgs a) {
   }
 }
 
-template <int BITS, int MT, int NT>
+template <int BITS, int MT, int NT, int WV>
 static hipError_t launch_prefill_cfg(const MfmaArgs& a, bool bf16, hipStream_t s) {
-  constexpr int BM = 64 * MT, BN = 64 * NT;
-  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM), block(256);
+  constexpr int BM = 64 * MT, BN = 32 * NT * (WV / 2);
+  const int tiles = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM);
+  dim3 grid(8 * ((tiles + 7) / 8)), block(WV * 64);          // 1-D: the kernel maps workgroup -> tile XCD-aware
   const size_t shmem = 2 * static_cast<size_t>(BM + BN) * PROW;
   if (shmem > 48 * 1024) {        // opt in to the large LDS carve-out once per instantiation
     static bool done[2] = {false, false};
     if (!done[bf16]) {
-      hipError_t e = bf16 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&qgemm_prefill_kernel<BITS, MT, NT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shmem))
-                          : hipFuncSetAttribute(reinterpret_cast<const void*>(&qgemm_prefill_kernel<BITS, MT, NT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shmem));
+      hipError_t e = bf16 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&qgemm_prefill_kernel<BITS, MT, NT, WV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shmem))
+                          : hipFuncSetAttribute(reinterpret_cast<const void*>(&qgemm_prefill_kernel<BITS, MT, NT, WV, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shmem));
       if (e != hipSuccess) return e;
       done[bf16] = true;
     }
   }
-  if (bf16) hipLaunchKernelGGL((qgemm_prefill_kernel<BITS, MT, NT, true>), grid, block, shmem, s, a);
-  else hipLaunchKernelGGL((qgemm_prefill_kernel<BITS, MT, NT, false>), grid, block, shmem, s, a);
+  if (bf16) hipLaunchKernelGGL((qgemm_prefill_kernel<BITS, MT, NT, WV, true>), grid, block, shmem, s, a);
+  else hipLaunchKernelGGL((qgemm_prefill_kernel<BITS, MT, NT, WV, false>), grid, block, shmem, s, a);
   return hipGetLastError();
 }
 
 template <int BITS>
 static hipError_t launch_prefill_bits(const MfmaArgs& a, bool bf16, hipStream_t s) {
-  static const int force = getenv("GBX_PREFILL_TILE") ? atoi(getenv("GBX_PREFILL_TILE")) : 0;   // tuning aid: 1, 2 or 3
-  // the biggest tile that still gives every CU a workgroup: LDS bytes per flop fall with the tile (measured on
-  // 32768 x 4096 x 4096: 128x128 ~600, 256x128 ~800, 256x256 ~870-900 TFLOP/s)
+  static const int force = getenv("GBX_PREFILL_TILE") ? atoi(getenv("GBX_PREFILL_TILE")) : 0;   // tuning aid: 1..4
+  // the biggest tile that still gives every CU a workgroup: LDS bytes per flop fall with the tile
   const long t256 = static_cast<long>((a.M + 255) / 256) * ((a.N + 255) / 256);
   const long t128 = static_cast<long>((a.M + 255) / 256) * ((a.N + 127) / 128);
-  if (force == 3 || (force == 0 && t256 >= 256)) return launch_prefill_cfg<BITS, 4, 4>(a, bf16, s);   // 256 x 256
-  if (force == 2 || (force == 0 && t128 >= 128 && a.M > 128)) return launch_prefill_cfg<BITS, 4, 2>(a, bf16, s);   // 256 x 128
-  return launch_prefill_cfg<BITS, 2, 2>(a, bf16, s);                                                  // 128 x 128
+  if (force == 4) return launch_prefill_cfg<BITS, 4, 4, 4>(a, bf16, s);                                 // 256 x 256, 4 waves
+  if (force == 3 || (force == 0 && t256 >= 256)) return launch_prefill_cfg<BITS, 4, 2, 8>(a, bf16, s);   // 256 x 256, 8 waves
+  if (force == 2 || (force == 0 && t128 >= 128 && a.M > 128)) return launch_prefill_cfg<BITS, 4, 2, 4>(a, bf16, s);   // 256 x 128
+  return launch_prefill_cfg<BITS, 2, 2, 4>(a, bf16, s);                                                  // 128 x 128
 }
 
 hipError_t launch_qgemm_mfma(const void* x, const uint32_t* qw, const void* sc, const void* ze, const void* bias, void* y,
@@ -233,6 +271,9 @@ hipError_t launch_qgemm_mfma(const void* x, const uint32_t* qw, const void* sc, 
   a.x = static_cast<const unsigned short*>(x); a.qweight = qw; a.scales = static_cast<const unsigned short*>(sc);
   a.zeros = static_cast<const unsigned short*>(ze); a.bias = static_cast<const unsigned short*>(bias);
   a.y = static_cast<unsigned short*>(y); a.M = M; a.N = N; a.K = K; a.log2g = log2g;
+#ifdef GBX_PSTAMPS
+  a.stamps = reinterpret_cast<long long*>(strtoull(getenv("GBX_STAMP_PTR") ? getenv("GBX_STAMP_PTR") : "0", nullptr, 0));
+#endif
   switch (bits) {
     case 2: return launch_prefill_bits<2>(a, bf16, s);
     case 3: return launch_prefill_bits<3>(a, bf16, s);
