@@ -333,6 +333,18 @@ int gbx_rope_append(void* q, const void* k, const void* v, void* kcache, void* v
   return GBX_OK;
 }
 
+int gbx_eminf_optimize(const void* logits, int32_t logits_dtype, float* best_logits, float* scratch, float* out_entropy,
+                       int32_t V, float alpha, float threshold, int32_t num_steps, void* hip_stream) {
+  if (V <= 0) return fail(GBX_ERR_INVALID, "bad vocabulary size %d", V);
+  if (!logits || !best_logits || !scratch || !out_entropy) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (logits_dtype != GBX_F16 && logits_dtype != GBX_BF16 && logits_dtype != GBX_F32) return fail(GBX_ERR_INVALID, "logits_dtype must be GBX_F16, GBX_BF16 or GBX_F32");
+  if (!(threshold > 0.f)) return fail(GBX_ERR_INVALID, "threshold must be positive");
+  hipError_t e = gbx::launch_eminf(logits, best_logits, scratch, out_entropy, V, logits_dtype, alpha, threshold, num_steps,
+                                   static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_eminf_optimize launch");
+  return GBX_OK;
+}
+
 int gbx_rmsnorm(const void* x, const void* w, void* y, int64_t M, int32_t K, float eps, int32_t act_dtype, void* hip_stream) {
   if (M == 0) return GBX_OK;
   if (!x || !w || !y) return fail(GBX_ERR_INVALID, "null device pointer");

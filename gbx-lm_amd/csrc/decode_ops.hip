@@ -483,4 +483,137 @@ hipError_t launch_rope_append(void* q, const void* k, const void* v, void* kcach
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ EMINF logits optimiser
+// Entropy minimisation at inference (gbx_lm/infer_opt.py:30-77): normalised-gradient descent on the entropy of the
+// next-token distribution, with accept / reject and step-size decay -- up to 3 + 15 r/(1+r) iterations of five reductions
+// over the vocabulary, each of which the reference (and a torch restatement) syncs to the host for.  Here the whole
+// optimisation is ONE launch of one 1024-thread workgroup: the logits (0.5 MB at V = 128K, L2-resident) are swept four
+// times per iteration, every decision is taken on the device.
+//   entropy(x) = -sum softmax(x) * log(softmax(x) + 1e-10)
+//   grad = p * (sum(p * (logp + 1)) - (logp + 1));  x' = x - alpha * grad / |grad|;  accept if entropy(x') < entropy(x),
+//   else alpha *= 0.65 (stop below 1e-4); stop once entropy < max(threshold, 0.1 * entropy0).
+// (Caching the probabilities between the passes was measured no faster: one CU's 64 B/clk path to L2 is the bound then.)
+struct EminfArgs {
+  const void* logits;       // [V] fp32 (in_mode 2) or act dtype
+  float* cur;               // [V] work / result: best logits
+  float* nxt;               // [V] scratch
+  float* out_entropy;       // [2]: best entropy, initial entropy
+  int V, in_mode;           // in_mode: 0 f16, 1 bf16, 2 f32
+  float alpha, threshold;
+  int num_steps;            // < 0: the reference's allocation from the initial entropy
+};
+
+__device__ __forceinline__ float block_sum(float v, float* red, int tid) {
+  v = wave_sum(v);
+  __syncthreads();                          // previous use of red[] is over
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) t += red[i];
+  return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red, int tid) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  float t = red[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) t = fmaxf(t, red[i]);
+  return t;
+}
+
+__global__ __launch_bounds__(1024) void eminf_kernel(const EminfArgs a) {
+  __shared__ float red[16];
+  const int tid = threadIdx.x, V = a.V;
+  float* cur = a.cur;
+  float* nxt = a.nxt;
+  // load + (max, sum exp) + entropy of the input   (every thread re-reads only elements it wrote itself)
+  float m0 = -3.0e38f;
+  for (int i = tid; i < V; i += 1024) {
+    float v;
+    if (a.in_mode == 2) v = static_cast<const float*>(a.logits)[i];
+    else if (a.in_mode == 1) v = act_to_f32<true>(static_cast<const unsigned short*>(a.logits)[i]);
+    else v = act_to_f32<false>(static_cast<const unsigned short*>(a.logits)[i]);
+    cur[i] = v;
+    m0 = fmaxf(m0, v);
+  }
+  float mx = block_max(m0, red, tid);
+  float z0 = 0.f;
+  for (int i = tid; i < V; i += 1024) z0 += __expf(cur[i] - mx);
+  float logz = __logf(block_sum(z0, red, tid));
+  float h = 0.f;
+  for (int i = tid; i < V; i += 1024) {
+    const float p = __expf(cur[i] - mx - logz);
+    h -= p * __logf(p + 1e-10f);
+  }
+  float hc = block_sum(h, red, tid);
+  const float h0 = hc;
+  float best_h = hc;
+  const float target = fmaxf(a.threshold, 0.1f * h0);
+  int steps = a.num_steps;
+  if (steps < 0) {
+    const float r = fmaxf(0.f, h0 - a.threshold) / a.threshold;
+    steps = static_cast<int>(3.f + 15.f * (r / (1.f + r)));
+  }
+  float alpha = a.alpha;
+  for (int st = 0; st < steps; ++st) {
+    if (hc < target) break;
+    // S = sum p (logp + 1); |grad|^2 = sum (p (S - (logp + 1)))^2
+    float s = 0.f;
+    for (int i = tid; i < V; i += 1024) {
+      const float lp = cur[i] - mx - logz;
+      s += __expf(lp) * (lp + 1.f);
+    }
+    const float S = block_sum(s, red, tid);
+    float g2 = 0.f;
+    for (int i = tid; i < V; i += 1024) {
+      const float lp = cur[i] - mx - logz;
+      const float g = __expf(lp) * (S - (lp + 1.f));
+      g2 += g * g;
+    }
+    const float gn = sqrtf(block_sum(g2, red, tid));
+    if (!(gn > 0.f)) break;
+    const float step = alpha / gn;
+    // update pass with an online (max, sum exp) of the new iterate, then ONE more pass for its entropy
+    float m2 = -3.0e38f, z2 = 0.f;
+    for (int i = tid; i < V; i += 1024) {
+      const float lp = cur[i] - mx - logz;
+      const float v = cur[i] - step * (__expf(lp) * (S - (lp + 1.f)));
+      nxt[i] = v;
+      if (v > m2) { z2 = z2 * __expf(m2 - v) + 1.f; m2 = v; }
+      else z2 += __expf(v - m2);
+    }
+    const float mx2 = block_max(m2, red, tid);
+    const float logz2 = __logf(block_sum(z2 * __expf(m2 - mx2), red, tid));
+    float hsum = 0.f;
+    for (int i = tid; i < V; i += 1024) {
+      const float p = __expf(nxt[i] - mx2 - logz2);
+      hsum -= p * __logf(p + 1e-10f);
+    }
+    const float hn = block_sum(hsum, red, tid);
+    if (hn < hc) {                              // accept: the new iterate becomes current (and best: entropy only falls)
+      float* t = cur; cur = nxt; nxt = t;
+      mx = mx2; logz = logz2; hc = hn;
+      if (hn < best_h) best_h = hn;
+    } else {
+      alpha *= 0.65f;
+      if (alpha < 1e-4f) break;
+    }
+  }
+  if (cur != a.cur) {                           // result always lands in a.cur
+    for (int i = tid; i < V; i += 1024) a.cur[i] = cur[i];
+  }
+  if (tid == 0) { a.out_entropy[0] = best_h; a.out_entropy[1] = h0; }
+}
+
+hipError_t launch_eminf(const void* logits, float* cur, float* nxt, float* out_entropy, int V, int in_mode, float alpha,
+                        float threshold, int num_steps, hipStream_t s) {
+  EminfArgs a{logits, cur, nxt, out_entropy, V, in_mode, alpha, threshold, num_steps};
+  hipLaunchKernelGGL(eminf_kernel, dim3(1), dim3(1024), 0, s, a);
+  return hipGetLastError();
+}
+
 }  // namespace gbx

@@ -40,6 +40,8 @@ hipError_t launch_pack_sz(const void* s0, const void* z0, const void* s1, const 
 hipError_t launch_rope_append(void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
                               const long long* pos, int batch, int n_heads, int n_kv, int hd, int capacity, float rope_scale,
                               int traditional, bool bf16, hipStream_t s);
+hipError_t launch_eminf(const void* logits, float* cur, float* nxt, float* out_entropy, int V, int in_mode, float alpha,
+                        float threshold, int num_steps, hipStream_t s);
 hipError_t launch_rmsnorm(const void* x, const void* w, void* y, int M, int K, float eps, bool bf16, hipStream_t s);
 
 }  // namespace gbx

@@ -29,7 +29,13 @@ def _step_allocation(h_init: float, h_target: float, min_step: int = 3, max_step
 
 
 def eminf_optimize(logits: torch.Tensor, alpha: float = 0.65, num_steps: Optional[int] = None, threshold: float = 0.05):
-    """infer_opt.py:30-77.  Returns (best_logits fp32, best_entropy 0-d tensor)."""
+    """infer_opt.py:30-77.  Returns (best_logits fp32, best_entropy 0-d tensor).  Device tensors run the whole optimisation
+    as ONE HIP launch with every accept / reject decision on the GPU (gbx_eminf_optimize); the loop below is the host-side
+    statement of the same algorithm (CPU tensors), with the reference's one scalar read-back per decision."""
+    if logits.is_cuda:
+        from . import ops
+        best, ent = ops.eminf_optimize(logits, alpha=alpha, num_steps=num_steps, threshold=threshold)
+        return best.reshape(logits.shape), ent[0]
     current_logits = logits.to(torch.float32)
     initial_alpha = alpha
     initial_entropy = _entropy(current_logits)

@@ -309,6 +309,24 @@ def dense_gemv(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = N
     return out
 
 
+def eminf_optimize(logits: torch.Tensor, alpha: float = 0.65, num_steps: Optional[int] = None, threshold: float = 0.05):
+    """EMINF logits optimiser on the device (gbx_eminf_optimize): returns ``(best_logits fp32 [V], entropies fp32 [2])``
+    with ``entropies = (best, initial)``; no host synchronisation."""
+    _require_cuda(logits, "logits")
+    x = logits.reshape(-1).contiguous()
+    if x.dtype not in _DT and x.dtype != torch.float32:
+        x = x.float()
+    code = 2 if x.dtype == torch.float32 else _DT[x.dtype]
+    v = x.numel()
+    best = torch.empty((v,), dtype=torch.float32, device=x.device)
+    scratch = torch.empty((v,), dtype=torch.float32, device=x.device)
+    ent = torch.empty((2,), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().gbx_eminf_optimize(x.data_ptr(), code, best.data_ptr(), scratch.data_ptr(), ent.data_ptr(), v,
+                                             float(alpha), float(threshold), -1 if num_steps is None else int(num_steps),
+                                             _stream_ptr(x.device)))
+    return best, ent
+
+
 def rope_append(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor,
                 inv_freq: torch.Tensor, pos: torch.Tensor, n_heads: int, n_kv: int, head_dim: int,
                 rope_scale: float, traditional: bool) -> None:

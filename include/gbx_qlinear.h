@@ -205,6 +205,15 @@ int gbx_rope_append(void* q, const void* k, const void* v, void* kcache, void* v
                     const int64_t* pos, int32_t batch, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int32_t capacity,
                     float rope_scale, int32_t traditional, int32_t act_dtype, void* hip_stream);
 
+/* EMINF test-time logits optimiser (gbx_lm/infer_opt.py:30-77, the second caller of the decode path, :79-142): normalised
+ * gradient descent on the entropy of softmax(logits) with accept / reject and step decay (alpha *= 0.65, stop below 1e-4),
+ * target entropy max(threshold, 0.1 * H0), num_steps < 0 -> int(3 + 15 r/(1+r)), r = max(0, H0 - threshold)/threshold.
+ * One launch, every decision on the device (the reference takes 4-5 host-synced scalars per iteration).
+ * logits [V] of logits_dtype (GBX_F16 / GBX_BF16 / GBX_F32); best_logits, scratch: float[V]; out_entropy: float[2] =
+ * {best entropy, initial entropy}. */
+int gbx_eminf_optimize(const void* logits, int32_t logits_dtype, float* best_logits, float* scratch, float* out_entropy,
+                       int32_t V, float alpha, float threshold, int32_t num_steps, void* hip_stream);
+
 /* y[M,K] = RMSNorm(x[M,K]) * w[K] (fp32 statistics, one rounding).  mx.nn.RMSNorm as used at qllama.py:125-128,155. */
 int gbx_rmsnorm(const void* x, const void* w, void* y, int64_t M, int32_t K, float eps, int32_t act_dtype,
                 void* hip_stream);

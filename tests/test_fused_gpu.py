@@ -387,3 +387,26 @@ def test_rope_append_batched(traditional):
     assert torch.allclose(kc[:, :, pos].float(), kr[:, :, 0].float(), atol=2e-2, rtol=2e-2)
     assert torch.equal(vc[:, :, pos], v.view(B, nkv, hd))
     assert torch.count_nonzero(kc[:, :, :pos]) == 0 and torch.count_nonzero(kc[:, :, pos + 1:]) == 0
+
+
+def test_eminf_optimize_on_device(golden_dir, oracle):
+    """gbx_eminf_optimize (one launch, decisions on the GPU) against the oracle's numpy restatement of
+    gbx_lm/infer_opt.py:30-77 on the committed fixture, plus random vectors at vocabulary size."""
+    import os
+    from gbx_lm_amd.infer_opt import eminf_optimize
+    z = np.load(os.path.join(golden_dir, "eminf.npz"))
+    best, h = eminf_optimize(torch.from_numpy(z["logits"]).to(DEV))
+    assert best.dtype == torch.float32 and best.shape == (512,)
+    assert np.abs(best.cpu().numpy() - z["best"]).max() < 2e-3 and abs(float(h) - float(z["entropy"])) < 2e-3
+    b2, h2 = eminf_optimize(torch.from_numpy(z["sharp"]).to(DEV))          # already below the target: input returned
+    assert np.abs(b2.cpu().numpy() - z["sharp_best"]).max() < 1e-5 and abs(float(h2) - float(z["sharp_entropy"])) < 1e-4
+    rng = np.random.default_rng(5)
+    for v, scale, dt in ((128256, 3.0, torch.bfloat16), (32000, 1.5, torch.float32), (1000, 6.0, torch.float16)):
+        lg = torch.from_numpy((rng.standard_normal(v) * scale).astype(np.float32)).to(dt)
+        want, hw = oracle.eminf_optimize(lg.float().numpy())
+        got, hg = eminf_optimize(lg.to(DEV))
+        assert abs(float(hg) - float(hw)) < 5e-3 * max(1.0, float(hw)), (v, float(hg), float(hw))
+        assert np.abs(got.cpu().numpy() - want).max() < 5e-3, (v, np.abs(got.cpu().numpy() - want).max())
+    fixed, _ = eminf_optimize(torch.from_numpy(z["logits"]).to(DEV), num_steps=2)
+    w2, _ = oracle.eminf_optimize(z["logits"], num_steps=2)
+    assert np.abs(fixed.cpu().numpy() - w2).max() < 2e-3
