@@ -94,6 +94,41 @@ class SuScaledRotaryEmbedding(nn.Module):
         return apply_rope((self.scale * x.float()).to(x.dtype), self.inv_freq, offset, 1.0, False)
 
 
+def _yarn_correction_dim(num_rotations, dim, base, max_pos):
+    return (dim * math.log(max_pos / (num_rotations * 2 * math.pi))) / (2 * math.log(base))
+
+
+def yarn_get_mscale(scale: float = 1, mscale: float = 1) -> float:
+    return 1.0 if scale <= 1 else 0.1 * mscale * math.log(scale) + 1.0
+
+
+class YarnRoPE(nn.Module):
+    """DeepSeek-V3 YaRN embedding (gbx_lm/models/qdeepseek_v3.py:49-125): interleaved ("traditional") rotation with
+    per-frequency interpolation between the original and the ``scaling_factor``-stretched periods inside the
+    [beta_fast, beta_slow] correction range, input scaled by mscale(factor, mscale) / mscale(factor, mscale_all_dim)."""
+
+    def __init__(self, dim: int, max_position_embeddings: int = 2048, base: float = 10000, scaling_factor: float = 1.0,
+                 original_max_position_embeddings: int = 4096, beta_fast: float = 32, beta_slow: float = 1,
+                 mscale: float = 1, mscale_all_dim: float = 0):
+        super().__init__()
+        self.dims, self.traditional, self.scale = dim, True, 1.0
+        self.mscale = yarn_get_mscale(scaling_factor, mscale) / yarn_get_mscale(scaling_factor, mscale_all_dim)
+        freq_extra = base ** (torch.arange(0, dim, 2, dtype=torch.float32) / dim)
+        freq_inter = scaling_factor * freq_extra
+        low = max(math.floor(_yarn_correction_dim(beta_fast, dim, base, original_max_position_embeddings)), 0)
+        high = min(math.ceil(_yarn_correction_dim(beta_slow, dim, base, original_max_position_embeddings)), dim - 1)
+        hi = high + 0.001 if low == high else high                   # prevent a singular ramp
+        ramp = torch.clip((torch.arange(dim // 2, dtype=torch.float32) - low) / (hi - low), 0, 1)
+        freq_mask = 1.0 - ramp
+        periods = (freq_inter * freq_extra) / (freq_inter * freq_mask + freq_extra * (1 - freq_mask))
+        self.register_buffer("inv_freq", 1.0 / periods, persistent=False)
+
+    def forward(self, x, offset: int = 0):
+        if self.mscale != 1.0:
+            x = (self.mscale * x.float()).to(x.dtype)
+        return apply_rope(x, self.inv_freq, offset, 1.0, True)
+
+
 def initialize_rope(dims, base, traditional, scaling_config: Optional[dict] = None,
                     max_position_embeddings: Optional[int] = None):
     """rope_utils.py:197-257 (dispatch on ``type`` / ``rope_type``)."""

@@ -13,7 +13,7 @@ from typing import Dict, Optional
 
 import torch
 
-from .models import qllama, qmixtral, qphi3, qqwen2, qqwen3, qqwen3_moe
+from .models import qdeepseek_v3, qllama, qmixtral, qphi3, qqwen2, qqwen3, qqwen3_moe
 from .models.switch_layers import QuantizedSwitchLinear
 from .models.quantized_linear_gba import QuantizedLinear
 
@@ -52,6 +52,13 @@ TINY_PHI3 = dict(model_type="phi3", hidden_size=256, intermediate_size=512, num_
                  max_position_embeddings=4096, original_max_position_embeddings=512, eos_token_id=511,
                  rope_scaling={"type": "su", "short_factor": [1.0] * 32,
                                "long_factor": [1.0 + 0.05 * i for i in range(32)]})
+TINY_DEEPSEEK = dict(model_type="deepseek_v3", vocab_size=512, hidden_size=256, intermediate_size=512, moe_intermediate_size=128,
+                     num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4, n_shared_experts=1, n_routed_experts=8,
+                     routed_scaling_factor=2.5, kv_lora_rank=128, q_lora_rank=128, qk_rope_head_dim=32, v_head_dim=32,
+                     qk_nope_head_dim=32, n_group=4, topk_group=2, num_experts_per_tok=2, first_k_dense_replace=1,
+                     max_position_embeddings=512, rms_norm_eps=1e-6, rope_theta=10000.0, eos_token_id=511,
+                     rope_scaling={"type": "yarn", "factor": 4.0, "original_max_position_embeddings": 128, "beta_fast": 32,
+                                   "beta_slow": 1, "mscale": 1.0, "mscale_all_dim": 1.0})
 TINY_QWEN3 = dict(model_type="qwen3", hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
                   num_key_value_heads=2, head_dim=64, rms_norm_eps=1e-6, vocab_size=512, rope_theta=1000000.0,
                   max_position_embeddings=512, tie_word_embeddings=False, eos_token_id=511)
@@ -80,6 +87,9 @@ def make_strategy(name: str, n_layers: int, group_size: int = 128) -> Dict:
     for i in range(n_layers):
         b = strategy_bits(name, i, n_layers)
         strat[f"model.layers.{i}"] = {p: {"bits": [b], "group_size": {str(b): group_size}} for p in PROJ}
+        for p in ("kv_a_proj_with_mqa", "kv_b_proj", "q_a_proj", "q_b_proj",            # DeepSeek-V3 latent attention
+                  "moe_shared_expert_gate_proj", "moe_shared_expert_up_proj", "moe_shared_expert_down_proj"):
+            strat[f"model.layers.{i}"][p] = {"bits": [b], "group_size": {str(b): group_size}}
         for p in ("qkv_proj", "gate_up_proj"):      # Phi-3 fused projections; the reference's substring scan reaches them only
             strat[f"model.layers.{i}"][p] = {"bits": [b], "group_size": {str(b): group_size}}   # when v_proj / up_proj are absent
         # stacked experts (QuantizedSwitchLinear): 'moe_expert_<proj>', one step narrower than the dense projections
@@ -121,7 +131,7 @@ def build_model(config: Dict, strategy: Optional[Dict] = None, device="cpu", see
                 act_dtype=torch.bfloat16, bits: int = 4, group_size: int = 64) -> qllama.Model:
     """Random-init model with real shapes, generated directly on ``device`` (no files)."""
     device = torch.device(device)
-    arch = {"qwen3_moe": qqwen3_moe, "qwen3": qqwen3, "qwen2": qqwen2, "mixtral": qmixtral, "phi3": qphi3}.get(config.get("model_type"), qllama)
+    arch = {"qwen3_moe": qqwen3_moe, "qwen3": qqwen3, "qwen2": qqwen2, "mixtral": qmixtral, "phi3": qphi3, "deepseek_v3": qdeepseek_v3}.get(config.get("model_type"), qllama)
     args = arch.ModelArgs.from_dict(config)
     with torch.device("meta"):
         model = arch.Model(args)
@@ -145,6 +155,11 @@ def build_model(config: Dict, strategy: Optional[Dict] = None, device="cpu", see
         elif isinstance(m, torch.nn.Linear):
             w = torch.randn(m.weight.shape, device=device, generator=gen) * 0.02
             m.weight = torch.nn.Parameter(w.to(act_dtype), requires_grad=False)
+        elif isinstance(m, qdeepseek_v3.MoEGate):
+            w = torch.randn(m.weight.shape, device=device, generator=gen) * 0.5
+            m.weight = torch.nn.Parameter(w.to(act_dtype), requires_grad=False)
+            m.e_score_correction_bias = torch.nn.Parameter(torch.randn(m.e_score_correction_bias.shape, device=device,
+                                                                       generator=gen) * 0.1, requires_grad=False)
         elif hasattr(m, "inv_freq") and isinstance(getattr(m, "inv_freq"), torch.Tensor):
             pass
     # rope tables are non-persistent buffers created on meta: rebuild them for real
@@ -180,6 +195,9 @@ def state_dict_for_disk(model: qllama.Model) -> Dict[str, torch.Tensor]:
                     out[f"{base}.experts.{e}.{proj}.{nm}"] = getattr(m, nm)[e].detach().cpu().contiguous()
         elif isinstance(m, (qllama.RMSNorm, torch.nn.Embedding, torch.nn.Linear)):
             out[f"{name}.weight"] = m.weight.detach().cpu().contiguous()
+        elif isinstance(m, qdeepseek_v3.MoEGate):
+            out[f"{name}.weight"] = m.weight.detach().cpu().contiguous()
+            out[f"{name}.e_score_correction_bias"] = m.e_score_correction_bias.detach().cpu().contiguous()
     return out
 
 

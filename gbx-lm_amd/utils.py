@@ -18,7 +18,7 @@ from typing import Any, Callable, Generator, List, Optional, Tuple, Type, Union
 import torch
 from torch import nn
 
-from .models import qllama, qmixtral, qphi3, qqwen2, qqwen3, qqwen3_moe
+from .models import qdeepseek_v3, qllama, qmixtral, qphi3, qqwen2, qqwen3, qqwen3_moe
 from .models import cache as cache_mod
 from .models.quantized_linear_gba import QuantizedLinear
 from .tokenizer_utils import TokenizerWrapper, load_tokenizer
@@ -26,6 +26,7 @@ from .tokenizer_utils import TokenizerWrapper, load_tokenizer
 MODEL_MAPPING = {
     "llama": qllama,
     "mistral": qllama,  # utils.py:52-61 maps mistral onto the llama graph
+    "deepseek_v3": qdeepseek_v3,
     "mixtral": qmixtral,
     "phi3": qphi3,
     "qwen2": qqwen2,

@@ -1,6 +1,7 @@
 """CPU: the other dense families of the reference registry that reuse the path with small graph deltas:
 Qwen2 (biased q/k/v), Qwen3 (per-head q/k RMSNorm), Mixtral (unquantised router, stacked experts named w1/w2/w3)
-and Phi-3 (fused qkv / gate_up projections, su-scaled RoPE) -- structure, loader contract, generate loop through the oracle."""
+Phi-3 (fused qkv / gate_up projections, su-scaled RoPE) and DeepSeek-V3 (latent attention, YaRN, group-limited routing
+with shared experts) -- structure, loader contract, generate loop through the oracle."""
 import pytest
 import torch
 
@@ -44,7 +45,8 @@ def test_registry_and_structure():
         U._get_classes({"model_type": "gpt_oss"})                  # not built: fails like the reference does (utils.py:153-156)
 
 
-@pytest.mark.parametrize("cfg", [S.TINY_QWEN2, S.TINY_QWEN3, S.TINY_MIXTRAL, S.TINY_PHI3], ids=["qwen2", "qwen3", "mixtral", "phi3"])
+@pytest.mark.parametrize("cfg", [S.TINY_QWEN2, S.TINY_QWEN3, S.TINY_MIXTRAL, S.TINY_PHI3, S.TINY_DEEPSEEK],
+                         ids=["qwen2", "qwen3", "mixtral", "phi3", "deepseek_v3"])
 def test_checkpoint_roundtrip_and_generate(tmp_path, cpu_oracle_op, cfg):
     strat = S.make_strategy("S22", 2, 64)
     extra = {"lm_head.weight": torch.zeros((cfg["vocab_size"], cfg["hidden_size"]))} if cfg.get("tie_word_embeddings") else None
@@ -69,3 +71,44 @@ def test_checkpoint_roundtrip_and_generate(tmp_path, cpu_oracle_op, cfg):
     lps = torch.stack([lp for _, lp, _ in U.generate_step(prompt, src, max_tokens=5)]).float()
     full_lp = full - torch.logsumexp(full, -1, keepdim=True)
     assert (full_lp - lps).abs().max().item() < 0.08
+
+
+def test_deepseek_router_matches_naive():
+    """group_expert_select against a per-token loop restatement of the noaux_tc routing (qdeepseek_v3.py:276-307)."""
+    import numpy as np
+    from gbx_lm_amd.models.qdeepseek_v3 import group_expert_select
+    rng = np.random.default_rng(3)
+    T, E, n_group, topk_group, k, rsf = 7, 16, 4, 2, 3, 2.5
+    gates = torch.from_numpy(rng.standard_normal((T, E)).astype(np.float32))
+    bias = torch.from_numpy((rng.standard_normal(E) * 0.2).astype(np.float32))
+    inds, w = group_expert_select(gates, bias, k, n_group, topk_group, rsf, True)
+    for t in range(T):
+        orig = 1 / (1 + np.exp(-gates[t].numpy()))
+        sc = (orig + bias.numpy()).reshape(n_group, -1)
+        gs = np.sort(sc, axis=1)[:, -2:].sum(1)
+        keep = np.argsort(-gs)[:topk_group]
+        masked = np.zeros_like(sc); masked[keep] = sc[keep]
+        top = np.argsort(-masked.reshape(-1))[:k]
+        assert set(top.tolist()) == set(inds[t].tolist())
+        ww = orig[inds[t].numpy()]; ww = ww / ww.sum() * rsf
+        assert np.allclose(w[t].numpy(), ww, rtol=1e-5)
+
+
+def test_deepseek_structure_and_strategy_keys():
+    from gbx_lm_amd.models import qdeepseek_v3
+    from gbx_lm_amd.models.rope_utils import YarnRoPE
+    from gbx_lm_amd.models.switch_layers import QuantizedSwitchLinear
+    strat = S.make_strategy("S22", 2, 64)
+    strat["model.layers.1"]["kv_b_proj"] = {"bits": [2], "group_size": {"2": 32}}
+    strat["model.layers.1"]["moe_shared_expert_up_proj"] = {"bits": [3], "group_size": {"3": 64}}
+    m = S.build_model(S.TINY_DEEPSEEK, strat, device="cpu", seed=1)
+    assert U.MODEL_MAPPING["deepseek_v3"] is qdeepseek_v3
+    at = m.model.layers[1].self_attn
+    assert isinstance(at.rope, YarnRoPE) and at.rope.traditional and at.q_head_dim == 64
+    assert at.kv_a_proj_with_mqa.output_dims == 128 + 32 and at.kv_b_proj.output_dims == 4 * (32 + 32)
+    assert (at.kv_b_proj.bits, at.kv_b_proj.group_size) == (2, 32)                       # 'kv_b_proj' entry, not 'v_proj'... see order
+    moe = m.model.layers[1].mlp
+    assert isinstance(moe.switch_mlp.gate_proj, QuantizedSwitchLinear) and moe.shared_experts.up_proj.bits == 3   # moe_shared_expert_*
+    assert isinstance(m.model.layers[0].mlp, qdeepseek_v3.DeepseekV3MLP)                # first_k_dense_replace = 1
+    w = m.sanitize({"model.layers.61.x": torch.zeros(1), "model.layers.0.y": torch.zeros(1)})
+    assert list(w) == ["model.layers.0.y"]

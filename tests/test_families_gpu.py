@@ -1,4 +1,4 @@
-"""GPU: Qwen2 / Qwen3 / Qwen3-MoE / Mixtral / Phi-3 graphs on the HIP kernels against the SAME weights run through the CPU oracle
+"""GPU: Qwen2 / Qwen3 / Qwen3-MoE / Mixtral / Phi-3 / DeepSeek-V3 graphs on the HIP kernels against the SAME weights run through the CPU oracle
 (prefill, then teacher-forced single-token steps; Qwen2's steps go through the graph-replayed generic decode runner)."""
 import numpy as np
 import pytest
@@ -8,12 +8,12 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("family", ["qwen2", "qwen3", "qwen3_moe", "mixtral", "phi3"])
+@pytest.mark.parametrize("family", ["qwen2", "qwen3", "qwen3_moe", "mixtral", "phi3", "deepseek_v3"])
 def test_family_gpu_matches_cpu_oracle(family, monkeypatch):
     import conftest
     from gbx_lm_amd import ops, synthetic as S
     from gbx_lm_amd.models.cache import make_prompt_cache
-    cfg = {"qwen2": S.TINY_QWEN2, "qwen3": S.TINY_QWEN3, "qwen3_moe": S.TINY_MOE, "mixtral": S.TINY_MIXTRAL, "phi3": S.TINY_PHI3}[family]
+    cfg = {"qwen2": S.TINY_QWEN2, "qwen3": S.TINY_QWEN3, "qwen3_moe": S.TINY_MOE, "mixtral": S.TINY_MIXTRAL, "phi3": S.TINY_PHI3, "deepseek_v3": S.TINY_DEEPSEEK}[family]
     strat = S.make_strategy("S22", 2, 64)
     strat["model.layers.0"]["k_proj"] = {"bits": [2], "group_size": {"2": 32}}
     strat["model.layers.1"]["up_proj"] = {"bits": [3], "group_size": {"3": 128}}
