@@ -318,6 +318,22 @@ int gbx_dense_gemv_argmax(const void* x, const void* w, void* y, const void* nor
   return GBX_OK;
 }
 
+int gbx_rope(const void* x, void* y, const float* inv_freq, const int64_t* pos, int64_t offset, int64_t B, int32_t H, int32_t L,
+             int32_t D, int32_t dims, int64_t stride_b, int64_t stride_h, int64_t stride_l, float scale, float mscale,
+             int32_t traditional, int32_t act_dtype, void* hip_stream) {
+  if (B == 0 || H == 0 || L == 0) return GBX_OK;
+  if (!x || !y || !inv_freq) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (x == y) return fail(GBX_ERR_INVALID, "gbx_rope is out of place");
+  if (B < 0 || H < 0 || L < 0 || D <= 0 || dims <= 0 || (dims & 1) || dims > D)
+    return fail(GBX_ERR_INVALID, "bad shape B=%lld H=%d L=%d D=%d dims=%d", (long long)B, H, L, D, dims);
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  hipError_t e = gbx::launch_rope(x, y, inv_freq, reinterpret_cast<const long long*>(pos), offset, B, H, L, D, dims, stride_b,
+                                  stride_h, stride_l, scale, mscale, traditional, act_dtype == GBX_BF16,
+                                  static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_rope launch");
+  return GBX_OK;
+}
+
 int gbx_rope_append(void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
                     const int64_t* pos, int32_t batch, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int32_t capacity,
                     float rope_scale, int32_t traditional, int32_t act_dtype, void* hip_stream) {

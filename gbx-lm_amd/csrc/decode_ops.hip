@@ -427,12 +427,87 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const unsigned short* __re
   for (int i = tid; i < K; i += 256) yr[i] = f32_to_act<BF16>(act_to_f32<BF16>(xr[i]) * rstd * act_to_f32<BF16>(w[i]));
 }
 
+// short rows (per-head q / k norms, K = head_dim): one wavefront per row, four rows per workgroup
+template <bool BF16>
+__global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
+                                                           unsigned short* __restrict__ y, long long M, int K, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long row = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const unsigned short* xr = x + row * K;
+  unsigned short* yr = y + row * K;
+  float ssq = 0.f;
+  for (int i = lane; i < K; i += 64) { const float v = act_to_f32<BF16>(xr[i]); ssq += v * v; }
+  ssq = wave_sum(ssq);
+  ssq = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ssq), 63));
+  const float rstd = rsqrtf(ssq / static_cast<float>(K) + eps);
+  for (int i = lane; i < K; i += 64) yr[i] = f32_to_act<BF16>(act_to_f32<BF16>(xr[i]) * rstd * act_to_f32<BF16>(w[i]));
+}
+
 hipError_t launch_rmsnorm(const void* x, const void* w, void* y, int M, int K, float eps, bool bf16, hipStream_t s) {
   auto X = static_cast<const unsigned short*>(x);
   auto W = static_cast<const unsigned short*>(w);
   auto Y = static_cast<unsigned short*>(y);
+  if (K <= 512) {
+    const unsigned blocks = static_cast<unsigned>((static_cast<long long>(M) + 3) / 4);
+    if (bf16) hipLaunchKernelGGL((rmsnorm_rows_kernel<true>), dim3(blocks), dim3(256), 0, s, X, W, Y, static_cast<long long>(M), K, eps);
+    else hipLaunchKernelGGL((rmsnorm_rows_kernel<false>), dim3(blocks), dim3(256), 0, s, X, W, Y, static_cast<long long>(M), K, eps);
+    return hipGetLastError();
+  }
   if (bf16) hipLaunchKernelGGL((rmsnorm_kernel<true>), dim3(M), dim3(256), 0, s, X, W, Y, K, eps);
   else hipLaunchKernelGGL((rmsnorm_kernel<false>), dim3(M), dim3(256), 0, s, X, W, Y, K, eps);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ RoPE on [rows, L, D]
+// mx.fast.rope semantics for any family (gbx_lm/models/rope_utils.py, su_rope.py, qdeepseek_v3.py:111-125): element pair i of
+// the first `dims` features of row (r, t) is rotated by angle (offset + t) * scale * inv_freq[i]; `traditional` pairs
+// (2i, 2i+1), else (i, i + dims/2); input scaled by `mscale` first (su / YaRN); fp32 math, one rounding.  The offset is
+// an immediate or, for graph-replayed decode, read from device memory.  Features past `dims` are copied.  x is a
+// strided [B, H, L, D] view (element strides sb, sh, sl; unit feature stride), y is contiguous and must not alias x.
+template <bool BF16>
+__global__ __launch_bounds__(256) void rope_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
+                                                   const float* __restrict__ inv_freq, const long long* __restrict__ posp,
+                                                   long long offset, long long nrows, int H, int L, int D, int dims,
+                                                   long long sb, long long sh, long long sl, float scale, float mscale,
+                                                   int traditional) {
+  const long long base = posp ? *posp : offset;
+  const int half = dims / 2;
+  const long long total = nrows * half;
+  for (long long e = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; e < total;
+       e += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const long long row = e / half;                     // row = (b * H + h) * L + t
+    const int i = static_cast<int>(e % half), t = static_cast<int>(row % L);
+    const long long bh = row / L;
+    const unsigned short* xr = x + (bh / H) * sb + (bh % H) * sh + t * sl;
+    const int i1 = traditional ? 2 * i : i, i2 = traditional ? 2 * i + 1 : i + half;
+    const float x1 = act_to_f32<BF16>(xr[i1]) * mscale, x2 = act_to_f32<BF16>(xr[i2]) * mscale;
+    const float ang = static_cast<float>(base + t) * scale * inv_freq[i];
+    float sn, cs;
+    sincosf(ang, &sn, &cs);
+    y[row * D + i1] = f32_to_act<BF16>(x1 * cs - x2 * sn);
+    y[row * D + i2] = f32_to_act<BF16>(x1 * sn + x2 * cs);
+  }
+  if (dims < D) {
+    const int tail = D - dims;
+    for (long long e = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; e < nrows * tail;
+         e += static_cast<long long>(gridDim.x) * blockDim.x) {
+      const long long row = e / tail, bh = row / L;
+      const int j = dims + static_cast<int>(e % tail);
+      y[row * D + j] = x[(bh / H) * sb + (bh % H) * sh + (row % L) * sl + j];
+    }
+  }
+}
+
+hipError_t launch_rope(const void* x, void* y, const float* inv_freq, const long long* posp, long long offset, long long B,
+                       int H, int L, int D, int dims, long long sb, long long sh, long long sl, float scale, float mscale,
+                       int traditional, bool bf16, hipStream_t s) {
+  const long long nrows = B * H * L, total = nrows * (dims / 2);
+  const unsigned blocks = static_cast<unsigned>(std::min<long long>((total + 255) / 256, 16384));
+  auto X = static_cast<const unsigned short*>(x);
+  auto Y = static_cast<unsigned short*>(y);
+  if (bf16) hipLaunchKernelGGL((rope_kernel<true>), dim3(blocks), dim3(256), 0, s, X, Y, inv_freq, posp, offset, nrows, H, L, D, dims, sb, sh, sl, scale, mscale, traditional);
+  else hipLaunchKernelGGL((rope_kernel<false>), dim3(blocks), dim3(256), 0, s, X, Y, inv_freq, posp, offset, nrows, H, L, D, dims, sb, sh, sl, scale, mscale, traditional);
   return hipGetLastError();
 }
 

@@ -37,6 +37,9 @@ hipError_t launch_embed_next(void* best, void* tok_io, void* pos, const void* ta
                              int advance, bool bf16, hipStream_t s);
 hipError_t launch_pack_sz(const void* s0, const void* z0, const void* s1, const void* z1, uint32_t* out, int N, int G,
                           hipStream_t s);
+hipError_t launch_rope(const void* x, void* y, const float* inv_freq, const long long* posp, long long offset, long long B,
+                       int H, int L, int D, int dims, long long sb, long long sh, long long sl, float scale, float mscale,
+                       int traditional, bool bf16, hipStream_t s);
 hipError_t launch_rope_append(void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
                               const long long* pos, int batch, int n_heads, int n_kv, int hd, int capacity, float rope_scale,
                               int traditional, bool bf16, hipStream_t s);

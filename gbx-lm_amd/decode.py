@@ -125,6 +125,73 @@ class DecodeRunner:
         return self.logits
 
 
+class GraphDecodeRunner:
+    """Family-agnostic single-token decode: the model's OWN forward is captured once in a HIP graph and replayed.
+
+    What makes an eager step uncapturable is only the KV cache (growing views, a host-side offset feeding RoPE): with the
+    caches switched to static mode (``KVCache.static_pos`` / ``static_active``: write at a device-resident position,
+    attend over the whole buffer under a position mask, RoPE reads the position from device memory) every family's graph
+    -- per-head norms, fused projections, expert routing with the expert-indexed GEMV -- replays unchanged."""
+
+    def __init__(self, model, caches: List[KVCache]):
+        self.model, self.caches = model, caches
+        self.dev = caches[0].keys.device
+        self.capacity = caches[0].capacity
+        self.batch = caches[0].keys.shape[0]
+        self.tok = torch.zeros((self.batch, 1), dtype=torch.long, device=self.dev)
+        self.pos = torch.zeros((1,), dtype=torch.long, device=self.dev)
+        for c in caches:
+            c.static_pos = self.pos
+        safe = min(max(caches[0].offset, 0), self.capacity - 1)
+        torch.cuda.synchronize(self.dev)
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):                                   # warm-up outside capture (lazy inits)
+                self.pos.fill_(safe)
+                self._forward()
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.logits = self._forward()
+
+    def _forward(self):
+        for c in self.caches:
+            c.static_active = True
+        try:
+            return self.model(self.tok, cache=self.caches)[:, -1, :]
+        finally:
+            for c in self.caches:
+                c.static_active = False
+
+    def step(self, token: torch.Tensor) -> torch.Tensor:
+        off = self.caches[0].offset
+        self.tok.copy_(token.reshape(self.batch, 1))
+        self.pos.fill_(off)
+        self.graph.replay()
+        for c in self.caches:
+            c.offset = off + 1
+        return self.logits
+
+
+def graph_decode_step(model, y: torch.Tensor, prompt_cache: List[KVCache]) -> torch.Tensor:
+    """``model.decode_step`` hook of the families without a hand-fused block: HIP-graph replay of the model's own forward."""
+    c0 = prompt_cache[0]
+    if not isinstance(c0, KVCache) or c0.keys is None or not c0.keys.is_cuda:
+        return model(y[None], cache=prompt_cache)[:, -1, :]
+    if c0.offset + 1 > c0.capacity:                               # grow every layer before (re)capturing
+        for c in prompt_cache:
+            c.reserve(1, c.keys[:, :, :1], c.values[:, :, :1])
+    runner = getattr(model, "_decode_runner", None)
+    if runner is None or runner.caches is not prompt_cache or runner.capacity != c0.capacity \
+            or c0.keys.data_ptr() != getattr(runner, "_kptr", None):
+        runner = GraphDecodeRunner(model, prompt_cache)
+        runner._kptr = c0.keys.data_ptr()
+        model._decode_runner = runner
+    return runner.step(y)
+
+
 def fused_eligible(model) -> bool:
     """The fused HIP decode block needs: no biases, q/k/v (and gate/up) packed alike, head_dim 64/128, full-width RoPE,
     16-bit activations and every (per-rank) K a multiple of 128.  Tensor-parallel shards qualify too."""

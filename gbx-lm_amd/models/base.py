@@ -49,10 +49,22 @@ def create_attention_mask(h: torch.Tensor, cache: Optional[Any] = None) -> Optio
     return None
 
 
+def cache_offset(cache):
+    """Position of the next token: the cache's host-side ``offset``, or -- inside a graph-replayed decode step -- its
+    device-resident ``static_pos`` (RoPE then reads the position from device memory)."""
+    if cache is None:
+        return 0
+    return cache.static_pos if getattr(cache, "static_active", False) else cache.offset
+
+
 def scaled_dot_product_attention(queries, keys, values, cache, scale: float, mask: Optional[torch.Tensor]):
     """[B, Hq, L, D] x [B, Hkv, S, D] -> [B, Hq, L, D]; GQA by head repetition like mx.fast.sdpa."""
     if getattr(cache, "bits", None) is not None:
         raise NotImplementedError("quantised KV cache is outside the QuantizedLinear hot path")
+    if getattr(cache, "static_active", False):    # whole buffer, positions past the device-resident index masked out
+        cap = keys.shape[2]
+        live = torch.arange(cap, device=keys.device)[None, None, None, :] <= cache.static_pos
+        mask = torch.where(live, 0.0, float("-inf")).to(queries.dtype)
     n_q, n_kv = queries.shape[1], keys.shape[1]
     if n_q != n_kv:
         rep = n_q // n_kv

@@ -24,6 +24,11 @@ class KVCache:
         self.values = None
         self.offset = 0
         self.step = step
+        # graph-replayed decode (gbx_lm_amd/decode.py:GraphDecodeRunner): while ``static_active`` the write position is the
+        # device-resident ``static_pos`` (int64 [1]) and attention runs over the whole buffer under a position mask, so one
+        # captured launch sequence serves every step
+        self.static_pos = None
+        self.static_active = False
 
     @property
     def capacity(self) -> int:
@@ -48,6 +53,10 @@ class KVCache:
                 self.keys, self.values = new_k, new_v
 
     def update_and_fetch(self, keys: torch.Tensor, values: torch.Tensor):
+        if self.static_active:                      # one new position at the device-resident index; shapes never change
+            self.keys.index_copy_(2, self.static_pos, keys)
+            self.values.index_copy_(2, self.static_pos, values)
+            return self.keys, self.values
         prev = self.offset
         self.reserve(keys.shape[2], keys, values)
         self.offset += keys.shape[2]

@@ -18,7 +18,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .base import BaseModelArgs, create_attention_mask, scaled_dot_product_attention
+from .base import BaseModelArgs, cache_offset, create_attention_mask, scaled_dot_product_attention
 from .qllama import RMSNorm
 from .quantized_linear_gba import QuantizedLinear
 from .rope_utils import RoPE, YarnRoPE, yarn_get_mscale
@@ -101,7 +101,7 @@ class DeepseekV3Attention(nn.Module):
         k_pe = k_pe.reshape(b, l, 1, self.qk_rope_head_dim).permute(0, 2, 1, 3)
         kv = self.kv_b_proj(self.kv_a_layernorm(ckv)).view(b, l, self.num_heads, -1).permute(0, 2, 1, 3)
         k_nope, values = torch.split(kv, [self.qk_nope_head_dim, self.v_head_dim], dim=-1)
-        start = cache.offset if cache is not None else 0
+        start = cache_offset(cache)
         q_pe, k_pe = self.rope(q_pe, offset=start), self.rope(k_pe, offset=start)
         keys = torch.cat([k_nope, k_pe.expand(-1, self.num_heads, -1, -1)], dim=-1)
         if cache is not None:
@@ -245,6 +245,11 @@ class Model(nn.Module):
                         weights.pop(f"{prefix}.mlp.experts.{e}.{m}.channel_scale")
                         weights.pop(f"{prefix}.mlp.experts.{e}.{m}.q_perm")
         return {k: v for k, v in weights.items() if not k.startswith("model.layers.61")}
+
+    def decode_step(self, y: torch.Tensor, prompt_cache) -> torch.Tensor:
+        """Single-token fast path: this graph captured once and replayed (gbx_lm_amd/decode.py:GraphDecodeRunner)."""
+        from ..decode import graph_decode_step
+        return graph_decode_step(self, y, prompt_cache)
 
     @property
     def layers(self):

@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .base import BaseModelArgs, create_attention_mask, scaled_dot_product_attention
+from .base import BaseModelArgs, cache_offset, create_attention_mask, scaled_dot_product_attention
 from .quantized_linear_gba import QuantizedLinear
 from .rope_utils import initialize_rope
 
@@ -57,6 +57,9 @@ class RMSNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(dims), requires_grad=False)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and self.weight.dtype == x.dtype:
+            from .. import ops                       # one HIP launch (gbx_rmsnorm), same arithmetic as the lines below
+            return ops.rmsnorm(x, self.weight, self.eps)
         x32 = x.float()
         inv = torch.rsqrt(x32.square().mean(dim=-1, keepdim=True) + self.eps)
         return (x32 * inv * self.weight.float()).to(x.dtype)
@@ -95,7 +98,7 @@ class Attention(nn.Module):
         q = _heads(self.q_proj(x), self.n_heads)
         k = _heads(self.k_proj(x), self.n_kv_heads)
         v = _heads(self.v_proj(x), self.n_kv_heads)
-        start = cache.offset if cache is not None else 0
+        start = cache_offset(cache)
         q, k = self.rope(q, offset=start), self.rope(k, offset=start)
         if cache is not None:
             k, v = cache.update_and_fetch(k, v)

@@ -126,6 +126,11 @@ class Model(nn.Module):
                         weights[f"{prefix}.switch_mlp.{m}.{t}"] = torch.stack(parts)
         return weights
 
+    def decode_step(self, y: torch.Tensor, prompt_cache) -> torch.Tensor:
+        """Single-token fast path: this graph captured once and replayed (gbx_lm_amd/decode.py:GraphDecodeRunner)."""
+        from ..decode import graph_decode_step
+        return graph_decode_step(self, y, prompt_cache)
+
     @property
     def layers(self):
         return self.model.layers

@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .base import BaseModelArgs, create_attention_mask, scaled_dot_product_attention
+from .base import BaseModelArgs, cache_offset, create_attention_mask, scaled_dot_product_attention
 from .qllama import RMSNorm
 from .quantized_linear_gba import QuantizedLinear
 from .rope_utils import RoPE, SuScaledRotaryEmbedding
@@ -82,7 +82,7 @@ class Attention(nn.Module):
         q = q.reshape(b, l, self.n_heads, -1).permute(0, 2, 1, 3)
         k = k.reshape(b, l, self.n_kv_heads, -1).permute(0, 2, 1, 3)
         v = v.reshape(b, l, self.n_kv_heads, -1).permute(0, 2, 1, 3)
-        start = cache.offset if cache is not None else 0
+        start = cache_offset(cache)
         q, k = self.rope(q, offset=start), self.rope(k, offset=start)
         if cache is not None:
             k, v = cache.update_and_fetch(k, v)
@@ -150,6 +150,11 @@ class Model(nn.Module):
         out = self.model(inputs, mask, cache)
         logits = self.lm_head(out)
         return (logits, out) if hidden_states else logits
+
+    def decode_step(self, y: torch.Tensor, prompt_cache) -> torch.Tensor:
+        """Single-token fast path: this graph captured once and replayed (gbx_lm_amd/decode.py:GraphDecodeRunner)."""
+        from ..decode import graph_decode_step
+        return graph_decode_step(self, y, prompt_cache)
 
     @property
     def layers(self):

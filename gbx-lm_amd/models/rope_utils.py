@@ -16,9 +16,15 @@ from torch import nn
 
 def apply_rope(x: torch.Tensor, inv_freq: torch.Tensor, offset: int, scale: float, traditional: bool) -> torch.Tensor:
     """x [B, H, L, D]; rotates the first 2*len(inv_freq) features."""
+    if x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and inv_freq.is_cuda and inv_freq.dtype == torch.float32:
+        from .. import ops                           # one HIP launch (gbx_rope) instead of ~10 elementwise kernels
+        return ops.rope(x, inv_freq, offset, scale, traditional)
     L = x.shape[-2]
     dims = inv_freq.numel() * 2
-    pos = (torch.arange(offset, offset + L, device=x.device, dtype=torch.float32) * scale)
+    if isinstance(offset, torch.Tensor):            # device-resident position (graph-replayed decode)
+        pos = (offset.to(torch.float32) + torch.arange(L, device=x.device, dtype=torch.float32)) * scale
+    else:
+        pos = (torch.arange(offset, offset + L, device=x.device, dtype=torch.float32) * scale)
     ang = pos[:, None] * inv_freq[None, :].to(x.device)
     cos, sin = torch.cos(ang), torch.sin(ang)
     xf = x[..., :dims].to(torch.float32)

@@ -327,6 +327,22 @@ def eminf_optimize(logits: torch.Tensor, alpha: float = 0.65, num_steps: Optiona
     return best, ent
 
 
+def rope(x: torch.Tensor, inv_freq: torch.Tensor, offset, scale: float = 1.0, traditional: bool = False,
+         mscale: float = 1.0) -> torch.Tensor:
+    """Rotary embedding of x [B, H, L, D] (any strides with a unit feature stride, e.g. the transposed projection output)
+    in one launch (gbx_rope); ``offset`` is an int or a device int64 tensor.  Returns a contiguous tensor."""
+    _require_cuda(x, "x")
+    if x.dim() != 4 or x.stride(-1) != 1:
+        x = x.reshape(-1, 1, x.shape[-2], x.shape[-1]).contiguous()
+    B, H, L, D = x.shape
+    y = torch.empty((B, H, L, D), dtype=x.dtype, device=x.device)
+    pos_ptr, off = (offset.data_ptr(), 0) if isinstance(offset, torch.Tensor) else (None, int(offset))
+    _lib.check(_lib.lib().gbx_rope(x.data_ptr(), y.data_ptr(), inv_freq.data_ptr(), pos_ptr, off, B, H, L, D,
+                                   inv_freq.numel() * 2, x.stride(0), x.stride(1), x.stride(2), float(scale), float(mscale),
+                                   int(bool(traditional)), _DT[x.dtype], _stream_ptr(x.device)))
+    return y
+
+
 def rope_append(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor,
                 inv_freq: torch.Tensor, pos: torch.Tensor, n_heads: int, n_kv: int, head_dim: int,
                 rope_scale: float, traditional: bool) -> None:

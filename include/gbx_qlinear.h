@@ -197,6 +197,16 @@ int gbx_embed_next_token(void* argmax_keys, int64_t* token_io, int64_t* pos, con
                          int32_t D, int32_t vocab, int32_t from_keys, int32_t advance_pos, int32_t act_dtype,
                          void* hip_stream);
 
+/* Rotary embedding of the strided view x[B, H, L, D] (element strides stride_b/h/l, unit feature stride) into the
+ * contiguous y[B, H, L, D] (out of place): pair i of the first `dims` features at time step t turns by
+ * (offset + t) * scale * inv_freq[i]; pairs are (2i, 2i+1) if traditional else (i, i + dims/2); x is scaled by mscale first
+ * (su / YaRN variants); features past dims are copied.  `pos` != NULL: the offset is read from device memory
+ * (graph-replayed decode).  mx.fast.rope as the model graphs call it (qllama.py:88-89, qphi3.py:99-103,
+ * qdeepseek_v3.py:113-125). */
+int gbx_rope(const void* x, void* y, const float* inv_freq, const int64_t* pos, int64_t offset, int64_t B, int32_t H, int32_t L,
+             int32_t D, int32_t dims, int64_t stride_b, int64_t stride_h, int64_t stride_l, float scale, float mscale,
+             int32_t traditional, int32_t act_dtype, void* hip_stream);
+
 /* Synchronous batched decode step, every sequence at position *pos (device int64): q[batch, n_heads*head_dim] is rotated
  * in place, k[batch, n_kv*head_dim] is rotated into kcache[b, kvh, *pos, :], v copied into vcache[b, kvh, *pos, :]
  * (caches [batch, n_kv, capacity, head_dim]).  rope(q), rope(k), cache.update_and_fetch of qllama.py:84-91 for one new

@@ -381,12 +381,49 @@ def test_rope_append_batched(traditional):
     rope = RoPE(hd, traditional=traditional).to(DEV)
     q0 = q.clone()
     ops.rope_append(q, k, v, kc, vc, rope.inv_freq, torch.tensor([pos], device=DEV), nh, nkv, hd, 1.0, traditional)
-    qr = apply_rope(q0.view(B, 1, nh, hd).transpose(1, 2), rope.inv_freq, pos, 1.0, traditional).transpose(1, 2).reshape(B, -1)
-    kr = apply_rope(k.view(B, 1, nkv, hd).transpose(1, 2), rope.inv_freq, pos, 1.0, traditional)
-    assert torch.allclose(q.float(), qr.float(), atol=2e-2, rtol=2e-2)
-    assert torch.allclose(kc[:, :, pos].float(), kr[:, :, 0].float(), atol=2e-2, rtol=2e-2)
+    inv = rope.inv_freq.cpu()                       # reference: the torch fp32 formulation on the CPU
+    qr = apply_rope(q0.cpu().view(B, 1, nh, hd).transpose(1, 2), inv, pos, 1.0, traditional).transpose(1, 2).reshape(B, -1)
+    kr = apply_rope(k.cpu().view(B, 1, nkv, hd).transpose(1, 2), inv, pos, 1.0, traditional)
+    assert torch.allclose(q.float().cpu(), qr.float(), atol=2e-2, rtol=2e-2)
+    assert torch.allclose(kc[:, :, pos].float().cpu(), kr[:, :, 0].float(), atol=2e-2, rtol=2e-2)
     assert torch.equal(vc[:, :, pos], v.view(B, nkv, hd))
     assert torch.count_nonzero(kc[:, :, :pos]) == 0 and torch.count_nonzero(kc[:, :, pos + 1:]) == 0
+
+
+@pytest.mark.parametrize("traditional", [False, True])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_rope_kernel_matches_torch_fp32(traditional, dt):
+    """gbx_rope (one launch; what apply_rope runs on the GPU for every family) against the torch fp32 formulation on
+    the CPU: strided (transposed projection) input, partial rotary dims, immediate and device-resident offsets."""
+    from gbx_lm_amd import ops
+    from gbx_lm_amd.models.rope_utils import apply_rope
+    g = torch.Generator().manual_seed(3)
+    for (B, H, L, D, dims, off, scale) in ((2, 8, 17, 128, 128, 0, 1.0), (1, 4, 1, 64, 32, 4099, 0.25), (3, 2, 5, 96, 96, 120000, 1.0)):
+        x = torch.randn(B, L, H, D, generator=g).to(dt)
+        inv = 1.0 / (10000.0 ** (torch.arange(0, dims, 2, dtype=torch.float32) / dims))
+        want = apply_rope(x.transpose(1, 2), inv, off, scale, traditional)
+        xd = x.to(DEV).transpose(1, 2)                                   # strided view, as the model graphs pass it
+        got = ops.rope(xd, inv.to(DEV), off, scale, traditional)
+        got_dev = apply_rope(xd, inv.to(DEV), torch.tensor([off], device=DEV), scale, traditional)
+        assert got.is_contiguous() and got.shape == want.shape
+        # one bf16/fp16 rounding of an fp32 result on both sides; angles near 1e5 rad carry ~1e-2 of fp32 phase error
+        tol = 4e-2 if off > 10000 else 1e-2
+        assert torch.allclose(got.float().cpu(), want.float(), atol=tol, rtol=2e-2), (B, H, L, D, dims, off)
+        assert torch.equal(got, got_dev)
+        if dims < D:
+            assert torch.equal(got[..., dims:].cpu(), x.transpose(1, 2)[..., dims:])
+
+
+def test_rmsnorm_short_rows():
+    """Per-head q / k norms (row length = head_dim): the wave-per-row variant of gbx_rmsnorm."""
+    from gbx_lm_amd import ops
+    for rows, k, dt in ((37, 128, torch.bfloat16), (4, 64, torch.float16), (1025, 512, torch.bfloat16)):
+        x = torch.randn(rows, k).to(dt)
+        w = (1 + 0.1 * torch.randn(k)).to(dt)
+        xf = x.float()
+        want = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6) * w.float())
+        got = ops.rmsnorm(x.to(DEV), w.to(DEV), 1e-6).float().cpu()
+        assert torch.allclose(got, want, atol=2e-2, rtol=1e-2), (rows, k)
 
 
 def test_eminf_optimize_on_device(golden_dir, oracle):
