@@ -1,0 +1,372 @@
+// Batched decode (2 <= M <= 32 rows of activations), 2- and 4-bit, group 128: y[M,N] = x[M,K] . dequant(W[N,K])^T without
+// dequantising.  Replaces mx.quantized_matmul for x of shape [B, 1, K] (gbx_lm/models/quantized_linear_gba.py:195-203).
+//
+// At these M the packed weights are read once and mfma_skinny.hip was bound by everything except HBM: ~4 VALU
+// instructions per weight element to build bf16 weights, the activation tile re-read from L2 by every wave (8 bytes of x
+// per byte of 2-bit weight at M = 32), and one window of loads per wave with nothing overlapping it.  Here:
+//   * the integer fields go to the matrix cores as they are.  A 2- or 4-bit field ORed under the exponent of 128.0
+//     (bf16) / 1024.0 (fp16) IS the number 128+q / 1024+q, and two fields 16 bits apart in a packed word make one MFMA
+//     operand dword with a shift and one v_and_or: 1 VALU instruction per element instead of 4.  Per group
+//     (= 128-value chunk) the MFMA accumulates t[m,n] = sum_k x[m,k] (C + q[n,k]) exactly as an fp32 sum of exact
+//     products, and the affine map is applied to the 32x32 partial tile once per group:
+//         acc[m,n] += s[n,g] * t[m,n] + (z[n,g] - C s[n,g]) * xsum[m,g],   xsum[m,g] = sum_{k in g} x[m,k]
+//     (w = s q + z is never rounded to the activation dtype, so this is closer to the fp64 oracle than the dequantising
+//     kernels; same tolerance in the tests).
+//   * the k order inside a chunk is free as long as both MFMA operands agree, so lane-group h of a wave owns the h-th
+//     1/H of the chunk: a lane loads ONLY the packed words it consumes (16 bytes per chunk at 2 bits), and the
+//     activation tile is stored in LDS in the pair order the fields come out of a word ((i, i+8) at 2 bits, (i, i+4) at
+//     4 bits) by the loader threads, which also produce xsum with v_dot2.
+//   * a workgroup is 8 compute waves = NG row groups x KG k-ranges, plus 4 loader waves.  The NG waves of a k-range
+//     share ONE activation slab, so x is read from L2 once per NG*TNW weight rows (128 rows for the wide projections:
+//     2 bytes of x per byte of weight).  The loader waves stage step s+1 (8 chunks across the workgroup: load, pair
+//     order, xsum, LDS) while the compute waves run step s with the packed words of step s+1 in flight; when every
+//     wave did both, the load-issue phase and the MFMA phase alternated (in-kernel stamps: 2.3k + 2.8k cycles of
+//     staging and barrier wait per 3.8k cycles of MFMA work).  The KG partial tiles meet in LDS at the end; one
+//     rounding to the activation dtype.
+// Measured at M = 32, 2 bits (scratch/bench_skinny32.py, us, split-K kernel -> this one): gate|up 28672x4096 45.2 -> 19.6,
+// down 4096x14336 33.6 -> 25.6, q|k|v 6144x4096 11.8 -> 10.7, o 4096x4096 9.6 -> 9.9.  What bounds it now is the L1 fill
+// rate per CU: every workgroup still pulls the whole 256 KB activation tile through its vector-memory path (57 MB
+// chip-wide beside 29 MB of weights for gate|up); sharing x further needs a k split ACROSS workgroups, i.e. a
+// caller-owned fp32 workspace in the ABI (next round).
+// -DBX_STAMPS: diagnostic build with s_memtime phase stamps (scratch/stamps_batch.py).
+#include "mfma_common.h"
+#include "kernels.h"
+
+namespace gbx {
+
+template <bool BF16> __device__ __forceinline__ float xdot2(unsigned v, float acc) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  if constexpr (BF16) return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, v), __builtin_bit_cast(bf2, 0x3F803F80u), acc, false);
+  else return __builtin_amdgcn_fdot2(as_h2(v), as_h2(0x3C003C00u), acc, false);
+}
+
+#ifdef BX_STAMPS
+__device__ long long* bx_stamp_ptr;                 // diagnostic build only (scratch/stamps_batch.py)
+#endif
+
+template <int BITS, int TNW, int NG, int KG, bool BF16>
+__global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
+  static_assert(NG * KG == 8 && (BITS == 2 || BITS == 4) && (TNW == 16 || TNW == 32), "unsupported shape");
+  constexpr int NCHW = 8 / KG;                      // chunks per step of one k-range (the workgroup does 8 per step)
+  constexpr int H = 64 / TNW;                       // lane groups of a wave (k split inside a chunk)
+  constexpr int UPL = 16 / H;                       // 16-byte activation units per lane and chunk = MFMA steps per chunk
+  constexpr int WL = UPL * BITS / 4;                // packed words per lane and chunk
+  constexpr int WPC = KC * BITS / 32;               // packed words per row and chunk
+  constexpr int MT = 32 / TNW;                      // activation row tiles (32 rows)
+  constexpr int AE = TNW == 32 ? 16 : 4;            // accumulator elements per lane and tile
+  constexpr int CHUNK = 32 * XROW;                  // slab bytes of one chunk (32 activation rows)
+  constexpr int BUF = 8 * CHUNK;                    // one step of the whole workgroup
+  constexpr unsigned MAGIC = BF16 ? 0x43004300u : 0x64006400u;   // 128.0 | 1024.0 twice
+  constexpr float CF = BF16 ? 128.f : 1024.f;
+  constexpr unsigned FMASK = BITS == 2 ? 0x00030003u : 0x000F000Fu;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][8 chunks][32 rows][XROW] | xsum [2][8][32]
+  float* xsum = reinterpret_cast<float*>(smem + 2 * BUF);
+  float* red = reinterpret_cast<float*>(smem);                            // after the main loop: [8 waves][MT*AE][64]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ng = wave % NG, kg = wave / NG;
+  const int r = lane & (TNW - 1), h = lane / TNW;
+  const int K = a.K, M = a.M;
+  const int W = K / 32 * BITS, G = K >> 7;
+  const int nchunks = K / KC, steps = nchunks / 8, cpk = nchunks / KG;
+
+  // segment of this workgroup's rows (uniform): a workgroup never straddles two matrices (launcher)
+  const int nwg = blockIdx.x * (NG * TNW);
+  const uint32_t* qw = a.qweight;
+  const unsigned short* sc = a.scales;
+  const unsigned short* ze = a.zeros;
+  const unsigned short* bs = a.bias;
+  unsigned short* yo = a.y;
+  int nl0 = nwg, NL = a.N;
+  if (a.nseg > 1) {
+    const int sg = (nwg >= a.n_seg[0]) + (nwg >= a.n_seg[0] + a.n_seg[1]);
+    NL = a.n_seg[sg];
+    if (sg > 0) {
+      nl0 = nwg - a.n_seg[0] - (sg > 1 ? a.n_seg[1] : 0);
+      qw = a.qweight_x[sg - 1]; sc = a.scales_x[sg - 1]; ze = a.zeros_x[sg - 1]; bs = a.bias_x[sg - 1]; yo = a.y_x[sg - 1];
+    }
+  }
+  const int nrow = min(nl0 + ng * TNW + r, NL - 1);
+  const uint32_t* wrow = qw + static_cast<size_t>(nrow) * W + h * WL + static_cast<size_t>(kg) * cpk * WPC;
+  const unsigned short* srow = sc + static_cast<size_t>(nrow) * G + kg * cpk;
+  const unsigned short* zrow = ze + static_cast<size_t>(nrow) * G + kg * cpk;
+
+  // loader role (waves 8..11): per step the workgroup stages 8 chunks x 32 rows x 256 B; loader thread -> 8 pieces of
+  // 32 B (16 k-values), one per chunk slot
+  const bool loader = wave >= 8;
+  const int lrow = (tid & 255) >> 3, lpc = tid & 7;
+  const unsigned short* xrow = a.x + static_cast<size_t>(min(lrow, M - 1)) * K + lpc * 16;
+  const int xdst0 = lrow * XROW + lpc * 32;         // slab byte offset inside a chunk slot
+  auto xoff = [&](int cs) { return ((cs / NCHW) * cpk + (cs % NCHW)) * KC; };   // element offset of slot cs at step 0
+
+  f32x16 acc32[TNW == 32 ? 1 : 1];
+  f32x4v acc16[TNW == 16 ? MT : 1];
+  acc32[0] = f32x16{0};
+#pragma unroll
+  for (int i = 0; i < (TNW == 16 ? MT : 1); ++i) acc16[i] = f32x4v{0};
+
+  unsigned wq[2][NCHW][WL];                        // packed words: current step, next step
+  constexpr int SR = NCHW >= 2 ? NCHW / 2 : 1;      // dwords holding the step's NCHW scales (zeros) of the lane's row
+  unsigned scq[2][SR], zeq[2][SR];
+  u32x4 xs[8][2];                                   // loader: activations of the step being staged
+
+  auto load_x = [&](int step) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const unsigned short* p = xrow + xoff(it) + step * (NCHW * KC);
+      xs[it][0] = *reinterpret_cast<const u32x4*>(p);
+      xs[it][1] = *reinterpret_cast<const u32x4*>(p + 8);
+    }
+  };
+  auto load_w = [&](unsigned (&wn)[NCHW][WL], unsigned (&sc_n)[SR], unsigned (&ze_n)[SR], int step) {
+#pragma unroll
+    for (int j = 0; j < NCHW; ++j) {
+      const uint32_t* src = wrow + static_cast<size_t>(step * NCHW + j) * WPC;
+      if constexpr (WL >= 4) {
+#pragma unroll
+        for (int q = 0; q < WL; q += 4) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(src + q);
+          wn[j][q] = v.x; wn[j][q + 1] = v.y; wn[j][q + 2] = v.z; wn[j][q + 3] = v.w;
+        }
+      } else {
+        const u32x2 v = *reinterpret_cast<const u32x2*>(src);
+        wn[j][0] = v.x; wn[j][1] = v.y;
+      }
+    }
+    // the step's NCHW consecutive scales / zeros of the row as ONE load each (a load costs a cycle per distinct line)
+    if constexpr (NCHW == 4) {
+      const u32x2 s2 = *reinterpret_cast<const u32x2*>(srow + step * 4), z2 = *reinterpret_cast<const u32x2*>(zrow + step * 4);
+      sc_n[0] = s2.x; sc_n[1] = s2.y; ze_n[0] = z2.x; ze_n[1] = z2.y;
+    } else if constexpr (NCHW == 2) {
+      sc_n[0] = *reinterpret_cast<const unsigned*>(srow + step * 2); ze_n[0] = *reinterpret_cast<const unsigned*>(zrow + step * 2);
+    } else {
+      sc_n[0] = srow[step]; ze_n[0] = zrow[step];
+    }
+  };
+  // registers -> pair order of the packed fields -> slab; xsum of the piece, reduced over the 8 lanes of a row chunk
+  auto store_x = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const u32x4 lo = xs[it][0], hi = xs[it][1];
+      u32x4 u0, u1;
+      if constexpr (BITS == 2) {                    // word of 16 fields: dword j of unit b = (x[4b+j], x[4b+j+8])
+        u0.x = __builtin_amdgcn_perm(hi.x, lo.x, 0x05040100u); u0.y = __builtin_amdgcn_perm(hi.x, lo.x, 0x07060302u);
+        u0.z = __builtin_amdgcn_perm(hi.y, lo.y, 0x05040100u); u0.w = __builtin_amdgcn_perm(hi.y, lo.y, 0x07060302u);
+        u1.x = __builtin_amdgcn_perm(hi.z, lo.z, 0x05040100u); u1.y = __builtin_amdgcn_perm(hi.z, lo.z, 0x07060302u);
+        u1.z = __builtin_amdgcn_perm(hi.w, lo.w, 0x05040100u); u1.w = __builtin_amdgcn_perm(hi.w, lo.w, 0x07060302u);
+      } else {                                      // word of 8 fields: dword j of its unit = (x[j], x[j+4])
+        u0.x = __builtin_amdgcn_perm(lo.z, lo.x, 0x05040100u); u0.y = __builtin_amdgcn_perm(lo.z, lo.x, 0x07060302u);
+        u0.z = __builtin_amdgcn_perm(lo.w, lo.y, 0x05040100u); u0.w = __builtin_amdgcn_perm(lo.w, lo.y, 0x07060302u);
+        u1.x = __builtin_amdgcn_perm(hi.z, hi.x, 0x05040100u); u1.y = __builtin_amdgcn_perm(hi.z, hi.x, 0x07060302u);
+        u1.z = __builtin_amdgcn_perm(hi.w, hi.y, 0x05040100u); u1.w = __builtin_amdgcn_perm(hi.w, hi.y, 0x07060302u);
+      }
+      unsigned char* dst = smem + buf * BUF + it * CHUNK + xdst0;
+      *reinterpret_cast<u32x4*>(dst) = u0;
+      *reinterpret_cast<u32x4*>(dst + 16) = u1;
+      float sm = xdot2<BF16>(lo.x, 0.f);
+      sm = xdot2<BF16>(lo.y, sm); sm = xdot2<BF16>(lo.z, sm); sm = xdot2<BF16>(lo.w, sm);
+      sm = xdot2<BF16>(hi.x, sm); sm = xdot2<BF16>(hi.y, sm); sm = xdot2<BF16>(hi.z, sm); sm = xdot2<BF16>(hi.w, sm);
+      sm += dpp_f32<0xB1>(sm);
+      sm += dpp_f32<0x4E>(sm);
+      sm += dpp_f32<0x141>(sm);                     // 8-lane total in every lane of the row chunk
+      if (lpc == 0) xsum[(buf * 8 + it) * 32 + lrow] = sm;
+    }
+  };
+  auto compute = [&](const unsigned (&wc)[NCHW][WL], const unsigned (&sc_c)[SR], const unsigned (&ze_c)[SR], int buf) {
+#pragma unroll
+    for (int j = 0; j < NCHW; ++j) {
+      const int cs = kg * NCHW + j;
+      const unsigned char* slab = smem + buf * BUF + cs * CHUNK;
+      const unsigned sw = sc_c[j >> 1], zw = ze_c[j >> 1];
+      const float s = act_to_f32<BF16>(static_cast<unsigned short>((j & 1) ? (sw >> 16) : (sw & 0xFFFFu)));
+      const float zz = act_to_f32<BF16>(static_cast<unsigned short>((j & 1) ? (zw >> 16) : (zw & 0xFFFFu))) - CF * s;
+      f32x16 g32;
+      f32x4v g16[TNW == 16 ? MT : 1];
+#pragma unroll
+      for (int t = 0; t < UPL; ++t) {
+        u32x4 bf;
+        if constexpr (BITS == 2) {
+          const unsigned w = wc[j][t >> 1];
+          const int sh = 8 * (t & 1);
+          bf.x = ((w >> sh) & FMASK) | MAGIC;       bf.y = ((w >> (sh + 2)) & FMASK) | MAGIC;
+          bf.z = ((w >> (sh + 4)) & FMASK) | MAGIC; bf.w = ((w >> (sh + 6)) & FMASK) | MAGIC;
+        } else {
+          const unsigned w = wc[j][t];
+          bf.x = (w & FMASK) | MAGIC;        bf.y = ((w >> 4) & FMASK) | MAGIC;
+          bf.z = ((w >> 8) & FMASK) | MAGIC; bf.w = ((w >> 12) & FMASK) | MAGIC;
+        }
+        if constexpr (TNW == 32) {
+          const u32x4 af = *reinterpret_cast<const u32x4*>(slab + r * XROW + (h * UPL + t) * 16);
+          g32 = mfma<BF16>(af, bf, t == 0 ? f32x16{0} : g32);
+        } else {
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            const u32x4 af = *reinterpret_cast<const u32x4*>(slab + (i * TNW + r) * XROW + (h * UPL + t) * 16);
+            g16[i] = mfma16<BF16>(af, bf, t == 0 ? f32x4v{0} : g16[i]);
+          }
+        }
+      }
+      // group flush: acc += s * t + (z - C s) * xsum[row]
+      const float* xsm = xsum + (buf * 8 + cs) * 32;
+      if constexpr (TNW == 32) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const f32x4v xv = *reinterpret_cast<const f32x4v*>(xsm + 8 * jj + 4 * (lane >> 5));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc32[0][4 * jj + e] = fmaf(s, g32[4 * jj + e], fmaf(zz, xv[e], acc32[0][4 * jj + e]));
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const f32x4v xv = *reinterpret_cast<const f32x4v*>(xsm + i * 16 + 4 * (lane >> 4));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc16[i][e] = fmaf(s, g16[i][e], fmaf(zz, xv[e], acc16[i][e]));
+        }
+      }
+    }
+  };
+
+  // Every workgroup walks its k range from a different starting step: at any moment the chip then reads all eight
+  // 128-byte pieces of the 1 KB rows instead of the same piece of every row (HBM channel camping).
+  const int rot = blockIdx.x % steps;
+  auto kstep = [&](int i) { const int t = i + rot; return t >= steps ? t - steps : t; };
+#ifdef BX_STAMPS
+  long long st[24];
+  int sti = 0;
+#define STAMP() { if (sti < 24) st[sti++] = __builtin_amdgcn_s_memtime(); }
+#else
+#define STAMP()
+#endif
+  // Producer / consumer split: while the 8 compute waves run step s out of slab[s & 1], the 4 loader waves turn the
+  // activations of step s+1 into slab[(s+1) & 1] (and have step s+2 in flight); one barrier per step.  With every wave
+  // doing both, the load-issue phase (TA-bound, all waves at once) and the MFMA phase alternated instead of overlapping.
+  // (two separate loops, not one loop with a role branch inside: the register allocator would keep both roles' state
+  // live across the shared back edge.  Both execute steps+1 barriers.)
+  STAMP();
+  if (loader) {
+    load_x(kstep(0));
+    store_x(0);
+    if (steps > 1) load_x(kstep(1));
+    STAMP();
+    __syncthreads();
+    for (int step = 0; step < steps; ++step) {
+      if (step + 1 < steps) {
+        store_x((step & 1) ^ 1);                    // step+1: registers -> slab (+ xsum)
+        if (step + 2 < steps) load_x(kstep(step + 2));
+      }
+      STAMP(); STAMP(); STAMP();
+      __syncthreads();                              // slab[buf ^ 1] complete, slab[buf] readers done
+      STAMP();
+    }
+  } else {
+    load_w(wq[1], scq[1], zeq[1], kstep(0));
+    STAMP();
+    __syncthreads();
+    for (int step = 0; step < steps; ++step) {
+#ifdef BX_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      STAMP();
+#pragma unroll
+      for (int j = 0; j < NCHW; ++j)
+#pragma unroll
+        for (int q = 0; q < WL; ++q) wq[0][j][q] = wq[1][j][q];
+#pragma unroll
+      for (int q = 0; q < SR; ++q) { scq[0][q] = scq[1][q]; zeq[0][q] = zeq[1][q]; }
+      if (step + 1 < steps) load_w(wq[1], scq[1], zeq[1], kstep(step + 1));
+      STAMP();
+      compute(wq[0], scq[0], zeq[0], step & 1);
+#ifdef BX_STAMPS
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      STAMP();
+      __syncthreads();
+      STAMP();
+    }
+  }
+  __syncthreads();                                  // the slabs become the reduction buffer
+
+  // ---- k-range reduction through LDS, one rounding to the activation dtype (+ bias as a second rounding) ----
+  constexpr int TE = MT * AE;                       // accumulator elements per lane (16 / 8)
+  if (!loader)
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int e = 0; e < AE; ++e) {
+      float v;
+      if constexpr (TNW == 32) v = acc32[0][e]; else v = acc16[i][e];
+      red[((kg * NG + ng) * TE + i * AE + e) * 64 + lane] = v;
+    }
+  __syncthreads();
+  for (int idx = tid; idx < NG * TE * 64; idx += 768) {
+    const int g = idx / (TE * 64), ie = (idx / 64) % TE, ln = idx & 63;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < KG; ++w) v += red[((w * NG + g) * TE + ie) * 64 + ln];
+    const int i = ie / AE, e = ie % AE;
+    const int n = nl0 + g * TNW + (ln & (TNW - 1));
+    // C/D layouts: 32x32: row = (e&3) + 8*(e>>2) + 4*(lane>>5); 16x16: row = 4*(lane>>4) + e
+    const int m = i * TNW + (TNW == 32 ? (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5) : 4 * (ln >> 4) + e);
+    if (n < NL && m < M) {
+      if (bs) v = act_to_f32<BF16>(f32_to_act<BF16>(v)) + act_to_f32<BF16>(bs[n]);
+      yo[static_cast<size_t>(m) * NL + n] = f32_to_act<BF16>(v);
+    }
+  }
+#ifdef BX_STAMPS
+  STAMP();
+  if (lane == 0 && bx_stamp_ptr) {
+    long long* o = bx_stamp_ptr + (static_cast<size_t>(blockIdx.x) * 12 + wave) * 24;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) o[i] = i < sti ? st[i] : 0;
+  }
+#endif
+}
+
+template <int BITS, int TNW, int NG, int KG>
+static hipError_t launch_batch_cfg(const MfmaArgs& a, bool bf16, hipStream_t s) {
+  constexpr int ROWS = NG * TNW;
+  constexpr int SHMEM = 2 * 8 * 32 * XROW + 2 * 8 * 32 * 4;
+  static bool done[2] = {false, false};
+  if (!done[bf16]) {
+    hipError_t e = bf16 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&qgemm_batch_kernel<BITS, TNW, NG, KG, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM)
+                        : hipFuncSetAttribute(reinterpret_cast<const void*>(&qgemm_batch_kernel<BITS, TNW, NG, KG, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
+    if (e != hipSuccess) return e;
+    done[bf16] = true;
+  }
+  dim3 grid((a.N + ROWS - 1) / ROWS), block(768);
+#ifdef BX_STAMPS
+  long long* sp = reinterpret_cast<long long*>(strtoull(getenv("GBX_STAMP_PTR") ? getenv("GBX_STAMP_PTR") : "0", nullptr, 0));
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(bx_stamp_ptr), &sp, sizeof(sp));
+#endif
+  if (bf16) hipLaunchKernelGGL((qgemm_batch_kernel<BITS, TNW, NG, KG, true>), grid, block, SHMEM, s, a);
+  else hipLaunchKernelGGL((qgemm_batch_kernel<BITS, TNW, NG, KG, false>), grid, block, SHMEM, s, a);
+  return hipGetLastError();
+}
+
+// workgroup rows: as many as still give ~200 workgroups (256 CUs, one workgroup each), and never across a segment
+template <int BITS>
+static hipError_t launch_batch_bits(const MfmaArgs& a, bool bf16, hipStream_t s) {
+  int rows = a.N >= 128 * 192 ? 128 : a.N >= 64 * 192 ? 64 : a.N >= 32 * 160 ? 32 : 16;
+  static const int forced = [] { const char* e = getenv("GBX_BATCH_ROWS"); return e ? atoi(e) : 0; }();
+  if (forced) rows = forced;
+  for (int i = 0; i < (a.nseg > 1 ? a.nseg : 0); ++i)
+    while (a.n_seg[i] % rows) rows >>= 1;
+  if (rows < 16) return hipErrorInvalidValue;
+  switch (rows) {
+    case 128: return launch_batch_cfg<BITS, 32, 4, 2>(a, bf16, s);
+    case 64: return launch_batch_cfg<BITS, 32, 2, 4>(a, bf16, s);
+    case 32: return launch_batch_cfg<BITS, 16, 2, 4>(a, bf16, s);
+    default: return launch_batch_cfg<BITS, 16, 1, 8>(a, bf16, s);
+  }
+}
+
+bool qgemm_batch_supported(int M, int K, int bits, int log2g) {
+  return M >= 2 && M <= 32 && (bits == 2 || bits == 4) && log2g == 7 && K % 1024 == 0;
+}
+
+hipError_t launch_qgemm_batch(const MfmaArgs& a, int bits, bool bf16, hipStream_t s) {
+  return bits == 2 ? launch_batch_bits<2>(a, bf16, s) : launch_batch_bits<4>(a, bf16, s);
+}
+
+}  // namespace gbx

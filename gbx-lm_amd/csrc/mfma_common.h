@@ -30,6 +30,10 @@ struct MfmaArgs {
 #endif
 };
 
+// mfma_batch.hip: 2 <= M <= 32, 2/4 bits, group 128 (no-dequant matrix-core kernel); false -> use the split-K kernel
+bool qgemm_batch_supported(int M, int K, int bits, int log2g);
+hipError_t launch_qgemm_batch(const MfmaArgs& a, int bits, bool bf16, hipStream_t s);
+
 constexpr int KC = 128;                 // k-values per chunk (one LDS stage of activations)
 constexpr int XROW = KC * 2 + 16;       // LDS bytes per activation row: 256 B + 16 B pad (conflict-free ds_read_b128)
 

@@ -241,6 +241,11 @@ static hipError_t launch_skinny_bits(const MfmaArgs& a, bool bf16, hipStream_t s
   return a.M <= 32 ? launch_skinny_mt<BITS, 32, 1>(a, bf16, s) : launch_skinny_mt<BITS, 32, 2>(a, bf16, s);
 }
 
+static bool use_batch_kernel(const MfmaArgs& a, int bits) {
+  static const bool off = getenv("GBX_NO_BATCH_KERNEL") != nullptr;   // diagnostic: time the split-K kernel instead
+  return !off && qgemm_batch_supported(a.M, a.K, bits, a.log2g);
+}
+
 hipError_t launch_qgemm_skinny_multi(const void* x, int nseg, const uint32_t* const* qw, const void* const* sc, const void* const* ze,
                                      const void* const* bias, void* const* y, const int* n, int M, int K, int bits, int log2g,
                                      bool bf16, hipStream_t s) {
@@ -254,6 +259,10 @@ hipError_t launch_qgemm_skinny_multi(const void* x, int nseg, const uint32_t* co
     a.qweight_x[i - 1] = qw[i]; a.scales_x[i - 1] = static_cast<const unsigned short*>(sc[i]);
     a.zeros_x[i - 1] = static_cast<const unsigned short*>(ze[i]); a.bias_x[i - 1] = static_cast<const unsigned short*>(bias[i]);
     a.y_x[i - 1] = static_cast<unsigned short*>(y[i]);
+  }
+  if (use_batch_kernel(a, bits)) {
+    const hipError_t e = launch_qgemm_batch(a, bits, bf16, s);
+    if (e != hipErrorInvalidValue) return e;        // segment rows the wide workgroups cannot tile: split-K kernel
   }
   switch (bits) {
     case 2: return launch_skinny_bits<2>(a, bf16, s);
@@ -269,6 +278,10 @@ hipError_t launch_qgemm_skinny(const void* x, const uint32_t* qw, const void* sc
   a.x = static_cast<const unsigned short*>(x); a.qweight = qw; a.scales = static_cast<const unsigned short*>(sc);
   a.zeros = static_cast<const unsigned short*>(ze); a.bias = static_cast<const unsigned short*>(bias);
   a.y = static_cast<unsigned short*>(y); a.M = M; a.N = N; a.K = K; a.log2g = log2g;
+  if (use_batch_kernel(a, bits)) {
+    const hipError_t e = launch_qgemm_batch(a, bits, bf16, s);
+    if (e != hipErrorInvalidValue) return e;        // segment rows the wide workgroups cannot tile: split-K kernel
+  }
   switch (bits) {
     case 2: return launch_skinny_bits<2>(a, bf16, s);
     case 3: return launch_skinny_bits<3>(a, bf16, s);

@@ -1,0 +1,29 @@
+"""In-kernel phase stamps of mfma_batch.hip (experiment build with -DBX_STAMPS): s_memtime per phase."""
+import os, sys, torch, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+dev = 'cuda:0'
+stamps = torch.zeros(2048 * 12 * 24, dtype=torch.int64, device=dev)
+os.environ["GBX_STAMP_PTR"] = str(stamps.data_ptr())
+from gbx_lm_amd import ops
+m, n, k, b, g = 32, int(sys.argv[1]), int(sys.argv[2]), 2, 128
+qw = torch.randint(0, 2**32, (n, k // 32 * b), dtype=torch.int64, device=dev).to(torch.int32).view(torch.uint32)
+sc = (torch.rand((n, k // g), device=dev) * 0.01).to(torch.bfloat16); ze = (-sc * 1.5).to(torch.bfloat16)
+x = torch.randn(m, k, device=dev).to(torch.bfloat16)
+big = torch.empty(300 * 2**20, dtype=torch.uint8, device=dev)
+for it in range(3):
+    big.zero_()                    # flush caches
+    stamps.zero_(); torch.cuda.synchronize()
+    ops.quantized_matmul(x, qw, sc, ze, group_size=g, bits=b); torch.cuda.synchronize()
+s = stamps.cpu().numpy().reshape(-1, 12, 24)[:, :8]     # compute waves
+s = s[s[:, 0, 0] > 0]
+nst = int((s[0, 0] > 0).sum())
+rel = (s - s[:, :, 0].min(axis=1)[:, None, None]).astype(np.float64)      # per workgroup: relative to its first wave's start
+names = ["start", "issued"] + sum([[f"s{i}.arrive", f"s{i}.issued", f"s{i}.computed", f"s{i}.barrier"] for i in range((nst - 3) // 4)], []) + ["end"]
+span = rel[:, :, nst - 1].max(axis=1)
+print("workgroups", s.shape[0], f"; s_memtime ticks; per-workgroup span mean {span.mean():.0f} min {span.min():.0f} max {span.max():.0f}")
+prev = None
+for i in range(nst):
+    col = rel[:, :, i]
+    d = "" if prev is None else f"  (+{col.mean() - prev:7.0f})"
+    print(f"{names[i]:12s} mean {col.mean():8.0f}  min {col.min():6.0f}  max {col.max():6.0f}{d}")
+    prev = col.mean()
