@@ -72,6 +72,9 @@ def _declare_optional(L) -> None:
     table = {
         "gbx_qlinear_fused_forward": [ctypes.POINTER(FusedDesc), p],
         "gbx_attn_decode": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, f32, f32, i32, i32, p],
+        "gbx_attn_decode_batched": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, f32, i32, i32, p],
+        "gbx_add_rmsnorm": [p, p, p, p, i64, i32, f32, i32, p],
+        "gbx_swiglu": [p, p, p, i64, i32, p],
         "gbx_dense_gemv": [p, p, p, p, f32, i32, i32, i32, p],
         "gbx_rmsnorm": [p, p, p, i64, i32, f32, i32, p],
         "gbx_dense_gemv_argmax": [p, p, p, p, f32, i32, i32, p, i32, p],

@@ -273,6 +273,16 @@ int gbx_attn_decode(const void* q, const void* k, const void* v, void* kcache, v
                     const int64_t* pos, void* out, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim,
                     int32_t capacity, float rope_scale, float sm_scale, int32_t traditional, int32_t act_dtype,
                     void* hip_stream) {
+  return gbx_attn_decode_batched(q, k, v, kcache, vcache, inv_freq, pos, out, 1, n_heads, n_kv_heads, head_dim, capacity,
+                                 rope_scale, sm_scale, traditional, act_dtype, hip_stream);
+}
+
+int gbx_attn_decode_batched(const void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
+                            const int64_t* pos, void* out, int32_t batch, int32_t n_heads, int32_t n_kv_heads,
+                            int32_t head_dim, int32_t capacity, float rope_scale, float sm_scale, int32_t traditional,
+                            int32_t act_dtype, void* hip_stream) {
+  if (batch == 0) return GBX_OK;
+  if (batch < 0 || batch > 65535) return fail(GBX_ERR_INVALID, "batch must be in [0, 65535] (got %d)", batch);
   if (!q || !k || !v || !kcache || !vcache || !inv_freq || !pos || !out) return fail(GBX_ERR_INVALID, "null device pointer");
   if (head_dim != 64 && head_dim != 128) return fail(GBX_ERR_UNSUPPORTED, "head_dim must be 64 or 128 (got %d)", head_dim);
   if (n_heads <= 0 || n_kv_heads <= 0 || n_heads % n_kv_heads) return fail(GBX_ERR_INVALID, "n_heads must be a multiple of n_kv_heads");
@@ -280,7 +290,7 @@ int gbx_attn_decode(const void* q, const void* k, const void* v, void* kcache, v
   if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
   if (!aligned(kcache, 16) || !aligned(vcache, 16)) return fail(GBX_ERR_INVALID, "KV cache must be 16-byte aligned");
   hipError_t e = gbx::launch_attn_decode(q, k, v, kcache, vcache, inv_freq, reinterpret_cast<const long long*>(pos), out,
-                                         n_heads, n_kv_heads, head_dim, capacity, rope_scale, sm_scale, traditional,
+                                         batch, n_heads, n_kv_heads, head_dim, capacity, rope_scale, sm_scale, traditional,
                                          act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));
   if (e != hipSuccess) return hip_fail(e, "gbx_attn_decode launch");
   return GBX_OK;
@@ -368,6 +378,28 @@ int gbx_rmsnorm(const void* x, const void* w, void* y, int64_t M, int32_t K, flo
   if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
   hipError_t e = gbx::launch_rmsnorm(x, w, y, static_cast<int>(M), K, eps, act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));
   if (e != hipSuccess) return hip_fail(e, "gbx_rmsnorm launch");
+  return GBX_OK;
+}
+
+int gbx_add_rmsnorm(void* h, const void* delta, const void* w, void* y, int64_t M, int32_t K, float eps, int32_t act_dtype,
+                    void* hip_stream) {
+  if (M == 0) return GBX_OK;
+  if (!h || !delta || !w || !y) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (M < 0 || M > 2147483647LL || K <= 0) return fail(GBX_ERR_INVALID, "bad shape M=%lld K=%d", (long long)M, K);
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  hipError_t e = gbx::launch_add_rmsnorm(h, delta, w, y, static_cast<int>(M), K, eps, act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_add_rmsnorm launch");
+  return GBX_OK;
+}
+
+int gbx_swiglu(const void* gate, const void* up, void* y, int64_t n, int32_t act_dtype, void* hip_stream) {
+  if (n == 0) return GBX_OK;
+  if (!gate || !up || !y) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (n < 0 || (n % 8)) return fail(GBX_ERR_INVALID, "element count must be a non-negative multiple of 8 (got %lld)", (long long)n);
+  if (!aligned(gate, 16) || !aligned(up, 16) || !aligned(y, 16)) return fail(GBX_ERR_INVALID, "gate, up and y must be 16-byte aligned");
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  hipError_t e = gbx::launch_swiglu(gate, up, y, n, act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_swiglu launch");
   return GBX_OK;
 }
 

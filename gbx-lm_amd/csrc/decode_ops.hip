@@ -25,7 +25,7 @@ struct AttnArgs {
 };
 
 template <bool BF16, int HD>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
   constexpr int LP = HD / 8;          // lanes that share one cached position (8 features = one 16-byte load each)
   constexpr int PPW = 64 / LP;        // positions per wave per iteration
   constexpr int NG = 4 * PPW;         // (wave, sub) groups that carry partial softmax state
@@ -39,6 +39,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   const int kvh = h / rep;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {                                   // synchronous batched decode: sequence blockIdx.y, every sequence at *pos
+    const size_t b = blockIdx.y;
+    a.q += b * a.n_heads * HD; a.out += b * a.n_heads * HD;
+    a.k += b * a.n_kv * HD; a.v += b * a.n_kv * HD;
+    a.kcache += b * a.n_kv * a.capacity * HD; a.vcache += b * a.n_kv * a.capacity * HD;
+  }
   // ---- the first UB0 * 4 * PPW cached positions are requested before anything else: their addresses depend neither on
   //      the position counter (clamped to the buffer; masked when consumed) nor on q, so the cache latency overlaps the
   //      q/k/v loads, RoPE and the barrier instead of following them (one dependent memory round trip less) ----
@@ -176,12 +182,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
 }
 
 hipError_t launch_attn_decode(const void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
-                              const long long* pos, void* out, int n_heads, int n_kv, int head_dim, int capacity,
+                              const long long* pos, void* out, int batch, int n_heads, int n_kv, int head_dim, int capacity,
                               float rope_scale, float sm_scale, int traditional, bool bf16, hipStream_t s) {
   AttnArgs a{static_cast<const unsigned short*>(q), static_cast<const unsigned short*>(k), static_cast<const unsigned short*>(v),
              static_cast<unsigned short*>(kcache), static_cast<unsigned short*>(vcache), inv_freq, pos,
              static_cast<unsigned short*>(out), n_heads, n_kv, capacity, rope_scale, sm_scale, traditional};
-  dim3 grid(n_heads), block(256);
+  dim3 grid(n_heads, batch), block(256);
   if (head_dim == 128) {
     if (bf16) hipLaunchKernelGGL((attn_decode_kernel<true, 128>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((attn_decode_kernel<false, 128>), grid, block, 0, s, a);
@@ -425,6 +431,73 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const unsigned short* __re
   __syncthreads();
   const float rstd = rsqrtf(((red[0] + red[1]) + (red[2] + red[3])) / static_cast<float>(K) + eps);
   for (int i = tid; i < K; i += 256) yr[i] = f32_to_act<BF16>(act_to_f32<BF16>(xr[i]) * rstd * act_to_f32<BF16>(w[i]));
+}
+
+// Residual add + RMSNorm in one pass (batched decode glue): h <- round(h + d) (the activation-dtype add the model graph
+// does, qllama.py:138-140), y = RMSNorm(h) * w.  h is updated in place.
+template <bool BF16>
+__global__ __launch_bounds__(256) void add_rmsnorm_kernel(unsigned short* __restrict__ h, const unsigned short* __restrict__ d,
+                                                          const unsigned short* __restrict__ w, unsigned short* __restrict__ y,
+                                                          int K, float eps) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned short* hr = h + static_cast<size_t>(blockIdx.x) * K;
+  const unsigned short* dr = d + static_cast<size_t>(blockIdx.x) * K;
+  unsigned short* yr = y + static_cast<size_t>(blockIdx.x) * K;
+  float ssq = 0.f;
+  for (int i = tid; i < K; i += 256) {
+    const unsigned short sb = f32_to_act<BF16>(act_to_f32<BF16>(hr[i]) + act_to_f32<BF16>(dr[i]));
+    hr[i] = sb;
+    const float v = act_to_f32<BF16>(sb);
+    ssq += v * v;
+  }
+  ssq = wave_sum(ssq);
+  if (lane == 0) red[wave] = ssq;
+  __syncthreads();
+  const float rstd = rsqrtf(((red[0] + red[1]) + (red[2] + red[3])) / static_cast<float>(K) + eps);
+  for (int i = tid; i < K; i += 256) yr[i] = f32_to_act<BF16>(act_to_f32<BF16>(hr[i]) * rstd * act_to_f32<BF16>(w[i]));
+}
+
+hipError_t launch_add_rmsnorm(void* h, const void* d, const void* w, void* y, int M, int K, float eps, bool bf16, hipStream_t s) {
+  auto H = static_cast<unsigned short*>(h);
+  auto D = static_cast<const unsigned short*>(d);
+  auto W = static_cast<const unsigned short*>(w);
+  auto Y = static_cast<unsigned short*>(y);
+  if (bf16) hipLaunchKernelGGL((add_rmsnorm_kernel<true>), dim3(M), dim3(256), 0, s, H, D, W, Y, K, eps);
+  else hipLaunchKernelGGL((add_rmsnorm_kernel<false>), dim3(M), dim3(256), 0, s, H, D, W, Y, K, eps);
+  return hipGetLastError();
+}
+
+// SwiGLU glue for batched decode: y = round(round(silu(g)) * u), the two roundings of `nn.silu(gate) * up` in the
+// activation dtype (qllama.py:115).  8 values (16 bytes) per thread.
+template <bool BF16>
+__global__ __launch_bounds__(256) void swiglu_kernel(const unsigned short* __restrict__ g, const unsigned short* __restrict__ u,
+                                                     unsigned short* __restrict__ y, long long n8) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n8; i += static_cast<long long>(gridDim.x) * 256) {
+    const u32x4 gv = reinterpret_cast<const u32x4*>(g)[i], uv = reinterpret_cast<const u32x4*>(u)[i];
+    const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, uw[4] = {uv.x, uv.y, uv.z, uv.w};
+    unsigned o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float g0 = act_lo<BF16>(gw[j]), g1 = act_hi<BF16>(gw[j]);
+      const float s0 = act_to_f32<BF16>(f32_to_act<BF16>(g0 / (1.f + __expf(-g0))));
+      const float s1 = act_to_f32<BF16>(f32_to_act<BF16>(g1 / (1.f + __expf(-g1))));
+      o[j] = static_cast<unsigned>(f32_to_act<BF16>(s0 * act_lo<BF16>(uw[j]))) |
+             (static_cast<unsigned>(f32_to_act<BF16>(s1 * act_hi<BF16>(uw[j]))) << 16);
+    }
+    reinterpret_cast<u32x4*>(y)[i] = u32x4{o[0], o[1], o[2], o[3]};
+  }
+}
+
+hipError_t launch_swiglu(const void* g, const void* u, void* y, long long n, bool bf16, hipStream_t s) {
+  const long long n8 = n / 8;
+  const unsigned blocks = static_cast<unsigned>(std::min<long long>((n8 + 255) / 256, 4096));
+  auto G = static_cast<const unsigned short*>(g);
+  auto U = static_cast<const unsigned short*>(u);
+  auto Y = static_cast<unsigned short*>(y);
+  if (bf16) hipLaunchKernelGGL((swiglu_kernel<true>), dim3(blocks), dim3(256), 0, s, G, U, Y, n8);
+  else hipLaunchKernelGGL((swiglu_kernel<false>), dim3(blocks), dim3(256), 0, s, G, U, Y, n8);
+  return hipGetLastError();
 }
 
 // short rows (per-head q / k norms, K = head_dim): one wavefront per row, four rows per workgroup

@@ -29,7 +29,7 @@ hipError_t launch_prepack_tiles(const uint32_t* qw, const void* sc, const void* 
 hipError_t launch_gemv_mfma(const void* x, const uint32_t* wt, const uint32_t* szt, void* y, int N, int K, const void* norm_w,
                             float eps, const void* residual, int swiglu, bool bf16, hipStream_t s);
 hipError_t launch_attn_decode(const void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
-                              const long long* pos, void* out, int n_heads, int n_kv, int head_dim, int capacity,
+                              const long long* pos, void* out, int batch, int n_heads, int n_kv, int head_dim, int capacity,
                               float rope_scale, float sm_scale, int traditional, bool bf16, hipStream_t s);
 hipError_t launch_dense_gemv(const void* x, const void* w, void* y, const void* norm_w, float eps, int N, int K, void* best,
                              bool bf16, hipStream_t s);
@@ -45,6 +45,8 @@ hipError_t launch_rope_append(void* q, const void* k, const void* v, void* kcach
                               int traditional, bool bf16, hipStream_t s);
 hipError_t launch_eminf(const void* logits, float* cur, float* nxt, float* out_entropy, int V, int in_mode, float alpha,
                         float threshold, int num_steps, hipStream_t s);
+hipError_t launch_add_rmsnorm(void* h, const void* d, const void* w, void* y, int M, int K, float eps, bool bf16, hipStream_t s);
+hipError_t launch_swiglu(const void* g, const void* u, void* y, long long n, bool bf16, hipStream_t s);
 hipError_t launch_rmsnorm(const void* x, const void* w, void* y, int M, int K, float eps, bool bf16, hipStream_t s);
 
 }  // namespace gbx

@@ -48,39 +48,50 @@ class DecodeRunner:
         m = self.model.model
         pos = self.pos
         B = self.batch
-        h = m.embed_tokens(self.tok)[:, None]                    # [B, 1, D]
-        mask = torch.where(self.ar[None, None, None, :] <= pos, 0.0, float("-inf")).to(self.dtype)
+        h = m.embed_tokens(self.tok)[:, None].contiguous()       # [B, 1, D]
+        mask = None
+        delta = None                                             # residual branch not yet added to h
         for layer, c in zip(m.layers, self.caches):
             at = layer.self_attn
-            x = ops.rmsnorm(h, layer.input_layernorm.weight, layer.input_layernorm.eps)     # one launch (gbx_rmsnorm)
+            norm = layer.input_layernorm
+            # residual add of the previous block fused with this norm (gbx_add_rmsnorm); plain norm for the first layer
+            x = ops.rmsnorm(h, norm.weight, norm.eps) if delta is None else ops.add_rmsnorm(h, delta, norm.weight, norm.eps)
             q, k, v = (t.reshape(B, -1) for t in ops.quantized_matmul_multi(x, (at.q_proj, at.k_proj, at.v_proj)))
-            if at.rope.inv_freq.numel() * 2 == self.hd and c.keys.is_contiguous() and c.values.is_contiguous():
-                # one launch: rotate q in place, rotate k / copy v into the cache at the device-resident position
-                ops.rope_append(q, k, v, c.keys, c.values, at.rope.inv_freq, pos, self.n_heads, self.n_kv, self.hd,
-                                getattr(at.rope, "scale", 1.0), at.rope.traditional)
-            else:                                                    # partial-width RoPE: torch glue
-                q = _rope_at(q.reshape(B, 1, self.n_heads, self.hd).transpose(1, 2), at.rope, pos).transpose(1, 2)
-                kr = _rope_at(k.reshape(B, 1, self.n_kv, self.hd).transpose(1, 2), at.rope, pos)
-                c.keys.index_copy_(2, pos, kr)
-                c.values.index_copy_(2, pos, v.reshape(B, 1, self.n_kv, self.hd).transpose(1, 2))
-            # grouped-query attention over the whole (static) cache buffer without materialising repeated K/V:
-            # q [B, n_kv, rep, hd] x K^T [B, n_kv, hd, cap]; positions past `pos` are masked
-            rep = self.n_heads // self.n_kv
-            qg = q.reshape(B, self.n_kv, rep, self.hd)
-            sc = torch.matmul(qg, c.keys.transpose(-1, -2)).float() * at.scale + mask.float()
-            p = torch.softmax(sc, dim=-1).to(self.dtype)
-            o = torch.matmul(p, c.values)                            # [B, n_kv, rep, hd]
+            full_rope = at.rope.inv_freq.numel() * 2 == self.hd and c.keys.is_contiguous() and c.values.is_contiguous()
+            if full_rope and self.hd in (64, 128):
+                # one launch per layer: RoPE(q, k) + cache append + softmax(q k^T) v for every sequence
+                o = torch.empty_like(q)
+                ops.attn_decode_batched(q, k, v, c.keys, c.values, at.rope.inv_freq, pos, o, self.n_heads, self.n_kv, self.hd,
+                                        getattr(at.rope, "scale", 1.0), at.scale, at.rope.traditional)
+            else:
+                if full_rope:
+                    ops.rope_append(q, k, v, c.keys, c.values, at.rope.inv_freq, pos, self.n_heads, self.n_kv, self.hd,
+                                    getattr(at.rope, "scale", 1.0), at.rope.traditional)
+                else:                                                # partial-width RoPE: torch glue
+                    q = _rope_at(q.reshape(B, 1, self.n_heads, self.hd).transpose(1, 2), at.rope, pos).transpose(1, 2)
+                    kr = _rope_at(k.reshape(B, 1, self.n_kv, self.hd).transpose(1, 2), at.rope, pos)
+                    c.keys.index_copy_(2, pos, kr)
+                    c.values.index_copy_(2, pos, v.reshape(B, 1, self.n_kv, self.hd).transpose(1, 2))
+                # grouped-query attention over the whole (static) cache buffer without materialising repeated K/V:
+                # q [B, n_kv, rep, hd] x K^T [B, n_kv, hd, cap]; positions past `pos` are masked
+                if mask is None:
+                    mask = torch.where(self.ar[None, None, None, :] <= pos, 0.0, float("-inf"))
+                rep = self.n_heads // self.n_kv
+                qg = q.reshape(B, self.n_kv, rep, self.hd)
+                sc = torch.matmul(qg, c.keys.transpose(-1, -2)).float() * at.scale + mask
+                o = torch.matmul(torch.softmax(sc, dim=-1).to(self.dtype), c.values)     # [B, n_kv, rep, hd]
             o = at.o_proj(o.reshape(B, 1, -1))
             if self.tp_world > 1:
                 all_reduce_(o, at.tp_group)
-            h = h + o
-            x = ops.rmsnorm(h, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.eps)
+            norm = layer.post_attention_layernorm
+            x = ops.add_rmsnorm(h, o.reshape(h.shape).contiguous(), norm.weight, norm.eps)
             mlp = layer.mlp
             if B > 1 and getattr(mlp, "tp_world", 1) == 1 and hasattr(mlp, "gate_proj"):
                 g, u = ops.quantized_matmul_multi(x, (mlp.gate_proj, mlp.up_proj))     # one launch for gate and up
-                h = h + mlp.down_proj(F.silu(g) * u)
+                delta = mlp.down_proj(ops.swiglu(g, u)).reshape(h.shape)
             else:
-                h = h + mlp(x)
+                delta = mlp(x).reshape(h.shape).contiguous()
+        h = h + delta
         out = ops.rmsnorm(h, m.norm.weight, m.norm.eps)
         return F.linear(out, self.model.head_weight())[:, -1, :]   # [B, V]
 

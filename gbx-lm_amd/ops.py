@@ -285,6 +285,39 @@ def attn_decode(q, k, v, kcache, vcache, inv_freq, pos, out, n_heads: int, n_kv:
                                           _DT[q.dtype], _stream_ptr(q.device)))
 
 
+def attn_decode_batched(q, k, v, kcache, vcache, inv_freq, pos, out, n_heads: int, n_kv: int, head_dim: int,
+                        rope_scale: float, sm_scale: float, traditional: bool) -> None:
+    """One new token per sequence, all at position ``pos`` (device int64): q/out [B, n_heads*hd], k/v [B, n_kv*hd],
+    caches [B, n_kv, capacity, hd] (gbx_attn_decode_batched: RoPE + cache append + softmax(q k^T) v in one launch)."""
+    _require_cuda(q, "q")
+    b, cap = kcache.shape[0], kcache.shape[2]
+    _lib.check(_lib.lib().gbx_attn_decode_batched(q.data_ptr(), k.data_ptr(), v.data_ptr(), kcache.data_ptr(), vcache.data_ptr(),
+                                                  inv_freq.data_ptr(), pos.data_ptr(), out.data_ptr(), b, n_heads, n_kv, head_dim,
+                                                  cap, float(rope_scale), float(sm_scale), int(bool(traditional)),
+                                                  _DT[q.dtype], _stream_ptr(q.device)))
+
+
+def add_rmsnorm(h: torch.Tensor, delta: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    """h += delta in place (activation-dtype add), returns RMSNorm(h) * w -- one launch (gbx_add_rmsnorm)."""
+    _require_cuda(h, "h")
+    k = h.shape[-1]
+    assert h.is_contiguous() and delta.is_contiguous() and delta.shape == h.shape
+    y = torch.empty_like(h)
+    _lib.check(_lib.lib().gbx_add_rmsnorm(h.data_ptr(), delta.data_ptr(), w.data_ptr(), y.data_ptr(), h.numel() // k, k,
+                                          float(eps), _DT[h.dtype], _stream_ptr(h.device)))
+    return y
+
+
+def swiglu(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """silu(gate) * up with the op-by-op roundings of the model graph, one launch (gbx_swiglu)."""
+    _require_cuda(gate, "gate")
+    assert gate.is_contiguous() and up.is_contiguous() and gate.shape == up.shape
+    y = torch.empty_like(gate)
+    _lib.check(_lib.lib().gbx_swiglu(gate.data_ptr(), up.data_ptr(), y.data_ptr(), gate.numel(), _DT[gate.dtype],
+                                     _stream_ptr(gate.device)))
+    return y
+
+
 def embed_next_token(keys: torch.Tensor, token_io: torch.Tensor, pos: torch.Tensor, table: torch.Tensor, h: torch.Tensor,
                      from_keys: bool, advance_pos: bool) -> None:
     """Device-side start of a decode step (see gbx_embed_next_token)."""

@@ -197,6 +197,21 @@ int gbx_embed_next_token(void* argmax_keys, int64_t* token_io, int64_t* pos, con
                          int32_t D, int32_t vocab, int32_t from_keys, int32_t advance_pos, int32_t act_dtype,
                          void* hip_stream);
 
+/* gbx_attn_decode for `batch` sequences that all stand at position *pos (synchronous batched decode): q / out
+ * [batch, n_heads * head_dim], k / v [batch, n_kv * head_dim], caches [batch, n_kv, capacity, head_dim]. */
+int gbx_attn_decode_batched(const void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
+                            const int64_t* pos, void* out, int32_t batch, int32_t n_heads, int32_t n_kv_heads,
+                            int32_t head_dim, int32_t capacity, float rope_scale, float sm_scale, int32_t traditional,
+                            int32_t act_dtype, void* hip_stream);
+
+/* Residual add + RMSNorm in one launch: h[M, K] <- h + delta (one rounding to the activation dtype, the add of
+ * qllama.py:138-140), y = RMSNorm(h) * w.  h is updated in place; y may not alias h. */
+int gbx_add_rmsnorm(void* h, const void* delta, const void* w, void* y, int64_t M, int32_t K, float eps, int32_t act_dtype,
+                    void* hip_stream);
+
+/* y = silu(gate) * up over n elements (n % 8 == 0), rounded like the two activation-dtype ops of qllama.py:115. */
+int gbx_swiglu(const void* gate, const void* up, void* y, int64_t n, int32_t act_dtype, void* hip_stream);
+
 /* Rotary embedding of the strided view x[B, H, L, D] (element strides stride_b/h/l, unit feature stride) into the
  * contiguous y[B, H, L, D] (out of place): pair i of the first `dims` features at time step t turns by
  * (offset + t) * scale * inv_freq[i]; pairs are (2i, 2i+1) if traditional else (i, i + dims/2); x is scaled by mscale first

@@ -89,8 +89,9 @@ def test_attn_decode_matches_torch(hd, nh, nkv, pos):
     p = torch.tensor([pos], dtype=torch.long, device=DEV)
     ops.attn_decode(q, k, v, kc, vc, rope.inv_freq, p, out, nh, nkv, hd, cap, 1.0, hd ** -0.5, False)
     # reference: torch fp32
-    qr = apply_rope(q.view(1, nh, 1, hd), rope.inv_freq, pos, 1.0, False)
-    kr = apply_rope(k.view(1, nkv, 1, hd), rope.inv_freq, pos, 1.0, False)
+    inv = rope.inv_freq.cpu()                       # reference RoPE: the torch fp32 formulation on the CPU
+    qr = apply_rope(q.cpu().view(1, nh, 1, hd), inv, pos, 1.0, False).to(DEV)
+    kr = apply_rope(k.cpu().view(1, nkv, 1, hd), inv, pos, 1.0, False).to(DEV)
     kc0[:, :, pos:pos + 1] = kr
     vc0[:, :, pos:pos + 1] = v.view(1, nkv, 1, hd)
     assert torch.equal(kc, kc0) or torch.allclose(kc.float(), kc0.float(), atol=2e-2), "cache append (k)"
@@ -101,6 +102,60 @@ def test_attn_decode_matches_torch(hd, nh, nkv, pos):
     s = (qr.float() @ K.transpose(-1, -2)) * hd ** -0.5
     want = (torch.softmax(s, -1) @ V).reshape(-1)
     assert torch.allclose(out.float(), want, atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("hd,nh,nkv,traditional", [(128, 8, 2, False), (64, 4, 4, True)])
+def test_attn_decode_batched_matches_torch(hd, nh, nkv, traditional):
+    """gbx_attn_decode_batched: B sequences at the same position, each against its own cache rows."""
+    from gbx_lm_amd import ops
+    from gbx_lm_amd.models.rope_utils import RoPE, apply_rope
+    torch.manual_seed(hd)
+    B, cap, pos = 5, 192, 131
+    q = torch.randn(B, nh * hd).to(torch.bfloat16)
+    k = torch.randn(B, nkv * hd).to(torch.bfloat16)
+    v = torch.randn(B, nkv * hd).to(torch.bfloat16)
+    kc = torch.randn(B, nkv, cap, hd).to(torch.bfloat16)
+    vc = torch.randn(B, nkv, cap, hd).to(torch.bfloat16)
+    rope = RoPE(hd, traditional=traditional, base=500000.0)
+    kd, vd = kc.to(DEV), vc.to(DEV)
+    out = torch.zeros(B, nh * hd, dtype=torch.bfloat16, device=DEV)
+    ops.attn_decode_batched(q.to(DEV), k.to(DEV), v.to(DEV), kd, vd, rope.inv_freq.to(DEV), torch.tensor([pos], device=DEV), out,
+                            nh, nkv, hd, 1.0, hd ** -0.5, traditional)
+    qr = apply_rope(q.view(B, 1, nh, hd).transpose(1, 2), rope.inv_freq, pos, 1.0, traditional)       # [B, nh, 1, hd]
+    kr = apply_rope(k.view(B, 1, nkv, hd).transpose(1, 2), rope.inv_freq, pos, 1.0, traditional)
+    kc[:, :, pos:pos + 1] = kr
+    vc[:, :, pos:pos + 1] = v.view(B, nkv, 1, hd)
+    assert torch.allclose(kd.float().cpu(), kc.float(), atol=2e-2) and torch.equal(vd.cpu(), vc)
+    rep = nh // nkv
+    K = kc[:, :, :pos + 1].repeat_interleave(rep, 1).float()
+    V = vc[:, :, :pos + 1].repeat_interleave(rep, 1).float()
+    want = (torch.softmax((qr.float() @ K.transpose(-1, -2)) * hd ** -0.5, -1) @ V).reshape(B, -1)
+    assert torch.allclose(out.float().cpu(), want, atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_add_rmsnorm_and_swiglu_glue(dt):
+    """Batched-decode glue kernels against the op-by-op torch formulation (same roundings): h += d; y = RMSNorm(h) w,
+    and silu(g) * u."""
+    from gbx_lm_amd import ops
+    g = torch.Generator().manual_seed(11)
+    M, K = 7, 4096
+    h = torch.randn(M, 1, K, generator=g).to(dt)
+    d = torch.randn(M, 1, K, generator=g).to(dt)
+    w = (1 + 0.1 * torch.randn(K, generator=g)).to(dt)
+    hd_ = h.to(DEV).clone()
+    y = ops.add_rmsnorm(hd_, d.to(DEV), w.to(DEV), 1e-5)
+    hs = h + d                                                         # one rounding to dt
+    assert torch.equal(hd_.cpu(), hs)
+    hf = hs.float()
+    want = hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + 1e-5) * w.float()
+    assert torch.allclose(y.float().cpu(), want, atol=2e-2, rtol=1e-2)
+    gate = (3 * torch.randn(M, 14336, generator=g)).to(dt)
+    up = torch.randn(M, 14336, generator=g).to(dt)
+    got = ops.swiglu(gate.to(DEV), up.to(DEV)).cpu()
+    ref = (torch.nn.functional.silu(gate.float()).to(dt) * up)          # silu rounded to dt, product rounded to dt
+    ulp = 2.0 ** (-7 if dt == torch.bfloat16 else -10)
+    assert torch.allclose(got.float(), ref.float(), rtol=2 * ulp, atol=1e-6)
 
 
 @pytest.mark.parametrize("n,k", [(1000, 256), (128256, 4096), (513, 3072)])
