@@ -435,6 +435,59 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const unsigned short* __re
 
 // Residual add + RMSNorm in one pass (batched decode glue): h <- round(h + d) (the activation-dtype add the model graph
 // does, qllama.py:138-140), y = RMSNorm(h) * w.  h is updated in place.
+// Rows up to 8192 values stay in registers between the two passes: 16-byte loads, one barrier.
+template <bool BF16, bool ADD>
+__global__ __launch_bounds__(256) void rmsnorm_vec_kernel(unsigned short* __restrict__ h, const unsigned short* __restrict__ d,
+                                                          const unsigned short* __restrict__ w, unsigned short* __restrict__ y,
+                                                          int K, float eps) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t row = static_cast<size_t>(blockIdx.x) * K;
+  const int n8 = K >> 3;                            // 16-byte pieces per row (K % 8 == 0, K <= 8192: at most 4 per thread)
+  u32x4 v[4];
+  float ssq = 0.f;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int p = it * 256 + tid;
+    if (p < n8) {
+      u32x4 hv = reinterpret_cast<const u32x4*>(h + row)[p];
+      if constexpr (ADD) {
+        const u32x4 dv = reinterpret_cast<const u32x4*>(d + row)[p];
+        const unsigned hw[4] = {hv.x, hv.y, hv.z, hv.w}, dw[4] = {dv.x, dv.y, dv.z, dv.w};
+        unsigned o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          o[j] = static_cast<unsigned>(f32_to_act<BF16>(act_lo<BF16>(hw[j]) + act_lo<BF16>(dw[j]))) |
+                 (static_cast<unsigned>(f32_to_act<BF16>(act_hi<BF16>(hw[j]) + act_hi<BF16>(dw[j]))) << 16);
+        hv = u32x4{o[0], o[1], o[2], o[3]};
+        reinterpret_cast<u32x4*>(h + row)[p] = hv;
+      }
+      v[it] = hv;
+      const unsigned hw[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float a0 = act_lo<BF16>(hw[j]), a1 = act_hi<BF16>(hw[j]); ssq = fmaf(a0, a0, fmaf(a1, a1, ssq)); }
+    }
+  }
+  ssq = wave_sum(ssq);
+  if (lane == 63) red[wave] = ssq;
+  __syncthreads();
+  const float rstd = rsqrtf(((red[0] + red[1]) + (red[2] + red[3])) / static_cast<float>(K) + eps);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int p = it * 256 + tid;
+    if (p < n8) {
+      const u32x4 wv = reinterpret_cast<const u32x4*>(w)[p];
+      const unsigned hw[4] = {v[it].x, v[it].y, v[it].z, v[it].w}, ww[4] = {wv.x, wv.y, wv.z, wv.w};
+      unsigned o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        o[j] = static_cast<unsigned>(f32_to_act<BF16>(act_lo<BF16>(hw[j]) * rstd * act_lo<BF16>(ww[j]))) |
+               (static_cast<unsigned>(f32_to_act<BF16>(act_hi<BF16>(hw[j]) * rstd * act_hi<BF16>(ww[j]))) << 16);
+      reinterpret_cast<u32x4*>(y + row)[p] = u32x4{o[0], o[1], o[2], o[3]};
+    }
+  }
+}
+
 template <bool BF16>
 __global__ __launch_bounds__(256) void add_rmsnorm_kernel(unsigned short* __restrict__ h, const unsigned short* __restrict__ d,
                                                           const unsigned short* __restrict__ w, unsigned short* __restrict__ y,
@@ -452,10 +505,15 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(unsigned short* __rest
     ssq += v * v;
   }
   ssq = wave_sum(ssq);
-  if (lane == 0) red[wave] = ssq;
+  if (lane == 63) red[wave] = ssq;
   __syncthreads();
   const float rstd = rsqrtf(((red[0] + red[1]) + (red[2] + red[3])) / static_cast<float>(K) + eps);
   for (int i = tid; i < K; i += 256) yr[i] = f32_to_act<BF16>(act_to_f32<BF16>(hr[i]) * rstd * act_to_f32<BF16>(w[i]));
+}
+
+static bool vec_ok(const void* a, const void* b, const void* c, const void* d, int K) {
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return K % 8 == 0 && K <= 8192 && al(a) && al(b) && al(c) && al(d);
 }
 
 hipError_t launch_add_rmsnorm(void* h, const void* d, const void* w, void* y, int M, int K, float eps, bool bf16, hipStream_t s) {
@@ -463,6 +521,11 @@ hipError_t launch_add_rmsnorm(void* h, const void* d, const void* w, void* y, in
   auto D = static_cast<const unsigned short*>(d);
   auto W = static_cast<const unsigned short*>(w);
   auto Y = static_cast<unsigned short*>(y);
+  if (vec_ok(h, d, w, y, K)) {
+    if (bf16) hipLaunchKernelGGL((rmsnorm_vec_kernel<true, true>), dim3(M), dim3(256), 0, s, H, D, W, Y, K, eps);
+    else hipLaunchKernelGGL((rmsnorm_vec_kernel<false, true>), dim3(M), dim3(256), 0, s, H, D, W, Y, K, eps);
+    return hipGetLastError();
+  }
   if (bf16) hipLaunchKernelGGL((add_rmsnorm_kernel<true>), dim3(M), dim3(256), 0, s, H, D, W, Y, K, eps);
   else hipLaunchKernelGGL((add_rmsnorm_kernel<false>), dim3(M), dim3(256), 0, s, H, D, W, Y, K, eps);
   return hipGetLastError();
@@ -525,6 +588,12 @@ hipError_t launch_rmsnorm(const void* x, const void* w, void* y, int M, int K, f
     const unsigned blocks = static_cast<unsigned>((static_cast<long long>(M) + 3) / 4);
     if (bf16) hipLaunchKernelGGL((rmsnorm_rows_kernel<true>), dim3(blocks), dim3(256), 0, s, X, W, Y, static_cast<long long>(M), K, eps);
     else hipLaunchKernelGGL((rmsnorm_rows_kernel<false>), dim3(blocks), dim3(256), 0, s, X, W, Y, static_cast<long long>(M), K, eps);
+    return hipGetLastError();
+  }
+  if (vec_ok(x, x, w, y, K)) {                      // one pass, rows in registers
+    auto Xm = const_cast<unsigned short*>(X);
+    if (bf16) hipLaunchKernelGGL((rmsnorm_vec_kernel<true, false>), dim3(M), dim3(256), 0, s, Xm, X, W, Y, K, eps);
+    else hipLaunchKernelGGL((rmsnorm_vec_kernel<false, false>), dim3(M), dim3(256), 0, s, Xm, X, W, Y, K, eps);
     return hipGetLastError();
   }
   if (bf16) hipLaunchKernelGGL((rmsnorm_kernel<true>), dim3(M), dim3(256), 0, s, X, W, Y, K, eps);
