@@ -181,12 +181,183 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
   }
 }
 
+// Batched decode variant: one workgroup per (kv head, sequence) serves all REP query heads of the group, so every cached
+// K / V row is read ONCE per group instead of once per query head (at B = 32 the per-head kernel moved 4x the cache
+// bytes: 67 MB per layer at context 128).  Same arithmetic and layout as attn_decode_kernel.
+template <bool BF16, int HD, int REP>
+__global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
+  constexpr int LP = HD / 8, PPW = 64 / LP, NG = 4 * PPW;
+  constexpr float NEG = -1e30f;
+  __shared__ float q_s[REP][HD], kn_s[HD], vn_s[HD];
+  __shared__ float gm[NG][REP], gl[NG][REP];
+  __shared__ float gacc[NG][REP][HD + 8];
+
+  const int kvh = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {
+    const size_t b = blockIdx.y;
+    a.q += b * a.n_heads * HD; a.out += b * a.n_heads * HD;
+    a.k += b * a.n_kv * HD; a.v += b * a.n_kv * HD;
+    a.kcache += b * a.n_kv * a.capacity * HD; a.vcache += b * a.n_kv * a.capacity * HD;
+  }
+  constexpr int UB0 = 4;
+  const int d0 = (lane % LP) * 8, sub = lane / LP;
+  const unsigned short* kbase = a.kcache + static_cast<size_t>(kvh) * a.capacity * HD;
+  const unsigned short* vbase = a.vcache + static_cast<size_t>(kvh) * a.capacity * HD;
+  u32x4 k0[UB0], v0[UB0];
+#pragma unroll
+  for (int u = 0; u < UB0; ++u) {                   // first 4 * 4 * PPW positions requested before *pos is known
+    const int tc = min(wave * PPW + u * 4 * PPW + sub, a.capacity - 1);
+    k0[u] = *reinterpret_cast<const u32x4*>(kbase + static_cast<size_t>(tc) * HD + d0);
+    v0[u] = *reinterpret_cast<const u32x4*>(vbase + static_cast<size_t>(tc) * HD + d0);
+  }
+  const int pos = static_cast<int>(*a.pos);
+
+  // RoPE on the REP query heads and the kv head's k; append k, v to the cache
+  for (int p = tid; p < (REP + 1) * (HD / 2); p += 256) {
+    const int hh = p / (HD / 2), i = p % (HD / 2);   // hh == REP: the k head
+    const bool isk = hh == REP;
+    const unsigned short* src = isk ? a.k + static_cast<size_t>(kvh) * HD : a.q + (static_cast<size_t>(kvh) * REP + hh) * HD;
+    const int i1 = a.traditional ? 2 * i : i;
+    const int i2 = a.traditional ? 2 * i + 1 : i + HD / 2;
+    const float x1 = act_to_f32<BF16>(src[i1]), x2 = act_to_f32<BF16>(src[i2]);
+    const float rev = static_cast<float>(pos) * a.rope_scale * a.inv_freq[i] * 0.15915494309189535f;
+    const float fr = rev - floorf(rev);
+    const float sn = __builtin_amdgcn_sinf(fr), cs = __builtin_amdgcn_cosf(fr);
+    const unsigned short r1 = f32_to_act<BF16>(x1 * cs - x2 * sn), r2 = f32_to_act<BF16>(x1 * sn + x2 * cs);
+    if (isk) {
+      kn_s[i1] = act_to_f32<BF16>(r1);
+      kn_s[i2] = act_to_f32<BF16>(r2);
+      unsigned short* dst = a.kcache + (static_cast<size_t>(kvh) * a.capacity + pos) * HD;
+      dst[i1] = r1;
+      dst[i2] = r2;
+    } else {
+      q_s[hh][i1] = act_to_f32<BF16>(r1) * a.sm_scale;
+      q_s[hh][i2] = act_to_f32<BF16>(r2) * a.sm_scale;
+    }
+  }
+  if (tid < HD) {
+    const unsigned short vb = a.v[static_cast<size_t>(kvh) * HD + tid];
+    vn_s[tid] = act_to_f32<BF16>(vb);
+    a.vcache[(static_cast<size_t>(kvh) * a.capacity + pos) * HD + tid] = vb;
+  }
+  __syncthreads();
+
+  float qr[REP][8], m[REP], l[REP], acc[REP][8];
+#pragma unroll
+  for (int r = 0; r < REP; ++r) {
+    m[r] = NEG; l[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { qr[r][j] = q_s[r][d0 + j]; acc[r][j] = 0.f; }
+  }
+  auto consume = [&](const u32x4& kq, const u32x4& vq, bool valid) {
+    const unsigned kw[4] = {kq.x, kq.y, kq.z, kq.w};
+    const unsigned vw[4] = {vq.x, vq.y, vq.z, vq.w};
+    float kf[8], vf[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      kf[2 * j] = act_lo<BF16>(kw[j]); kf[2 * j + 1] = act_hi<BF16>(kw[j]);
+      vf[2 * j] = act_lo<BF16>(vw[j]); vf[2 * j + 1] = act_hi<BF16>(vw[j]);
+    }
+#pragma unroll
+    for (int r = 0; r < REP; ++r) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s = fmaf(qr[r][j], kf[j], s);
+      s += dpp_f32<0xB1>(s);
+      s += dpp_f32<0x4E>(s);
+      s += dpp_f32<0x141>(s);
+      if constexpr (LP == 16) s += dpp_f32<0x140>(s);
+      const float mn = valid ? fmaxf(m[r], s) : m[r];
+      const float corr = __expf(m[r] - mn);
+      const float p = valid ? __expf(s - mn) : 0.f;
+      l[r] = l[r] * corr + p;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[r][j] = acc[r][j] * corr + p * vf[j];
+      m[r] = mn;
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < UB0; ++u) consume(k0[u], v0[u], wave * PPW + u * 4 * PPW + sub < pos);
+  constexpr int UB = 4;
+  for (int t0 = UB0 * 4 * PPW + wave * PPW; t0 < pos; t0 += 4 * PPW * UB) {
+    u32x4 kv4[UB], vv4[UB];
+    bool valid[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int t = t0 + u * 4 * PPW + sub;
+      valid[u] = t < pos;
+      const int tc = valid[u] ? t : pos - 1;
+      kv4[u] = *reinterpret_cast<const u32x4*>(kbase + static_cast<size_t>(tc) * HD + d0);
+      vv4[u] = *reinterpret_cast<const u32x4*>(vbase + static_cast<size_t>(tc) * HD + d0);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) consume(kv4[u], vv4[u], valid[u]);
+  }
+  // the new token itself (k, v in LDS)
+  if (wave == 0 && sub == 0) {
+#pragma unroll
+    for (int r = 0; r < REP; ++r) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s = fmaf(qr[r][j], kn_s[d0 + j], s);
+      s += dpp_f32<0xB1>(s);
+      s += dpp_f32<0x4E>(s);
+      s += dpp_f32<0x141>(s);
+      if constexpr (LP == 16) s += dpp_f32<0x140>(s);
+      const float mn = fmaxf(m[r], s);
+      const float corr = __expf(m[r] - mn), p = __expf(s - mn);
+      l[r] = l[r] * corr + p;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[r][j] = acc[r][j] * corr + p * vn_s[d0 + j];
+      m[r] = mn;
+    }
+  }
+  const int g = wave * PPW + sub;
+#pragma unroll
+  for (int r = 0; r < REP; ++r) {
+    if (lane % LP == 0) { gm[g][r] = m[r]; gl[g][r] = l[r]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gacc[g][r][d0 + j] = acc[r][j];
+  }
+  __syncthreads();
+  for (int o = tid; o < REP * HD; o += 256) {
+    const int r = o / HD, f = o % HD;
+    float M = NEG;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) M = fmaxf(M, gm[i][r]);
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const float w = __expf(gm[i][r] - M);
+      num = fmaf(w, gacc[i][r][f], num);
+      den = fmaf(w, gl[i][r], den);
+    }
+    a.out[(static_cast<size_t>(kvh) * REP + r) * HD + f] = f32_to_act<BF16>(num / den);
+  }
+}
+
+template <int HD, int REP>
+static hipError_t launch_attn_gqa(const AttnArgs& a, int batch, bool bf16, hipStream_t s) {
+  dim3 grid(a.n_kv, batch), block(256);
+  if (bf16) hipLaunchKernelGGL((attn_decode_gqa_kernel<true, HD, REP>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((attn_decode_gqa_kernel<false, HD, REP>), grid, block, 0, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_attn_decode(const void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
                               const long long* pos, void* out, int batch, int n_heads, int n_kv, int head_dim, int capacity,
                               float rope_scale, float sm_scale, int traditional, bool bf16, hipStream_t s) {
   AttnArgs a{static_cast<const unsigned short*>(q), static_cast<const unsigned short*>(k), static_cast<const unsigned short*>(v),
              static_cast<unsigned short*>(kcache), static_cast<unsigned short*>(vcache), inv_freq, pos,
              static_cast<unsigned short*>(out), n_heads, n_kv, capacity, rope_scale, sm_scale, traditional};
+  if (batch > 1 && head_dim == 128) {              // batched decode: one workgroup per kv group
+    const int rep = n_heads / n_kv;
+    if (rep == 4) return launch_attn_gqa<128, 4>(a, batch, bf16, s);
+    if (rep == 3) return launch_attn_gqa<128, 3>(a, batch, bf16, s);
+    if (rep == 2) return launch_attn_gqa<128, 2>(a, batch, bf16, s);
+  }
   dim3 grid(n_heads, batch), block(256);
   if (head_dim == 128) {
     if (bf16) hipLaunchKernelGGL((attn_decode_kernel<true, 128>), grid, block, 0, s, a);

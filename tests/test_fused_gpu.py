@@ -104,7 +104,7 @@ def test_attn_decode_matches_torch(hd, nh, nkv, pos):
     assert torch.allclose(out.float(), want, atol=2e-2, rtol=2e-2)
 
 
-@pytest.mark.parametrize("hd,nh,nkv,traditional", [(128, 8, 2, False), (64, 4, 4, True)])
+@pytest.mark.parametrize("hd,nh,nkv,traditional", [(128, 8, 2, False), (64, 4, 4, True), (128, 6, 2, True), (128, 4, 2, False)])
 def test_attn_decode_batched_matches_torch(hd, nh, nkv, traditional):
     """gbx_attn_decode_batched: B sequences at the same position, each against its own cache rows."""
     from gbx_lm_amd import ops
