@@ -51,6 +51,31 @@ def test_version_and_host_side_validation(lib):
     assert lib.gbx_qlinear_workspace_bytes(1, 4096, 4096, 4, 128) == 0
 
 
+def test_glue_entry_points_validate_arguments_on_the_host(lib):
+    """Empty inputs succeed, malformed ones return GBX_ERR_INVALID / UNSUPPORTED with a message -- all before any HIP call."""
+    from gbx_lm_amd import _lib
+    one = ctypes.c_void_p(16)                                   # a non-null, 16-byte aligned stand-in (never dereferenced)
+    assert lib.gbx_swiglu(None, None, None, 0, _lib.GBX_BF16, None) == _lib.GBX_OK
+    assert lib.gbx_swiglu(one, one, one, 12, _lib.GBX_BF16, None) == _lib.GBX_ERR_INVALID          # n % 8
+    assert lib.gbx_swiglu(one, one, one, 16, _lib.GBX_F32, None) == _lib.GBX_ERR_INVALID           # activation dtype
+    assert lib.gbx_add_rmsnorm(None, None, None, None, 0, 4096, 1e-5, _lib.GBX_BF16, None) == _lib.GBX_OK
+    assert lib.gbx_add_rmsnorm(one, None, one, one, 4, 4096, 1e-5, _lib.GBX_BF16, None) == _lib.GBX_ERR_INVALID
+    assert lib.gbx_rmsnorm(None, None, None, 0, 128, 1e-5, _lib.GBX_BF16, None) == _lib.GBX_OK
+    assert lib.gbx_rope(None, None, None, None, 0, 0, 8, 1, 128, 128, 0, 0, 0, 1.0, 1.0, 0, _lib.GBX_BF16, None) == _lib.GBX_OK
+    assert lib.gbx_rope(one, one, one, None, 0, 1, 8, 1, 128, 128, 1024, 128, 128, 1.0, 1.0, 0, _lib.GBX_BF16, None) \
+        == _lib.GBX_ERR_INVALID                                                                    # in place
+    assert b"out of place" in lib.gbx_last_error()
+    two = ctypes.c_void_p(32)
+    assert lib.gbx_rope(one, two, one, None, 0, 1, 8, 1, 128, 130, 1024, 128, 128, 1.0, 1.0, 0, _lib.GBX_BF16, None) \
+        == _lib.GBX_ERR_INVALID                                                                    # dims > D
+    args = (one, one, one, one, one, one, one, one)
+    assert lib.gbx_attn_decode_batched(*args, 0, 8, 2, 128, 64, 1.0, 0.1, 0, _lib.GBX_BF16, None) == _lib.GBX_OK
+    assert lib.gbx_attn_decode_batched(*args, 2, 8, 2, 96, 64, 1.0, 0.1, 0, _lib.GBX_BF16, None) == _lib.GBX_ERR_UNSUPPORTED
+    assert lib.gbx_attn_decode_batched(*args, 2, 8, 3, 128, 64, 1.0, 0.1, 0, _lib.GBX_BF16, None) == _lib.GBX_ERR_INVALID
+    with pytest.raises(NotImplementedError, match="head_dim"):
+        _lib.check(lib.gbx_attn_decode_batched(*args, 2, 8, 2, 96, 64, 1.0, 0.1, 0, _lib.GBX_BF16, None))
+
+
 def test_product_path_never_imports_oracle():
     """The shipped package must not reference oracle/ (a product path through the oracle voids parity)."""
     pkg = os.path.join(ROOT, "gbx-lm_amd")
