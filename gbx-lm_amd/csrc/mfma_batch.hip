@@ -28,6 +28,10 @@
 // rate per CU: every workgroup still pulls the whole 256 KB activation tile through its vector-memory path (57 MB
 // chip-wide beside 29 MB of weights for gate|up); sharing x further needs a k split ACROSS workgroups, i.e. a
 // caller-owned fp32 workspace in the ABI (next round).
+// Also tried: holding the loader waves back one barrier so that the compute waves' 6 loads per step are not queued behind
+// the loaders' 64 (19.6 -> 23.4 us: the phase then starts late for the loaders).  What the numbers fit is a fill-rate
+// limit per CU of ~24 KB/us from L2 or HBM alike (256 CUs x 24 GB/s = the 6.2 TB/s copy ceiling of the chip): a workgroup
+// here pulls 256 KB of x + 128 KB of weights = 16 us.
 // -DBX_STAMPS: diagnostic build with s_memtime phase stamps (scratch/stamps_batch.py).
 #include "mfma_common.h"
 #include "kernels.h"
