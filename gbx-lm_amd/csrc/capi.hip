@@ -381,6 +381,49 @@ int gbx_rmsnorm(const void* x, const void* w, void* y, int64_t M, int32_t K, flo
   return GBX_OK;
 }
 
+int gbx_attn_cached(const void* q, const void* kcache, const void* vcache, const int64_t* pos, void* out, int32_t batch,
+                    int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int32_t capacity, float sm_scale, int32_t act_dtype,
+                    void* hip_stream) {
+  if (batch == 0) return GBX_OK;
+  if (!q || !kcache || !vcache || !pos || !out) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (batch < 0 || batch > 65535) return fail(GBX_ERR_INVALID, "batch must be in [0, 65535] (got %d)", batch);
+  if (head_dim != 64 && head_dim != 128) return fail(GBX_ERR_UNSUPPORTED, "head_dim must be 64 or 128 (got %d)", head_dim);
+  if (n_heads <= 0 || n_kv_heads <= 0 || n_heads % n_kv_heads) return fail(GBX_ERR_INVALID, "n_heads must be a multiple of n_kv_heads");
+  if (capacity <= 0) return fail(GBX_ERR_INVALID, "capacity must be positive");
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  if (!aligned(kcache, 16) || !aligned(vcache, 16)) return fail(GBX_ERR_INVALID, "KV cache must be 16-byte aligned");
+  hipError_t e = gbx::launch_attn_static(q, kcache, vcache, reinterpret_cast<const long long*>(pos), out, batch, n_heads, n_kv_heads,
+                                         head_dim, capacity, sm_scale, act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_attn_cached launch");
+  return GBX_OK;
+}
+
+int gbx_moe_route(const void* logits, int32_t* indices, void* scores, int64_t tokens, int32_t num_experts, int32_t top_k,
+                  int32_t mode, int32_t renormalize, int32_t act_dtype, void* hip_stream) {
+  if (tokens == 0) return GBX_OK;
+  if (!logits || !indices || !scores) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (tokens < 0 || tokens > 2147483647LL) return fail(GBX_ERR_INVALID, "bad token count %lld", (long long)tokens);
+  if (num_experts <= 0 || num_experts > 1024) return fail(GBX_ERR_UNSUPPORTED, "num_experts must be in [1, 1024] (got %d)", num_experts);
+  if (top_k <= 0 || top_k > 8 || top_k > num_experts) return fail(GBX_ERR_UNSUPPORTED, "top_k must be in [1, min(8, num_experts)] (got %d)", top_k);
+  if (mode != 0 && mode != 1) return fail(GBX_ERR_INVALID, "mode must be 0 (softmax then top-k) or 1 (top-k then softmax)");
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  hipError_t e = gbx::launch_moe_route(logits, indices, scores, static_cast<int>(tokens), num_experts, top_k, mode, renormalize ? 1 : 0,
+                                       act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_moe_route launch");
+  return GBX_OK;
+}
+
+int gbx_moe_combine(const void* y, const void* scores, void* out, int64_t tokens, int32_t top_k, int32_t D, int32_t act_dtype,
+                    void* hip_stream) {
+  if (tokens == 0) return GBX_OK;
+  if (!y || !scores || !out) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (tokens < 0 || tokens > 65535 || top_k <= 0 || D <= 0 || (D & 1)) return fail(GBX_ERR_INVALID, "bad shape tokens=%lld top_k=%d D=%d", (long long)tokens, top_k, D);
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  hipError_t e = gbx::launch_moe_combine(y, scores, out, static_cast<int>(tokens), top_k, D, act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_moe_combine launch");
+  return GBX_OK;
+}
+
 int gbx_add_rmsnorm(void* h, const void* delta, const void* w, void* y, int64_t M, int32_t K, float eps, int32_t act_dtype,
                     void* hip_stream) {
   if (M == 0) return GBX_OK;

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
 // Batched decode variant: one workgroup per (kv head, sequence) serves all REP query heads of the group, so every cached
 // K / V row is read ONCE per group instead of once per query head (at B = 32 the per-head kernel moved 4x the cache
 // bytes: 67 MB per layer at context 128).  Same arithmetic and layout as attn_decode_kernel.
-template <bool BF16, int HD, int REP>
+template <bool BF16, int HD, int REP, bool STATIC>
 __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
   constexpr int LP = HD / 8, PPW = 64 / LP, NG = 4 * PPW;
   constexpr float NEG = -1e30f;
@@ -192,7 +192,11 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
   __shared__ float gm[NG][REP], gl[NG][REP];
   __shared__ float gacc[NG][REP][HD + 8];
 
-  const int kvh = blockIdx.x;
+  // STATIC (family-agnostic graph decode, models/base.py): q is already rotated, the new token's k, v are already in
+  // the cache at *pos -- plain softmax(q K^T) V over positions 0..*pos.  A workgroup then serves REP of the group's
+  // rep = n_heads / n_kv query heads (blockIdx.x = kv head * parts + part).
+  const int rep = a.n_heads / a.n_kv, parts = rep / REP;
+  const int kvh = blockIdx.x / parts, hq0 = kvh * rep + (blockIdx.x % parts) * REP;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   {
@@ -213,12 +217,16 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
     v0[u] = *reinterpret_cast<const u32x4*>(vbase + static_cast<size_t>(tc) * HD + d0);
   }
   const int pos = static_cast<int>(*a.pos);
+  const int nctx = STATIC ? pos + 1 : pos;          // cached positions to visit
 
+  if constexpr (STATIC) {
+    for (int p = tid; p < REP * HD; p += 256) q_s[p / HD][p % HD] = act_to_f32<BF16>(a.q[static_cast<size_t>(hq0) * HD + p]) * a.sm_scale;
+  } else {
   // RoPE on the REP query heads and the kv head's k; append k, v to the cache
   for (int p = tid; p < (REP + 1) * (HD / 2); p += 256) {
     const int hh = p / (HD / 2), i = p % (HD / 2);   // hh == REP: the k head
     const bool isk = hh == REP;
-    const unsigned short* src = isk ? a.k + static_cast<size_t>(kvh) * HD : a.q + (static_cast<size_t>(kvh) * REP + hh) * HD;
+    const unsigned short* src = isk ? a.k + static_cast<size_t>(kvh) * HD : a.q + (static_cast<size_t>(hq0) + hh) * HD;
     const int i1 = a.traditional ? 2 * i : i;
     const int i2 = a.traditional ? 2 * i + 1 : i + HD / 2;
     const float x1 = act_to_f32<BF16>(src[i1]), x2 = act_to_f32<BF16>(src[i2]);
@@ -241,6 +249,7 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
     const unsigned short vb = a.v[static_cast<size_t>(kvh) * HD + tid];
     vn_s[tid] = act_to_f32<BF16>(vb);
     a.vcache[(static_cast<size_t>(kvh) * a.capacity + pos) * HD + tid] = vb;
+  }
   }
   __syncthreads();
 
@@ -279,16 +288,16 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
     }
   };
 #pragma unroll
-  for (int u = 0; u < UB0; ++u) consume(k0[u], v0[u], wave * PPW + u * 4 * PPW + sub < pos);
+  for (int u = 0; u < UB0; ++u) consume(k0[u], v0[u], wave * PPW + u * 4 * PPW + sub < nctx);
   constexpr int UB = 4;
-  for (int t0 = UB0 * 4 * PPW + wave * PPW; t0 < pos; t0 += 4 * PPW * UB) {
+  for (int t0 = UB0 * 4 * PPW + wave * PPW; t0 < nctx; t0 += 4 * PPW * UB) {
     u32x4 kv4[UB], vv4[UB];
     bool valid[UB];
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
       const int t = t0 + u * 4 * PPW + sub;
-      valid[u] = t < pos;
-      const int tc = valid[u] ? t : pos - 1;
+      valid[u] = t < nctx;
+      const int tc = valid[u] ? t : nctx - 1;
       kv4[u] = *reinterpret_cast<const u32x4*>(kbase + static_cast<size_t>(tc) * HD + d0);
       vv4[u] = *reinterpret_cast<const u32x4*>(vbase + static_cast<size_t>(tc) * HD + d0);
     }
@@ -296,7 +305,7 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
     for (int u = 0; u < UB; ++u) consume(kv4[u], vv4[u], valid[u]);
   }
   // the new token itself (k, v in LDS)
-  if (wave == 0 && sub == 0) {
+  if (!STATIC && wave == 0 && sub == 0) {
 #pragma unroll
     for (int r = 0; r < REP; ++r) {
       float s = 0.f;
@@ -334,16 +343,51 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
       num = fmaf(w, gacc[i][r][f], num);
       den = fmaf(w, gl[i][r], den);
     }
-    a.out[(static_cast<size_t>(kvh) * REP + r) * HD + f] = f32_to_act<BF16>(num / den);
+    a.out[(static_cast<size_t>(hq0) + r) * HD + f] = f32_to_act<BF16>(num / den);
   }
 }
 
 template <int HD, int REP>
 static hipError_t launch_attn_gqa(const AttnArgs& a, int batch, bool bf16, hipStream_t s) {
   dim3 grid(a.n_kv, batch), block(256);
-  if (bf16) hipLaunchKernelGGL((attn_decode_gqa_kernel<true, HD, REP>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((attn_decode_gqa_kernel<false, HD, REP>), grid, block, 0, s, a);
+  if (bf16) hipLaunchKernelGGL((attn_decode_gqa_kernel<true, HD, REP, false>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((attn_decode_gqa_kernel<false, HD, REP, false>), grid, block, 0, s, a);
   return hipGetLastError();
+}
+
+template <int HD, int REP>
+static hipError_t launch_attn_static_cfg(const AttnArgs& a, int batch, bool bf16, hipStream_t s) {
+  dim3 grid(a.n_kv * (a.n_heads / a.n_kv / REP), batch), block(256);
+  if (bf16) hipLaunchKernelGGL((attn_decode_gqa_kernel<true, HD, REP, true>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((attn_decode_gqa_kernel<false, HD, REP, true>), grid, block, 0, s, a);
+  return hipGetLastError();
+}
+
+// softmax(q K^T * sm_scale) V over cache positions 0..*pos for one (already rotated) query token per sequence
+hipError_t launch_attn_static(const void* q, const void* kcache, const void* vcache, const long long* pos, void* out, int batch,
+                              int n_heads, int n_kv, int head_dim, int capacity, float sm_scale, bool bf16, hipStream_t s) {
+  AttnArgs a{static_cast<const unsigned short*>(q), nullptr, nullptr,
+             static_cast<unsigned short*>(const_cast<void*>(kcache)), static_cast<unsigned short*>(const_cast<void*>(vcache)),
+             nullptr, pos, static_cast<unsigned short*>(out), n_heads, n_kv, capacity, 1.f, sm_scale, 0};
+  const int rep = n_heads / n_kv;
+  const int R = rep % 4 == 0 ? 4 : rep % 3 == 0 ? 3 : rep % 2 == 0 ? 2 : 1;
+  if (head_dim == 128) {
+    switch (R) {
+      case 4: return launch_attn_static_cfg<128, 4>(a, batch, bf16, s);
+      case 3: return launch_attn_static_cfg<128, 3>(a, batch, bf16, s);
+      case 2: return launch_attn_static_cfg<128, 2>(a, batch, bf16, s);
+      default: return launch_attn_static_cfg<128, 1>(a, batch, bf16, s);
+    }
+  }
+  if (head_dim == 64) {
+    switch (R) {
+      case 4: return launch_attn_static_cfg<64, 4>(a, batch, bf16, s);
+      case 3: return launch_attn_static_cfg<64, 3>(a, batch, bf16, s);
+      case 2: return launch_attn_static_cfg<64, 2>(a, batch, bf16, s);
+      default: return launch_attn_static_cfg<64, 1>(a, batch, bf16, s);
+    }
+  }
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_attn_decode(const void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,

@@ -45,6 +45,11 @@ hipError_t launch_rope_append(void* q, const void* k, const void* v, void* kcach
                               int traditional, bool bf16, hipStream_t s);
 hipError_t launch_eminf(const void* logits, float* cur, float* nxt, float* out_entropy, int V, int in_mode, float alpha,
                         float threshold, int num_steps, hipStream_t s);
+hipError_t launch_attn_static(const void* q, const void* kcache, const void* vcache, const long long* pos, void* out, int batch,
+                              int n_heads, int n_kv, int head_dim, int capacity, float sm_scale, bool bf16, hipStream_t s);
+hipError_t launch_moe_route(const void* logits, int* inds, void* scores, int T, int E, int k, int mode, int renorm, bool bf16,
+                            hipStream_t s);
+hipError_t launch_moe_combine(const void* y, const void* scores, void* out, int T, int k, int D, bool bf16, hipStream_t s);
 hipError_t launch_add_rmsnorm(void* h, const void* d, const void* w, void* y, int M, int K, float eps, bool bf16, hipStream_t s);
 hipError_t launch_swiglu(const void* g, const void* u, void* y, long long n, bool bf16, hipStream_t s);
 hipError_t launch_rmsnorm(const void* x, const void* w, void* y, int M, int K, float eps, bool bf16, hipStream_t s);

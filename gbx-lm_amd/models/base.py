@@ -62,6 +62,11 @@ def scaled_dot_product_attention(queries, keys, values, cache, scale: float, mas
     if getattr(cache, "bits", None) is not None:
         raise NotImplementedError("quantised KV cache is outside the QuantizedLinear hot path")
     if getattr(cache, "static_active", False):    # whole buffer, positions past the device-resident index masked out
+        if (queries.is_cuda and queries.shape[2] == 1 and queries.shape[3] in (64, 128) and values.shape[3] == queries.shape[3]
+                and queries.dtype in (torch.bfloat16, torch.float16) and keys.dtype == queries.dtype
+                and keys.is_contiguous() and values.is_contiguous()):
+            from .. import ops                     # one launch: K / V read once per kv group (gbx_attn_cached)
+            return ops.attn_cached(queries, keys, values, cache.static_pos, scale)
         cap = keys.shape[2]
         live = torch.arange(cap, device=keys.device)[None, None, None, :] <= cache.static_pos
         mask = torch.where(live, 0.0, float("-inf")).to(queries.dtype)

@@ -14,6 +14,7 @@ from typing import Any, Dict, List, Optional, Union
 import torch
 from torch import nn
 
+from .. import ops
 from . import qllama
 from .base import BaseModelArgs, create_attention_mask
 from .switch_layers import SwitchGLU
@@ -61,6 +62,10 @@ class MixtralSparseMoeBlock(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         gates = self.gate(x)
+        if (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and gates.dtype == x.dtype and self.num_experts <= 1024
+                and self.num_experts_per_tok <= 8 and x.numel() // x.shape[-1] <= 65535):
+            inds, scores = ops.moe_route(gates, self.num_experts_per_tok, 1, False)     # top-k of the logits, softmax over them
+            return ops.moe_combine(self.switch_mlp(x, inds), scores)
         top, inds = torch.topk(gates, self.num_experts_per_tok, dim=-1)       # the reference's argpartition: same set
         scores = torch.softmax(top.float(), dim=-1).to(x.dtype)
         y = self.switch_mlp(x, inds)

@@ -15,6 +15,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .. import ops
 from .base import BaseModelArgs, cache_offset, create_attention_mask, scaled_dot_product_attention
 from .qllama import RMSNorm
 from .quantized_linear_gba import QuantizedLinear
@@ -86,6 +87,11 @@ class MLP(nn.Module):
         return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
 
 
+def _device_routing(x: torch.Tensor, num_experts: int, top_k: int) -> bool:
+    return (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and num_experts <= 1024 and top_k <= 8
+            and x.shape[-1] % 2 == 0 and x.numel() // x.shape[-1] <= 65535)
+
+
 class Qwen3MoeSparseMoeBlock(nn.Module):
     """Router (a QuantizedLinear) -> softmax (fp32) -> top-k -> optional renormalisation -> SwitchGLU -> weighted sum
     (qqwen3_moe.py:112-141).  The reference picks the k largest with argpartition (unordered); topk here -- the set and
@@ -98,6 +104,10 @@ class Qwen3MoeSparseMoeBlock(nn.Module):
         self.switch_mlp = SwitchGLU(args.hidden_size, args.moe_intermediate_size, args.num_experts, quant=True)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if _device_routing(x, self.num_experts, self.top_k):
+            # routing decisions and the weighted sum as two launches (gbx_moe_route / gbx_moe_combine)
+            inds, scores = ops.moe_route(self.gate(x), self.top_k, 0, self.norm_topk_prob)
+            return ops.moe_combine(self.switch_mlp(x, inds), scores)
         gates = torch.softmax(self.gate(x).float(), dim=-1).to(x.dtype)
         scores, inds = torch.topk(gates, self.top_k, dim=-1)
         if self.norm_topk_prob:

@@ -297,6 +297,42 @@ def attn_decode_batched(q, k, v, kcache, vcache, inv_freq, pos, out, n_heads: in
                                                   _DT[q.dtype], _stream_ptr(q.device)))
 
 
+def attn_cached(q: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, pos: torch.Tensor, scale: float) -> torch.Tensor:
+    """softmax(q K^T * scale) V for ONE query token per sequence over cache positions 0..pos (device int64), the new
+    token's k / v already stored: q [B, Hq, 1, D] (rotated), caches [B, Hkv, cap, D] -> [B, Hq, 1, D] (gbx_attn_cached)."""
+    _require_cuda(q, "q")
+    b, hq, _, d = q.shape
+    qc = q.contiguous()
+    out = torch.empty_like(qc)
+    _lib.check(_lib.lib().gbx_attn_cached(qc.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), pos.data_ptr(), out.data_ptr(), b, hq,
+                                          kcache.shape[1], d, kcache.shape[2], float(scale), _DT[q.dtype], _stream_ptr(q.device)))
+    return out
+
+
+def moe_route(logits: torch.Tensor, top_k: int, mode: int = 0, renormalize: bool = True):
+    """Router logits [..., E] -> (indices int32 [..., k], scores [..., k]) in one launch (gbx_moe_route)."""
+    _require_cuda(logits, "logits")
+    e = logits.shape[-1]
+    lg = logits.reshape(-1, e).contiguous()
+    inds = torch.empty((lg.shape[0], top_k), dtype=torch.int32, device=logits.device)
+    scores = torch.empty((lg.shape[0], top_k), dtype=logits.dtype, device=logits.device)
+    _lib.check(_lib.lib().gbx_moe_route(lg.data_ptr(), inds.data_ptr(), scores.data_ptr(), lg.shape[0], e, top_k, mode,
+                                        int(bool(renormalize)), _DT[logits.dtype], _stream_ptr(logits.device)))
+    lead = tuple(logits.shape[:-1])
+    return inds.reshape(*lead, top_k), scores.reshape(*lead, top_k)
+
+
+def moe_combine(y: torch.Tensor, scores: torch.Tensor) -> torch.Tensor:
+    """sum_s scores[..., s] * y[..., s, :] in one launch (gbx_moe_combine)."""
+    _require_cuda(y, "y")
+    k, d = y.shape[-2], y.shape[-1]
+    yc, sc = y.contiguous(), scores.contiguous()
+    out = torch.empty(tuple(y.shape[:-2]) + (d,), dtype=y.dtype, device=y.device)
+    _lib.check(_lib.lib().gbx_moe_combine(yc.data_ptr(), sc.data_ptr(), out.data_ptr(), yc.numel() // (k * d), k, d, _DT[y.dtype],
+                                          _stream_ptr(y.device)))
+    return out
+
+
 def add_rmsnorm(h: torch.Tensor, delta: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
     """h += delta in place (activation-dtype add), returns RMSNorm(h) * w -- one launch (gbx_add_rmsnorm)."""
     _require_cuda(h, "h")

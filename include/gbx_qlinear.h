@@ -204,6 +204,27 @@ int gbx_attn_decode_batched(const void* q, const void* k, const void* v, void* k
                             int32_t head_dim, int32_t capacity, float rope_scale, float sm_scale, int32_t traditional,
                             int32_t act_dtype, void* hip_stream);
 
+/* Single-token attention over a cache that already holds the new token: out[b, h, :] = softmax(q[b, h, :] . K[b, kv(h), 0..*pos, :]^T
+ * * sm_scale) V[b, kv(h), 0..*pos, :] with q [batch, n_heads, head_dim] already rotated, caches [batch, n_kv, capacity, head_dim],
+ * `pos` a DEVICE int64.  mx.fast.scaled_dot_product_attention as every model graph calls it for L = 1 (models/base.py:65-92),
+ * grouped-query heads served from one read of K / V. */
+int gbx_attn_cached(const void* q, const void* kcache, const void* vcache, const int64_t* pos, void* out, int32_t batch,
+                    int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int32_t capacity, float sm_scale, int32_t act_dtype,
+                    void* hip_stream);
+
+/* Expert routing of `tokens` rows of router logits[tokens, num_experts] on the device: indices[tokens, top_k] (int32, best
+ * first, ties to the lowest expert) and mixing weights scores[tokens, top_k] in the activation dtype.
+ * mode 0: softmax over all experts (fp32, rounded), top_k largest, divided by their sum if `renormalize`
+ *         (gbx_lm/models/qqwen3_moe.py:126-137); mode 1: top_k of the logits, softmax over those (qmixtral.py).
+ * num_experts <= 1024, top_k <= 8. */
+int gbx_moe_route(const void* logits, int32_t* indices, void* scores, int64_t tokens, int32_t num_experts, int32_t top_k,
+                  int32_t mode, int32_t renormalize, int32_t act_dtype, void* hip_stream);
+
+/* out[t, :] = sum_s scores[t, s] * y[t, s, :] with y [tokens, top_k, D]: the weighted sum after SwitchGLU
+ * (qqwen3_moe.py:139-141); products rounded to the activation dtype, fp32 sum, one rounding.  D even. */
+int gbx_moe_combine(const void* y, const void* scores, void* out, int64_t tokens, int32_t top_k, int32_t D, int32_t act_dtype,
+                    void* hip_stream);
+
 /* Residual add + RMSNorm in one launch: h[M, K] <- h + delta (one rounding to the activation dtype, the add of
  * qllama.py:138-140), y = RMSNorm(h) * w.  h is updated in place; y may not alias h. */
 int gbx_add_rmsnorm(void* h, const void* delta, const void* w, void* y, int64_t M, int32_t K, float eps, int32_t act_dtype,

@@ -133,6 +133,24 @@ def test_attn_decode_batched_matches_torch(hd, nh, nkv, traditional):
     assert torch.allclose(out.float().cpu(), want, atol=2e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("hd,nh,nkv", [(128, 8, 2), (128, 32, 4), (64, 6, 2), (64, 5, 5), (128, 4, 2)])
+def test_attn_cached_matches_torch(hd, nh, nkv):
+    """gbx_attn_cached (what the SDPA helper runs inside a graph-replayed decode step): rotated q against a cache that
+    already holds the new token, positions past *pos ignored; rep = 4, 8 (two passes of 4), 3, 1, 2."""
+    from gbx_lm_amd import ops
+    torch.manual_seed(nh)
+    B, cap, pos = 3, 160, 77
+    q = torch.randn(B, nh, 1, hd).to(torch.bfloat16)
+    kc = torch.randn(B, nkv, cap, hd).to(torch.bfloat16)
+    vc = torch.randn(B, nkv, cap, hd).to(torch.bfloat16)
+    out = ops.attn_cached(q.to(DEV), kc.to(DEV), vc.to(DEV), torch.tensor([pos], device=DEV), hd ** -0.5)
+    rep = nh // nkv
+    K = kc[:, :, :pos + 1].repeat_interleave(rep, 1).float()
+    V = vc[:, :, :pos + 1].repeat_interleave(rep, 1).float()
+    want = torch.softmax((q.float() @ K.transpose(-1, -2)) * hd ** -0.5, -1) @ V
+    assert out.shape == q.shape and torch.allclose(out.float().cpu(), want, atol=2e-2, rtol=2e-2)
+
+
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 def test_add_rmsnorm_and_swiglu_glue(dt):
     """Batched-decode glue kernels against the op-by-op torch formulation (same roundings): h += d; y = RMSNorm(h) w,

@@ -77,3 +77,38 @@ def test_qwen3_moe_model_matches_fixture(golden_dir):
     # the reference API end to end on the MoE family
     toks = [t for t, _, _ in U.generate_step(torch.tensor(z["prompt"]), model, max_tokens=4)]
     assert len(toks) == 4
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_moe_route_and_combine_kernels(dt):
+    """gbx_moe_route / gbx_moe_combine against the op-by-op torch formulation of the two routing flavours
+    (qqwen3_moe.py:126-141: softmax -> top-k -> renormalise; qmixtral: top-k -> softmax), plus the weighted sum."""
+    from gbx_lm_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for (T, E, k, mode, renorm) in ((1, 128, 8, 0, True), (5, 8, 2, 1, False), (3, 256, 6, 0, False), (2, 60, 4, 0, True)):
+        logits = (2.5 * torch.randn(T, E, generator=g)).to(dt)
+        inds, scores = ops.moe_route(logits.to(DEV), k, mode, renorm)
+        assert inds.dtype == torch.int32 and inds.shape == (T, k) and scores.dtype == dt
+        if mode == 0:
+            gates = torch.softmax(logits.float(), -1).to(dt)
+            ws, wi = torch.topk(gates, k, dim=-1)
+            if renorm:
+                ws = ws / ws.sum(-1, keepdim=True)
+        else:
+            top, wi = torch.topk(logits, k, dim=-1)
+            ws = torch.softmax(top.float(), -1).to(dt)
+        # same SET of experts (ties in the rounded probabilities may order differently), same weights per expert
+        for t in range(T):
+            got = {int(e): float(w) for e, w in zip(inds[t].cpu(), scores[t].float().cpu())}
+            want = {int(e): float(w) for e, w in zip(wi[t], ws[t].float())}
+            vals_g, vals_w = sorted(got.values()), sorted(want.values())
+            assert np.allclose(vals_g, vals_w, rtol=2e-2, atol=1e-4), (T, E, k, mode)
+            common = set(got) & set(want)
+            assert len(common) >= k - 1                               # at most one boundary tie may pick another expert
+            for e in common:
+                assert abs(got[e] - want[e]) <= 2e-2 * abs(want[e]) + 1e-4
+        D = 256
+        y = torch.randn(T, k, D, generator=g).to(dt)
+        out = ops.moe_combine(y.to(DEV), scores)
+        ref = (y * scores.cpu().unsqueeze(-1)).sum(dim=-2)
+        assert torch.allclose(out.float().cpu(), ref.float(), rtol=2e-2, atol=2e-2)
