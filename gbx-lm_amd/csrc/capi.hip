@@ -424,6 +424,19 @@ int gbx_moe_combine(const void* y, const void* scores, void* out, int64_t tokens
   return GBX_OK;
 }
 
+int gbx_kv_append(const void* k, const void* v, void* kcache, void* vcache, const int64_t* pos, int64_t rows, int32_t capacity,
+                  int32_t k_dim, int32_t v_dim, int32_t act_dtype, void* hip_stream) {
+  if (rows == 0) return GBX_OK;
+  if (!k || !v || !kcache || !vcache || !pos) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (rows < 0 || rows > 2147483647LL || capacity <= 0 || k_dim <= 0 || v_dim <= 0)
+    return fail(GBX_ERR_INVALID, "bad shape rows=%lld capacity=%d k_dim=%d v_dim=%d", (long long)rows, capacity, k_dim, v_dim);
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  hipError_t e = gbx::launch_kv_append(k, v, kcache, vcache, reinterpret_cast<const long long*>(pos), static_cast<int>(rows), capacity,
+                                       k_dim, v_dim, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_kv_append launch");
+  return GBX_OK;
+}
+
 int gbx_add_rmsnorm(void* h, const void* delta, const void* w, void* y, int64_t M, int32_t K, float eps, int32_t act_dtype,
                     void* hip_stream) {
   if (M == 0) return GBX_OK;

@@ -11,32 +11,31 @@
 
 namespace gbx {
 
-__device__ __forceinline__ float wave_max_f32(float v) {
-  v = fmaxf(v, dpp_f32<0xB1>(v));
-  v = fmaxf(v, dpp_f32<0x4E>(v));
-  v = fmaxf(v, dpp_f32<0x141>(v));
-  v = fmaxf(v, dpp_f32<0x140>(v));
-  v = fmaxf(v, __shfl_xor(v, 16));
-  v = fmaxf(v, __shfl_xor(v, 32));
-  return v;
+// order-preserving map float -> uint (so that the DPP integer max of gbx_device.h serves floats of either sign)
+__device__ __forceinline__ unsigned f2key(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
-template <bool BF16>
+template <bool BF16, int VPL>
 __global__ __launch_bounds__(64) void moe_route_kernel(const unsigned short* __restrict__ logits, int* __restrict__ inds,
                                                        unsigned short* __restrict__ scores, int E, int k, int mode, int renorm) {
-  constexpr int VPL = 16;                           // experts per lane: E <= 1024
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x;                     // expert e = lane + 64 i, i < VPL (E <= 64 VPL)
   const unsigned short* row = logits + static_cast<size_t>(blockIdx.x) * E;
+  constexpr float NEG = -3.0e38f;
   float v[VPL];
-  float mx = -3.0e38f;
+  float mx = NEG;
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     const int e = lane + 64 * i;
-    v[i] = e < E ? act_to_f32<BF16>(row[e]) : -3.0e38f;
+    v[i] = e < E ? act_to_f32<BF16>(row[e]) : NEG;
     mx = fmaxf(mx, v[i]);
   }
   if (mode == 0) {                                  // probabilities over all experts, rounded to the activation dtype
-    mx = wave_max_f32(mx);
+    mx = key2f(wave_max_u32(f2key(mx)));
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
@@ -45,7 +44,7 @@ __global__ __launch_bounds__(64) void moe_route_kernel(const unsigned short* __r
     }
     sum = wave_sum(sum);
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) v[i] = lane + 64 * i < E ? act_to_f32<BF16>(f32_to_act<BF16>(v[i] / sum)) : -3.0e38f;
+    for (int i = 0; i < VPL; ++i) v[i] = lane + 64 * i < E ? act_to_f32<BF16>(f32_to_act<BF16>(v[i] / sum)) : NEG;
   }
   // k rounds of wave-wide argmax (ties: lowest expert index)
   float top[8];
@@ -53,20 +52,20 @@ __global__ __launch_bounds__(64) void moe_route_kernel(const unsigned short* __r
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     if (s < k) {
-      float best = -3.0e38f;
+      float best = NEG;
       int bi = 0x7fffffff;
 #pragma unroll
       for (int i = 0; i < VPL; ++i)
         if (v[i] > best) { best = v[i]; bi = lane + 64 * i; }
-      const float wbest = wave_max_f32(best);
-      unsigned cand = best == wbest ? ~static_cast<unsigned>(bi) : 0u;     // larger key = smaller index
-      cand = wave_max_u32(cand);
+      const unsigned kb = f2key(best);
+      const unsigned wk = wave_max_u32(kb);
+      const unsigned cand = wave_max_u32(kb == wk ? ~static_cast<unsigned>(bi) : 0u);     // larger key = smaller index
       const int win = static_cast<int>(~cand);
-      top[s] = wbest;
+      top[s] = key2f(wk);
       topi[s] = win;
 #pragma unroll
       for (int i = 0; i < VPL; ++i)
-        if (lane + 64 * i == win) v[i] = -3.0e38f;
+        if (lane + 64 * i == win) v[i] = NEG;
     }
   }
   if (lane == 0) {
@@ -88,12 +87,21 @@ __global__ __launch_bounds__(64) void moe_route_kernel(const unsigned short* __r
   }
 }
 
+template <int VPL>
+static void launch_route_vpl(const unsigned short* L, int* inds, unsigned short* S, int T, int E, int k, int mode, int renorm,
+                             bool bf16, hipStream_t s) {
+  if (bf16) hipLaunchKernelGGL((moe_route_kernel<true, VPL>), dim3(T), dim3(64), 0, s, L, inds, S, E, k, mode, renorm);
+  else hipLaunchKernelGGL((moe_route_kernel<false, VPL>), dim3(T), dim3(64), 0, s, L, inds, S, E, k, mode, renorm);
+}
+
 hipError_t launch_moe_route(const void* logits, int* inds, void* scores, int T, int E, int k, int mode, int renorm, bool bf16,
                             hipStream_t s) {
   auto L = static_cast<const unsigned short*>(logits);
   auto S = static_cast<unsigned short*>(scores);
-  if (bf16) hipLaunchKernelGGL((moe_route_kernel<true>), dim3(T), dim3(64), 0, s, L, inds, S, E, k, mode, renorm);
-  else hipLaunchKernelGGL((moe_route_kernel<false>), dim3(T), dim3(64), 0, s, L, inds, S, E, k, mode, renorm);
+  if (E <= 64) launch_route_vpl<1>(L, inds, S, T, E, k, mode, renorm, bf16, s);
+  else if (E <= 128) launch_route_vpl<2>(L, inds, S, T, E, k, mode, renorm, bf16, s);
+  else if (E <= 256) launch_route_vpl<4>(L, inds, S, T, E, k, mode, renorm, bf16, s);
+  else launch_route_vpl<16>(L, inds, S, T, E, k, mode, renorm, bf16, s);
   return hipGetLastError();
 }
 
@@ -121,6 +129,25 @@ hipError_t launch_moe_combine(const void* y, const void* scores, void* out, int 
   dim3 grid((D / 2 + 255) / 256, T), block(256);
   if (bf16) hipLaunchKernelGGL((moe_combine_kernel<true>), grid, block, 0, s, Y, S, O, k, D);
   else hipLaunchKernelGGL((moe_combine_kernel<false>), grid, block, 0, s, Y, S, O, k, D);
+  return hipGetLastError();
+}
+
+// One new token per sequence into both caches at the device-resident position (the static-mode
+// cache.update_and_fetch of gbx_lm/models/cache.py:222-244): rows = batch * kv heads.
+__global__ __launch_bounds__(256) void kv_append_kernel(const unsigned short* __restrict__ k, const unsigned short* __restrict__ v,
+                                                        unsigned short* __restrict__ kc, unsigned short* __restrict__ vc,
+                                                        const long long* __restrict__ posp, int cap, int dk, int dv) {
+  const long long pos = *posp;
+  const size_t r = blockIdx.x;
+  for (int i = threadIdx.x; i < dk; i += 256) kc[(r * cap + pos) * dk + i] = k[r * dk + i];
+  for (int i = threadIdx.x; i < dv; i += 256) vc[(r * cap + pos) * dv + i] = v[r * dv + i];
+}
+
+hipError_t launch_kv_append(const void* k, const void* v, void* kc, void* vc, const long long* pos, int rows, int cap, int dk, int dv,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(kv_append_kernel, dim3(rows), dim3(256), 0, s, static_cast<const unsigned short*>(k),
+                     static_cast<const unsigned short*>(v), static_cast<unsigned short*>(kc), static_cast<unsigned short*>(vc), pos,
+                     cap, dk, dv);
   return hipGetLastError();
 }
 

@@ -54,8 +54,13 @@ class KVCache:
 
     def update_and_fetch(self, keys: torch.Tensor, values: torch.Tensor):
         if self.static_active:                      # one new position at the device-resident index; shapes never change
-            self.keys.index_copy_(2, self.static_pos, keys)
-            self.values.index_copy_(2, self.static_pos, values)
+            if (keys.is_cuda and keys.shape[2] == 1 and keys.dtype in (torch.bfloat16, torch.float16) and values.dtype == keys.dtype
+                    and self.keys.is_contiguous() and self.values.is_contiguous()):
+                from .. import ops                  # both caches in one launch (gbx_kv_append)
+                ops.kv_append(self.keys, self.values, keys, values, self.static_pos)
+            else:
+                self.keys.index_copy_(2, self.static_pos, keys)
+                self.values.index_copy_(2, self.static_pos, values)
             return self.keys, self.values
         prev = self.offset
         self.reserve(keys.shape[2], keys, values)

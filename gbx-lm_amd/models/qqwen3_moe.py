@@ -65,9 +65,11 @@ class Attention(nn.Module):
 
     def forward(self, x: torch.Tensor, mask: Optional[torch.Tensor] = None, cache: Optional[Any] = None) -> torch.Tensor:
         b, l, _ = x.shape
-        q = self.q_norm(self.q_proj(x).view(b, l, self.n_heads, -1)).permute(0, 2, 1, 3)
-        k = self.k_norm(self.k_proj(x).view(b, l, self.n_kv_heads, -1)).permute(0, 2, 1, 3)
-        v = self.v_proj(x).view(b, l, self.n_kv_heads, -1).permute(0, 2, 1, 3)
+        q, k, v = ops.quantized_matmul_multi(x, (self.q_proj, self.k_proj, self.v_proj)) if x.is_cuda else \
+            (self.q_proj(x), self.k_proj(x), self.v_proj(x))           # decode-sized x: one launch for the three
+        q = self.q_norm(q.view(b, l, self.n_heads, -1)).permute(0, 2, 1, 3)
+        k = self.k_norm(k.view(b, l, self.n_kv_heads, -1)).permute(0, 2, 1, 3)
+        v = v.view(b, l, self.n_kv_heads, -1).permute(0, 2, 1, 3)
         start = cache_offset(cache)
         q, k = self.rope(q, offset=start), self.rope(k, offset=start)
         if cache is not None:

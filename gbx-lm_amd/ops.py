@@ -137,6 +137,16 @@ def quantized_matmul_multi(x: torch.Tensor, mods) -> list:
     x2 = x.reshape(-1, k)
     rows = x2.shape[0]
     same = all((m.bits, m.group_size, m.input_dims) == (m0.bits, m0.group_size, k) for m in mods)
+    if (same and x.is_cuda and rows == 1 and 1 < len(mods) <= 3 and k % 128 == 0 and x.dtype in _DT
+            and all(m.bias is None and m.scales is not None and m.scales.dtype == x.dtype and m.zeros.dtype == x.dtype for m in mods)):
+        # one token: the multi-segment decode GEMV (gbx_qlinear_fused_forward without norm / residual fusion)
+        x1 = x2.contiguous()
+        ys = [torch.empty((1, m.output_dims), dtype=x.dtype, device=x.device) for m in mods]
+        try:
+            qlinear_fused(make_fused_desc(x1, mods, ys), x.device)
+        except NotImplementedError:                     # a shape the streaming kernel does not take: one call per module
+            return [m(x) for m in mods]
+        return [y.reshape(*x.shape[:-1], m.output_dims) for y, m in zip(ys, mods)]
     if not (same and x.is_cuda and 2 <= rows <= 64 and k >= 512 and k % 128 == 0 and 1 < len(mods) <= 3
             and all(m.output_dims % 32 == 0 and m.scales is not None and m.scales.dtype == x.dtype for m in mods)):
         return [m(x) for m in mods]
@@ -331,6 +341,16 @@ def moe_combine(y: torch.Tensor, scores: torch.Tensor) -> torch.Tensor:
     _lib.check(_lib.lib().gbx_moe_combine(yc.data_ptr(), sc.data_ptr(), out.data_ptr(), yc.numel() // (k * d), k, d, _DT[y.dtype],
                                           _stream_ptr(y.device)))
     return out
+
+
+def kv_append(kcache: torch.Tensor, vcache: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos: torch.Tensor) -> None:
+    """caches[:, :, pos] = k, v for one new token per sequence at the device-resident position -- one launch
+    (gbx_kv_append).  caches [B, H, cap, Dk|Dv] contiguous, k / v [B, H, 1, Dk|Dv]."""
+    _require_cuda(k, "k")
+    b, h, cap, dk = kcache.shape
+    kc, vc = k.contiguous(), v.contiguous()
+    _lib.check(_lib.lib().gbx_kv_append(kc.data_ptr(), vc.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), pos.data_ptr(),
+                                        b * h, cap, dk, vcache.shape[3], _DT[k.dtype], _stream_ptr(k.device)))
 
 
 def add_rmsnorm(h: torch.Tensor, delta: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:

@@ -225,6 +225,12 @@ int gbx_moe_route(const void* logits, int32_t* indices, void* scores, int64_t to
 int gbx_moe_combine(const void* y, const void* scores, void* out, int64_t tokens, int32_t top_k, int32_t D, int32_t act_dtype,
                     void* hip_stream);
 
+/* kcache[r, *pos, :] = k[r, :], vcache[r, *pos, :] = v[r, :] for rows = batch * kv heads: the single-token
+ * cache.update_and_fetch of gbx_lm/models/cache.py:222-244 at a DEVICE-resident position (16-bit elements; k_dim and v_dim
+ * may differ: DeepSeek's latent attention). */
+int gbx_kv_append(const void* k, const void* v, void* kcache, void* vcache, const int64_t* pos, int64_t rows, int32_t capacity,
+                  int32_t k_dim, int32_t v_dim, int32_t act_dtype, void* hip_stream);
+
 /* Residual add + RMSNorm in one launch: h[M, K] <- h + delta (one rounding to the activation dtype, the add of
  * qllama.py:138-140), y = RMSNorm(h) * w.  h is updated in place; y may not alias h. */
 int gbx_add_rmsnorm(void* h, const void* delta, const void* w, void* y, int64_t M, int32_t K, float eps, int32_t act_dtype,

@@ -151,6 +151,31 @@ def test_attn_cached_matches_torch(hd, nh, nkv):
     assert out.shape == q.shape and torch.allclose(out.float().cpu(), want, atol=2e-2, rtol=2e-2)
 
 
+def test_kv_append_and_single_token_multi_matrix(oracle):
+    """gbx_kv_append writes exactly one position of both caches (different k / v widths); quantized_matmul_multi at
+    one token (the multi-segment decode GEMV) equals one call per module bit for bit."""
+    from gbx_lm_amd import ops
+    from gbx_lm_amd.models.quantized_linear_gba import QuantizedLinear
+    B, H, cap, dk, dv, pos = 3, 2, 40, 192, 128, 17
+    kc = torch.randn(B, H, cap, dk).to(torch.bfloat16).to(DEV); vc = torch.randn(B, H, cap, dv).to(torch.bfloat16).to(DEV)
+    k0, v0 = kc.clone(), vc.clone()
+    k = torch.randn(B, 1, H, dk).to(torch.bfloat16).to(DEV).permute(0, 2, 1, 3)
+    v = torch.randn(B, 1, H, dv).to(torch.bfloat16).to(DEV).permute(0, 2, 1, 3)
+    ops.kv_append(kc, vc, k, v, torch.tensor([pos], device=DEV))
+    k0[:, :, pos:pos + 1] = k; v0[:, :, pos:pos + 1] = v
+    assert torch.equal(kc, k0) and torch.equal(vc, v0)
+    mods = []
+    for i, n in enumerate((512, 128, 128)):
+        d = oracle.synth_layer(n, 1024, 2, 128, seed=40 + i)
+        q = QuantizedLinear(1024, n, False, 128, 2)
+        q._buffers["qweight"] = torch.from_numpy(d["qweight"].view(np.int32)).view(torch.uint32).to(DEV)
+        q._buffers["scales"], q._buffers["zeros"] = d["scales"].to(DEV), d["zeros"].to(DEV)
+        mods.append(q)
+    x = torch.randn(1, 1, 1024).to(torch.bfloat16).to(DEV)
+    for y, q in zip(ops.quantized_matmul_multi(x, mods), mods):
+        assert y.shape == (1, 1, q.output_dims) and torch.equal(y, q(x))
+
+
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 def test_add_rmsnorm_and_swiglu_glue(dt):
     """Batched-decode glue kernels against the op-by-op torch formulation (same roundings): h += d; y = RMSNorm(h) w,
