@@ -49,6 +49,16 @@ def create_attention_mask(h: torch.Tensor, cache: Optional[Any] = None) -> Optio
     return None
 
 
+def swiglu(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """``nn.silu(gate) * up`` (qllama.py:115): one HIP launch over both operands on the GPU (same two roundings to the
+    activation dtype), the torch ops elsewhere."""
+    if (gate.is_cuda and gate.dtype in (torch.bfloat16, torch.float16) and gate.shape == up.shape and up.dtype == gate.dtype
+            and gate.numel() % 8 == 0 and gate.is_contiguous() and up.is_contiguous()):
+        from .. import ops
+        return ops.swiglu(gate, up)
+    return F.silu(gate) * up
+
+
 def cache_offset(cache):
     """Position of the next token: the cache's host-side ``offset``, or -- inside a graph-replayed decode step -- its
     device-resident ``static_pos`` (RoPE then reads the position from device memory)."""

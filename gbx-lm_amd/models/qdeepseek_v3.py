@@ -18,7 +18,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .base import BaseModelArgs, cache_offset, create_attention_mask, scaled_dot_product_attention
+from .base import BaseModelArgs, cache_offset, create_attention_mask, scaled_dot_product_attention, swiglu
 from .qllama import RMSNorm
 from .quantized_linear_gba import QuantizedLinear
 from .rope_utils import RoPE, YarnRoPE, yarn_get_mscale
@@ -122,7 +122,7 @@ class DeepseekV3MLP(nn.Module):
         self.down_proj = QuantizedLinear(self.intermediate_size, self.hidden_size, bias=False)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
+        return self.down_proj(swiglu(self.gate_proj(x), self.up_proj(x)))
 
 
 def group_expert_select(gates, e_score_correction_bias, top_k: int, n_group: int, topk_group: int,

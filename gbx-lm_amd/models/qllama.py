@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .base import BaseModelArgs, cache_offset, create_attention_mask, scaled_dot_product_attention
+from .base import BaseModelArgs, cache_offset, create_attention_mask, scaled_dot_product_attention, swiglu
 from .quantized_linear_gba import QuantizedLinear
 from .rope_utils import initialize_rope
 
@@ -122,7 +122,7 @@ class MLP(nn.Module):
         self.tp_world, self.tp_group = 1, None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        out = self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
+        out = self.down_proj(swiglu(self.gate_proj(x), self.up_proj(x)))
         if self.tp_world > 1:
             from ..tp import all_reduce_
             all_reduce_(out, self.tp_group)

@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .base import BaseModelArgs, cache_offset, create_attention_mask, scaled_dot_product_attention
+from .base import BaseModelArgs, cache_offset, create_attention_mask, scaled_dot_product_attention, swiglu
 from .qllama import RMSNorm
 from .quantized_linear_gba import QuantizedLinear
 from .rope_utils import RoPE, SuScaledRotaryEmbedding
@@ -98,7 +98,7 @@ class MLP(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         gate, up = torch.chunk(self.gate_up_proj(x), 2, dim=-1)
-        return self.down_proj(F.silu(gate) * up)
+        return self.down_proj(swiglu(gate, up))
 
 
 class TransformerBlock(nn.Module):

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import ops
-from .base import BaseModelArgs, cache_offset, create_attention_mask, scaled_dot_product_attention
+from .base import BaseModelArgs, cache_offset, create_attention_mask, scaled_dot_product_attention, swiglu
 from .qllama import RMSNorm
 from .quantized_linear_gba import QuantizedLinear
 from .rope_utils import RoPE
@@ -86,7 +86,7 @@ class MLP(nn.Module):
         self.up_proj = QuantizedLinear(dim, hidden_dim, bias=False)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
+        return self.down_proj(swiglu(self.gate_proj(x), self.up_proj(x)))
 
 
 def _device_routing(x: torch.Tensor, num_experts: int, top_k: int) -> bool:
