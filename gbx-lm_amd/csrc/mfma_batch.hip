@@ -366,7 +366,7 @@ static hipError_t launch_batch_bits(const MfmaArgs& a, bool bf16, hipStream_t s)
 }
 
 bool qgemm_batch_supported(int M, int K, int bits, int log2g) {
-  return M >= 2 && M <= 32 && (bits == 2 || bits == 4) && log2g == 7 && K % 1024 == 0;
+  return M >= 1 && M <= 32 && (bits == 2 || bits == 4) && log2g == 7 && K % 1024 == 0;
 }
 
 hipError_t launch_qgemm_batch(const MfmaArgs& a, int bits, bool bf16, hipStream_t s) {

@@ -243,7 +243,27 @@ static hipError_t launch_skinny_bits(const MfmaArgs& a, bool bf16, hipStream_t s
 
 static bool use_batch_kernel(const MfmaArgs& a, int bits) {
   static const bool off = getenv("GBX_NO_BATCH_KERNEL") != nullptr;   // diagnostic: time the split-K kernel instead
-  return !off && qgemm_batch_supported(a.M, a.K, bits, a.log2g);
+  // 33..64 rows: two passes pay off only where the wide (128-row) workgroups apply (gate|up: 61 -> 40 us at M = 64;
+  // the narrow projections are faster in one pass of the dequantising kernel)
+  if (a.M > 32 && a.N < 128 * 192) return false;
+  return !off && a.M <= 64 && qgemm_batch_supported(a.M <= 32 ? a.M : 32, a.K, bits, a.log2g);
+}
+
+// The no-dequant kernel takes 32 activation rows; 33..64 rows run as two launches (the second pass finds the packed
+// weights in L2 / Infinity Cache), which still beats one pass of the dequantising kernel.
+static hipError_t launch_batch_rows(const MfmaArgs& a, int bits, bool bf16, hipStream_t s) {
+  if (a.M <= 32) return launch_qgemm_batch(a, bits, bf16, s);
+  MfmaArgs lo = a;
+  lo.M = 32;
+  hipError_t e = launch_qgemm_batch(lo, bits, bf16, s);
+  if (e != hipSuccess) return e;
+  MfmaArgs hi = a;
+  hi.M = a.M - 32;
+  hi.x = a.x + static_cast<size_t>(32) * a.K;
+  const bool multi = a.nseg > 1;
+  hi.y = a.y + static_cast<size_t>(32) * (multi ? a.n_seg[0] : a.N);
+  for (int i = 1; i < a.nseg; ++i) hi.y_x[i - 1] = a.y_x[i - 1] + static_cast<size_t>(32) * a.n_seg[i];
+  return launch_qgemm_batch(hi, bits, bf16, s);
 }
 
 hipError_t launch_qgemm_skinny_multi(const void* x, int nseg, const uint32_t* const* qw, const void* const* sc, const void* const* ze,
@@ -261,7 +281,7 @@ hipError_t launch_qgemm_skinny_multi(const void* x, int nseg, const uint32_t* co
     a.y_x[i - 1] = static_cast<unsigned short*>(y[i]);
   }
   if (use_batch_kernel(a, bits)) {
-    const hipError_t e = launch_qgemm_batch(a, bits, bf16, s);
+    const hipError_t e = launch_batch_rows(a, bits, bf16, s);
     if (e != hipErrorInvalidValue) return e;        // segment rows the wide workgroups cannot tile: split-K kernel
   }
   switch (bits) {
@@ -279,7 +299,7 @@ hipError_t launch_qgemm_skinny(const void* x, const uint32_t* qw, const void* sc
   a.zeros = static_cast<const unsigned short*>(ze); a.bias = static_cast<const unsigned short*>(bias);
   a.y = static_cast<unsigned short*>(y); a.M = M; a.N = N; a.K = K; a.log2g = log2g;
   if (use_batch_kernel(a, bits)) {
-    const hipError_t e = launch_qgemm_batch(a, bits, bf16, s);
+    const hipError_t e = launch_batch_rows(a, bits, bf16, s);
     if (e != hipErrorInvalidValue) return e;        // segment rows the wide workgroups cannot tile: split-K kernel
   }
   switch (bits) {
