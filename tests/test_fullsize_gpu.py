@@ -78,6 +78,24 @@ def test_mfma_gemm_vs_dequantized_matmul(bits, m):
         _close(y, x.double() @ w.double().t(), f"mfma M{m} N{n} K{k} b{bits} g{g}")
 
 
+@pytest.mark.parametrize("bits", [2, 4])
+def test_batch_kernel_full_size_rows_equal_single_token_gemv(bits):
+    """cfg5 at full size (B = 32 rows, every 8B projection shape, g = 128): each row of the no-dequant matrix-core GEMM
+    (mfma_batch.hip) against (1) fp64 x . dequantised weights and (2) the streaming GEMV of that row alone -- two
+    kernels with unrelated arithmetic orders must agree within the output-dtype tolerance."""
+    from gbx_lm_amd import ops
+    for (n, k) in [(4096, 4096), (6144, 4096), (28672, 4096), (4096, 14336)]:
+        qw, sc, ze = _layer(n, k, bits, 128, seed=n + bits)
+        x = torch.randn((32, k), device=DEV).to(torch.bfloat16)
+        x[3, 100] = 60.0                                    # an outlier row entry
+        y = ops.quantized_matmul(x, qw, sc, ze, group_size=128, bits=bits)
+        w = ops.dequantize(qw, sc, ze, group_size=128, bits=bits, dtype=torch.float32)
+        _close(y, x.double() @ w.double().t(), f"batch N{n} K{k} b{bits}")
+        for i in (0, 3, 31):
+            yi = ops.quantized_matmul(x[i:i + 1], qw, sc, ze, group_size=128, bits=bits)
+            assert torch.allclose(y[i:i + 1].float(), yi.float(), rtol=2e-2, atol=2e-2 * yi.float().pow(2).mean().sqrt().item())
+
+
 def test_fused_qkv_and_swiglu_full_size():
     """Fused entry points at the 8B block shapes against the unfused op + torch glue."""
     from gbx_lm_amd import ops
