@@ -46,6 +46,7 @@ def lib() -> ctypes.CDLL:
         L.gbx_qlinear_workspace_bytes.argtypes = [i64, i32, i32, i32, i32]
         L.gbx_qlinear_workspace_bytes.restype = ctypes.c_size_t
         L.gbx_qlinear_forward.argtypes = [p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, p]
+        L.gbx_qlinear_forward_ws.argtypes = [p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, p, ctypes.c_size_t, p]
         L.gbx_unpack.argtypes = [p, p, i32, i32, i32, p]
         L.gbx_dequantize.argtypes = [p, p, p, p, i32, i32, i32, i32, i32, i32, p]
         _declare_optional(L)

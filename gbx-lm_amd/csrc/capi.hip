@@ -53,11 +53,20 @@ int gbx_qlinear_check(int64_t M, int32_t N, int32_t K, int32_t bits, int32_t gro
   return check_shape(M, N, K, bits, group_size);
 }
 
-size_t gbx_qlinear_workspace_bytes(int64_t, int32_t, int32_t, int32_t, int32_t) { return 0; }
+size_t gbx_qlinear_workspace_bytes(int64_t M, int32_t N, int32_t K, int32_t bits, int32_t group_size) {
+  if (check_shape(M, N, K, bits, group_size) != GBX_OK || M < 2 || M > 32) return 0;
+  return gbx::qgemm_batch_workspace_bytes(static_cast<int>(M), N, K, bits, log2_group(group_size));
+}
 
 int gbx_qlinear_forward(const void* x, const uint32_t* qweight, const void* scales, const void* zeros,
                         const void* bias, void* y, int64_t M, int32_t N, int32_t K, int32_t bits,
                         int32_t group_size, int32_t act_dtype, void* hip_stream) {
+  return gbx_qlinear_forward_ws(x, qweight, scales, zeros, bias, y, M, N, K, bits, group_size, act_dtype, nullptr, 0, hip_stream);
+}
+
+int gbx_qlinear_forward_ws(const void* x, const uint32_t* qweight, const void* scales, const void* zeros,
+                           const void* bias, void* y, int64_t M, int32_t N, int32_t K, int32_t bits,
+                           int32_t group_size, int32_t act_dtype, void* workspace, size_t workspace_bytes, void* hip_stream) {
   int rc = check_shape(M, N, K, bits, group_size);
   if (rc) return rc;
   if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
@@ -75,7 +84,11 @@ int gbx_qlinear_forward(const void* x, const uint32_t* qweight, const void* scal
   const int max_k = bits == 2 ? gbx::gemv_max_k<2>() : bits == 3 ? gbx::gemv_max_k<3>() : gbx::gemv_max_k<4>();
   hipError_t e;
   if (!force_generic && M > 1 && M <= 64 && (K % 128) == 0 && K >= 512) {
-    e = gbx::launch_qgemm_skinny(x, qweight, scales, zeros, bias, y, static_cast<int>(M), N, K, bits, log2g, bf16, stream);
+    // a sufficient, 16-byte aligned workspace lets the batched-decode kernel split k across workgroups
+    float* ws = nullptr;
+    const size_t need = M <= 32 ? gbx::qgemm_batch_workspace_bytes(static_cast<int>(M), N, K, bits, log2g) : 0;
+    if (workspace && need && workspace_bytes >= need && aligned(workspace, 16)) ws = static_cast<float*>(workspace);
+    e = gbx::launch_qgemm_skinny(x, qweight, scales, zeros, bias, y, static_cast<int>(M), N, K, bits, log2g, bf16, stream, ws);
   } else if (!force_generic && M > 1 && (K % 128) == 0) {
     e = gbx::launch_qgemm_mfma(x, qweight, scales, zeros, bias, y, static_cast<int>(M), N, K, bits, log2g, bf16, stream);
   } else if (!force_generic && (K % 128) == 0 && K <= max_k) {

@@ -38,6 +38,8 @@
 
 namespace gbx {
 
+bool qgemm_batch_supported(int M, int K, int bits, int log2g);
+
 template <bool BF16> __device__ __forceinline__ float xdot2(unsigned v, float acc) {
   typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
   if constexpr (BF16) return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, v), __builtin_bit_cast(bf2, 0x3F803F80u), acc, false);
@@ -73,7 +75,10 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
   const int r = lane & (TNW - 1), h = lane / TNW;
   const int K = a.K, M = a.M;
   const int W = K / 32 * BITS, G = K >> 7;
-  const int nchunks = K / KC, steps = nchunks / 8, cpk = nchunks / KG;
+  // this workgroup's slice of the k range (the whole row unless the launch splits k across workgroups)
+  const int ksplit = a.ws ? a.ksplit : 1;
+  const int nchunks = K / KC / ksplit, cbase = blockIdx.y * nchunks;
+  const int steps = nchunks / 8, cpk = nchunks / KG;
 
   // segment of this workgroup's rows (uniform): a workgroup never straddles two matrices (launcher)
   const int nwg = blockIdx.x * (NG * TNW);
@@ -92,9 +97,9 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
     }
   }
   const int nrow = min(nl0 + ng * TNW + r, NL - 1);
-  const uint32_t* wrow = qw + static_cast<size_t>(nrow) * W + h * WL + static_cast<size_t>(kg) * cpk * WPC;
-  const unsigned short* srow = sc + static_cast<size_t>(nrow) * G + kg * cpk;
-  const unsigned short* zrow = ze + static_cast<size_t>(nrow) * G + kg * cpk;
+  const uint32_t* wrow = qw + static_cast<size_t>(nrow) * W + h * WL + static_cast<size_t>(cbase + kg * cpk) * WPC;
+  const unsigned short* srow = sc + static_cast<size_t>(nrow) * G + cbase + kg * cpk;
+  const unsigned short* zrow = ze + static_cast<size_t>(nrow) * G + cbase + kg * cpk;
 
   // loader role (waves 8..11): per step the workgroup stages 8 chunks x 32 rows x 256 B; loader thread -> 8 pieces of
   // 32 B (16 k-values), one per chunk slot
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
   const int lrow = (tid & 255) >> 3, lpc = tid & 7;
   const unsigned short* xrow = a.x + static_cast<size_t>(min(lrow, M - 1)) * K + lpc * 16;
   const int xdst0 = lrow * XROW + lpc * 32;         // slab byte offset inside a chunk slot
-  auto xoff = [&](int cs) { return ((cs / NCHW) * cpk + (cs % NCHW)) * KC; };   // element offset of slot cs at step 0
+  auto xoff = [&](int cs) { return (cbase + (cs / NCHW) * cpk + (cs % NCHW)) * KC; };   // element offset of slot cs at step 0
 
   f32x16 acc32[TNW == 32 ? 1 : 1];
   f32x4v acc16[TNW == 16 ? MT : 1];
@@ -313,8 +318,12 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
     // C/D layouts: 32x32: row = (e&3) + 8*(e>>2) + 4*(lane>>5); 16x16: row = 4*(lane>>4) + e
     const int m = i * TNW + (TNW == 32 ? (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5) : 4 * (ln >> 4) + e);
     if (n < NL && m < M) {
-      if (bs) v = act_to_f32<BF16>(f32_to_act<BF16>(v)) + act_to_f32<BF16>(bs[n]);
-      yo[static_cast<size_t>(m) * NL + n] = f32_to_act<BF16>(v);
+      if (ksplit > 1) {                             // fp32 partial of this k slice (single-matrix launches only)
+        a.ws[(static_cast<size_t>(blockIdx.y) * M + m) * NL + n] = v;
+      } else {
+        if (bs) v = act_to_f32<BF16>(f32_to_act<BF16>(v)) + act_to_f32<BF16>(bs[n]);
+        yo[static_cast<size_t>(m) * NL + n] = f32_to_act<BF16>(v);
+      }
     }
   }
 #ifdef BX_STAMPS
@@ -325,6 +334,28 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
     for (int i = 0; i < 24; ++i) o[i] = i < sti ? st[i] : 0;
   }
 #endif
+}
+
+// second launch of a k-split GEMM: y = round(sum of the slices) (+ bias as a second rounding); 4 outputs per thread
+template <bool BF16>
+__global__ __launch_bounds__(256) void batch_finish_kernel(const float* __restrict__ ws, const unsigned short* __restrict__ bias,
+                                                           unsigned short* __restrict__ y, int slices, long long mn, int N) {
+  const long long i = (blockIdx.x * 256LL + threadIdx.x) * 4;
+  if (i >= mn) return;
+  f32x4v v = *reinterpret_cast<const f32x4v*>(ws + i);
+  for (int s = 1; s < slices; ++s) {
+    const f32x4v u = *reinterpret_cast<const f32x4v*>(ws + s * mn + i);
+    v += u;
+  }
+  unsigned short o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float t = v[j];
+    if (bias) t = act_to_f32<BF16>(f32_to_act<BF16>(t)) + act_to_f32<BF16>(bias[(i + j) % N]);
+    o[j] = f32_to_act<BF16>(t);
+  }
+  *reinterpret_cast<u32x2*>(y + i) = u32x2{static_cast<unsigned>(o[0]) | (static_cast<unsigned>(o[1]) << 16),
+                                          static_cast<unsigned>(o[2]) | (static_cast<unsigned>(o[3]) << 16)};
 }
 
 template <int BITS, int TNW, int NG, int KG>
@@ -338,7 +369,7 @@ static hipError_t launch_batch_cfg(const MfmaArgs& a, bool bf16, hipStream_t s) 
     if (e != hipSuccess) return e;
     done[bf16] = true;
   }
-  dim3 grid((a.N + ROWS - 1) / ROWS), block(768);
+  dim3 grid((a.N + ROWS - 1) / ROWS, a.ws ? a.ksplit : 1), block(768);
 #ifdef BX_STAMPS
   long long* sp = reinterpret_cast<long long*>(strtoull(getenv("GBX_STAMP_PTR") ? getenv("GBX_STAMP_PTR") : "0", nullptr, 0));
   (void)hipMemcpyToSymbol(HIP_SYMBOL(bx_stamp_ptr), &sp, sizeof(sp));
@@ -348,9 +379,39 @@ static hipError_t launch_batch_cfg(const MfmaArgs& a, bool bf16, hipStream_t s) 
   return hipGetLastError();
 }
 
+// k split across workgroups (needs the caller's fp32 workspace): worth it where the rows are long and few -- the down
+// projection, N = 4096 x K = 14336 -- because every workgroup stages the activations of its whole k range: 16-row
+// workgroups pull 256 x 917 KB of x through the CUs, 128-row workgroups x 7 slices pull 224 x 131 KB.
+static int batch_ksplit(int N, int K, int nseg) {
+  if (nseg > 1 || N % 4 || N > 8192 || K < 8192) return 1;
+  const int tiles = (N + 127) / 128, nchunks = K / KC;
+  int best = 1;
+  for (int s = 2; s <= 16; ++s)
+    if (nchunks % (8 * s) == 0 && tiles * s <= 256) best = s;
+  return best;
+}
+
+size_t qgemm_batch_workspace_bytes(int M, int N, int K, int bits, int log2g) {
+  if (!qgemm_batch_supported(M < 32 ? M : 32, K, bits, log2g)) return 0;
+  const int s = batch_ksplit(N, K, 1);
+  return s > 1 ? static_cast<size_t>(s) * M * N * sizeof(float) : 0;
+}
+
 // workgroup rows: as many as still give ~200 workgroups (256 CUs, one workgroup each), and never across a segment
 template <int BITS>
-static hipError_t launch_batch_bits(const MfmaArgs& a, bool bf16, hipStream_t s) {
+static hipError_t launch_batch_bits(const MfmaArgs& a0, bool bf16, hipStream_t s) {
+  MfmaArgs a = a0;
+  a.ksplit = a.ws ? batch_ksplit(a.N, a.K, a.nseg) : 1;
+  if (a.ksplit <= 1) a.ws = nullptr;
+  if (a.ws) {                                       // 128-row workgroups x ksplit slices, then the summing launch
+    hipError_t e = launch_batch_cfg<BITS, 32, 4, 2>(a, bf16, s);
+    if (e != hipSuccess) return e;
+    const long long mn = static_cast<long long>(a.M) * a.N;
+    const unsigned blocks = static_cast<unsigned>((mn / 4 + 255) / 256);
+    if (bf16) hipLaunchKernelGGL((batch_finish_kernel<true>), dim3(blocks), dim3(256), 0, s, a.ws, a.bias, a.y, a.ksplit, mn, a.N);
+    else hipLaunchKernelGGL((batch_finish_kernel<false>), dim3(blocks), dim3(256), 0, s, a.ws, a.bias, a.y, a.ksplit, mn, a.N);
+    return hipGetLastError();
+  }
   int rows = a.N >= 128 * 192 ? 128 : a.N >= 64 * 192 ? 64 : a.N >= 32 * 160 ? 32 : 16;
   static const int forced = [] { const char* e = getenv("GBX_BATCH_ROWS"); return e ? atoi(e) : 0; }();
   if (forced) rows = forced;

@@ -25,6 +25,10 @@ struct MfmaArgs {
   const unsigned short* zeros_x[2];
   const unsigned short* bias_x[2];
   unsigned short* y_x[2];
+  // batch kernel only: k split ACROSS workgroups (gridDim.y = ksplit slices of the k range); slice s writes its fp32
+  // partial tile to ws[s][M][N] (caller-owned workspace) and a second launch sums the slices
+  float* ws;
+  int ksplit;
 #ifdef GBX_PSTAMPS
   long long* stamps;            // diagnostic build only: [workgroup][wave][4] s_memtime totals
 #endif
@@ -33,6 +37,8 @@ struct MfmaArgs {
 // mfma_batch.hip: 2 <= M <= 32, 2/4 bits, group 128 (no-dequant matrix-core kernel); false -> use the split-K kernel
 bool qgemm_batch_supported(int M, int K, int bits, int log2g);
 hipError_t launch_qgemm_batch(const MfmaArgs& a, int bits, bool bf16, hipStream_t s);
+// fp32 workspace bytes with which launch_qgemm_batch splits k across workgroups (0: it would not)
+size_t qgemm_batch_workspace_bytes(int M, int N, int K, int bits, int log2g);
 
 constexpr int KC = 128;                 // k-values per chunk (one LDS stage of activations)
 constexpr int XROW = KC * 2 + 16;       // LDS bytes per activation row: 256 B + 16 B pad (conflict-free ds_read_b128)

@@ -293,11 +293,12 @@ hipError_t launch_qgemm_skinny_multi(const void* x, int nseg, const uint32_t* co
 }
 
 hipError_t launch_qgemm_skinny(const void* x, const uint32_t* qw, const void* sc, const void* ze, const void* bias, void* y,
-                               int M, int N, int K, int bits, int log2g, bool bf16, hipStream_t s) {
+                               int M, int N, int K, int bits, int log2g, bool bf16, hipStream_t s, float* ws) {
   MfmaArgs a{};
   a.x = static_cast<const unsigned short*>(x); a.qweight = qw; a.scales = static_cast<const unsigned short*>(sc);
   a.zeros = static_cast<const unsigned short*>(ze); a.bias = static_cast<const unsigned short*>(bias);
   a.y = static_cast<unsigned short*>(y); a.M = M; a.N = N; a.K = K; a.log2g = log2g;
+  a.ws = M <= 32 ? ws : nullptr;                    // caller-owned fp32 workspace: k split across workgroups (mfma_batch.hip)
   if (use_batch_kernel(a, bits)) {
     const hipError_t e = launch_batch_rows(a, bits, bf16, s);
     if (e != hipErrorInvalidValue) return e;        // segment rows the wide workgroups cannot tile: split-K kernel

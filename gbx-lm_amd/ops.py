@@ -73,10 +73,19 @@ def quantized_matmul(x: torch.Tensor, w: torch.Tensor, scales: torch.Tensor, bia
         out = torch.empty((m, n), dtype=x.dtype, device=x.device)
     elif out.shape != (m, n) or out.dtype != x.dtype or not out.is_contiguous():
         raise ValueError("out must be a contiguous [M, N] tensor of the activation dtype")
-    rc = _lib.lib().gbx_qlinear_forward(
-        x2.data_ptr(), w.data_ptr(), scales.data_ptr(), biases.data_ptr(),
-        bias.data_ptr() if bias is not None else None, out.data_ptr(),
-        m, n, k, bits, group_size, _DT[x.dtype], _stream_ptr(x.device))
+    L = _lib.lib()
+    need = L.gbx_qlinear_workspace_bytes(m, n, k, bits, group_size) if 2 <= m <= 32 else 0
+    if need:                                            # batched decode of a long-row projection: split k across workgroups
+        ws = torch.empty((need,), dtype=torch.uint8, device=x.device)      # caller-owned scratch (caching allocator: no sync)
+        rc = L.gbx_qlinear_forward_ws(
+            x2.data_ptr(), w.data_ptr(), scales.data_ptr(), biases.data_ptr(),
+            bias.data_ptr() if bias is not None else None, out.data_ptr(),
+            m, n, k, bits, group_size, _DT[x.dtype], ws.data_ptr(), need, _stream_ptr(x.device))
+    else:
+        rc = L.gbx_qlinear_forward(
+            x2.data_ptr(), w.data_ptr(), scales.data_ptr(), biases.data_ptr(),
+            bias.data_ptr() if bias is not None else None, out.data_ptr(),
+            m, n, k, bits, group_size, _DT[x.dtype], _stream_ptr(x.device))
     _lib.check(rc)
     return out.reshape(*x.shape[:-1], n)
 

@@ -66,8 +66,17 @@ int gbx_qlinear_forward(const void* x, const uint32_t* qweight, const void* scal
                         int64_t M, int32_t N, int32_t K, int32_t bits, int32_t group_size,
                         int32_t act_dtype, void* hip_stream);
 
-/* Bytes of caller-provided scratch some shapes of gbx_qlinear_forward may use in later
- * versions; the current kernels need none and this returns 0. */
+/* gbx_qlinear_forward with a caller-owned scratch buffer of at least gbx_qlinear_workspace_bytes(M, N, K, bits, group_size)
+ * bytes (16-byte aligned device memory, contents undefined before and after, never retained).  With it the
+ * batched-decode kernel (2 <= M <= 32) splits long rows across workgroups -- the down projection of a B = 32 decode
+ * step: 25 -> 13 us -- and sums the fp32 slices in a second launch; without it (or where the size query returns 0)
+ * the call is identical to gbx_qlinear_forward.  Results differ from it only in the fp32 association of the k sum. */
+int gbx_qlinear_forward_ws(const void* x, const uint32_t* qweight, const void* scales, const void* zeros,
+                           const void* bias, void* y, int64_t M, int32_t N, int32_t K, int32_t bits,
+                           int32_t group_size, int32_t act_dtype, void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* Bytes of caller-provided scratch with which gbx_qlinear_forward_ws runs this shape faster (0: no use for it; today
+ * non-zero for 2 <= M <= 32, 2/4 bits, group 128, N <= 8192 and K >= 8192). */
 size_t gbx_qlinear_workspace_bytes(int64_t M, int32_t N, int32_t K, int32_t bits, int32_t group_size);
 
 /* q[N,K] int32 = integer fields of qweight (kernel-side unpack dump; the bit-exact half of
