@@ -383,7 +383,8 @@ static hipError_t launch_batch_cfg(const MfmaArgs& a, bool bf16, hipStream_t s) 
 // projection, N = 4096 x K = 14336 -- because every workgroup stages the activations of its whole k range: 16-row
 // workgroups pull 256 x 917 KB of x through the CUs, 128-row workgroups x 7 slices pull 224 x 131 KB.
 static int batch_ksplit(int N, int K, int nseg) {
-  if (nseg > 1 || N % 4 || N > 8192 || K < 8192) return 1;
+  static const int min_k = [] { const char* e = getenv("GBX_BATCH_KSPLIT_MINK"); return e ? atoi(e) : 8192; }();   // tuning aid
+  if (nseg > 1 || N % 4 || N > 8192 || K < min_k) return 1;
   const int tiles = (N + 127) / 128, nchunks = K / KC;
   int best = 1;
   for (int s = 2; s <= 16; ++s)
