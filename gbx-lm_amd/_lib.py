@@ -86,6 +86,7 @@ def _declare_optional(L) -> None:
         "gbx_embed_next_token": [p, p, p, p, p, i32, i32, i32, i32, i32, p],
         "gbx_qlinear_forward_multi": [p, i32, p, p, p, p, p, p, i64, i32, i32, i32, i32, p],
         "gbx_gather_qlinear_forward": [p, p, p, p, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, p],
+        "gbx_gather_swiglu_forward": [p, p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, p],
         "gbx_eminf_optimize": [p, i32, p, p, p, i32, f32, f32, i32, p],
         "gbx_rope": [p, p, p, p, i64, i64, i32, i32, i32, i32, i64, i64, i64, f32, f32, i32, i32, p],
         "gbx_rope_append": [p, p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, i32, i32, p],

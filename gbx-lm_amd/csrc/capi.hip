@@ -240,6 +240,46 @@ int gbx_gather_qlinear_forward(const void* x, const uint32_t* qweight, const voi
   return GBX_OK;
 }
 
+int gbx_gather_swiglu_forward(const void* x, const uint32_t* gate_qweight, const void* gate_scales, const void* gate_zeros,
+                              const uint32_t* up_qweight, const void* up_scales, const void* up_zeros, const int32_t* indices,
+                              void* y, int32_t pairs, int32_t x_div, int32_t num_experts, int32_t N, int32_t K, int32_t bits,
+                              int32_t group_size, int32_t act_dtype, void* hip_stream) {
+  int rc = check_shape(1, N, K, bits, group_size);
+  if (rc) return rc;
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  if (pairs < 0 || pairs > 65535 || x_div < 1 || num_experts < 1)
+    return fail(GBX_ERR_INVALID, "bad gather shape: pairs=%d x_div=%d num_experts=%d", pairs, x_div, num_experts);
+  if (pairs == 0) return GBX_OK;
+  if (!x || !gate_qweight || !gate_scales || !gate_zeros || !up_qweight || !up_scales || !up_zeros || !indices || !y)
+    return fail(GBX_ERR_INVALID, "null device pointer");
+  if (!aligned(gate_qweight, 16) || !aligned(up_qweight, 16) || !aligned(x, 16)) return fail(GBX_ERR_INVALID, "x and qweight must be 16-byte aligned");
+  const int max_k = bits == 2 ? gbx::gemv_max_k<2>() : bits == 3 ? gbx::gemv_max_k<3>() : gbx::gemv_max_k<4>();
+  if ((K % 128) != 0 || K > max_k)
+    return fail(GBX_ERR_UNSUPPORTED, "gather path needs K %% 128 == 0 and K <= %d at %d bits (K = %d)", max_k, bits, K);
+  if ((static_cast<long long>(N) * (K / 32 * bits) * 4) % 16 != 0) return fail(GBX_ERR_UNSUPPORTED, "expert stride must keep 16-byte alignment");
+  gbx::GemvArgs a{};
+  a.x = x;
+  a.seg[0] = gbx::GemvSeg{gate_qweight, static_cast<const unsigned short*>(gate_scales), static_cast<const unsigned short*>(gate_zeros),
+                          static_cast<unsigned short*>(y), N};
+  a.seg[1] = gbx::GemvSeg{up_qweight, static_cast<const unsigned short*>(up_scales), static_cast<const unsigned short*>(up_zeros),
+                          static_cast<unsigned short*>(y), N};
+  a.seg[2] = a.seg[0]; a.seg[2].N = 0;
+  a.nseg = 2; a.N = N; a.K = K; a.log2g = log2_group(group_size); a.swiglu = 1;
+  a.expert_idx = indices; a.x_div = x_div; a.num_experts = num_experts;
+  a.e_stride_w = static_cast<long long>(N) * (K / 32 * bits);
+  a.e_stride_g = static_cast<long long>(N) * (K / group_size);
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  const bool bf16 = act_dtype == GBX_BF16;
+  hipError_t e;
+  switch (bits) {
+    case 2: e = gbx::launch_gemv<2>(a, pairs, bf16, stream); break;
+    case 3: e = gbx::launch_gemv<3>(a, pairs, bf16, stream); break;
+    default: e = gbx::launch_gemv<4>(a, pairs, bf16, stream); break;
+  }
+  if (e != hipSuccess) return hip_fail(e, "gbx_gather_swiglu_forward launch");
+  return GBX_OK;
+}
+
 static int check_tiled(int32_t N, int32_t K, int32_t bits, int32_t group_size) {
   int rc = check_shape(1, N, K, bits, group_size);
   if (rc) return rc;

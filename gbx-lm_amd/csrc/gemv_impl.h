@@ -269,9 +269,9 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
   // computed index instead makes hipcc fetch it with VECTOR loads and drain vmcnt on every row.)
   constexpr int RS_FLAGS = 0x00020000, RS_ALL = 0x7FFFFFFF;
   auto rsrc = [](const void* ptr) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, RS_ALL, RS_FLAGS); };
-  const uint32_t* const q0 = a.seg[0].qweight + (GATHER ? eo * a.e_stride_w : 0); const uint32_t* const q1 = a.seg[1].qweight; const uint32_t* const q2 = a.seg[2].qweight;
-  const unsigned short* const s0 = a.seg[0].scales + (GATHER ? eo * a.e_stride_g : 0); const unsigned short* const s1 = a.seg[1].scales; const unsigned short* const s2 = a.seg[2].scales;
-  const unsigned short* const z0 = a.seg[0].zeros + (GATHER ? eo * a.e_stride_g : 0); const unsigned short* const z1 = a.seg[1].zeros; const unsigned short* const z2 = a.seg[2].zeros;
+  const uint32_t* const q0 = a.seg[0].qweight + (GATHER ? eo * a.e_stride_w : 0); const uint32_t* const q1 = a.seg[1].qweight + (GATHER ? eo * a.e_stride_w : 0); const uint32_t* const q2 = a.seg[2].qweight;
+  const unsigned short* const s0 = a.seg[0].scales + (GATHER ? eo * a.e_stride_g : 0); const unsigned short* const s1 = a.seg[1].scales + (GATHER ? eo * a.e_stride_g : 0); const unsigned short* const s2 = a.seg[2].scales;
+  const unsigned short* const z0 = a.seg[0].zeros + (GATHER ? eo * a.e_stride_g : 0); const unsigned short* const z1 = a.seg[1].zeros + (GATHER ? eo * a.e_stride_g : 0); const unsigned short* const z2 = a.seg[2].zeros;
   unsigned short* const y0 = a.seg[0].y; unsigned short* const y1 = a.seg[1].y; unsigned short* const y2 = a.seg[2].y;
   const int n1 = a.seg[1].N, n2 = a.seg[2].N;
   // row of batch element i -> (segment, local row); wave-uniform

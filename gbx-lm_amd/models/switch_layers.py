@@ -105,7 +105,13 @@ class SwitchGLU(nn.Module):
 
     def forward(self, x: torch.Tensor, indices: torch.Tensor) -> torch.Tensor:
         x = x.unsqueeze(-2).unsqueeze(-3)                          # [..., 1, 1, D]: one row shared by the k slots
-        x_up = self.up_proj(x, indices)
-        x_gate = self.gate_proj(x, indices)
-        y = self.down_proj(self.activation(x_up, x_gate), indices)  # [..., k, 1, D]
+        act = None
+        if (isinstance(self.activation, SwiGLU) and isinstance(self.gate_proj, QuantizedSwitchLinear)
+                and isinstance(self.up_proj, QuantizedSwitchLinear) and x.is_cuda):
+            act = ops.gather_swiglu(x, self.gate_proj, self.up_proj, indices)    # one expert-indexed launch, or None
+        if act is None:
+            x_up = self.up_proj(x, indices)
+            x_gate = self.gate_proj(x, indices)
+            act = self.activation(x_up, x_gate)
+        y = self.down_proj(act, indices)                            # [..., k, 1, D]
         return y.squeeze(-2)

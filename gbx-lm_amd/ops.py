@@ -216,6 +216,28 @@ def gather_quantized_matmul(x: torch.Tensor, w: torch.Tensor, scales: torch.Tens
     return y.reshape(*lead, k, 1, N)
 
 
+def gather_swiglu(x: torch.Tensor, gate, up, rhs_indices: torch.Tensor):
+    """``silu(gate_proj(x, indices)) * up_proj(x, indices)`` of SwitchGLU for a decode-sized index set in ONE expert-indexed
+    launch (gbx_gather_swiglu_forward); ``gate`` / ``up`` are QuantizedSwitchLinear modules.  Returns None when the shapes
+    are outside that launch (the caller then runs the three ops)."""
+    K, N, k = x.shape[-1], gate.output_dims, rhs_indices.shape[-1]
+    pairs = rhs_indices.numel()
+    max_k = 512 * (64 if gate.bits == 2 else 32)
+    if not (x.is_cuda and x.dtype in _DT and pairs <= 64 and K % 128 == 0 and K <= max_k and x.shape[-2] == 1 and x.shape[-3] in (1, k)
+            and (gate.bits, gate.group_size, gate.output_dims, gate.input_dims) == (up.bits, up.group_size, up.output_dims, up.input_dims)
+            and getattr(gate, "bias", None) is None and getattr(up, "bias", None) is None
+            and gate.scales.dtype == x.dtype and up.scales.dtype == x.dtype and rhs_indices.dtype == torch.int32):
+        return None
+    xr = x.reshape(-1, K).contiguous()
+    idx = rhs_indices.reshape(-1).contiguous()
+    y = torch.empty((pairs, N), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().gbx_gather_swiglu_forward(
+        xr.data_ptr(), gate.qweight.data_ptr(), gate.scales.data_ptr(), gate.zeros.data_ptr(), up.qweight.data_ptr(),
+        up.scales.data_ptr(), up.zeros.data_ptr(), idx.data_ptr(), y.data_ptr(), pairs, k if x.shape[-3] == 1 else 1,
+        gate.qweight.shape[0], N, K, gate.bits, gate.group_size, _DT[x.dtype], _stream_ptr(x.device)))
+    return y.reshape(*rhs_indices.shape[:-1], k, 1, N)
+
+
 def prepack_tiles(mod, mod_up=None):
     """Load-time tiled form of a 2-bit / group-128 QuantizedLinear for the matrix-core decode GEMV
     (gbx_qlinear_prepack_tiles): returns ``(wt, szt)`` int32 tensors.  With ``mod_up`` the pair (gate_proj, up_proj) is

@@ -154,6 +154,15 @@ int gbx_gather_qlinear_forward(const void* x, const uint32_t* qweight, const voi
                                int32_t num_experts, int32_t N, int32_t K, int32_t bits, int32_t group_size,
                                int32_t act_dtype, void* hip_stream);
 
+/* gate and up projection of SwitchGLU in one expert-indexed launch: y[p, :] = silu(x_p . gate[e_p]^T) * (x_p . up[e_p]^T)
+ * with e_p = indices[p], both stacked tensors [num_experts, N, ...] of one (bits, group_size), roundings as the three
+ * activation-dtype ops of gbx_lm/models/switch_layers.py:194-199 (up_proj, gate_proj, activation).  Other arguments as
+ * gbx_gather_qlinear_forward. */
+int gbx_gather_swiglu_forward(const void* x, const uint32_t* gate_qweight, const void* gate_scales, const void* gate_zeros,
+                              const uint32_t* up_qweight, const void* up_scales, const void* up_zeros, const int32_t* indices,
+                              void* y, int32_t pairs, int32_t x_div, int32_t num_experts, int32_t N, int32_t K, int32_t bits,
+                              int32_t group_size, int32_t act_dtype, void* hip_stream);
+
 /* Load-time re-tiling for the matrix-core decode GEMV (2-bit, group_size 128, K % 1024 == 0): 16-row tiles, K-steps of
  * 256 values, so that a wavefront load is one contiguous 1 KiB block that IS the int8 MFMA operand layout, plus the
  * (scale | zero << 16) dwords as [tile][group][16 rows].  With a second matrix (qweight_up != NULL: gate_proj / up_proj

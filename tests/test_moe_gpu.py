@@ -112,3 +112,25 @@ def test_moe_route_and_combine_kernels(dt):
         out = ops.moe_combine(y.to(DEV), scores)
         ref = (y * scores.cpu().unsqueeze(-1)).sum(dim=-2)
         assert torch.allclose(out.float().cpu(), ref.float(), rtol=2e-2, atol=2e-2)
+
+
+def test_gather_swiglu_launch_equals_the_three_ops():
+    """gbx_gather_swiglu_forward (gate, up and SwiGLU of the selected experts in one launch) against
+    gate_proj / up_proj / activation run separately through the same library."""
+    from gbx_lm_amd import ops
+    from gbx_lm_amd.models.switch_layers import QuantizedSwitchLinear, SwiGLU
+    torch.manual_seed(2)
+    E, K, N, k = 8, 1024, 384, 3
+    def mk():
+        m = QuantizedSwitchLinear(K, N, E, bias=False, group_size=128, bits=2)
+        m.qweight = torch.randint(0, 2**31 - 1, (E, N, K // 16), dtype=torch.int32).view(torch.uint32).to(DEV)
+        m.scales = (torch.rand(E, N, K // 128) * 0.01 + 0.002).to(torch.bfloat16).to(DEV)
+        m.zeros = (-m.scales.float() * 1.5).to(torch.bfloat16)
+        return m
+    gate, up = mk(), mk()
+    x = torch.randn(2, 1, 1, K).to(torch.bfloat16).to(DEV)
+    inds = torch.tensor([[1, 7, 3], [0, 3, 5]], dtype=torch.int32, device=DEV)
+    got = ops.gather_swiglu(x, gate, up, inds)
+    assert got is not None and got.shape == (2, k, 1, N)
+    want = SwiGLU()(up(x, inds).contiguous(), gate(x, inds).contiguous())
+    assert torch.allclose(got.float(), want.float(), rtol=2e-2, atol=2e-3 * want.float().abs().max().item())
