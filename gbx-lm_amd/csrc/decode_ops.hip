@@ -22,6 +22,10 @@ struct AttnArgs {
   int n_heads, n_kv, capacity;
   float rope_scale, sm_scale;
   int traditional;
+  // grouped kernel only: optional per-head RMSNorm of q and k before RoPE (Qwen3's q_norm / k_norm, weights [HD])
+  const unsigned short* qn_w;
+  const unsigned short* kn_w;
+  float norm_eps;
 };
 
 template <bool BF16, int HD>
@@ -222,6 +226,20 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
   if constexpr (STATIC) {
     for (int p = tid; p < REP * HD; p += 256) q_s[p / HD][p % HD] = act_to_f32<BF16>(a.q[static_cast<size_t>(hq0) * HD + p]) * a.sm_scale;
   } else {
+  __shared__ float ssq_s[REP + 1];
+  const bool normed = a.qn_w != nullptr;
+  const bool writer = blockIdx.x % parts == 0;      // one workgroup of the kv group appends k, v
+  if (normed) {                                     // sum of squares per head (q heads of this part, then the k head)
+    if (tid <= REP) ssq_s[tid] = 0.f;
+    __syncthreads();
+    for (int p = tid; p < (REP + 1) * (HD / 2); p += 256) {
+      const int hh = p / (HD / 2), i = p % (HD / 2);
+      const unsigned short* src = hh == REP ? a.k + static_cast<size_t>(kvh) * HD : a.q + (static_cast<size_t>(hq0) + hh) * HD;
+      const float x1 = act_to_f32<BF16>(src[2 * i]), x2 = act_to_f32<BF16>(src[2 * i + 1]);
+      atomicAdd(&ssq_s[hh], x1 * x1 + x2 * x2);
+    }
+    __syncthreads();
+  }
   // RoPE on the REP query heads and the kv head's k; append k, v to the cache
   for (int p = tid; p < (REP + 1) * (HD / 2); p += 256) {
     const int hh = p / (HD / 2), i = p % (HD / 2);   // hh == REP: the k head
@@ -229,7 +247,13 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
     const unsigned short* src = isk ? a.k + static_cast<size_t>(kvh) * HD : a.q + (static_cast<size_t>(hq0) + hh) * HD;
     const int i1 = a.traditional ? 2 * i : i;
     const int i2 = a.traditional ? 2 * i + 1 : i + HD / 2;
-    const float x1 = act_to_f32<BF16>(src[i1]), x2 = act_to_f32<BF16>(src[i2]);
+    float x1 = act_to_f32<BF16>(src[i1]), x2 = act_to_f32<BF16>(src[i2]);
+    if (normed) {                                   // RMSNorm output rounded to the activation dtype, like the separate op
+      const float rstd = rsqrtf(ssq_s[hh] / static_cast<float>(HD) + a.norm_eps);
+      const unsigned short* w = isk ? a.kn_w : a.qn_w;
+      x1 = act_to_f32<BF16>(f32_to_act<BF16>(x1 * rstd * act_to_f32<BF16>(w[i1])));
+      x2 = act_to_f32<BF16>(f32_to_act<BF16>(x2 * rstd * act_to_f32<BF16>(w[i2])));
+    }
     const float rev = static_cast<float>(pos) * a.rope_scale * a.inv_freq[i] * 0.15915494309189535f;
     const float fr = rev - floorf(rev);
     const float sn = __builtin_amdgcn_sinf(fr), cs = __builtin_amdgcn_cosf(fr);
@@ -237,9 +261,11 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
     if (isk) {
       kn_s[i1] = act_to_f32<BF16>(r1);
       kn_s[i2] = act_to_f32<BF16>(r2);
-      unsigned short* dst = a.kcache + (static_cast<size_t>(kvh) * a.capacity + pos) * HD;
-      dst[i1] = r1;
-      dst[i2] = r2;
+      if (writer) {
+        unsigned short* dst = a.kcache + (static_cast<size_t>(kvh) * a.capacity + pos) * HD;
+        dst[i1] = r1;
+        dst[i2] = r2;
+      }
     } else {
       q_s[hh][i1] = act_to_f32<BF16>(r1) * a.sm_scale;
       q_s[hh][i2] = act_to_f32<BF16>(r2) * a.sm_scale;
@@ -248,7 +274,7 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
   if (tid < HD) {
     const unsigned short vb = a.v[static_cast<size_t>(kvh) * HD + tid];
     vn_s[tid] = act_to_f32<BF16>(vb);
-    a.vcache[(static_cast<size_t>(kvh) * a.capacity + pos) * HD + tid] = vb;
+    if (writer) a.vcache[(static_cast<size_t>(kvh) * a.capacity + pos) * HD + tid] = vb;
   }
   }
   __syncthreads();
@@ -349,7 +375,7 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
 
 template <int HD, int REP>
 static hipError_t launch_attn_gqa(const AttnArgs& a, int batch, bool bf16, hipStream_t s) {
-  dim3 grid(a.n_kv, batch), block(256);
+  dim3 grid(a.n_kv * (a.n_heads / a.n_kv / REP), batch), block(256);
   if (bf16) hipLaunchKernelGGL((attn_decode_gqa_kernel<true, HD, REP, false>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((attn_decode_gqa_kernel<false, HD, REP, false>), grid, block, 0, s, a);
   return hipGetLastError();
@@ -368,7 +394,7 @@ hipError_t launch_attn_static(const void* q, const void* kcache, const void* vca
                               int n_heads, int n_kv, int head_dim, int capacity, float sm_scale, bool bf16, hipStream_t s) {
   AttnArgs a{static_cast<const unsigned short*>(q), nullptr, nullptr,
              static_cast<unsigned short*>(const_cast<void*>(kcache)), static_cast<unsigned short*>(const_cast<void*>(vcache)),
-             nullptr, pos, static_cast<unsigned short*>(out), n_heads, n_kv, capacity, 1.f, sm_scale, 0};
+             nullptr, pos, static_cast<unsigned short*>(out), n_heads, n_kv, capacity, 1.f, sm_scale, 0, nullptr, nullptr, 0.f};
   const int rep = n_heads / n_kv;
   const int R = rep % 4 == 0 ? 4 : rep % 3 == 0 ? 3 : rep % 2 == 0 ? 2 : 1;
   if (head_dim == 128) {
@@ -392,15 +418,32 @@ hipError_t launch_attn_static(const void* q, const void* kcache, const void* vca
 
 hipError_t launch_attn_decode(const void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
                               const long long* pos, void* out, int batch, int n_heads, int n_kv, int head_dim, int capacity,
-                              float rope_scale, float sm_scale, int traditional, bool bf16, hipStream_t s) {
+                              float rope_scale, float sm_scale, int traditional, bool bf16, hipStream_t s,
+                              const void* q_norm_w, const void* k_norm_w, float norm_eps) {
   AttnArgs a{static_cast<const unsigned short*>(q), static_cast<const unsigned short*>(k), static_cast<const unsigned short*>(v),
              static_cast<unsigned short*>(kcache), static_cast<unsigned short*>(vcache), inv_freq, pos,
-             static_cast<unsigned short*>(out), n_heads, n_kv, capacity, rope_scale, sm_scale, traditional};
-  if (batch > 1 && head_dim == 128) {              // batched decode: one workgroup per kv group
-    const int rep = n_heads / n_kv;
-    if (rep == 4) return launch_attn_gqa<128, 4>(a, batch, bf16, s);
-    if (rep == 3) return launch_attn_gqa<128, 3>(a, batch, bf16, s);
-    if (rep == 2) return launch_attn_gqa<128, 2>(a, batch, bf16, s);
+             static_cast<unsigned short*>(out), n_heads, n_kv, capacity, rope_scale, sm_scale, traditional,
+             static_cast<const unsigned short*>(q_norm_w), static_cast<const unsigned short*>(k_norm_w), norm_eps};
+  const int rep = n_heads / n_kv;
+  if (q_norm_w || (batch > 1 && rep > 1)) {         // grouped kernel: batched decode, or q/k norms (any batch)
+    const int R = rep % 4 == 0 ? 4 : rep % 3 == 0 ? 3 : rep % 2 == 0 ? 2 : 1;
+    if (head_dim == 128) {
+      switch (R) {
+        case 4: return launch_attn_gqa<128, 4>(a, batch, bf16, s);
+        case 3: return launch_attn_gqa<128, 3>(a, batch, bf16, s);
+        case 2: return launch_attn_gqa<128, 2>(a, batch, bf16, s);
+        default: return launch_attn_gqa<128, 1>(a, batch, bf16, s);
+      }
+    }
+    if (head_dim == 64) {
+      switch (R) {
+        case 4: return launch_attn_gqa<64, 4>(a, batch, bf16, s);
+        case 3: return launch_attn_gqa<64, 3>(a, batch, bf16, s);
+        case 2: return launch_attn_gqa<64, 2>(a, batch, bf16, s);
+        default: return launch_attn_gqa<64, 1>(a, batch, bf16, s);
+      }
+    }
+    return hipErrorInvalidValue;
   }
   dim3 grid(n_heads, batch), block(256);
   if (head_dim == 128) {

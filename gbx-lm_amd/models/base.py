@@ -59,6 +59,32 @@ def swiglu(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
     return F.silu(gate) * up
 
 
+def fused_decode_attention(q, k, v, cache, rope, scale: float, n_heads: int, n_kv_heads: int, head_dim: int,
+                           q_norm=None, k_norm=None):
+    """One new token per sequence inside a graph-replayed decode step (static cache): optional per-head q / k RMSNorm, RoPE,
+    cache append and grouped-query attention in ONE launch (gbx_attn_decode_normed) from the raw projections
+    q [B, 1, Hq*D], k / v [B, 1, Hkv*D].  Returns the context [B, 1, Hq*D], or None when the layer is outside that launch
+    (prefill, eager cache, partial or rescaled-amplitude RoPE, head_dim not 64 / 128) -- callers then run the op-by-op graph."""
+    from .rope_utils import RoPE, Llama3RoPE
+    if not (cache is not None and getattr(cache, "static_active", False) and q.is_cuda and q.shape[1] == 1
+            and head_dim in (64, 128) and type(rope) in (RoPE, Llama3RoPE) and rope.inv_freq.numel() * 2 == head_dim
+            and q.dtype in (torch.bfloat16, torch.float16) and cache.keys is not None and cache.keys.dtype == q.dtype
+            and cache.keys.is_contiguous() and cache.values.is_contiguous() and cache.keys.shape[3] == head_dim
+            and cache.values.shape[3] == head_dim and n_heads % n_kv_heads == 0):
+        return None
+    if (q_norm is None) != (k_norm is None) or (q_norm is not None and q_norm.weight.dtype != q.dtype):
+        return None
+    from .. import ops
+    bsz = q.shape[0]
+    q2, k2, v2 = (t.reshape(bsz, -1).contiguous() for t in (q, k, v))
+    out = torch.empty_like(q2)
+    ops.attn_decode_batched(q2, k2, v2, cache.keys, cache.values, rope.inv_freq, cache.static_pos, out, n_heads, n_kv_heads, head_dim,
+                            getattr(rope, "scale", 1.0), scale, rope.traditional,
+                            q_norm.weight if q_norm is not None else None, k_norm.weight if k_norm is not None else None,
+                            q_norm.eps if q_norm is not None else 0.0)
+    return out.reshape(bsz, 1, -1)
+
+
 def cache_offset(cache):
     """Position of the next token: the cache's host-side ``offset``, or -- inside a graph-replayed decode step -- its
     device-resident ``static_pos`` (RoPE then reads the position from device memory)."""

@@ -16,7 +16,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .base import BaseModelArgs, cache_offset, create_attention_mask, scaled_dot_product_attention, swiglu
+from .base import (BaseModelArgs, cache_offset, create_attention_mask, fused_decode_attention, scaled_dot_product_attention,
+                   swiglu)
 from .quantized_linear_gba import QuantizedLinear
 from .rope_utils import initialize_rope
 
@@ -95,9 +96,15 @@ class Attention(nn.Module):
 
     def forward(self, x: torch.Tensor, mask: Optional[torch.Tensor] = None, cache: Optional[Any] = None) -> torch.Tensor:
         b, l, _ = x.shape
-        q = _heads(self.q_proj(x), self.n_heads)
-        k = _heads(self.k_proj(x), self.n_kv_heads)
-        v = _heads(self.v_proj(x), self.n_kv_heads)
+        q, k, v = self.q_proj(x), self.k_proj(x), self.v_proj(x)
+        ctx = fused_decode_attention(q, k, v, cache, self.rope, self.scale, self.n_heads, self.n_kv_heads, self.head_dim)
+        if ctx is not None:                             # graph-replayed decode: RoPE, cache append and attention in one launch
+            out = self.o_proj(ctx)
+            if self.tp_world > 1:
+                from ..tp import all_reduce_
+                all_reduce_(out, self.tp_group)
+            return out
+        q, k, v = _heads(q, self.n_heads), _heads(k, self.n_kv_heads), _heads(v, self.n_kv_heads)
         start = cache_offset(cache)
         q, k = self.rope(q, offset=start), self.rope(k, offset=start)
         if cache is not None:

@@ -16,7 +16,8 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import ops
-from .base import BaseModelArgs, cache_offset, create_attention_mask, scaled_dot_product_attention, swiglu
+from .base import (BaseModelArgs, cache_offset, create_attention_mask, fused_decode_attention, scaled_dot_product_attention,
+                   swiglu)
 from .qllama import RMSNorm
 from .quantized_linear_gba import QuantizedLinear
 from .rope_utils import RoPE
@@ -67,6 +68,10 @@ class Attention(nn.Module):
         b, l, _ = x.shape
         q, k, v = ops.quantized_matmul_multi(x, (self.q_proj, self.k_proj, self.v_proj)) if x.is_cuda else \
             (self.q_proj(x), self.k_proj(x), self.v_proj(x))           # decode-sized x: one launch for the three
+        ctx = fused_decode_attention(q, k, v, cache, self.rope, self.scale, self.n_heads, self.n_kv_heads, q.shape[-1] // self.n_heads,
+                                     self.q_norm, self.k_norm)
+        if ctx is not None:                             # graph-replayed decode: norms, RoPE, cache append and attention in one launch
+            return self.o_proj(ctx)
         q = self.q_norm(q.view(b, l, self.n_heads, -1)).permute(0, 2, 1, 3)
         k = self.k_norm(k.view(b, l, self.n_kv_heads, -1)).permute(0, 2, 1, 3)
         v = v.view(b, l, self.n_kv_heads, -1).permute(0, 2, 1, 3)

@@ -222,6 +222,15 @@ int gbx_attn_decode_batched(const void* q, const void* k, const void* v, void* k
                             int32_t head_dim, int32_t capacity, float rope_scale, float sm_scale, int32_t traditional,
                             int32_t act_dtype, void* hip_stream);
 
+/* gbx_attn_decode_batched with an optional per-head RMSNorm of q and k before RoPE (both weights [head_dim], or both
+ * NULL): Qwen3's q_norm / k_norm (gbx_lm/models/qqwen3.py:  self.q_norm(queries...), self.k_norm(keys...)) -- the whole
+ * attention block between the q|k|v projection and o_proj in one launch, any batch >= 1. */
+int gbx_attn_decode_normed(const void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
+                           const int64_t* pos, void* out, int32_t batch, int32_t n_heads, int32_t n_kv_heads,
+                           int32_t head_dim, int32_t capacity, float rope_scale, float sm_scale, int32_t traditional,
+                           const void* q_norm_weight, const void* k_norm_weight, float norm_eps, int32_t act_dtype,
+                           void* hip_stream);
+
 /* Single-token attention over a cache that already holds the new token: out[b, h, :] = softmax(q[b, h, :] . K[b, kv(h), 0..*pos, :]^T
  * * sm_scale) V[b, kv(h), 0..*pos, :] with q [batch, n_heads, head_dim] already rotated, caches [batch, n_kv, capacity, head_dim],
  * `pos` a DEVICE int64.  mx.fast.scaled_dot_product_attention as every model graph calls it for L = 1 (models/base.py:65-92),

@@ -133,6 +133,37 @@ def test_attn_decode_batched_matches_torch(hd, nh, nkv, traditional):
     assert torch.allclose(out.float().cpu(), want, atol=2e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("B,hd,nh,nkv", [(1, 128, 32, 4), (3, 128, 8, 2), (2, 64, 6, 2), (1, 128, 5, 5)])
+def test_attn_decode_with_qk_norm_matches_torch(B, hd, nh, nkv):
+    """gbx_attn_decode_normed: per-head RMSNorm of q and k, RoPE, cache append and grouped attention in one launch
+    (Qwen3's attention block at decode) against the op-by-op torch formulation; rep = 8 (two workgroups per kv group,
+    one of them appends), 4, 3, 1."""
+    from gbx_lm_amd import ops
+    from gbx_lm_amd.models.rope_utils import RoPE, apply_rope
+    torch.manual_seed(nh + B)
+    cap, pos, eps = 96, 41, 1e-6
+    q = torch.randn(B, nh * hd).to(torch.bfloat16); k = torch.randn(B, nkv * hd).to(torch.bfloat16)
+    v = torch.randn(B, nkv * hd).to(torch.bfloat16)
+    kc = torch.randn(B, nkv, cap, hd).to(torch.bfloat16); vc = torch.randn(B, nkv, cap, hd).to(torch.bfloat16)
+    qw = (1 + 0.2 * torch.randn(hd)).to(torch.bfloat16); kw = (1 + 0.2 * torch.randn(hd)).to(torch.bfloat16)
+    rope = RoPE(hd, base=1000000.0)
+    kd, vd = kc.to(DEV), vc.to(DEV)
+    out = torch.zeros(B, nh * hd, dtype=torch.bfloat16, device=DEV)
+    ops.attn_decode_batched(q.to(DEV), k.to(DEV), v.to(DEV), kd, vd, rope.inv_freq.to(DEV), torch.tensor([pos], device=DEV), out,
+                            nh, nkv, hd, 1.0, hd ** -0.5, False, qw.to(DEV), kw.to(DEV), eps)
+    def norm(x, w):
+        xf = x.float()
+        return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps) * w.float()).to(torch.bfloat16)
+    qn = norm(q.view(B, 1, nh, hd), qw).transpose(1, 2); kn = norm(k.view(B, 1, nkv, hd), kw).transpose(1, 2)
+    qr = apply_rope(qn, rope.inv_freq, pos, 1.0, False); kr = apply_rope(kn, rope.inv_freq, pos, 1.0, False)
+    kc[:, :, pos:pos + 1] = kr; vc[:, :, pos:pos + 1] = v.view(B, nkv, 1, hd)
+    assert torch.allclose(kd.float().cpu(), kc.float(), atol=3e-2) and torch.equal(vd.cpu(), vc)
+    rep = nh // nkv
+    K = kc[:, :, :pos + 1].repeat_interleave(rep, 1).float(); V = vc[:, :, :pos + 1].repeat_interleave(rep, 1).float()
+    want = (torch.softmax((qr.float() @ K.transpose(-1, -2)) * hd ** -0.5, -1) @ V).reshape(B, -1)
+    assert torch.allclose(out.float().cpu(), want, atol=3e-2, rtol=3e-2)
+
+
 @pytest.mark.parametrize("hd,nh,nkv", [(128, 8, 2), (128, 32, 4), (64, 6, 2), (64, 5, 5), (128, 4, 2)])
 def test_attn_cached_matches_torch(hd, nh, nkv):
     """gbx_attn_cached (what the SDPA helper runs inside a graph-replayed decode step): rotated q against a cache that
