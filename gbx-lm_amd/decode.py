@@ -219,6 +219,11 @@ def fused_eligible(model) -> bool:
             return False
         if at.head_dim not in (64, 128) or at.rope.inv_freq.numel() * 2 != at.head_dim:
             return False
+        if type(at.rope).__name__ not in ("RoPE", "Llama3RoPE"):          # amplitude-rescaling variants (su / YaRN): generic path
+            return False
+        qn, kn = getattr(at, "q_norm", None), getattr(at, "k_norm", None)    # Qwen3: per-head norms inside the attention launch
+        if (qn is None) != (kn is None) or (qn is not None and (qn.weight.dtype != dt or kn.weight.dtype != dt)):
+            return False
         vpl = lambda m: 64 if m.bits == 2 else 32
         if at.q_proj.input_dims // vpl(at.q_proj) > 128 or mlp.gate_proj.input_dims // vpl(mlp.gate_proj) > 128:
             return False
@@ -285,9 +290,15 @@ class FusedDecodeRunner(DecodeRunner):
         for blk, c, (d_qkv, d_o, d_gu, d_dn) in zip(m.layers, self.caches, self.descs):
             at = blk.self_attn
             ops.qlinear_fused(d_qkv, dev)
-            ops.attn_decode(self.qb, self.kb, self.vb, c.keys, c.values, at.rope.inv_freq, self.pos, self.ab,
-                            at.n_heads, at.n_kv_heads, at.head_dim, c.capacity, getattr(at.rope, "scale", 1.0), at.scale,
-                            at.rope.traditional)
+            if getattr(at, "q_norm", None) is not None:     # Qwen3: q_norm / k_norm + RoPE + append + attention in one launch
+                ops.attn_decode_batched(self.qb.view(1, -1), self.kb.view(1, -1), self.vb.view(1, -1), c.keys, c.values,
+                                        at.rope.inv_freq, self.pos, self.ab.view(1, -1), at.n_heads, at.n_kv_heads, at.head_dim,
+                                        getattr(at.rope, "scale", 1.0), at.scale, at.rope.traditional, at.q_norm.weight,
+                                        at.k_norm.weight, at.q_norm.eps)
+            else:
+                ops.attn_decode(self.qb, self.kb, self.vb, c.keys, c.values, at.rope.inv_freq, self.pos, self.ab,
+                                at.n_heads, at.n_kv_heads, at.head_dim, c.capacity, getattr(at.rope, "scale", 1.0), at.scale,
+                                at.rope.traditional)
             ops.qlinear_fused(d_o, dev)
             if self.tp_world > 1:            # K-split layer: partial sums (+ rank 0's residual) meet over RCCL in pb
                 all_reduce_(self.pb, at.tp_group)

@@ -102,8 +102,16 @@ class Model(nn.Module):
         return weights
 
     def decode_step(self, y: torch.Tensor, prompt_cache) -> torch.Tensor:
-        """Single-token fast path: this graph captured once and replayed (gbx_lm_amd/decode.py:GraphDecodeRunner)."""
-        from ..decode import graph_decode_step
+        """Single-token fast path: the hand-fused five-launch block of the Llama graph when the checkpoint qualifies (the
+        per-head q / k norms run inside the attention launch), else this model's own forward captured once and replayed
+        (gbx_lm_amd/decode.py:FusedDecodeRunner / GraphDecodeRunner)."""
+        from ..decode import decode_step, fused_eligible, graph_decode_step
+        ok = getattr(self, "_fused_ok", None)
+        if ok is None:
+            ok = self._fused_ok = bool(next(self.parameters()).is_cuda and fused_eligible(self))
+        c0 = prompt_cache[0]
+        if ok and getattr(c0, "keys", None) is not None and c0.keys.shape[0] == 1:
+            return decode_step(self, y, prompt_cache)
         return graph_decode_step(self, y, prompt_cache)
 
     @property

@@ -39,6 +39,9 @@ QWEN3_30B_A3B = dict(model_type="qwen3_moe", hidden_size=2048, intermediate_size
                      num_experts_per_tok=8, decoder_sparse_step=1, mlp_only_layers=[], norm_topk_prob=True,
                      rms_norm_eps=1e-6, vocab_size=151936, rope_theta=1000000.0, max_position_embeddings=40960,
                      tie_word_embeddings=False, eos_token_id=151645)          # public Qwen3-30B-A3B shapes
+QWEN3_8B = dict(model_type="qwen3", hidden_size=4096, intermediate_size=12288, num_hidden_layers=36, num_attention_heads=32,
+                num_key_value_heads=8, head_dim=128, rms_norm_eps=1e-6, vocab_size=151936, rope_theta=1000000.0,
+                max_position_embeddings=40960, tie_word_embeddings=False, eos_token_id=151645)     # public Qwen3-8B shapes
 TINY_MOE = dict(model_type="qwen3_moe", hidden_size=256, intermediate_size=512, moe_intermediate_size=128,
                 num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, head_dim=64, num_experts=8,
                 num_experts_per_tok=2, decoder_sparse_step=1, mlp_only_layers=[], norm_topk_prob=True,
