@@ -74,7 +74,7 @@ def _declare_optional(L) -> None:
         "gbx_qlinear_fused_forward": [ctypes.POINTER(FusedDesc), p],
         "gbx_attn_decode": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, f32, f32, i32, i32, p],
         "gbx_attn_decode_batched": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, f32, i32, i32, p],
-        "gbx_attn_decode_normed": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, f32, i32, p, p, f32, i32, p],
+        "gbx_attn_decode_normed": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, f32, i32, p, p, f32, p, p, p, i32, p],
         "gbx_attn_cached": [p, p, p, p, p, i32, i32, i32, i32, i32, f32, i32, p],
         "gbx_moe_route": [p, p, p, i64, i32, i32, i32, i32, i32, p],
         "gbx_moe_combine": [p, p, p, i64, i32, i32, i32, p],

@@ -335,15 +335,18 @@ int gbx_attn_decode_batched(const void* q, const void* k, const void* v, void* k
                             int32_t head_dim, int32_t capacity, float rope_scale, float sm_scale, int32_t traditional,
                             int32_t act_dtype, void* hip_stream) {
   return gbx_attn_decode_normed(q, k, v, kcache, vcache, inv_freq, pos, out, batch, n_heads, n_kv_heads, head_dim, capacity,
-                                rope_scale, sm_scale, traditional, nullptr, nullptr, 0.f, act_dtype, hip_stream);
+                                rope_scale, sm_scale, traditional, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, act_dtype,
+                                hip_stream);
 }
 
 int gbx_attn_decode_normed(const void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
                            const int64_t* pos, void* out, int32_t batch, int32_t n_heads, int32_t n_kv_heads,
                            int32_t head_dim, int32_t capacity, float rope_scale, float sm_scale, int32_t traditional,
-                           const void* q_norm_weight, const void* k_norm_weight, float norm_eps, int32_t act_dtype,
-                           void* hip_stream) {
+                           const void* q_norm_weight, const void* k_norm_weight, float norm_eps, const void* q_bias,
+                           const void* k_bias, const void* v_bias, int32_t act_dtype, void* hip_stream) {
   if ((q_norm_weight == nullptr) != (k_norm_weight == nullptr)) return fail(GBX_ERR_INVALID, "q and k norm weights come together");
+  if ((q_bias == nullptr) != (k_bias == nullptr) || (q_bias == nullptr) != (v_bias == nullptr))
+    return fail(GBX_ERR_INVALID, "q, k and v biases come together");
   if (batch == 0) return GBX_OK;
   if (batch < 0 || batch > 65535) return fail(GBX_ERR_INVALID, "batch must be in [0, 65535] (got %d)", batch);
   if (!q || !k || !v || !kcache || !vcache || !inv_freq || !pos || !out) return fail(GBX_ERR_INVALID, "null device pointer");
@@ -355,7 +358,7 @@ int gbx_attn_decode_normed(const void* q, const void* k, const void* v, void* kc
   hipError_t e = gbx::launch_attn_decode(q, k, v, kcache, vcache, inv_freq, reinterpret_cast<const long long*>(pos), out,
                                          batch, n_heads, n_kv_heads, head_dim, capacity, rope_scale, sm_scale, traditional,
                                          act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream), q_norm_weight, k_norm_weight,
-                                         norm_eps);
+                                         norm_eps, q_bias, k_bias, v_bias);
   if (e != hipSuccess) return hip_fail(e, "gbx_attn_decode launch");
   return GBX_OK;
 }

@@ -26,6 +26,11 @@ struct AttnArgs {
   const unsigned short* qn_w;
   const unsigned short* kn_w;
   float norm_eps;
+  // grouped kernel only: optional biases of the q / k / v projections (Qwen2), added here as the second rounding the
+  // projection's `+ bias` would have done (all three or none)
+  const unsigned short* q_bias;
+  const unsigned short* k_bias;
+  const unsigned short* v_bias;
 };
 
 template <bool BF16, int HD>
@@ -227,6 +232,11 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
     for (int p = tid; p < REP * HD; p += 256) q_s[p / HD][p % HD] = act_to_f32<BF16>(a.q[static_cast<size_t>(hq0) * HD + p]) * a.sm_scale;
   } else {
   __shared__ float ssq_s[REP + 1];
+  // projection output (+ bias, rounded to the activation dtype like the projection's own `+ bias`)
+  auto ldb = [](const unsigned short* src, const unsigned short* bias, int i) {
+    const float x = act_to_f32<BF16>(src[i]);
+    return bias ? act_to_f32<BF16>(f32_to_act<BF16>(x + act_to_f32<BF16>(bias[i]))) : x;
+  };
   const bool normed = a.qn_w != nullptr;
   const bool writer = blockIdx.x % parts == 0;      // one workgroup of the kv group appends k, v
   if (normed) {                                     // sum of squares per head (q heads of this part, then the k head)
@@ -235,7 +245,8 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
     for (int p = tid; p < (REP + 1) * (HD / 2); p += 256) {
       const int hh = p / (HD / 2), i = p % (HD / 2);
       const unsigned short* src = hh == REP ? a.k + static_cast<size_t>(kvh) * HD : a.q + (static_cast<size_t>(hq0) + hh) * HD;
-      const float x1 = act_to_f32<BF16>(src[2 * i]), x2 = act_to_f32<BF16>(src[2 * i + 1]);
+      const unsigned short* bsrc = !a.q_bias ? nullptr : hh == REP ? a.k_bias + static_cast<size_t>(kvh) * HD : a.q_bias + (static_cast<size_t>(hq0) + hh) * HD;
+      const float x1 = ldb(src, bsrc, 2 * i), x2 = ldb(src, bsrc, 2 * i + 1);
       atomicAdd(&ssq_s[hh], x1 * x1 + x2 * x2);
     }
     __syncthreads();
@@ -247,7 +258,8 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
     const unsigned short* src = isk ? a.k + static_cast<size_t>(kvh) * HD : a.q + (static_cast<size_t>(hq0) + hh) * HD;
     const int i1 = a.traditional ? 2 * i : i;
     const int i2 = a.traditional ? 2 * i + 1 : i + HD / 2;
-    float x1 = act_to_f32<BF16>(src[i1]), x2 = act_to_f32<BF16>(src[i2]);
+    const unsigned short* bsrc = !a.q_bias ? nullptr : isk ? a.k_bias + static_cast<size_t>(kvh) * HD : a.q_bias + (static_cast<size_t>(hq0) + hh) * HD;
+    float x1 = ldb(src, bsrc, i1), x2 = ldb(src, bsrc, i2);
     if (normed) {                                   // RMSNorm output rounded to the activation dtype, like the separate op
       const float rstd = rsqrtf(ssq_s[hh] / static_cast<float>(HD) + a.norm_eps);
       const unsigned short* w = isk ? a.kn_w : a.qn_w;
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
     }
   }
   if (tid < HD) {
-    const unsigned short vb = a.v[static_cast<size_t>(kvh) * HD + tid];
+    const unsigned short vb = f32_to_act<BF16>(ldb(a.v + static_cast<size_t>(kvh) * HD, a.v_bias ? a.v_bias + static_cast<size_t>(kvh) * HD : nullptr, tid));
     vn_s[tid] = act_to_f32<BF16>(vb);
     if (writer) a.vcache[(static_cast<size_t>(kvh) * a.capacity + pos) * HD + tid] = vb;
   }
@@ -394,7 +406,7 @@ hipError_t launch_attn_static(const void* q, const void* kcache, const void* vca
                               int n_heads, int n_kv, int head_dim, int capacity, float sm_scale, bool bf16, hipStream_t s) {
   AttnArgs a{static_cast<const unsigned short*>(q), nullptr, nullptr,
              static_cast<unsigned short*>(const_cast<void*>(kcache)), static_cast<unsigned short*>(const_cast<void*>(vcache)),
-             nullptr, pos, static_cast<unsigned short*>(out), n_heads, n_kv, capacity, 1.f, sm_scale, 0, nullptr, nullptr, 0.f};
+             nullptr, pos, static_cast<unsigned short*>(out), n_heads, n_kv, capacity, 1.f, sm_scale, 0, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr};
   const int rep = n_heads / n_kv;
   const int R = rep % 4 == 0 ? 4 : rep % 3 == 0 ? 3 : rep % 2 == 0 ? 2 : 1;
   if (head_dim == 128) {
@@ -419,13 +431,16 @@ hipError_t launch_attn_static(const void* q, const void* kcache, const void* vca
 hipError_t launch_attn_decode(const void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
                               const long long* pos, void* out, int batch, int n_heads, int n_kv, int head_dim, int capacity,
                               float rope_scale, float sm_scale, int traditional, bool bf16, hipStream_t s,
-                              const void* q_norm_w, const void* k_norm_w, float norm_eps) {
+                              const void* q_norm_w, const void* k_norm_w, float norm_eps, const void* q_bias, const void* k_bias,
+                              const void* v_bias) {
   AttnArgs a{static_cast<const unsigned short*>(q), static_cast<const unsigned short*>(k), static_cast<const unsigned short*>(v),
              static_cast<unsigned short*>(kcache), static_cast<unsigned short*>(vcache), inv_freq, pos,
              static_cast<unsigned short*>(out), n_heads, n_kv, capacity, rope_scale, sm_scale, traditional,
-             static_cast<const unsigned short*>(q_norm_w), static_cast<const unsigned short*>(k_norm_w), norm_eps};
+             static_cast<const unsigned short*>(q_norm_w), static_cast<const unsigned short*>(k_norm_w), norm_eps,
+             static_cast<const unsigned short*>(q_bias), static_cast<const unsigned short*>(k_bias),
+             static_cast<const unsigned short*>(v_bias)};
   const int rep = n_heads / n_kv;
-  if (q_norm_w || (batch > 1 && rep > 1)) {         // grouped kernel: batched decode, or q/k norms (any batch)
+  if (q_norm_w || q_bias || (batch > 1 && rep > 1)) {         // grouped kernel: batched decode, or q/k norms (any batch)
     const int R = rep % 4 == 0 ? 4 : rep % 3 == 0 ? 3 : rep % 2 == 0 ? 2 : 1;
     if (head_dim == 128) {
       switch (R) {

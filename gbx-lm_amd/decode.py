@@ -212,7 +212,12 @@ def fused_eligible(model) -> bool:
     for blk in model.model.layers:
         at, mlp = blk.self_attn, blk.mlp
         mods = (at.q_proj, at.k_proj, at.v_proj, at.o_proj, mlp.gate_proj, mlp.up_proj, mlp.down_proj)
-        if any(m.bias is not None or m.input_dims % 128 or m.scales is None or m.scales.dtype != dt for m in mods):
+        if any(m.input_dims % 128 or m.scales is None or m.scales.dtype != dt for m in mods):
+            return False
+        # biases: none, or q / k / v all three (Qwen2) -- those ride in the attention launch
+        qkv_b = [m.bias for m in (at.q_proj, at.k_proj, at.v_proj)]
+        if any(m.bias is not None for m in mods[3:]) or (any(b is not None for b in qkv_b) and
+                                                         not all(b is not None and b.dtype == dt for b in qkv_b)):
             return False
         sig = lambda m: (m.bits, m.group_size)
         if not (sig(at.q_proj) == sig(at.k_proj) == sig(at.v_proj)) or sig(mlp.gate_proj) != sig(mlp.up_proj):
@@ -269,7 +274,7 @@ class FusedDecodeRunner(DecodeRunner):
             self.packed.append((p_qkv, p_o, p_gu, p_dn))
             self.descs.append((
                 ops.make_fused_desc(self.hb, (at.q_proj, at.k_proj, at.v_proj), (self.qb, self.kb, self.vb),
-                                    norm_weight=blk.input_layernorm.weight, eps=eps, packed=p_qkv),
+                                    norm_weight=blk.input_layernorm.weight, eps=eps, packed=p_qkv, bias_elsewhere=True),
                 ops.make_fused_desc(self.ab, (at.o_proj,), (self.pb,), residual=self.hb if r0 else None, packed=p_o) if tp else
                 ops.make_fused_desc(self.ab, (at.o_proj,), (self.hb,), residual=self.hb, packed=p_o),
                 ops.make_fused_desc(self.pb if tp else self.hb, (mlp.gate_proj, mlp.up_proj), (self.actb,),
@@ -290,11 +295,14 @@ class FusedDecodeRunner(DecodeRunner):
         for blk, c, (d_qkv, d_o, d_gu, d_dn) in zip(m.layers, self.caches, self.descs):
             at = blk.self_attn
             ops.qlinear_fused(d_qkv, dev)
-            if getattr(at, "q_norm", None) is not None:     # Qwen3: q_norm / k_norm + RoPE + append + attention in one launch
+            qn = getattr(at, "q_norm", None)
+            if qn is not None or at.q_proj.bias is not None:
+                # Qwen3 (per-head q / k norms) and Qwen2 (q / k / v biases): the grouped kernel takes both in its prologue
                 ops.attn_decode_batched(self.qb.view(1, -1), self.kb.view(1, -1), self.vb.view(1, -1), c.keys, c.values,
                                         at.rope.inv_freq, self.pos, self.ab.view(1, -1), at.n_heads, at.n_kv_heads, at.head_dim,
-                                        getattr(at.rope, "scale", 1.0), at.scale, at.rope.traditional, at.q_norm.weight,
-                                        at.k_norm.weight, at.q_norm.eps)
+                                        getattr(at.rope, "scale", 1.0), at.scale, at.rope.traditional,
+                                        qn.weight if qn is not None else None, at.k_norm.weight if qn is not None else None,
+                                        qn.eps if qn is not None else 0.0, at.q_proj.bias, at.k_proj.bias, at.v_proj.bias)
             else:
                 ops.attn_decode(self.qb, self.kb, self.vb, c.keys, c.values, at.rope.inv_freq, self.pos, self.ab,
                                 at.n_heads, at.n_kv_heads, at.head_dim, c.capacity, getattr(at.rope, "scale", 1.0), at.scale,

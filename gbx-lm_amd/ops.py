@@ -277,7 +277,8 @@ def gemv_tiled(x: torch.Tensor, wt: torch.Tensor, szt: torch.Tensor, n: int, k: 
 
 
 def make_fused_desc(x: torch.Tensor, mods, ys, norm_weight: Optional[torch.Tensor] = None, eps: float = 0.0,
-                    residual: Optional[torch.Tensor] = None, swiglu: bool = False, packed=None) -> "_lib.FusedDesc":
+                    residual: Optional[torch.Tensor] = None, swiglu: bool = False, packed=None,
+                    bias_elsewhere: bool = False) -> "_lib.FusedDesc":
     """Descriptor for one launch over 1-3 QuantizedLinear modules sharing ``x`` (q/k/v, gate/up, or a single one).
     ``packed``: ``pack_scales_zeros`` companion of the launch (per-module packs concatenated in order, or the one
     gate/up-interleaved tensor with ``swiglu``).
@@ -286,7 +287,7 @@ def make_fused_desc(x: torch.Tensor, mods, ys, norm_weight: Optional[torch.Tenso
     for m in mods:
         if (m.bits, m.group_size, m.input_dims) != (m0.bits, m0.group_size, m0.input_dims):
             raise ValueError("fused segments must share bits, group_size and input_dims")
-        if m.bias is not None:
+        if m.bias is not None and not bias_elsewhere:     # (q/k/v biases can ride in the attention launch instead)
             raise NotImplementedError("fused decode path does not carry a bias")
         for t in (m.qweight, m.scales, m.zeros):
             _require_cuda(t, "QuantizedLinear tensor")
@@ -328,7 +329,7 @@ def attn_decode(q, k, v, kcache, vcache, inv_freq, pos, out, n_heads: int, n_kv:
 
 def attn_decode_batched(q, k, v, kcache, vcache, inv_freq, pos, out, n_heads: int, n_kv: int, head_dim: int,
                         rope_scale: float, sm_scale: float, traditional: bool, q_norm_w=None, k_norm_w=None,
-                        norm_eps: float = 0.0) -> None:
+                        norm_eps: float = 0.0, q_bias=None, k_bias=None, v_bias=None) -> None:
     """One new token per sequence, all at position ``pos`` (device int64): q/out [B, n_heads*hd], k/v [B, n_kv*hd],
     caches [B, n_kv, capacity, hd] (gbx_attn_decode_batched: RoPE + cache append + softmax(q k^T) v in one launch)."""
     _require_cuda(q, "q")
@@ -338,6 +339,9 @@ def attn_decode_batched(q, k, v, kcache, vcache, inv_freq, pos, out, n_heads: in
                                                  cap, float(rope_scale), float(sm_scale), int(bool(traditional)),
                                                  q_norm_w.data_ptr() if q_norm_w is not None else None,
                                                  k_norm_w.data_ptr() if k_norm_w is not None else None, float(norm_eps),
+                                                 q_bias.data_ptr() if q_bias is not None else None,
+                                                 k_bias.data_ptr() if k_bias is not None else None,
+                                                 v_bias.data_ptr() if v_bias is not None else None,
                                                  _DT[q.dtype], _stream_ptr(q.device)))
 
 

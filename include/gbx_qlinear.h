@@ -223,13 +223,15 @@ int gbx_attn_decode_batched(const void* q, const void* k, const void* v, void* k
                             int32_t act_dtype, void* hip_stream);
 
 /* gbx_attn_decode_batched with an optional per-head RMSNorm of q and k before RoPE (both weights [head_dim], or both
- * NULL): Qwen3's q_norm / k_norm (gbx_lm/models/qqwen3.py:  self.q_norm(queries...), self.k_norm(keys...)) -- the whole
- * attention block between the q|k|v projection and o_proj in one launch, any batch >= 1. */
+ * NULL): Qwen3's q_norm / k_norm (gbx_lm/models/qqwen3.py:  self.q_norm(queries...), self.k_norm(keys...)), and with the
+ * optional biases of the q / k / v projections (all three [n_heads|n_kv * head_dim], or all NULL: Qwen2,
+ * gbx_lm/models/qqwen2.py:44-47), added with the rounding of the projection's own `+ bias` -- the whole attention block
+ * between the bias-free q|k|v matmul and o_proj in one launch, any batch >= 1. */
 int gbx_attn_decode_normed(const void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
                            const int64_t* pos, void* out, int32_t batch, int32_t n_heads, int32_t n_kv_heads,
                            int32_t head_dim, int32_t capacity, float rope_scale, float sm_scale, int32_t traditional,
-                           const void* q_norm_weight, const void* k_norm_weight, float norm_eps, int32_t act_dtype,
-                           void* hip_stream);
+                           const void* q_norm_weight, const void* k_norm_weight, float norm_eps, const void* q_bias,
+                           const void* k_bias, const void* v_bias, int32_t act_dtype, void* hip_stream);
 
 /* Single-token attention over a cache that already holds the new token: out[b, h, :] = softmax(q[b, h, :] . K[b, kv(h), 0..*pos, :]^T
  * * sm_scale) V[b, kv(h), 0..*pos, :] with q [batch, n_heads, head_dim] already rotated, caches [batch, n_kv, capacity, head_dim],

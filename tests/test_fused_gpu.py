@@ -164,6 +164,34 @@ def test_attn_decode_with_qk_norm_matches_torch(B, hd, nh, nkv):
     assert torch.allclose(out.float().cpu(), want, atol=3e-2, rtol=3e-2)
 
 
+def test_attn_decode_with_qkv_bias_matches_torch():
+    """Qwen2: the q / k / v projection biases ride in the attention launch (second rounding like the projection's own
+    `+ bias`), B = 1 and B = 2."""
+    from gbx_lm_amd import ops
+    from gbx_lm_amd.models.rope_utils import RoPE, apply_rope
+    torch.manual_seed(4)
+    hd, nh, nkv, cap, pos = 128, 4, 2, 64, 19
+    for B in (1, 2):
+        q = torch.randn(B, nh * hd).to(torch.bfloat16); k = torch.randn(B, nkv * hd).to(torch.bfloat16)
+        v = torch.randn(B, nkv * hd).to(torch.bfloat16)
+        bq, bk, bv = (torch.randn(n * hd).to(torch.bfloat16) for n in (nh, nkv, nkv))
+        kc = torch.randn(B, nkv, cap, hd).to(torch.bfloat16); vc = torch.randn(B, nkv, cap, hd).to(torch.bfloat16)
+        rope = RoPE(hd, base=1000000.0)
+        kd, vd = kc.to(DEV), vc.to(DEV)
+        out = torch.zeros(B, nh * hd, dtype=torch.bfloat16, device=DEV)
+        ops.attn_decode_batched(q.to(DEV), k.to(DEV), v.to(DEV), kd, vd, rope.inv_freq.to(DEV), torch.tensor([pos], device=DEV), out,
+                                nh, nkv, hd, 1.0, hd ** -0.5, False, None, None, 0.0, bq.to(DEV), bk.to(DEV), bv.to(DEV))
+        qb, kb, vb = q + bq, k + bk, v + bv                          # bf16 adds: one rounding
+        qr = apply_rope(qb.view(B, 1, nh, hd).transpose(1, 2), rope.inv_freq, pos, 1.0, False)
+        kr = apply_rope(kb.view(B, 1, nkv, hd).transpose(1, 2), rope.inv_freq, pos, 1.0, False)
+        kc[:, :, pos:pos + 1] = kr; vc[:, :, pos:pos + 1] = vb.view(B, nkv, 1, hd)
+        assert torch.allclose(kd.float().cpu(), kc.float(), atol=3e-2) and torch.equal(vd.cpu(), vc)
+        rep = nh // nkv
+        K = kc[:, :, :pos + 1].repeat_interleave(rep, 1).float(); V = vc[:, :, :pos + 1].repeat_interleave(rep, 1).float()
+        want = (torch.softmax((qr.float() @ K.transpose(-1, -2)) * hd ** -0.5, -1) @ V).reshape(B, -1)
+        assert torch.allclose(out.float().cpu(), want, atol=3e-2, rtol=3e-2)
+
+
 @pytest.mark.parametrize("hd,nh,nkv", [(128, 8, 2), (128, 32, 4), (64, 6, 2), (64, 5, 5), (128, 4, 2)])
 def test_attn_cached_matches_torch(hd, nh, nkv):
     """gbx_attn_cached (what the SDPA helper runs inside a graph-replayed decode step): rotated q against a cache that
