@@ -78,6 +78,7 @@ def _declare_optional(L) -> None:
         "gbx_attn_cached": [p, p, p, p, p, i32, i32, i32, i32, i32, f32, i32, p],
         "gbx_moe_route": [p, p, p, i64, i32, i32, i32, i32, i32, p],
         "gbx_moe_combine": [p, p, p, i64, i32, i32, i32, p],
+        "gbx_moe_combine_residual": [p, p, p, p, i64, i32, i32, i32, p],
         "gbx_kv_append": [p, p, p, p, p, i64, i32, i32, i32, i32, p],
         "gbx_add_rmsnorm": [p, p, p, p, i64, i32, f32, i32, p],
         "gbx_swiglu": [p, p, p, i64, i32, p],

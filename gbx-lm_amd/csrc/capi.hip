@@ -482,11 +482,16 @@ int gbx_moe_route(const void* logits, int32_t* indices, void* scores, int64_t to
 
 int gbx_moe_combine(const void* y, const void* scores, void* out, int64_t tokens, int32_t top_k, int32_t D, int32_t act_dtype,
                     void* hip_stream) {
+  return gbx_moe_combine_residual(y, scores, nullptr, out, tokens, top_k, D, act_dtype, hip_stream);
+}
+
+int gbx_moe_combine_residual(const void* y, const void* scores, const void* residual, void* out, int64_t tokens, int32_t top_k,
+                             int32_t D, int32_t act_dtype, void* hip_stream) {
   if (tokens == 0) return GBX_OK;
   if (!y || !scores || !out) return fail(GBX_ERR_INVALID, "null device pointer");
   if (tokens < 0 || tokens > 65535 || top_k <= 0 || D <= 0 || (D & 1)) return fail(GBX_ERR_INVALID, "bad shape tokens=%lld top_k=%d D=%d", (long long)tokens, top_k, D);
   if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
-  hipError_t e = gbx::launch_moe_combine(y, scores, out, static_cast<int>(tokens), top_k, D, act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));
+  hipError_t e = gbx::launch_moe_combine(y, scores, out, static_cast<int>(tokens), top_k, D, act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream), residual);
   if (e != hipSuccess) return hip_fail(e, "gbx_moe_combine launch");
   return GBX_OK;
 }

@@ -52,7 +52,8 @@ hipError_t launch_attn_static(const void* q, const void* kcache, const void* vca
                               int n_heads, int n_kv, int head_dim, int capacity, float sm_scale, bool bf16, hipStream_t s);
 hipError_t launch_moe_route(const void* logits, int* inds, void* scores, int T, int E, int k, int mode, int renorm, bool bf16,
                             hipStream_t s);
-hipError_t launch_moe_combine(const void* y, const void* scores, void* out, int T, int k, int D, bool bf16, hipStream_t s);
+hipError_t launch_moe_combine(const void* y, const void* scores, void* out, int T, int k, int D, bool bf16, hipStream_t s,
+                              const void* residual = nullptr);
 hipError_t launch_kv_append(const void* k, const void* v, void* kc, void* vc, const long long* pos, int rows, int cap, int dk, int dv,
                             hipStream_t s);
 hipError_t launch_add_rmsnorm(void* h, const void* d, const void* w, void* y, int M, int K, float eps, bool bf16, hipStream_t s);

@@ -107,7 +107,8 @@ hipError_t launch_moe_route(const void* logits, int* inds, void* scores, int T, 
 
 template <bool BF16>
 __global__ __launch_bounds__(256) void moe_combine_kernel(const unsigned short* __restrict__ y, const unsigned short* __restrict__ scores,
-                                                          unsigned short* __restrict__ out, int k, int D) {
+                                                          unsigned short* __restrict__ out, int k, int D,
+                                                          const unsigned short* __restrict__ residual) {
   const size_t t = blockIdx.y;
   const int d = (blockIdx.x * 256 + threadIdx.x) * 2;
   if (d >= D) return;
@@ -118,17 +119,24 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const unsigned short* 
     a0 += act_to_f32<BF16>(f32_to_act<BF16>(w * act_lo<BF16>(v)));
     a1 += act_to_f32<BF16>(f32_to_act<BF16>(w * act_hi<BF16>(v)));
   }
+  if (residual) {                                   // h + mlp(...): the block's residual add as a second rounding
+    const unsigned r = *reinterpret_cast<const unsigned*>(residual + t * D + d);
+    a0 = act_lo<BF16>(r) + act_to_f32<BF16>(f32_to_act<BF16>(a0));
+    a1 = act_hi<BF16>(r) + act_to_f32<BF16>(f32_to_act<BF16>(a1));
+  }
   *reinterpret_cast<unsigned*>(out + t * D + d) =
       static_cast<unsigned>(f32_to_act<BF16>(a0)) | (static_cast<unsigned>(f32_to_act<BF16>(a1)) << 16);
 }
 
-hipError_t launch_moe_combine(const void* y, const void* scores, void* out, int T, int k, int D, bool bf16, hipStream_t s) {
+hipError_t launch_moe_combine(const void* y, const void* scores, void* out, int T, int k, int D, bool bf16, hipStream_t s,
+                              const void* residual) {
   auto Y = static_cast<const unsigned short*>(y);
   auto S = static_cast<const unsigned short*>(scores);
   auto O = static_cast<unsigned short*>(out);
+  auto R = static_cast<const unsigned short*>(residual);
   dim3 grid((D / 2 + 255) / 256, T), block(256);
-  if (bf16) hipLaunchKernelGGL((moe_combine_kernel<true>), grid, block, 0, s, Y, S, O, k, D);
-  else hipLaunchKernelGGL((moe_combine_kernel<false>), grid, block, 0, s, Y, S, O, k, D);
+  if (bf16) hipLaunchKernelGGL((moe_combine_kernel<true>), grid, block, 0, s, Y, S, O, k, D, R);
+  else hipLaunchKernelGGL((moe_combine_kernel<false>), grid, block, 0, s, Y, S, O, k, D, R);
   return hipGetLastError();
 }
 

@@ -64,13 +64,20 @@ class Attention(nn.Module):
         self.k_norm = RMSNorm(self.head_dim, eps=args.rms_norm_eps)
         self.rope = RoPE(self.head_dim, traditional=False, base=args.rope_theta)
 
-    def forward(self, x: torch.Tensor, mask: Optional[torch.Tensor] = None, cache: Optional[Any] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, mask: Optional[torch.Tensor] = None, cache: Optional[Any] = None,
+                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``residual`` (decode fast path of the decoder layer): returns residual + attention(x)."""
         b, l, _ = x.shape
         q, k, v = ops.quantized_matmul_multi(x, (self.q_proj, self.k_proj, self.v_proj)) if x.is_cuda else \
             (self.q_proj(x), self.k_proj(x), self.v_proj(x))           # decode-sized x: one launch for the three
         ctx = fused_decode_attention(q, k, v, cache, self.rope, self.scale, self.n_heads, self.n_kv_heads, q.shape[-1] // self.n_heads,
                                      self.q_norm, self.k_norm)
         if ctx is not None:                             # graph-replayed decode: norms, RoPE, cache append and attention in one launch
+            if residual is not None:                    # ... and the block's residual add in the o_proj launch
+                out = ops.qlinear_residual(self.o_proj, ctx, residual)
+                if out is not None:
+                    return out
+                return residual + self.o_proj(ctx)
             return self.o_proj(ctx)
         q = self.q_norm(q.view(b, l, self.n_heads, -1)).permute(0, 2, 1, 3)
         k = self.k_norm(k.view(b, l, self.n_kv_heads, -1)).permute(0, 2, 1, 3)
@@ -80,7 +87,8 @@ class Attention(nn.Module):
         if cache is not None:
             k, v = cache.update_and_fetch(k, v)
         ctx = scaled_dot_product_attention(q, k, v, cache=cache, scale=self.scale, mask=mask)
-        return self.o_proj(ctx.permute(0, 2, 1, 3).reshape(b, l, -1))
+        out = self.o_proj(ctx.permute(0, 2, 1, 3).reshape(b, l, -1))
+        return out if residual is None else residual + out
 
 
 class MLP(nn.Module):
@@ -110,11 +118,14 @@ class Qwen3MoeSparseMoeBlock(nn.Module):
         self.gate = QuantizedLinear(args.hidden_size, args.num_experts, bias=False)
         self.switch_mlp = SwitchGLU(args.hidden_size, args.moe_intermediate_size, args.num_experts, quant=True)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``residual`` (decode fast path): returns residual + block(x), the add fused into the mixing launch."""
         if _device_routing(x, self.num_experts, self.top_k):
             # routing decisions and the weighted sum as two launches (gbx_moe_route / gbx_moe_combine)
             inds, scores = ops.moe_route(self.gate(x), self.top_k, 0, self.norm_topk_prob)
-            return ops.moe_combine(self.switch_mlp(x, inds), scores)
+            return ops.moe_combine(self.switch_mlp(x, inds), scores, residual)
+        if residual is not None:
+            return residual + self.forward(x)
         gates = torch.softmax(self.gate(x).float(), dim=-1).to(x.dtype)
         scores, inds = torch.topk(gates, self.top_k, dim=-1)
         if self.norm_topk_prob:
@@ -136,6 +147,12 @@ class Qwen3MoeDecoderLayer(nn.Module):
         self.mlp = Qwen3MoeSparseMoeBlock(args) if sparse else MLP(args.hidden_size, args.intermediate_size)
 
     def forward(self, x: torch.Tensor, mask: Optional[torch.Tensor] = None, cache: Optional[Any] = None) -> torch.Tensor:
+        if getattr(cache, "static_active", False) and x.is_cuda and x.shape[1] == 1:
+            # graph-replayed decode: both residual adds ride in the launch that produces the branch (o_proj GEMV / expert mixing)
+            h = self.self_attn(self.input_layernorm(x), mask, cache, residual=x)
+            if isinstance(self.mlp, Qwen3MoeSparseMoeBlock):
+                return self.mlp(self.post_attention_layernorm(h), residual=h)
+            return h + self.mlp(self.post_attention_layernorm(h))
         h = x + self.self_attn(self.input_layernorm(x), mask, cache)
         return h + self.mlp(self.post_attention_layernorm(h))
 

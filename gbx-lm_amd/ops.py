@@ -370,15 +370,32 @@ def moe_route(logits: torch.Tensor, top_k: int, mode: int = 0, renormalize: bool
     return inds.reshape(*lead, top_k), scores.reshape(*lead, top_k)
 
 
-def moe_combine(y: torch.Tensor, scores: torch.Tensor) -> torch.Tensor:
-    """sum_s scores[..., s] * y[..., s, :] in one launch (gbx_moe_combine)."""
+def moe_combine(y: torch.Tensor, scores: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sum_s scores[..., s] * y[..., s, :] (+ residual, the decoder layer's ``h + mlp(...)``) in one launch
+    (gbx_moe_combine_residual)."""
     _require_cuda(y, "y")
     k, d = y.shape[-2], y.shape[-1]
     yc, sc = y.contiguous(), scores.contiguous()
     out = torch.empty(tuple(y.shape[:-2]) + (d,), dtype=y.dtype, device=y.device)
-    _lib.check(_lib.lib().gbx_moe_combine(yc.data_ptr(), sc.data_ptr(), out.data_ptr(), yc.numel() // (k * d), k, d, _DT[y.dtype],
-                                          _stream_ptr(y.device)))
+    rc = residual.contiguous() if residual is not None else None
+    _lib.check(_lib.lib().gbx_moe_combine_residual(yc.data_ptr(), sc.data_ptr(), rc.data_ptr() if rc is not None else None,
+                                                   out.data_ptr(), yc.numel() // (k * d), k, d, _DT[y.dtype], _stream_ptr(y.device)))
     return out
+
+
+def qlinear_residual(mod, x: torch.Tensor, residual: torch.Tensor) -> Optional[torch.Tensor]:
+    """``residual + mod(x)`` for ONE token through the decode GEMV with the add in its epilogue (gbx_qlinear_fused_forward);
+    None when the call is outside that launch (several rows, bias, unsupported K) -- the caller then adds itself."""
+    k = mod.input_dims
+    vpl = 64 if mod.bits == 2 else 32
+    if not (x.is_cuda and x.numel() == k and residual.numel() == mod.output_dims and mod.bias is None and k % 128 == 0
+            and k // vpl <= 512 and x.dtype in _DT and mod.scales is not None and mod.scales.dtype == x.dtype
+            and mod.zeros.dtype == x.dtype and residual.dtype == x.dtype):
+        return None
+    x1, r1 = x.reshape(1, k).contiguous(), residual.reshape(1, -1).contiguous()
+    y = torch.empty_like(r1)
+    qlinear_fused(make_fused_desc(x1, (mod,), (y,), residual=r1), x.device)
+    return y.reshape(residual.shape)
 
 
 def kv_append(kcache: torch.Tensor, vcache: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos: torch.Tensor) -> None:

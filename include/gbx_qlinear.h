@@ -254,6 +254,11 @@ int gbx_moe_route(const void* logits, int32_t* indices, void* scores, int64_t to
 int gbx_moe_combine(const void* y, const void* scores, void* out, int64_t tokens, int32_t top_k, int32_t D, int32_t act_dtype,
                     void* hip_stream);
 
+/* gbx_moe_combine with the block's residual add fused: out[t, :] = residual[t, :] + (sum_s scores * y) -- `h + self.mlp(...)`
+ * of the decoder layer (qqwen3_moe.py:165-170), the sum rounded first, then the add (two roundings, like the two ops). */
+int gbx_moe_combine_residual(const void* y, const void* scores, const void* residual, void* out, int64_t tokens, int32_t top_k,
+                             int32_t D, int32_t act_dtype, void* hip_stream);
+
 /* kcache[r, *pos, :] = k[r, :], vcache[r, *pos, :] = v[r, :] for rows = batch * kv heads: the single-token
  * cache.update_and_fetch of gbx_lm/models/cache.py:222-244 at a DEVICE-resident position (16-bit elements; k_dim and v_dim
  * may differ: DeepSeek's latent attention). */

@@ -112,6 +112,9 @@ def test_moe_route_and_combine_kernels(dt):
         out = ops.moe_combine(y.to(DEV), scores)
         ref = (y * scores.cpu().unsqueeze(-1)).sum(dim=-2)
         assert torch.allclose(out.float().cpu(), ref.float(), rtol=2e-2, atol=2e-2)
+        res = torch.randn(T, D, generator=g).to(dt)                   # the decoder layer's `h + mlp(...)` fused in
+        out2 = ops.moe_combine(y.to(DEV), scores, res.to(DEV))
+        assert torch.allclose(out2.float().cpu(), (res + ref).float(), rtol=2e-2, atol=3e-2)
 
 
 def test_gather_swiglu_launch_equals_the_three_ops():
