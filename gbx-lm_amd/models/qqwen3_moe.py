@@ -65,10 +65,13 @@ class Attention(nn.Module):
         self.rope = RoPE(self.head_dim, traditional=False, base=args.rope_theta)
 
     def forward(self, x: torch.Tensor, mask: Optional[torch.Tensor] = None, cache: Optional[Any] = None,
-                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """``residual`` (decode fast path of the decoder layer): returns residual + attention(x)."""
+                residual: Optional[torch.Tensor] = None, pre_norm: Optional[nn.Module] = None) -> torch.Tensor:
+        """Decode fast path of the decoder layer: ``residual`` -> returns residual + attention(.); ``pre_norm`` -> x is the
+        un-normalised stream and the layer norm runs in the prologue of the q|k|v launch."""
         b, l, _ = x.shape
-        q, k, v = ops.quantized_matmul_multi(x, (self.q_proj, self.k_proj, self.v_proj)) if x.is_cuda else \
+        if pre_norm is not None and not x.is_cuda:
+            x, pre_norm = pre_norm(x), None
+        q, k, v = ops.quantized_matmul_multi(x, (self.q_proj, self.k_proj, self.v_proj), pre_norm) if x.is_cuda else \
             (self.q_proj(x), self.k_proj(x), self.v_proj(x))           # decode-sized x: one launch for the three
         ctx = fused_decode_attention(q, k, v, cache, self.rope, self.scale, self.n_heads, self.n_kv_heads, q.shape[-1] // self.n_heads,
                                      self.q_norm, self.k_norm)
@@ -149,7 +152,7 @@ class Qwen3MoeDecoderLayer(nn.Module):
     def forward(self, x: torch.Tensor, mask: Optional[torch.Tensor] = None, cache: Optional[Any] = None) -> torch.Tensor:
         if getattr(cache, "static_active", False) and x.is_cuda and x.shape[1] == 1:
             # graph-replayed decode: both residual adds ride in the launch that produces the branch (o_proj GEMV / expert mixing)
-            h = self.self_attn(self.input_layernorm(x), mask, cache, residual=x)
+            h = self.self_attn(x, mask, cache, residual=x, pre_norm=self.input_layernorm)
             if isinstance(self.mlp, Qwen3MoeSparseMoeBlock):
                 return self.mlp(self.post_attention_layernorm(h), residual=h)
             return h + self.mlp(self.post_attention_layernorm(h))

@@ -137,15 +137,27 @@ def pack_scales_zeros(mod, mod2=None) -> torch.Tensor:
     return out
 
 
-def quantized_matmul_multi(x: torch.Tensor, mods) -> list:
+def quantized_matmul_multi(x: torch.Tensor, mods, pre_norm=None) -> list:
     """[m(x) for m in mods] for 2-3 QuantizedLinear modules that share ``x`` (q/k/v, gate/up) -- ONE launch of the
-    split-K matrix-core kernel when the batch is decode-sized (gbx_qlinear_forward_multi), else one call per module."""
+    split-K matrix-core kernel when the batch is decode-sized (gbx_qlinear_forward_multi), else one call per module.
+    ``pre_norm`` (an RMSNorm module): the modules see ``pre_norm(x)``; at one token the norm runs in the GEMV's prologue."""
     import ctypes
     m0 = mods[0]
     k = m0.input_dims
     x2 = x.reshape(-1, k)
     rows = x2.shape[0]
     same = all((m.bits, m.group_size, m.input_dims) == (m0.bits, m0.group_size, k) for m in mods)
+    if pre_norm is not None:
+        vpl = 64 if m0.bits == 2 else 32
+        if (same and x.is_cuda and rows == 1 and 1 <= len(mods) <= 3 and k % 128 == 0 and k // vpl <= 128 and x.dtype in _DT
+                and pre_norm.weight.dtype == x.dtype
+                and all(m.bias is None and m.scales is not None and m.scales.dtype == x.dtype and m.zeros.dtype == x.dtype for m in mods)):
+            x1 = x2.contiguous()
+            ys = [torch.empty((1, m.output_dims), dtype=x.dtype, device=x.device) for m in mods]
+            qlinear_fused(make_fused_desc(x1, mods, ys, norm_weight=pre_norm.weight, eps=pre_norm.eps), x.device)
+            return [y.reshape(*x.shape[:-1], m.output_dims) for y, m in zip(ys, mods)]
+        x = pre_norm(x)
+        x2 = x.reshape(-1, k)
     if (same and x.is_cuda and rows == 1 and 1 < len(mods) <= 3 and k % 128 == 0 and x.dtype in _DT
             and all(m.bias is None and m.scales is not None and m.scales.dtype == x.dtype and m.zeros.dtype == x.dtype for m in mods)):
         # one token: the multi-segment decode GEMV (gbx_qlinear_fused_forward without norm / residual fusion)
