@@ -1,4 +1,4 @@
-// Batched decode (2 <= M <= 32 rows of activations), 2- and 4-bit, group 128: y[M,N] = x[M,K] . dequant(W[N,K])^T without
+// Batched decode (2 <= M <= 32 rows of activations), 2-, 3- and 4-bit, group 128: y[M,N] = x[M,K] . dequant(W[N,K])^T without
 // dequantising.  Replaces mx.quantized_matmul for x of shape [B, 1, K] (gbx_lm/models/quantized_linear_gba.py:195-203).
 //
 // At these M the packed weights are read once and mfma_skinny.hip was bound by everything except HBM: ~4 VALU
@@ -52,7 +52,7 @@ __device__ long long* bx_stamp_ptr;                 // diagnostic build only (sc
 
 template <int BITS, int TNW, int NG, int KG, bool BF16>
 __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
-  static_assert(NG * KG == 8 && (BITS == 2 || BITS == 4) && (TNW == 16 || TNW == 32), "unsupported shape");
+  static_assert(NG * KG == 8 && BITS >= 2 && BITS <= 4 && (TNW == 16 || TNW == 32), "unsupported shape");
   constexpr int NCHW = 8 / KG;                      // chunks per step of one k-range (the workgroup does 8 per step)
   constexpr int H = 64 / TNW;                       // lane groups of a wave (k split inside a chunk)
   constexpr int UPL = 16 / H;                       // 16-byte activation units per lane and chunk = MFMA steps per chunk
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
   constexpr int BUF = 8 * CHUNK;                    // one step of the whole workgroup
   constexpr unsigned MAGIC = BF16 ? 0x43004300u : 0x64006400u;   // 128.0 | 1024.0 twice
   constexpr float CF = BF16 ? 128.f : 1024.f;
-  constexpr unsigned FMASK = BITS == 2 ? 0x00030003u : 0x000F000Fu;
+  constexpr unsigned FMASK = BITS == 2 ? 0x00030003u : BITS == 3 ? 0x00070007u : 0x000F000Fu;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][8 chunks][32 rows][XROW] | xsum [2][8][32]
   float* xsum = reinterpret_cast<float*>(smem + 2 * BUF);
   float* red = reinterpret_cast<float*>(smem);                            // after the main loop: [8 waves][MT*AE][64]
@@ -132,7 +132,15 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
 #pragma unroll
     for (int j = 0; j < NCHW; ++j) {
       const uint32_t* src = wrow + static_cast<size_t>(step * NCHW + j) * WPC;
-      if constexpr (WL >= 4) {
+      if constexpr (WL == 6) {                      // 3 bits, 32-row tiles: 24 bytes per lane and chunk (8-byte aligned)
+#pragma unroll
+        for (int q = 0; q < 6; q += 2) {
+          const u32x2 v = *reinterpret_cast<const u32x2*>(src + q);
+          wn[j][q] = v.x; wn[j][q + 1] = v.y;
+        }
+      } else if constexpr (WL == 3) {               // 3 bits, 16-row tiles: 12 bytes
+        wn[j][0] = src[0]; wn[j][1] = src[1]; wn[j][2] = src[2];
+      } else if constexpr (WL >= 4) {
 #pragma unroll
         for (int q = 0; q < WL; q += 4) {
           const u32x4 v = *reinterpret_cast<const u32x4*>(src + q);
@@ -164,6 +172,8 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
         u0.z = __builtin_amdgcn_perm(hi.y, lo.y, 0x05040100u); u0.w = __builtin_amdgcn_perm(hi.y, lo.y, 0x07060302u);
         u1.x = __builtin_amdgcn_perm(hi.z, lo.z, 0x05040100u); u1.y = __builtin_amdgcn_perm(hi.z, lo.z, 0x07060302u);
         u1.z = __builtin_amdgcn_perm(hi.w, lo.w, 0x05040100u); u1.w = __builtin_amdgcn_perm(hi.w, lo.w, 0x07060302u);
+      } else if constexpr (BITS == 3) {             // fields leave a 24-bit window in adjacent pairs: natural order
+        u0 = lo; u1 = hi;
       } else {                                      // word of 8 fields: dword j of its unit = (x[j], x[j+4])
         u0.x = __builtin_amdgcn_perm(lo.z, lo.x, 0x05040100u); u0.y = __builtin_amdgcn_perm(lo.z, lo.x, 0x07060302u);
         u0.z = __builtin_amdgcn_perm(lo.w, lo.y, 0x05040100u); u0.w = __builtin_amdgcn_perm(lo.w, lo.y, 0x07060302u);
@@ -200,6 +210,14 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
           const int sh = 8 * (t & 1);
           bf.x = ((w >> sh) & FMASK) | MAGIC;       bf.y = ((w >> (sh + 2)) & FMASK) | MAGIC;
           bf.z = ((w >> (sh + 4)) & FMASK) | MAGIC; bf.w = ((w >> (sh + 6)) & FMASK) | MAGIC;
+        } else if constexpr (BITS == 3) {
+          // unit t = the 24-bit window at bit 24 t of the lane's words; fields (2j, 2j+1) of it sit 3 bits apart: the low
+          // field stays, the window shifted 13 bits up puts its neighbour on bit 16 of the same dword
+          const int b0 = 24 * t, wi = b0 >> 5, sh = b0 & 31;       // constants after unrolling
+          const unsigned win = sh == 0 ? wc[j][wi] : __builtin_amdgcn_alignbit(wc[j][wi + 1 < WL ? wi + 1 : WL - 1], wc[j][wi], sh);
+          const unsigned p0 = win, p1 = win >> 6, p2 = win >> 12, p3 = win >> 18;
+          bf.x = (((p0 & 7u) | (p0 << 13)) & FMASK) | MAGIC; bf.y = (((p1 & 7u) | (p1 << 13)) & FMASK) | MAGIC;
+          bf.z = (((p2 & 7u) | (p2 << 13)) & FMASK) | MAGIC; bf.w = (((p3 & 7u) | (p3 << 13)) & FMASK) | MAGIC;
         } else {
           const unsigned w = wc[j][t];
           bf.x = (w & FMASK) | MAGIC;        bf.y = ((w >> 4) & FMASK) | MAGIC;
@@ -428,11 +446,11 @@ static hipError_t launch_batch_bits(const MfmaArgs& a0, bool bf16, hipStream_t s
 }
 
 bool qgemm_batch_supported(int M, int K, int bits, int log2g) {
-  return M >= 1 && M <= 32 && (bits == 2 || bits == 4) && log2g == 7 && K % 1024 == 0;
+  return M >= 1 && M <= 32 && bits >= 2 && bits <= 4 && log2g == 7 && K % 1024 == 0;
 }
 
 hipError_t launch_qgemm_batch(const MfmaArgs& a, int bits, bool bf16, hipStream_t s) {
-  return bits == 2 ? launch_batch_bits<2>(a, bf16, s) : launch_batch_bits<4>(a, bf16, s);
+  return bits == 2 ? launch_batch_bits<2>(a, bf16, s) : bits == 3 ? launch_batch_bits<3>(a, bf16, s) : launch_batch_bits<4>(a, bf16, s);
 }
 
 }  // namespace gbx

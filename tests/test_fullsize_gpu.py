@@ -78,7 +78,7 @@ def test_mfma_gemm_vs_dequantized_matmul(bits, m):
         _close(y, x.double() @ w.double().t(), f"mfma M{m} N{n} K{k} b{bits} g{g}")
 
 
-@pytest.mark.parametrize("bits", [2, 4])
+@pytest.mark.parametrize("bits", [2, 3, 4])
 def test_batch_kernel_full_size_rows_equal_single_token_gemv(bits):
     """cfg5 at full size (B = 32 rows, every 8B projection shape, g = 128): each row of the no-dequant matrix-core GEMM
     (mfma_batch.hip) against (1) fp64 x . dequantised weights and (2) the streaming GEMV of that row alone -- two
