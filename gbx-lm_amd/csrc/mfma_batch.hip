@@ -1,4 +1,4 @@
-// Batched decode (2 <= M <= 32 rows of activations), 2-, 3- and 4-bit, group 128: y[M,N] = x[M,K] . dequant(W[N,K])^T without
+// Batched decode (2 <= M <= 32 rows of activations), 2-, 3- and 4-bit at group 128, 2-bit also at groups 64 / 32: y[M,N] = x[M,K] . dequant(W[N,K])^T without
 // dequantising.  Replaces mx.quantized_matmul for x of shape [B, 1, K] (gbx_lm/models/quantized_linear_gba.py:195-203).
 //
 // At these M the packed weights are read once and mfma_skinny.hip was bound by everything except HBM: ~4 VALU
@@ -50,13 +50,21 @@ template <bool BF16> __device__ __forceinline__ float xdot2(unsigned v, float ac
 __device__ long long* bx_stamp_ptr;                 // diagnostic build only (scratch/stamps_batch.py)
 #endif
 
-template <int BITS, int TNW, int NG, int KG, bool BF16>
+template <int BITS, int TNW, int NG, int KG, int GRP, bool BF16>
 __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
   static_assert(NG * KG == 8 && BITS >= 2 && BITS <= 4 && (TNW == 16 || TNW == 32), "unsupported shape");
+  static_assert(GRP == 128 || (BITS == 2 && (GRP == 64 || GRP == 32)), "groups of 64 / 32 are built for 2 bits");
+  // Groups smaller than the chunk (IL): an MFMA step must stay inside one group, so the k assignment is interleaved --
+  // step t covers the 16 * H consecutive k-values [16 H t, 16 H (t+1)) with lane group h on unit t*H + h -- instead of
+  // lane group h owning the h-th 1/H of the chunk; every lane then loads the chunk's 8 words and shifts by its half.
+  // NF group flushes per chunk, SPG MFMA steps per group.
+  constexpr bool IL = GRP < 128;
+  constexpr int NF = 128 / GRP;
   constexpr int NCHW = 8 / KG;                      // chunks per step of one k-range (the workgroup does 8 per step)
   constexpr int H = 64 / TNW;                       // lane groups of a wave (k split inside a chunk)
   constexpr int UPL = 16 / H;                       // 16-byte activation units per lane and chunk = MFMA steps per chunk
-  constexpr int WL = UPL * BITS / 4;                // packed words per lane and chunk
+  constexpr int WL = IL ? 8 : UPL * BITS / 4;       // packed words per lane and chunk
+  constexpr int SPG = UPL / NF;                     // MFMA steps per group (>= 1: TNW = 16 at GRP = 32 -> 1)
   constexpr int WPC = KC * BITS / 32;               // packed words per row and chunk
   constexpr int MT = 32 / TNW;                      // activation row tiles (32 rows)
   constexpr int AE = TNW == 32 ? 16 : 4;            // accumulator elements per lane and tile
@@ -65,7 +73,7 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
   constexpr unsigned MAGIC = BF16 ? 0x43004300u : 0x64006400u;   // 128.0 | 1024.0 twice
   constexpr float CF = BF16 ? 128.f : 1024.f;
   constexpr unsigned FMASK = BITS == 2 ? 0x00030003u : BITS == 3 ? 0x00070007u : 0x000F000Fu;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][8 chunks][32 rows][XROW] | xsum [2][8][32]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][8 chunks][32 rows][XROW] | xsum [2][8][NF][32]
   float* xsum = reinterpret_cast<float*>(smem + 2 * BUF);
   float* red = reinterpret_cast<float*>(smem);                            // after the main loop: [8 waves][MT*AE][64]
 
@@ -74,7 +82,7 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
   const int ng = wave % NG, kg = wave / NG;
   const int r = lane & (TNW - 1), h = lane / TNW;
   const int K = a.K, M = a.M;
-  const int W = K / 32 * BITS, G = K >> 7;
+  const int W = K / 32 * BITS, G = K / GRP;
   // this workgroup's slice of the k range (the whole row unless the launch splits k across workgroups)
   const int ksplit = a.ws ? a.ksplit : 1;
   const int nchunks = K / KC / ksplit, cbase = blockIdx.y * nchunks;
@@ -97,9 +105,9 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
     }
   }
   const int nrow = min(nl0 + ng * TNW + r, NL - 1);
-  const uint32_t* wrow = qw + static_cast<size_t>(nrow) * W + h * WL + static_cast<size_t>(cbase + kg * cpk) * WPC;
-  const unsigned short* srow = sc + static_cast<size_t>(nrow) * G + cbase + kg * cpk;
-  const unsigned short* zrow = ze + static_cast<size_t>(nrow) * G + cbase + kg * cpk;
+  const uint32_t* wrow = qw + static_cast<size_t>(nrow) * W + (IL ? 0 : h * WL) + static_cast<size_t>(cbase + kg * cpk) * WPC;
+  const unsigned short* srow = sc + static_cast<size_t>(nrow) * G + (cbase + kg * cpk) * NF;
+  const unsigned short* zrow = ze + static_cast<size_t>(nrow) * G + (cbase + kg * cpk) * NF;
 
   // loader role (waves 8..11): per step the workgroup stages 8 chunks x 32 rows x 256 B; loader thread -> 8 pieces of
   // 32 B (16 k-values), one per chunk slot
@@ -116,7 +124,7 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
   for (int i = 0; i < (TNW == 16 ? MT : 1); ++i) acc16[i] = f32x4v{0};
 
   unsigned wq[2][NCHW][WL];                        // packed words: current step, next step
-  constexpr int SR = NCHW >= 2 ? NCHW / 2 : 1;      // dwords holding the step's NCHW scales (zeros) of the lane's row
+  constexpr int SR = NCHW * NF >= 2 ? NCHW * NF / 2 : 1;   // dwords holding the step's NCHW * NF scales (zeros) of the lane's row
   unsigned scq[2][SR], zeq[2][SR];
   u32x4 xs[8][2];                                   // loader: activations of the step being staged
 
@@ -151,14 +159,23 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
         wn[j][0] = v.x; wn[j][1] = v.y;
       }
     }
-    // the step's NCHW consecutive scales / zeros of the row as ONE load each (a load costs a cycle per distinct line)
-    if constexpr (NCHW == 4) {
-      const u32x2 s2 = *reinterpret_cast<const u32x2*>(srow + step * 4), z2 = *reinterpret_cast<const u32x2*>(zrow + step * 4);
+    // the step's NCHW * NF consecutive scales / zeros of the row as wide loads (a load costs a cycle per distinct line)
+    const unsigned short* sp = srow + step * (NCHW * NF);
+    const unsigned short* zp = zrow + step * (NCHW * NF);
+    if constexpr (SR >= 4) {
+#pragma unroll
+      for (int q = 0; q < SR; q += 4) {
+        const u32x4 s4 = *reinterpret_cast<const u32x4*>(sp + 2 * q), z4 = *reinterpret_cast<const u32x4*>(zp + 2 * q);
+        sc_n[q] = s4.x; sc_n[q + 1] = s4.y; sc_n[q + 2] = s4.z; sc_n[q + 3] = s4.w;
+        ze_n[q] = z4.x; ze_n[q + 1] = z4.y; ze_n[q + 2] = z4.z; ze_n[q + 3] = z4.w;
+      }
+    } else if constexpr (SR == 2) {
+      const u32x2 s2 = *reinterpret_cast<const u32x2*>(sp), z2 = *reinterpret_cast<const u32x2*>(zp);
       sc_n[0] = s2.x; sc_n[1] = s2.y; ze_n[0] = z2.x; ze_n[1] = z2.y;
-    } else if constexpr (NCHW == 2) {
-      sc_n[0] = *reinterpret_cast<const unsigned*>(srow + step * 2); ze_n[0] = *reinterpret_cast<const unsigned*>(zrow + step * 2);
+    } else if constexpr (NCHW * NF == 2) {
+      sc_n[0] = *reinterpret_cast<const unsigned*>(sp); ze_n[0] = *reinterpret_cast<const unsigned*>(zp);
     } else {
-      sc_n[0] = srow[step]; ze_n[0] = zrow[step];
+      sc_n[0] = sp[0]; ze_n[0] = zp[0];
     }
   };
   // registers -> pair order of the packed fields -> slab; xsum of the piece, reduced over the 8 lanes of a row chunk
@@ -186,10 +203,10 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
       float sm = xdot2<BF16>(lo.x, 0.f);
       sm = xdot2<BF16>(lo.y, sm); sm = xdot2<BF16>(lo.z, sm); sm = xdot2<BF16>(lo.w, sm);
       sm = xdot2<BF16>(hi.x, sm); sm = xdot2<BF16>(hi.y, sm); sm = xdot2<BF16>(hi.z, sm); sm = xdot2<BF16>(hi.w, sm);
-      sm += dpp_f32<0xB1>(sm);
-      sm += dpp_f32<0x4E>(sm);
-      sm += dpp_f32<0x141>(sm);                     // 8-lane total in every lane of the row chunk
-      if (lpc == 0) xsum[(buf * 8 + it) * 32 + lrow] = sm;
+      sm += dpp_f32<0xB1>(sm);                      // 2 pieces = 32 k
+      if constexpr (NF <= 2) sm += dpp_f32<0x4E>(sm);   // 4 pieces = 64 k
+      if constexpr (NF == 1) sm += dpp_f32<0x141>(sm);  // 8 pieces: the row chunk
+      if (lpc % (8 / NF) == 0) xsum[((buf * 8 + it) * NF + lpc / (8 / NF)) * 32 + lrow] = sm;
     }
   };
   auto compute = [&](const unsigned (&wc)[NCHW][WL], const unsigned (&sc_c)[SR], const unsigned (&ze_c)[SR], int buf) {
@@ -197,15 +214,18 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
     for (int j = 0; j < NCHW; ++j) {
       const int cs = kg * NCHW + j;
       const unsigned char* slab = smem + buf * BUF + cs * CHUNK;
-      const unsigned sw = sc_c[j >> 1], zw = ze_c[j >> 1];
-      const float s = act_to_f32<BF16>(static_cast<unsigned short>((j & 1) ? (sw >> 16) : (sw & 0xFFFFu)));
-      const float zz = act_to_f32<BF16>(static_cast<unsigned short>((j & 1) ? (zw >> 16) : (zw & 0xFFFFu))) - CF * s;
       f32x16 g32;
       f32x4v g16[TNW == 16 ? MT : 1];
 #pragma unroll
       for (int t = 0; t < UPL; ++t) {
         u32x4 bf;
-        if constexpr (BITS == 2) {
+        if constexpr (IL) {                         // 2 bits: unit t*H + h = half (h & 1) of word t (H = 2) / 2t + (h >> 1) (H = 4)
+          unsigned w;
+          if constexpr (H == 2) w = wc[j][t] >> (8 * h);
+          else w = ((h >> 1) ? wc[j][2 * t + 1] : wc[j][2 * t]) >> (8 * (h & 1));
+          bf.x = (w & FMASK) | MAGIC;        bf.y = ((w >> 2) & FMASK) | MAGIC;
+          bf.z = ((w >> 4) & FMASK) | MAGIC; bf.w = ((w >> 6) & FMASK) | MAGIC;
+        } else if constexpr (BITS == 2) {
           const unsigned w = wc[j][t >> 1];
           const int sh = 8 * (t & 1);
           bf.x = ((w >> sh) & FMASK) | MAGIC;       bf.y = ((w >> (sh + 2)) & FMASK) | MAGIC;
@@ -223,32 +243,39 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
           bf.x = (w & FMASK) | MAGIC;        bf.y = ((w >> 4) & FMASK) | MAGIC;
           bf.z = ((w >> 8) & FMASK) | MAGIC; bf.w = ((w >> 12) & FMASK) | MAGIC;
         }
+        const int aoff = (IL ? t * H + h : h * UPL + t) * 16;
+        const bool first = t % SPG == 0;            // first step of a group: the accumulator tile restarts from zero
         if constexpr (TNW == 32) {
-          const u32x4 af = *reinterpret_cast<const u32x4*>(slab + r * XROW + (h * UPL + t) * 16);
-          g32 = mfma<BF16>(af, bf, t == 0 ? f32x16{0} : g32);
+          const u32x4 af = *reinterpret_cast<const u32x4*>(slab + r * XROW + aoff);
+          g32 = mfma<BF16>(af, bf, first ? f32x16{0} : g32);
         } else {
 #pragma unroll
           for (int i = 0; i < MT; ++i) {
-            const u32x4 af = *reinterpret_cast<const u32x4*>(slab + (i * TNW + r) * XROW + (h * UPL + t) * 16);
-            g16[i] = mfma16<BF16>(af, bf, t == 0 ? f32x4v{0} : g16[i]);
+            const u32x4 af = *reinterpret_cast<const u32x4*>(slab + (i * TNW + r) * XROW + aoff);
+            g16[i] = mfma16<BF16>(af, bf, first ? f32x4v{0} : g16[i]);
           }
         }
-      }
-      // group flush: acc += s * t + (z - C s) * xsum[row]
-      const float* xsm = xsum + (buf * 8 + cs) * 32;
-      if constexpr (TNW == 32) {
+        if (t % SPG == SPG - 1) {                   // group flush: acc += s * t + (z - C s) * xsum[row]
+          const int gi = t / SPG, si = j * NF + gi;  // group inside the chunk; its scale / zero inside the step
+          const unsigned sw = sc_c[si >> 1], zw = ze_c[si >> 1];
+          const float s = act_to_f32<BF16>(static_cast<unsigned short>((si & 1) ? (sw >> 16) : (sw & 0xFFFFu)));
+          const float zz = act_to_f32<BF16>(static_cast<unsigned short>((si & 1) ? (zw >> 16) : (zw & 0xFFFFu))) - CF * s;
+          const float* xsm = xsum + ((buf * 8 + cs) * NF + gi) * 32;
+          if constexpr (TNW == 32) {
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const f32x4v xv = *reinterpret_cast<const f32x4v*>(xsm + 8 * jj + 4 * (lane >> 5));
+            for (int jj = 0; jj < 4; ++jj) {
+              const f32x4v xv = *reinterpret_cast<const f32x4v*>(xsm + 8 * jj + 4 * (lane >> 5));
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc32[0][4 * jj + e] = fmaf(s, g32[4 * jj + e], fmaf(zz, xv[e], acc32[0][4 * jj + e]));
-        }
-      } else {
+              for (int e = 0; e < 4; ++e) acc32[0][4 * jj + e] = fmaf(s, g32[4 * jj + e], fmaf(zz, xv[e], acc32[0][4 * jj + e]));
+            }
+          } else {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const f32x4v xv = *reinterpret_cast<const f32x4v*>(xsm + i * 16 + 4 * (lane >> 4));
+            for (int i = 0; i < MT; ++i) {
+              const f32x4v xv = *reinterpret_cast<const f32x4v*>(xsm + i * 16 + 4 * (lane >> 4));
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc16[i][e] = fmaf(s, g16[i][e], fmaf(zz, xv[e], acc16[i][e]));
+              for (int e = 0; e < 4; ++e) acc16[i][e] = fmaf(s, g16[i][e], fmaf(zz, xv[e], acc16[i][e]));
+            }
+          }
         }
       }
     }
@@ -354,6 +381,18 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
 #endif
 }
 
+template <int BITS, int TNW, int NG, int KG, int GRP>
+static hipError_t launch_batch_grp(const MfmaArgs& a, bool bf16, hipStream_t s);
+
+template <int BITS, int TNW, int NG, int KG>
+static hipError_t launch_batch_cfg(const MfmaArgs& a, bool bf16, hipStream_t s) {
+  if constexpr (BITS == 2) {
+    if (a.log2g == 6) return launch_batch_grp<BITS, TNW, NG, KG, 64>(a, bf16, s);
+    if (a.log2g == 5) return launch_batch_grp<BITS, TNW, NG, KG, 32>(a, bf16, s);
+  }
+  return launch_batch_grp<BITS, TNW, NG, KG, 128>(a, bf16, s);
+}
+
 // second launch of a k-split GEMM: y = round(sum of the slices) (+ bias as a second rounding); 4 outputs per thread
 template <bool BF16>
 __global__ __launch_bounds__(256) void batch_finish_kernel(const float* __restrict__ ws, const unsigned short* __restrict__ bias,
@@ -376,14 +415,14 @@ __global__ __launch_bounds__(256) void batch_finish_kernel(const float* __restri
                                           static_cast<unsigned>(o[2]) | (static_cast<unsigned>(o[3]) << 16)};
 }
 
-template <int BITS, int TNW, int NG, int KG>
-static hipError_t launch_batch_cfg(const MfmaArgs& a, bool bf16, hipStream_t s) {
+template <int BITS, int TNW, int NG, int KG, int GRP>
+static hipError_t launch_batch_grp(const MfmaArgs& a, bool bf16, hipStream_t s) {
   constexpr int ROWS = NG * TNW;
-  constexpr int SHMEM = 2 * 8 * 32 * XROW + 2 * 8 * 32 * 4;
+  constexpr int SHMEM = 2 * 8 * 32 * XROW + 2 * 8 * (128 / GRP) * 32 * 4;
   static bool done[2] = {false, false};
   if (!done[bf16]) {
-    hipError_t e = bf16 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&qgemm_batch_kernel<BITS, TNW, NG, KG, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM)
-                        : hipFuncSetAttribute(reinterpret_cast<const void*>(&qgemm_batch_kernel<BITS, TNW, NG, KG, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
+    hipError_t e = bf16 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&qgemm_batch_kernel<BITS, TNW, NG, KG, GRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM)
+                        : hipFuncSetAttribute(reinterpret_cast<const void*>(&qgemm_batch_kernel<BITS, TNW, NG, KG, GRP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
     if (e != hipSuccess) return e;
     done[bf16] = true;
   }
@@ -392,8 +431,8 @@ static hipError_t launch_batch_cfg(const MfmaArgs& a, bool bf16, hipStream_t s) 
   long long* sp = reinterpret_cast<long long*>(strtoull(getenv("GBX_STAMP_PTR") ? getenv("GBX_STAMP_PTR") : "0", nullptr, 0));
   (void)hipMemcpyToSymbol(HIP_SYMBOL(bx_stamp_ptr), &sp, sizeof(sp));
 #endif
-  if (bf16) hipLaunchKernelGGL((qgemm_batch_kernel<BITS, TNW, NG, KG, true>), grid, block, SHMEM, s, a);
-  else hipLaunchKernelGGL((qgemm_batch_kernel<BITS, TNW, NG, KG, false>), grid, block, SHMEM, s, a);
+  if (bf16) hipLaunchKernelGGL((qgemm_batch_kernel<BITS, TNW, NG, KG, GRP, true>), grid, block, SHMEM, s, a);
+  else hipLaunchKernelGGL((qgemm_batch_kernel<BITS, TNW, NG, KG, GRP, false>), grid, block, SHMEM, s, a);
   return hipGetLastError();
 }
 
@@ -411,7 +450,7 @@ static int batch_ksplit(int N, int K, int nseg) {
 }
 
 size_t qgemm_batch_workspace_bytes(int M, int N, int K, int bits, int log2g) {
-  if (!qgemm_batch_supported(M < 32 ? M : 32, K, bits, log2g)) return 0;
+  if (log2g != 7 || !qgemm_batch_supported(M < 32 ? M : 32, K, bits, log2g)) return 0;   // (the split runs the 128-row shape)
   const int s = batch_ksplit(N, K, 1);
   return s > 1 ? static_cast<size_t>(s) * M * N * sizeof(float) : 0;
 }
@@ -420,7 +459,7 @@ size_t qgemm_batch_workspace_bytes(int M, int N, int K, int bits, int log2g) {
 template <int BITS>
 static hipError_t launch_batch_bits(const MfmaArgs& a0, bool bf16, hipStream_t s) {
   MfmaArgs a = a0;
-  a.ksplit = a.ws ? batch_ksplit(a.N, a.K, a.nseg) : 1;
+  a.ksplit = (a.ws && a.log2g == 7) ? batch_ksplit(a.N, a.K, a.nseg) : 1;
   if (a.ksplit <= 1) a.ws = nullptr;
   if (a.ws) {                                       // 128-row workgroups x ksplit slices, then the summing launch
     hipError_t e = launch_batch_cfg<BITS, 32, 4, 2>(a, bf16, s);
@@ -434,6 +473,7 @@ static hipError_t launch_batch_bits(const MfmaArgs& a0, bool bf16, hipStream_t s
   int rows = a.N >= 128 * 192 ? 128 : a.N >= 64 * 192 ? 64 : a.N >= 32 * 160 ? 32 : 16;
   static const int forced = [] { const char* e = getenv("GBX_BATCH_ROWS"); return e ? atoi(e) : 0; }();
   if (forced) rows = forced;
+  if (a.log2g < 7 && rows == 128) rows = 64;        // small groups: twice the packed words per lane -- the 128-row shape spills
   for (int i = 0; i < (a.nseg > 1 ? a.nseg : 0); ++i)
     while (a.n_seg[i] % rows) rows >>= 1;
   if (rows < 16) return hipErrorInvalidValue;
@@ -446,7 +486,7 @@ static hipError_t launch_batch_bits(const MfmaArgs& a0, bool bf16, hipStream_t s
 }
 
 bool qgemm_batch_supported(int M, int K, int bits, int log2g) {
-  return M >= 1 && M <= 32 && bits >= 2 && bits <= 4 && log2g == 7 && K % 1024 == 0;
+  return M >= 1 && M <= 32 && bits >= 2 && bits <= 4 && (log2g == 7 || (bits == 2 && (log2g == 6 || log2g == 5))) && K % 1024 == 0;
 }
 
 hipError_t launch_qgemm_batch(const MfmaArgs& a, int bits, bool bf16, hipStream_t s) {

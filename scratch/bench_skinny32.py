@@ -3,7 +3,7 @@ import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gbx_lm_amd import ops
 dev = 'cuda:0'
-def run(m, n, k, b, g=128, iters=50):
+def run(m, n, k, b, g=int(os.environ.get('GROUP', '128')), iters=50):
     copies = max(2, int(600e6 // (n * k * b // 8)) + 1)
     ws = []
     for _ in range(copies):

@@ -222,6 +222,23 @@ def test_batch_kernel_no_dequant(ops, oracle, c_oracle, bits, dt, m, n, k):
     oracle.assert_close(y, y64, dt, f"batch M={m} N={n} K={k} b{bits} {dt}")
 
 
+@pytest.mark.parametrize("g", [64, 32])
+@pytest.mark.parametrize("m,n,k", [(32, 24576, 1024), (9, 12288, 2048), (16, 6144, 3072), (5, 4096, 4096), (32, 1000, 1024),
+                                   (20, 4096, 14336)])
+def test_batch_kernel_small_groups(ops, oracle, c_oracle, g, m, n, k):
+    """2-bit weights with groups of 64 / 32 on the no-dequant kernel: the k assignment is interleaved so that every MFMA
+    step stays inside one group, 2 / 4 affine flushes per chunk; every workgroup shape, ragged N."""
+    for dt in ("bf16", "f16"):
+        d = oracle.synth_layer(n, k, 2, g, seed=m + g + n % 11, m=m, act_dtype=dt)
+        x = d["x"].clone()
+        x[0, 37] = -70.0
+        d["x"] = x
+        dd = _dev(d)
+        y = ops.quantized_matmul(dd["x"], dd["qweight"], dd["scales"], dd["zeros"], group_size=g, bits=2)
+        y64 = c_oracle.qlinear(d["x"], d["qweight"], d["scales"], d["zeros"], 2, g, acc64=True)
+        oracle.assert_close(y, y64, dt, f"batch g{g} M={m} N={n} K={k} {dt}")
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("n,k", [(4096, 4096), (130, 1024), (1000, 2048), (4096, 14336), (28672, 4096)])
 def test_tiled_matrix_core_gemv(ops, oracle, c_oracle, dt, n, k):
