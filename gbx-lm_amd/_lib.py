@@ -49,6 +49,7 @@ def lib() -> ctypes.CDLL:
         L.gbx_qlinear_forward_ws.argtypes = [p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, p, ctypes.c_size_t, p]
         L.gbx_unpack.argtypes = [p, p, i32, i32, i32, p]
         L.gbx_dequantize.argtypes = [p, p, p, p, i32, i32, i32, i32, i32, i32, p]
+        L.gbx_logprobs_workspace_bytes.restype = ctypes.c_size_t
         _declare_optional(L)
         _lib = L
     return _lib
@@ -80,6 +81,7 @@ def _declare_optional(L) -> None:
         "gbx_moe_combine": [p, p, p, i64, i32, i32, i32, p],
         "gbx_moe_combine_residual": [p, p, p, p, i64, i32, i32, i32, p],
         "gbx_kv_append": [p, p, p, p, p, i64, i32, i32, i32, i32, p],
+        "gbx_logprobs_argmax": [p, p, p, p, i32, i32, p],
         "gbx_add_rmsnorm": [p, p, p, p, i64, i32, f32, i32, p],
         "gbx_swiglu": [p, p, p, i64, i32, p],
         "gbx_dense_gemv": [p, p, p, p, f32, i32, i32, i32, p],

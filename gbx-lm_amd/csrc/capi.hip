@@ -509,6 +509,22 @@ int gbx_kv_append(const void* k, const void* v, void* kcache, void* vcache, cons
   return GBX_OK;
 }
 
+size_t gbx_logprobs_workspace_bytes(void) { return 128 * 8 + 16; }
+
+int gbx_logprobs_argmax(const void* logits, void* logprobs, int64_t* token, void* workspace, int32_t vocab, int32_t act_dtype,
+                        void* hip_stream) {
+  if (!logits || !logprobs || !token || !workspace) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (vocab <= 0) return fail(GBX_ERR_INVALID, "vocab must be positive (got %d)", vocab);
+  if (!aligned(workspace, 8)) return fail(GBX_ERR_INVALID, "workspace must be 8-byte aligned");
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  char* ws = static_cast<char*>(workspace);
+  hipError_t e = gbx::launch_logprobs_argmax(logits, logprobs, ws, reinterpret_cast<unsigned long long*>(ws + 128 * 8),
+                                             reinterpret_cast<long long*>(token), vocab, act_dtype == GBX_BF16,
+                                             static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_logprobs_argmax launch");
+  return GBX_OK;
+}
+
 int gbx_add_rmsnorm(void* h, const void* delta, const void* w, void* y, int64_t M, int32_t K, float eps, int32_t act_dtype,
                     void* hip_stream) {
   if (M == 0) return GBX_OK;

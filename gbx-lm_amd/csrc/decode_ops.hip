@@ -689,6 +689,88 @@ hipError_t launch_dense_gemv(const void* x, const void* w, void* y, const void* 
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ logprobs + greedy token
+// The tail of a generate_step (gbx_lm/utils.py:305-306,285): logprobs = logits - logsumexp(logits) and, for the default
+// sampler, token = argmax(logprobs) -- three launches over the vocabulary instead of torch's reductions (~100 us per token
+// at V = 128 K): (1) per-workgroup (max, sum exp) partials, (2) every workgroup folds the partials into the fp32
+// logsumexp, rounds it to the activation dtype like `.astype(logits.dtype)`, writes its slice of logprobs (activation-dtype
+// subtraction) and bids its slice's best (value, lowest index) into one 64-bit key, (3) one thread turns the key into the
+// int64 token.
+constexpr int LP_WGS = 128;
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void logprob_partials_kernel(const unsigned short* __restrict__ logits, float2* __restrict__ part,
+                                                               unsigned long long* __restrict__ key, int V) {
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (blockIdx.x == 0 && tid == 0) *key = 0ull;
+  const int per = (V + LP_WGS - 1) / LP_WGS, lo = blockIdx.x * per, hi = min(lo + per, V);
+  float m = -3.0e38f;
+  for (int i = lo + tid; i < hi; i += 256) m = fmaxf(m, act_to_f32<BF16>(logits[i]));
+  m = key2f(wave_max_u32(f2key(m)));
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int i = lo + tid; i < hi; i += 256) sum += __expf(act_to_f32<BF16>(logits[i]) - m);
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  if (tid == 0) part[blockIdx.x] = float2{m, (red[4] + red[5]) + (red[6] + red[7])};
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void logprob_write_kernel(const unsigned short* __restrict__ logits, const float2* __restrict__ part,
+                                                            unsigned short* __restrict__ logprobs, unsigned long long* __restrict__ key,
+                                                            int V) {
+  __shared__ unsigned long long best[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // fold the partials (every workgroup repeats it: 128 pairs)
+  float M = -3.0e38f;
+  for (int g = 0; g < LP_WGS; ++g) M = fmaxf(M, part[g].x);
+  float S = 0.f;
+  for (int g = 0; g < LP_WGS; ++g) S += part[g].y * __expf(part[g].x - M);
+  const float lse = act_to_f32<BF16>(f32_to_act<BF16>(M + __logf(S)));
+  const int per = (V + LP_WGS - 1) / LP_WGS, lo = blockIdx.x * per, hi = min(lo + per, V);
+  unsigned long long k = 0ull;
+  for (int i = lo + tid; i < hi; i += 256) {
+    const unsigned short o = f32_to_act<BF16>(act_to_f32<BF16>(logits[i]) - lse);
+    logprobs[i] = o;
+    const unsigned long long c = (static_cast<unsigned long long>(f2key(act_to_f32<BF16>(o))) << 32) | static_cast<unsigned>(~i);
+    k = c > k ? c : k;                                // larger value first, then the smaller index
+  }
+  // wave max of a 64-bit key: high word first, then the low word among the lanes that hold that high word
+  const unsigned hi32 = wave_max_u32(static_cast<unsigned>(k >> 32));
+  const unsigned lo32 = wave_max_u32(static_cast<unsigned>(k >> 32) == hi32 ? static_cast<unsigned>(k) : 0u);
+  if (lane == 0) best[wave] = (static_cast<unsigned long long>(hi32) << 32) | lo32;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long b = best[0];
+    for (int w = 1; w < 4; ++w) b = best[w] > b ? best[w] : b;
+    if (hi > lo) atomicMax(key, b);
+  }
+}
+
+__global__ void logprob_token_kernel(const unsigned long long* __restrict__ key, long long* __restrict__ token) {
+  *token = static_cast<long long>(~static_cast<unsigned>(*key));
+}
+
+hipError_t launch_logprobs_argmax(const void* logits, void* logprobs, void* partials, unsigned long long* key, long long* token,
+                                  int V, bool bf16, hipStream_t s) {
+  auto L = static_cast<const unsigned short*>(logits);
+  auto O = static_cast<unsigned short*>(logprobs);
+  auto P = static_cast<float2*>(partials);
+  if (bf16) {
+    hipLaunchKernelGGL((logprob_partials_kernel<true>), dim3(LP_WGS), dim3(256), 0, s, L, P, key, V);
+    hipLaunchKernelGGL((logprob_write_kernel<true>), dim3(LP_WGS), dim3(256), 0, s, L, P, O, key, V);
+  } else {
+    hipLaunchKernelGGL((logprob_partials_kernel<false>), dim3(LP_WGS), dim3(256), 0, s, L, P, key, V);
+    hipLaunchKernelGGL((logprob_write_kernel<false>), dim3(LP_WGS), dim3(256), 0, s, L, P, O, key, V);
+  }
+  hipLaunchKernelGGL(logprob_token_kernel, dim3(1), dim3(1), 0, s, key, token);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ RMSNorm (standalone)
 template <bool BF16>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,

@@ -70,6 +70,15 @@ __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_f32<0x143, 0xC>(v);   // row_bcast31 into rows 2,3 -> lane 63 holds the total
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// order-preserving map float -> uint (so that the DPP integer max serves floats of either sign) and back
+__device__ __forceinline__ unsigned f2key(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
 // Sums of TWO accumulators at once: v_permlane32_swap folds the wave in half (lanes 0-31 carry `a`, lanes 32-63 carry
 // `b`), four DPP steps finish the 16-lane rows, row_bcast15 joins the two rows of each half.
 // Result: a's total in lanes 16..31, b's total in lanes 48..63 (callers read lane 31 / lane 63).

@@ -11,15 +11,6 @@
 
 namespace gbx {
 
-// order-preserving map float -> uint (so that the DPP integer max of gbx_device.h serves floats of either sign)
-__device__ __forceinline__ unsigned f2key(float f) {
-  const unsigned u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float key2f(unsigned k) {
-  return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
-}
-
 template <bool BF16, int VPL>
 __global__ __launch_bounds__(64) void moe_route_kernel(const unsigned short* __restrict__ logits, int* __restrict__ inds,
                                                        unsigned short* __restrict__ scores, int E, int k, int mode, int renorm) {

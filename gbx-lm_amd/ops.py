@@ -420,6 +420,22 @@ def kv_append(kcache: torch.Tensor, vcache: torch.Tensor, k: torch.Tensor, v: to
                                         b * h, cap, dk, vcache.shape[3], _DT[k.dtype], _stream_ptr(k.device)))
 
 
+def logprobs_argmax(logits: torch.Tensor):
+    """(logits - logsumexp(logits), argmax) for one row of logits [1, V] or [V] on the device (gbx_logprobs_argmax):
+    returns (logprobs with the shape of ``logits``, token int64 [1])."""
+    _require_cuda(logits, "logits")
+    lg = logits.contiguous()
+    v = lg.shape[-1]
+    assert lg.numel() == v, "one row of logits"
+    L = _lib.lib()
+    out = torch.empty_like(lg)
+    token = torch.empty((1,), dtype=torch.int64, device=lg.device)
+    ws = torch.empty((L.gbx_logprobs_workspace_bytes(),), dtype=torch.uint8, device=lg.device)
+    _lib.check(L.gbx_logprobs_argmax(lg.data_ptr(), out.data_ptr(), token.data_ptr(), ws.data_ptr(), v, _DT[lg.dtype],
+                                     _stream_ptr(lg.device)))
+    return out, token
+
+
 def add_rmsnorm(h: torch.Tensor, delta: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
     """h += delta in place (activation-dtype add), returns RMSNorm(h) * w -- one launch (gbx_add_rmsnorm)."""
     _require_cuda(h, "h")

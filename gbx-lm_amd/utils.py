@@ -257,6 +257,7 @@ def generate_step(prompt: torch.Tensor, model: nn.Module, *, max_tokens: int = 2
     elif len(prompt_cache) != len(model.layers):
         raise ValueError("Wrong number of layers in the prompt cache.")
     prompt_progress_callback = prompt_progress_callback or (lambda *_: None)
+    default_sampler = sampler is None                     # greedy (utils.py:285): token and logprobs can come from one device op
     sampler = sampler or (lambda x: torch.argmax(x, dim=-1))
     fast_decode = getattr(model, "decode_step", None) if not logits_processors else None
 
@@ -275,6 +276,10 @@ def generate_step(prompt: torch.Tensor, model: nn.Module, *, max_tokens: int = 2
             tokens = torch.cat([tokens, y]) if tokens is not None else y
             for processor in logits_processors:
                 logits = processor(tokens, logits)
+        if default_sampler and logits.is_cuda and logits.shape[0] == 1 and logits.dtype in (torch.bfloat16, torch.float16):
+            from . import ops                                     # logsumexp, subtraction and argmax in three small launches
+            logprobs, y = ops.logprobs_argmax(logits)
+            return y.reshape(-1), logprobs.squeeze(0), prompt_hidden_states
         logprobs = logits - torch.logsumexp(logits.float(), dim=-1, keepdim=True).to(logits.dtype)
         y = sampler(logprobs)
         return y.reshape(-1), logprobs.squeeze(0), prompt_hidden_states

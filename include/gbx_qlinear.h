@@ -265,6 +265,14 @@ int gbx_moe_combine_residual(const void* y, const void* scores, const void* resi
 int gbx_kv_append(const void* k, const void* v, void* kcache, void* vcache, const int64_t* pos, int64_t rows, int32_t capacity,
                   int32_t k_dim, int32_t v_dim, int32_t act_dtype, void* hip_stream);
 
+/* The tail of one generate_step (gbx_lm/utils.py:305-306 and the default sampler, :285): logprobs[vocab] = logits -
+ * logsumexp(logits) (fp32 logsumexp rounded to the activation dtype, activation-dtype subtraction) and *token =
+ * argmax(logprobs) (lowest index on ties) -- three small launches, nothing leaves the device.  `workspace`: caller-owned
+ * scratch of gbx_logprobs_workspace_bytes() bytes (8-byte aligned). */
+size_t gbx_logprobs_workspace_bytes(void);
+int gbx_logprobs_argmax(const void* logits, void* logprobs, int64_t* token, void* workspace, int32_t vocab, int32_t act_dtype,
+                        void* hip_stream);
+
 /* Residual add + RMSNorm in one launch: h[M, K] <- h + delta (one rounding to the activation dtype, the add of
  * qllama.py:138-140), y = RMSNorm(h) * w.  h is updated in place; y may not alias h. */
 int gbx_add_rmsnorm(void* h, const void* delta, const void* w, void* y, int64_t M, int32_t K, float eps, int32_t act_dtype,

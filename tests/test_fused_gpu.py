@@ -210,6 +210,27 @@ def test_attn_cached_matches_torch(hd, nh, nkv):
     assert out.shape == q.shape and torch.allclose(out.float().cpu(), want, atol=2e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_logprobs_argmax_matches_torch(dt):
+    """gbx_logprobs_argmax against the two torch ops of generate_step (utils.py:305-306,285), vocabulary sizes that do and
+    do not divide by the workgroup count, a tie (lowest index wins) and a dominant token."""
+    from gbx_lm_amd import ops
+    g = torch.Generator().manual_seed(8)
+    for v in (128256, 32000, 517, 100):
+        lg = (3 * torch.randn(1, v, generator=g)).to(dt)
+        lg[0, v // 3] = lg.max()                                   # a tie with an earlier / later index
+        want_lp = lg - torch.logsumexp(lg.float(), -1, keepdim=True).to(dt)
+        lp, tok = ops.logprobs_argmax(lg.to(DEV))
+        assert lp.shape == lg.shape and tok.dtype == torch.int64 and tok.shape == (1,)
+        ulp = 2.0 ** (-7 if dt == torch.bfloat16 else -10)
+        assert torch.allclose(lp.float().cpu(), want_lp.float(), rtol=2 * ulp, atol=2 * ulp * want_lp.float().abs().max().item())
+        assert int(tok) == int(torch.argmax(lp.cpu(), -1))         # first maximum of what the kernel itself wrote
+        assert lp.float().cpu()[0, int(tok)] == lp.float().cpu().max()
+    peaked = torch.full((1, 4096), -20.0).to(dt); peaked[0, 77] = 9.0
+    lp, tok = ops.logprobs_argmax(peaked.to(DEV))
+    assert int(tok) == 77 and abs(float(lp[0, 77])) < 1e-2
+
+
 def test_kv_append_and_single_token_multi_matrix(oracle):
     """gbx_kv_append writes exactly one position of both caches (different k / v widths); quantized_matmul_multi at
     one token (the multi-segment decode GEMV) equals one call per module bit for bit."""
