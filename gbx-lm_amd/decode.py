@@ -58,12 +58,18 @@ class DecodeRunner:
             x = ops.rmsnorm(h, norm.weight, norm.eps) if delta is None else ops.add_rmsnorm(h, delta, norm.weight, norm.eps)
             q, k, v = (t.reshape(B, -1) for t in ops.quantized_matmul_multi(x, (at.q_proj, at.k_proj, at.v_proj)))
             full_rope = at.rope.inv_freq.numel() * 2 == self.hd and c.keys.is_contiguous() and c.values.is_contiguous()
-            if full_rope and self.hd in (64, 128):
-                # one launch per layer: RoPE(q, k) + cache append + softmax(q k^T) v for every sequence
+            qn, kn = getattr(at, "q_norm", None), getattr(at, "k_norm", None)       # Qwen3: per-head norms before RoPE
+            if full_rope and self.hd in (64, 128) and type(at.rope).__name__ in ("RoPE", "Llama3RoPE"):
+                # one launch per layer: (q / k norm +) RoPE(q, k) + cache append + softmax(q k^T) v for every sequence
                 o = torch.empty_like(q)
                 ops.attn_decode_batched(q, k, v, c.keys, c.values, at.rope.inv_freq, pos, o, self.n_heads, self.n_kv, self.hd,
-                                        getattr(at.rope, "scale", 1.0), at.scale, at.rope.traditional)
+                                        getattr(at.rope, "scale", 1.0), at.scale, at.rope.traditional,
+                                        qn.weight if qn is not None else None, kn.weight if kn is not None else None,
+                                        qn.eps if qn is not None else 0.0)
             else:
+                if qn is not None:
+                    q = qn(q.reshape(B, self.n_heads, self.hd)).reshape(B, -1)
+                    k = kn(k.reshape(B, self.n_kv, self.hd)).reshape(B, -1)
                 if full_rope:
                     ops.rope_append(q, k, v, c.keys, c.values, at.rope.inv_freq, pos, self.n_heads, self.n_kv, self.hd,
                                     getattr(at.rope, "scale", 1.0), at.rope.traditional)

@@ -85,7 +85,8 @@ def test_load_and_generate_text(tmp_path):
     assert rs[-1].finish_reason in ("length", "stop") and rs[-1].generation_tps > 0 and rs[-1].peak_memory > 0
 
 
-def test_batched_decode_runner_matches_per_sequence_eager():
+@pytest.mark.parametrize("family", ["llama", "qwen3", "qwen2"])
+def test_batched_decode_runner_matches_per_sequence_eager(family):
     """Synchronous batched decode (B = 4 sequences at the same position) through the graph-replayed runner: every
     sequence's logits equal the eager single-batch forward of that sequence fed the same tokens (QuantizedLinear runs
     the split-K MFMA kernel at M = 4 and the GEMV at M = 1: both within the oracle tolerance of each other)."""
@@ -94,7 +95,7 @@ def test_batched_decode_runner_matches_per_sequence_eager():
     from gbx_lm_amd.decode import DecodeRunner
     from gbx_lm_amd.models.cache import make_prompt_cache
     dev = torch.device("cuda:0")
-    cfg = dict(S.TINY)
+    cfg = dict({"llama": S.TINY, "qwen3": S.TINY_QWEN3, "qwen2": S.TINY_QWEN2}[family])   # per-head norms / q,k,v biases
     model = S.build_model(cfg, S.make_strategy("S22", cfg["num_hidden_layers"], 64), device=dev, seed=3)
     B, ctx, steps = 4, 9, 6
     toks = torch.randint(0, cfg["vocab_size"], (B, ctx), device=dev)
