@@ -54,8 +54,10 @@ int gbx_qlinear_check(int64_t M, int32_t N, int32_t K, int32_t bits, int32_t gro
 }
 
 size_t gbx_qlinear_workspace_bytes(int64_t M, int32_t N, int32_t K, int32_t bits, int32_t group_size) {
-  if (check_shape(M, N, K, bits, group_size) != GBX_OK || M < 2 || M > 32) return 0;
-  return gbx::qgemm_batch_workspace_bytes(static_cast<int>(M), N, K, bits, log2_group(group_size));
+  if (check_shape(M, N, K, bits, group_size) != GBX_OK || M < 2) return 0;
+  if (M <= 32) return gbx::qgemm_batch_workspace_bytes(static_cast<int>(M), N, K, bits, log2_group(group_size));
+  if (M > 64 && (K % 128) == 0) return gbx::qgemm_prefill_workspace_bytes(static_cast<int>(M), N, K);
+  return 0;
 }
 
 int gbx_qlinear_forward(const void* x, const uint32_t* qweight, const void* scales, const void* zeros,
@@ -90,7 +92,10 @@ int gbx_qlinear_forward_ws(const void* x, const uint32_t* qweight, const void* s
     if (workspace && need && workspace_bytes >= need && aligned(workspace, 16)) ws = static_cast<float*>(workspace);
     e = gbx::launch_qgemm_skinny(x, qweight, scales, zeros, bias, y, static_cast<int>(M), N, K, bits, log2g, bf16, stream, ws);
   } else if (!force_generic && M > 1 && (K % 128) == 0) {
-    e = gbx::launch_qgemm_mfma(x, qweight, scales, zeros, bias, y, static_cast<int>(M), N, K, bits, log2g, bf16, stream);
+    float* ws = nullptr;                            // short prompts: k split across workgroups when the caller brought scratch
+    const size_t need = gbx::qgemm_prefill_workspace_bytes(static_cast<int>(M), N, K);
+    if (workspace && need && workspace_bytes >= need && aligned(workspace, 16)) ws = static_cast<float*>(workspace);
+    e = gbx::launch_qgemm_mfma(x, qweight, scales, zeros, bias, y, static_cast<int>(M), N, K, bits, log2g, bf16, stream, ws);
   } else if (!force_generic && (K % 128) == 0 && K <= max_k) {
     gbx::GemvArgs a{};
     a.x = x;

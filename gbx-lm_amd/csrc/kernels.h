@@ -18,8 +18,9 @@ hipError_t launch_qlinear_generic(const void* x, const uint32_t* qw, const void*
                                   void* y, int M, int N, int K, int bits, int log2g, bool bf16, hipStream_t s);
 
 hipError_t launch_qgemm_mfma(const void* x, const uint32_t* qw, const void* sc, const void* ze, const void* bias, void* y,
-                             int M, int N, int K, int bits, int log2g, bool bf16, hipStream_t s);
+                             int M, int N, int K, int bits, int log2g, bool bf16, hipStream_t s, float* ws = nullptr);
 size_t qgemm_batch_workspace_bytes(int M, int N, int K, int bits, int log2g);
+size_t qgemm_prefill_workspace_bytes(int M, int N, int K);
 hipError_t launch_qgemm_skinny(const void* x, const uint32_t* qw, const void* sc, const void* ze, const void* bias, void* y,
                                int M, int N, int K, int bits, int log2g, bool bf16, hipStream_t s, float* ws = nullptr);
 hipError_t launch_qgemm_skinny_multi(const void* x, int nseg, const uint32_t* const* qw, const void* const* sc, const void* const* ze,

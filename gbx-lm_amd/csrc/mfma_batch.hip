@@ -464,11 +464,7 @@ static hipError_t launch_batch_bits(const MfmaArgs& a0, bool bf16, hipStream_t s
   if (a.ws) {                                       // 128-row workgroups x ksplit slices, then the summing launch
     hipError_t e = launch_batch_cfg<BITS, 32, 4, 2>(a, bf16, s);
     if (e != hipSuccess) return e;
-    const long long mn = static_cast<long long>(a.M) * a.N;
-    const unsigned blocks = static_cast<unsigned>((mn / 4 + 255) / 256);
-    if (bf16) hipLaunchKernelGGL((batch_finish_kernel<true>), dim3(blocks), dim3(256), 0, s, a.ws, a.bias, a.y, a.ksplit, mn, a.N);
-    else hipLaunchKernelGGL((batch_finish_kernel<false>), dim3(blocks), dim3(256), 0, s, a.ws, a.bias, a.y, a.ksplit, mn, a.N);
-    return hipGetLastError();
+    return launch_splitk_finish(a.ws, a.bias, a.y, a.ksplit, a.M, a.N, bf16, s);
   }
   int rows = a.N >= 128 * 192 ? 128 : a.N >= 64 * 192 ? 64 : a.N >= 32 * 160 ? 32 : 16;
   static const int forced = [] { const char* e = getenv("GBX_BATCH_ROWS"); return e ? atoi(e) : 0; }();
@@ -483,6 +479,15 @@ static hipError_t launch_batch_bits(const MfmaArgs& a0, bool bf16, hipStream_t s
     case 32: return launch_batch_cfg<BITS, 16, 2, 4>(a, bf16, s);
     default: return launch_batch_cfg<BITS, 16, 1, 8>(a, bf16, s);
   }
+}
+
+hipError_t launch_splitk_finish(const float* ws, const unsigned short* bias, unsigned short* y, int slices, int M, int N, bool bf16,
+                                hipStream_t s) {
+  const long long mn = static_cast<long long>(M) * N;       // N % 4 == 0 (callers)
+  const unsigned blocks = static_cast<unsigned>((mn / 4 + 255) / 256);
+  if (bf16) hipLaunchKernelGGL((batch_finish_kernel<true>), dim3(blocks), dim3(256), 0, s, ws, bias, y, slices, mn, N);
+  else hipLaunchKernelGGL((batch_finish_kernel<false>), dim3(blocks), dim3(256), 0, s, ws, bias, y, slices, mn, N);
+  return hipGetLastError();
 }
 
 bool qgemm_batch_supported(int M, int K, int bits, int log2g) {

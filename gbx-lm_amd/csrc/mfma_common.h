@@ -37,6 +37,11 @@ struct MfmaArgs {
 // mfma_batch.hip: 2 <= M <= 32, 2/4 bits, group 128 (no-dequant matrix-core kernel); false -> use the split-K kernel
 bool qgemm_batch_supported(int M, int K, int bits, int log2g);
 hipError_t launch_qgemm_batch(const MfmaArgs& a, int bits, bool bf16, hipStream_t s);
+// second launch of a k-split GEMM: y = round(sum of the fp32 slices ws[slices][M][N]) (+ bias as a second rounding)
+hipError_t launch_splitk_finish(const float* ws, const unsigned short* bias, unsigned short* y, int slices, int M, int N, bool bf16,
+                                hipStream_t s);
+// same for the prefill tiling at short prompts (mfma_gemm.hip)
+size_t qgemm_prefill_workspace_bytes(int M, int N, int K);
 // fp32 workspace bytes with which launch_qgemm_batch splits k across workgroups (0: it would not)
 size_t qgemm_batch_workspace_bytes(int M, int N, int K, int bits, int log2g);
 

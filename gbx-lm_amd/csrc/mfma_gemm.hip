@@ -59,7 +59,10 @@ __global__ __launch_bounds__(WV * 64) void qgemm_prefill_kernel(const MfmaArgs a
   const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (tile >= tiles) return;
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * PBN;
-  const int nchunks = K / PKC;
+  // k split across workgroups (blockIdx.y; short prompts leave most CUs without a tile): this workgroup's chunk range
+  const int ksplit = a.ws ? a.ksplit : 1;
+  const int nchunks = K / PKC / ksplit;
+  const int kbase = blockIdx.y * nchunks * PKC;
 
   // B loader: unit u = tid*NU + j -> row u/2 of the tile, 32-value half u%2 of the chunk (NU = 2: the whole row chunk)
   const int brow = (tid * NU) >> 1, bhalf = (tid * NU) & 1;
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(WV * 64) void qgemm_prefill_kernel(const MfmaArgs a
   // every wave for ~1k cycles).  Part 0 carries the scales / zeros and packed words, every part a quarter of the
   // activation pieces.  Clamped: late prefetches re-read the final chunk.
   auto load_part = [&](int set, int c, int t) {
-    const int kc = min(c, nchunks - 1) * PKC;
+    const int kc = kbase + min(c, nchunks - 1) * PKC;
     if (t == 0) {
 #pragma unroll
       for (int j = 0; j < NU; ++j) {
@@ -225,8 +228,12 @@ __global__ __launch_bounds__(WV * 64) void qgemm_prefill_kernel(const MfmaArgs a
         const int m = m0 + (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;   // C/D layout of the 32x32 tile
         if (m < M) {
           float v = acc[i][j][e];
-          if (a.bias) v = act_to_f32<BF16>(f32_to_act<BF16>(v)) + b;
-          a.y[static_cast<size_t>(m) * N + n] = f32_to_act<BF16>(v);
+          if (ksplit > 1) {                         // fp32 partial of this k slice; launch_splitk_finish sums and rounds
+            a.ws[(static_cast<size_t>(blockIdx.y) * M + m) * N + n] = v;
+          } else {
+            if (a.bias) v = act_to_f32<BF16>(f32_to_act<BF16>(v)) + b;
+            a.y[static_cast<size_t>(m) * N + n] = f32_to_act<BF16>(v);
+          }
         }
       }
     }
@@ -237,7 +244,7 @@ template <int BITS, int MT, int NT, int WV>
 static hipError_t launch_prefill_cfg(const MfmaArgs& a, bool bf16, hipStream_t s) {
   constexpr int BM = 64 * MT, BN = 32 * NT * (WV / 2);
   const int tiles = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM);
-  dim3 grid(8 * ((tiles + 7) / 8)), block(WV * 64);          // 1-D: the kernel maps workgroup -> tile XCD-aware
+  dim3 grid(8 * ((tiles + 7) / 8), a.ws ? a.ksplit : 1), block(WV * 64);   // x: the kernel maps workgroup -> tile XCD-aware
   const size_t shmem = 2 * static_cast<size_t>(BM + BN) * PROW;
   if (shmem > 48 * 1024) {        // opt in to the large LDS carve-out once per instantiation
     static bool done[2] = {false, false};
@@ -253,8 +260,33 @@ static hipError_t launch_prefill_cfg(const MfmaArgs& a, bool bf16, hipStream_t s
   return hipGetLastError();
 }
 
+// Short prompts (65..~512 rows) give the 128 x 128 tiling only N/128 x M/128 workgroups, each walking all of K alone
+// (48 us for 4096 x 4096 at any M <= 512, 160 us for the down projection): with caller scratch the k range is split
+// over up to 8 workgroups per tile and a second launch sums the fp32 slices (mfma_batch.hip: launch_splitk_finish).
+static int prefill_ksplit(int M, int N, int K) {
+  const long tiles = static_cast<long>((M + 127) / 128) * ((N + 127) / 128);
+  if (M > 2048 || tiles > 128 || (N & 3)) return 1;   // (measured: beyond 128 tiles the split and its summing launch lose)
+  int best = 1;
+  for (int s = 2; s <= 8; s *= 2)
+    if ((K / PKC) % (2 * s) == 0 && tiles * s <= 512) best = s;
+  return best;
+}
+
+size_t qgemm_prefill_workspace_bytes(int M, int N, int K) {
+  const int s = prefill_ksplit(M, N, K);
+  return s > 1 ? static_cast<size_t>(s) * M * N * sizeof(float) : 0;
+}
+
 template <int BITS>
-static hipError_t launch_prefill_bits(const MfmaArgs& a, bool bf16, hipStream_t s) {
+static hipError_t launch_prefill_bits(const MfmaArgs& a0, bool bf16, hipStream_t s) {
+  MfmaArgs a = a0;
+  a.ksplit = a.ws ? prefill_ksplit(a.M, a.N, a.K) : 1;
+  if (a.ksplit <= 1) a.ws = nullptr;
+  if (a.ws) {
+    hipError_t e = launch_prefill_cfg<BITS, 2, 2, 4>(a, bf16, s);                                        // 128 x 128 x ksplit
+    if (e != hipSuccess) return e;
+    return launch_splitk_finish(a.ws, a.bias, a.y, a.ksplit, a.M, a.N, bf16, s);
+  }
   static const int force = getenv("GBX_PREFILL_TILE") ? atoi(getenv("GBX_PREFILL_TILE")) : 0;   // tuning aid: 1..4
   // the biggest tile that still gives every CU a workgroup: LDS bytes per flop fall with the tile
   const long t256 = static_cast<long>((a.M + 255) / 256) * ((a.N + 255) / 256);
@@ -266,8 +298,9 @@ static hipError_t launch_prefill_bits(const MfmaArgs& a, bool bf16, hipStream_t 
 }
 
 hipError_t launch_qgemm_mfma(const void* x, const uint32_t* qw, const void* sc, const void* ze, const void* bias, void* y,
-                             int M, int N, int K, int bits, int log2g, bool bf16, hipStream_t s) {
+                             int M, int N, int K, int bits, int log2g, bool bf16, hipStream_t s, float* ws) {
   MfmaArgs a{};
+  a.ws = ws;
   a.x = static_cast<const unsigned short*>(x); a.qweight = qw; a.scales = static_cast<const unsigned short*>(sc);
   a.zeros = static_cast<const unsigned short*>(ze); a.bias = static_cast<const unsigned short*>(bias);
   a.y = static_cast<unsigned short*>(y); a.M = M; a.N = N; a.K = K; a.log2g = log2g;

@@ -76,7 +76,8 @@ int gbx_qlinear_forward_ws(const void* x, const uint32_t* qweight, const void* s
                            int32_t group_size, int32_t act_dtype, void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /* Bytes of caller-provided scratch with which gbx_qlinear_forward_ws runs this shape faster (0: no use for it; today
- * non-zero for 2 <= M <= 32, 2/4 bits, group 128, N <= 8192 and K >= 8192). */
+ * non-zero for decode batches 2 <= M <= 32 on long-row projections -- group 128, N <= 8192, K >= 8192 -- and for short
+ * prompts, 64 < M <= 2048, whose 128 x 128 tiling would leave most of the chip idle). */
 size_t gbx_qlinear_workspace_bytes(int64_t M, int32_t N, int32_t K, int32_t bits, int32_t group_size);
 
 /* q[N,K] int32 = integer fields of qweight (kernel-side unpack dump; the bit-exact half of
