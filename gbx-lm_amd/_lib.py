@@ -50,6 +50,7 @@ def lib() -> ctypes.CDLL:
         L.gbx_unpack.argtypes = [p, p, i32, i32, i32, p]
         L.gbx_dequantize.argtypes = [p, p, p, p, i32, i32, i32, i32, i32, i32, p]
         L.gbx_logprobs_workspace_bytes.restype = ctypes.c_size_t
+        L.gbx_attn_workspace_bytes.restype = ctypes.c_size_t
         _declare_optional(L)
         _lib = L
     return _lib
@@ -76,6 +77,8 @@ def _declare_optional(L) -> None:
         "gbx_attn_decode": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, f32, f32, i32, i32, p],
         "gbx_attn_decode_batched": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, f32, i32, i32, p],
         "gbx_attn_decode_normed": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, f32, i32, p, p, f32, p, p, p, i32, p],
+        "gbx_attn_decode_ws": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, f32, i32, p, p, f32, p, p, p, i32, p, ctypes.c_size_t, p],
+        "gbx_attn_workspace_bytes": [i32, i32, i32, i32, i32],
         "gbx_attn_cached": [p, p, p, p, p, i32, i32, i32, i32, i32, f32, i32, p],
         "gbx_moe_route": [p, p, p, i64, i32, i32, i32, i32, i32, p],
         "gbx_moe_combine": [p, p, p, i64, i32, i32, i32, p],

@@ -349,6 +349,22 @@ int gbx_attn_decode_normed(const void* q, const void* k, const void* v, void* kc
                            int32_t head_dim, int32_t capacity, float rope_scale, float sm_scale, int32_t traditional,
                            const void* q_norm_weight, const void* k_norm_weight, float norm_eps, const void* q_bias,
                            const void* k_bias, const void* v_bias, int32_t act_dtype, void* hip_stream) {
+  return gbx_attn_decode_ws(q, k, v, kcache, vcache, inv_freq, pos, out, batch, n_heads, n_kv_heads, head_dim, capacity, rope_scale,
+                            sm_scale, traditional, q_norm_weight, k_norm_weight, norm_eps, q_bias, k_bias, v_bias, act_dtype, nullptr, 0,
+                            hip_stream);
+}
+
+size_t gbx_attn_workspace_bytes(int32_t batch, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int32_t capacity) {
+  if (batch <= 0 || n_heads <= 0 || n_kv_heads <= 0 || n_heads % n_kv_heads || capacity <= 0 || (head_dim != 64 && head_dim != 128)) return 0;
+  return gbx::attn_workspace_bytes(batch, n_heads, n_kv_heads, head_dim, capacity);
+}
+
+int gbx_attn_decode_ws(const void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
+                       const int64_t* pos, void* out, int32_t batch, int32_t n_heads, int32_t n_kv_heads,
+                       int32_t head_dim, int32_t capacity, float rope_scale, float sm_scale, int32_t traditional,
+                       const void* q_norm_weight, const void* k_norm_weight, float norm_eps, const void* q_bias,
+                       const void* k_bias, const void* v_bias, int32_t act_dtype, void* workspace, size_t workspace_bytes,
+                       void* hip_stream) {
   if ((q_norm_weight == nullptr) != (k_norm_weight == nullptr)) return fail(GBX_ERR_INVALID, "q and k norm weights come together");
   if ((q_bias == nullptr) != (k_bias == nullptr) || (q_bias == nullptr) != (v_bias == nullptr))
     return fail(GBX_ERR_INVALID, "q, k and v biases come together");
@@ -360,10 +376,15 @@ int gbx_attn_decode_normed(const void* q, const void* k, const void* v, void* kc
   if (capacity <= 0) return fail(GBX_ERR_INVALID, "capacity must be positive");
   if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
   if (!aligned(kcache, 16) || !aligned(vcache, 16)) return fail(GBX_ERR_INVALID, "KV cache must be 16-byte aligned");
+  float* ws = nullptr;                              // enough caller scratch: long contexts are split over workgroups
+  {
+    const size_t need = gbx::attn_workspace_bytes(batch, n_heads, n_kv_heads, head_dim, capacity);
+    if (workspace && need && workspace_bytes >= need && aligned(workspace, 16)) ws = static_cast<float*>(workspace);
+  }
   hipError_t e = gbx::launch_attn_decode(q, k, v, kcache, vcache, inv_freq, reinterpret_cast<const long long*>(pos), out,
                                          batch, n_heads, n_kv_heads, head_dim, capacity, rope_scale, sm_scale, traditional,
                                          act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream), q_norm_weight, k_norm_weight,
-                                         norm_eps, q_bias, k_bias, v_bias);
+                                         norm_eps, q_bias, k_bias, v_bias, ws);
   if (e != hipSuccess) return hip_fail(e, "gbx_attn_decode launch");
   return GBX_OK;
 }

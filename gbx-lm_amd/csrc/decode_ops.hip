@@ -6,6 +6,7 @@
 // All read the decode position from DEVICE memory so one captured HIP graph serves every token.
 #include "gbx_device.h"
 #include "kernels.h"
+#include <cstdlib>
 
 namespace gbx {
 
@@ -31,6 +32,10 @@ struct AttnArgs {
   const unsigned short* q_bias;
   const unsigned short* k_bias;
   const unsigned short* v_bias;
+  // grouped kernel only: long contexts split the cached positions over gridDim.z workgroups per (kv group, sequence);
+  // split s writes (num[HD], max, den) per head to ws[((b * n_heads + head) * splits + s) * (HD + 2)] and a second launch
+  // merges them (caller-owned scratch)
+  float* ws;
 };
 
 template <bool BF16, int HD>
@@ -227,6 +232,11 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
   }
   const int pos = static_cast<int>(*a.pos);
   const int nctx = STATIC ? pos + 1 : pos;          // cached positions to visit
+  // this workgroup's slice of them (all of them unless the launch splits the context)
+  const int nsplit = a.ws ? static_cast<int>(gridDim.z) : 1, sp = a.ws ? static_cast<int>(blockIdx.z) : 0;
+  const int per = nsplit > 1 ? (((nctx + nsplit - 1) / nsplit + 4 * PPW - 1) / (4 * PPW)) * (4 * PPW) : nctx;
+  const int tb = sp * per, te = min(nctx, tb + per);
+  const bool last_split = sp == nsplit - 1;
 
   if constexpr (STATIC) {
     for (int p = tid; p < REP * HD; p += 256) q_s[p / HD][p % HD] = act_to_f32<BF16>(a.q[static_cast<size_t>(hq0) * HD + p]) * a.sm_scale;
@@ -238,7 +248,7 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
     return bias ? act_to_f32<BF16>(f32_to_act<BF16>(x + act_to_f32<BF16>(bias[i]))) : x;
   };
   const bool normed = a.qn_w != nullptr;
-  const bool writer = blockIdx.x % parts == 0;      // one workgroup of the kv group appends k, v
+  const bool writer = blockIdx.x % parts == 0 && blockIdx.z == 0;   // one workgroup of the kv group appends k, v
   if (normed) {                                     // sum of squares per head (q heads of this part, then the k head)
     if (tid <= REP) ssq_s[tid] = 0.f;
     __syncthreads();
@@ -326,16 +336,17 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
     }
   };
 #pragma unroll
-  for (int u = 0; u < UB0; ++u) consume(k0[u], v0[u], wave * PPW + u * 4 * PPW + sub < nctx);
+  // (the speculative first positions belong to split 0; the other splits start their own slice below)
+  for (int u = 0; u < UB0; ++u) consume(k0[u], v0[u], sp == 0 && wave * PPW + u * 4 * PPW + sub < te);
   constexpr int UB = 4;
-  for (int t0 = UB0 * 4 * PPW + wave * PPW; t0 < nctx; t0 += 4 * PPW * UB) {
+  for (int t0 = (sp == 0 ? UB0 * 4 * PPW : tb) + wave * PPW; t0 < te; t0 += 4 * PPW * UB) {
     u32x4 kv4[UB], vv4[UB];
     bool valid[UB];
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
       const int t = t0 + u * 4 * PPW + sub;
-      valid[u] = t < nctx;
-      const int tc = valid[u] ? t : nctx - 1;
+      valid[u] = t < te;
+      const int tc = valid[u] ? t : max(te - 1, 0);
       kv4[u] = *reinterpret_cast<const u32x4*>(kbase + static_cast<size_t>(tc) * HD + d0);
       vv4[u] = *reinterpret_cast<const u32x4*>(vbase + static_cast<size_t>(tc) * HD + d0);
     }
@@ -343,7 +354,7 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
     for (int u = 0; u < UB; ++u) consume(kv4[u], vv4[u], valid[u]);
   }
   // the new token itself (k, v in LDS)
-  if (!STATIC && wave == 0 && sub == 0) {
+  if (!STATIC && last_split && wave == 0 && sub == 0) {
 #pragma unroll
     for (int r = 0; r < REP; ++r) {
       float s = 0.f;
@@ -381,15 +392,43 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
       num = fmaf(w, gacc[i][r][f], num);
       den = fmaf(w, gl[i][r], den);
     }
-    a.out[(static_cast<size_t>(hq0) + r) * HD + f] = f32_to_act<BF16>(num / den);
+    if (nsplit > 1) {                               // partial of this slice: merged by attn_merge_kernel
+      float* wsp = a.ws + ((static_cast<size_t>(blockIdx.y) * a.n_heads + hq0 + r) * nsplit + sp) * (HD + 2);
+      wsp[f] = num;
+      if (f == 0) { wsp[HD] = M; wsp[HD + 1] = den; }
+    } else {
+      a.out[(static_cast<size_t>(hq0) + r) * HD + f] = f32_to_act<BF16>(num / den);
+    }
   }
 }
 
+// second launch of a split-context attention: out[b, head, :] = sum_s e^(M_s - M) num_s / sum_s e^(M_s - M) den_s
+template <bool BF16, int HD>
+__global__ __launch_bounds__(HD) void attn_merge_kernel(const float* __restrict__ ws, unsigned short* __restrict__ out, int n_heads,
+                                                        int nsplit) {
+  const size_t bh = static_cast<size_t>(blockIdx.y) * n_heads + blockIdx.x;
+  const float* p = ws + bh * nsplit * (HD + 2);
+  const int f = threadIdx.x;
+  float M = -1e30f;
+  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, p[s * (HD + 2) + HD]);
+  float num = 0.f, den = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float w = __expf(p[s * (HD + 2) + HD] - M);
+    num = fmaf(w, p[s * (HD + 2) + f], num);
+    den = fmaf(w, p[s * (HD + 2) + HD + 1], den);
+  }
+  out[bh * HD + f] = f32_to_act<BF16>(num / den);
+}
+
 template <int HD, int REP>
-static hipError_t launch_attn_gqa(const AttnArgs& a, int batch, bool bf16, hipStream_t s) {
-  dim3 grid(a.n_kv * (a.n_heads / a.n_kv / REP), batch), block(256);
+static hipError_t launch_attn_gqa(const AttnArgs& a, int batch, bool bf16, hipStream_t s, int splits = 1) {
+  dim3 grid(a.n_kv * (a.n_heads / a.n_kv / REP), batch, a.ws ? splits : 1), block(256);
   if (bf16) hipLaunchKernelGGL((attn_decode_gqa_kernel<true, HD, REP, false>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((attn_decode_gqa_kernel<false, HD, REP, false>), grid, block, 0, s, a);
+  if (a.ws && splits > 1) {
+    if (bf16) hipLaunchKernelGGL((attn_merge_kernel<true, HD>), dim3(a.n_heads, batch), dim3(HD), 0, s, a.ws, a.out, a.n_heads, splits);
+    else hipLaunchKernelGGL((attn_merge_kernel<false, HD>), dim3(a.n_heads, batch), dim3(HD), 0, s, a.ws, a.out, a.n_heads, splits);
+  }
   return hipGetLastError();
 }
 
@@ -406,7 +445,8 @@ hipError_t launch_attn_static(const void* q, const void* kcache, const void* vca
                               int n_heads, int n_kv, int head_dim, int capacity, float sm_scale, bool bf16, hipStream_t s) {
   AttnArgs a{static_cast<const unsigned short*>(q), nullptr, nullptr,
              static_cast<unsigned short*>(const_cast<void*>(kcache)), static_cast<unsigned short*>(const_cast<void*>(vcache)),
-             nullptr, pos, static_cast<unsigned short*>(out), n_heads, n_kv, capacity, 1.f, sm_scale, 0, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr};
+             nullptr, pos, static_cast<unsigned short*>(out), n_heads, n_kv, capacity, 1.f, sm_scale, 0, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr,
+             nullptr};
   const int rep = n_heads / n_kv;
   const int R = rep % 4 == 0 ? 4 : rep % 3 == 0 ? 3 : rep % 2 == 0 ? 2 : 1;
   if (head_dim == 128) {
@@ -428,34 +468,54 @@ hipError_t launch_attn_static(const void* q, const void* kcache, const void* vca
   return hipErrorInvalidValue;
 }
 
+// Context splits of the grouped kernel (needs caller scratch): enough workgroups to fill the chip once the cache is long,
+// 256+ positions per slice.  The per-head batch-1 kernel gives a 2048-token context 32 workgroups that each re-read their
+// kv head (measured: 456 tok/s at context 2048 against 773 at 128).
+int attn_splits(int batch, int n_heads, int n_kv, int capacity) {
+  const int rep = n_heads / n_kv;
+  const int R = rep % 4 == 0 ? 4 : rep % 3 == 0 ? 3 : rep % 2 == 0 ? 2 : 1;
+  const int wgs = n_kv * (rep / R) * batch;
+  if (capacity < 1024) return 1;                    // short caches: the un-split kernels win (649 vs 774 tok/s at context 128)
+  int s = std::min(std::min(512 / std::max(wgs, 1), capacity / 256), 32);   // (128-position slices measured no better)
+  return s < 2 ? 1 : s;
+}
+
+size_t attn_workspace_bytes(int batch, int n_heads, int n_kv, int head_dim, int capacity) {
+  const int s = attn_splits(batch, n_heads, n_kv, capacity);
+  return s > 1 ? static_cast<size_t>(batch) * n_heads * s * (head_dim + 2) * sizeof(float) : 0;
+}
+
 hipError_t launch_attn_decode(const void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
                               const long long* pos, void* out, int batch, int n_heads, int n_kv, int head_dim, int capacity,
                               float rope_scale, float sm_scale, int traditional, bool bf16, hipStream_t s,
                               const void* q_norm_w, const void* k_norm_w, float norm_eps, const void* q_bias, const void* k_bias,
-                              const void* v_bias) {
+                              const void* v_bias, float* ws) {
   AttnArgs a{static_cast<const unsigned short*>(q), static_cast<const unsigned short*>(k), static_cast<const unsigned short*>(v),
              static_cast<unsigned short*>(kcache), static_cast<unsigned short*>(vcache), inv_freq, pos,
              static_cast<unsigned short*>(out), n_heads, n_kv, capacity, rope_scale, sm_scale, traditional,
              static_cast<const unsigned short*>(q_norm_w), static_cast<const unsigned short*>(k_norm_w), norm_eps,
              static_cast<const unsigned short*>(q_bias), static_cast<const unsigned short*>(k_bias),
-             static_cast<const unsigned short*>(v_bias)};
+             static_cast<const unsigned short*>(v_bias), nullptr};
   const int rep = n_heads / n_kv;
-  if (q_norm_w || q_bias || (batch > 1 && rep > 1)) {         // grouped kernel: batched decode, or q/k norms (any batch)
+  const int splits = ws ? attn_splits(batch, n_heads, n_kv, capacity) : 1;
+  if (splits > 1) a.ws = ws;
+  static const bool force_grouped = getenv("GBX_ATTN_GROUPED") != nullptr;    // tuning aid: grouped kernel at batch 1 too
+  if (q_norm_w || q_bias || (batch > 1 && rep > 1) || (force_grouped && rep > 1) || splits > 1) {         // grouped kernel: batched decode, or q/k norms (any batch)
     const int R = rep % 4 == 0 ? 4 : rep % 3 == 0 ? 3 : rep % 2 == 0 ? 2 : 1;
     if (head_dim == 128) {
       switch (R) {
-        case 4: return launch_attn_gqa<128, 4>(a, batch, bf16, s);
-        case 3: return launch_attn_gqa<128, 3>(a, batch, bf16, s);
-        case 2: return launch_attn_gqa<128, 2>(a, batch, bf16, s);
-        default: return launch_attn_gqa<128, 1>(a, batch, bf16, s);
+        case 4: return launch_attn_gqa<128, 4>(a, batch, bf16, s, splits);
+        case 3: return launch_attn_gqa<128, 3>(a, batch, bf16, s, splits);
+        case 2: return launch_attn_gqa<128, 2>(a, batch, bf16, s, splits);
+        default: return launch_attn_gqa<128, 1>(a, batch, bf16, s, splits);
       }
     }
     if (head_dim == 64) {
       switch (R) {
-        case 4: return launch_attn_gqa<64, 4>(a, batch, bf16, s);
-        case 3: return launch_attn_gqa<64, 3>(a, batch, bf16, s);
-        case 2: return launch_attn_gqa<64, 2>(a, batch, bf16, s);
-        default: return launch_attn_gqa<64, 1>(a, batch, bf16, s);
+        case 4: return launch_attn_gqa<64, 4>(a, batch, bf16, s, splits);
+        case 3: return launch_attn_gqa<64, 3>(a, batch, bf16, s, splits);
+        case 2: return launch_attn_gqa<64, 2>(a, batch, bf16, s, splits);
+        default: return launch_attn_gqa<64, 1>(a, batch, bf16, s, splits);
       }
     }
     return hipErrorInvalidValue;

@@ -34,7 +34,10 @@ hipError_t launch_attn_decode(const void* q, const void* k, const void* v, void*
                               const long long* pos, void* out, int batch, int n_heads, int n_kv, int head_dim, int capacity,
                               float rope_scale, float sm_scale, int traditional, bool bf16, hipStream_t s,
                               const void* q_norm_w = nullptr, const void* k_norm_w = nullptr, float norm_eps = 0.f,
-                              const void* q_bias = nullptr, const void* k_bias = nullptr, const void* v_bias = nullptr);
+                              const void* q_bias = nullptr, const void* k_bias = nullptr, const void* v_bias = nullptr,
+                              float* ws = nullptr);
+int attn_splits(int batch, int n_heads, int n_kv, int capacity);
+size_t attn_workspace_bytes(int batch, int n_heads, int n_kv, int head_dim, int capacity);
 hipError_t launch_dense_gemv(const void* x, const void* w, void* y, const void* norm_w, float eps, int N, int K, void* best,
                              bool bf16, hipStream_t s);
 hipError_t launch_embed_next(void* best, void* tok_io, void* pos, const void* table, void* h, int D, int vocab, int mode,

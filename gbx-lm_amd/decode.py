@@ -266,6 +266,9 @@ class FusedDecodeRunner(DecodeRunner):
         r0 = getattr(model, "tp_rank", 0) == 0
         self.logits_buf = torch.zeros((1, model.head_weight().shape[0]), dtype=dt, device=dev)
         self.keys = torch.zeros((64,), dtype=torch.int64, device=dev)      # sharded (value, index) argmax keys (uint64 bits)
+        from . import _lib as _l
+        need = _l.lib().gbx_attn_workspace_bytes(1, a0.n_heads, a0.n_kv_heads, a0.head_dim, caches[0].capacity)
+        self.attn_ws = torch.empty((need,), dtype=torch.uint8, device=dev) if need else None   # context split of long caches
         self.chain = False                  # True while capturing / replaying the on-device greedy chain
         self.graph_chain = None
         self.descs = []
@@ -302,13 +305,15 @@ class FusedDecodeRunner(DecodeRunner):
             at = blk.self_attn
             ops.qlinear_fused(d_qkv, dev)
             qn = getattr(at, "q_norm", None)
-            if qn is not None or at.q_proj.bias is not None:
-                # Qwen3 (per-head q / k norms) and Qwen2 (q / k / v biases): the grouped kernel takes both in its prologue
+            if qn is not None or at.q_proj.bias is not None or self.attn_ws is not None:
+                # Qwen3 (per-head q / k norms) and Qwen2 (q / k / v biases): the grouped kernel takes both in its prologue;
+                # long caches: the same kernel with the context split over workgroups (scratch from the runner)
                 ops.attn_decode_batched(self.qb.view(1, -1), self.kb.view(1, -1), self.vb.view(1, -1), c.keys, c.values,
                                         at.rope.inv_freq, self.pos, self.ab.view(1, -1), at.n_heads, at.n_kv_heads, at.head_dim,
                                         getattr(at.rope, "scale", 1.0), at.scale, at.rope.traditional,
                                         qn.weight if qn is not None else None, at.k_norm.weight if qn is not None else None,
-                                        qn.eps if qn is not None else 0.0, at.q_proj.bias, at.k_proj.bias, at.v_proj.bias)
+                                        qn.eps if qn is not None else 0.0, at.q_proj.bias, at.k_proj.bias, at.v_proj.bias,
+                                        workspace=self.attn_ws)
             else:
                 ops.attn_decode(self.qb, self.kb, self.vb, c.keys, c.values, at.rope.inv_freq, self.pos, self.ab,
                                 at.n_heads, at.n_kv_heads, at.head_dim, c.capacity, getattr(at.rope, "scale", 1.0), at.scale,

@@ -341,20 +341,24 @@ def attn_decode(q, k, v, kcache, vcache, inv_freq, pos, out, n_heads: int, n_kv:
 
 def attn_decode_batched(q, k, v, kcache, vcache, inv_freq, pos, out, n_heads: int, n_kv: int, head_dim: int,
                         rope_scale: float, sm_scale: float, traditional: bool, q_norm_w=None, k_norm_w=None,
-                        norm_eps: float = 0.0, q_bias=None, k_bias=None, v_bias=None) -> None:
+                        norm_eps: float = 0.0, q_bias=None, k_bias=None, v_bias=None, workspace=None) -> None:
     """One new token per sequence, all at position ``pos`` (device int64): q/out [B, n_heads*hd], k/v [B, n_kv*hd],
     caches [B, n_kv, capacity, hd] (gbx_attn_decode_batched: RoPE + cache append + softmax(q k^T) v in one launch)."""
     _require_cuda(q, "q")
     b, cap = kcache.shape[0], kcache.shape[2]
-    _lib.check(_lib.lib().gbx_attn_decode_normed(q.data_ptr(), k.data_ptr(), v.data_ptr(), kcache.data_ptr(), vcache.data_ptr(),
-                                                 inv_freq.data_ptr(), pos.data_ptr(), out.data_ptr(), b, n_heads, n_kv, head_dim,
+    if workspace is None:                               # long caches: scratch for the context split (flash-decoding)
+        need = _lib.lib().gbx_attn_workspace_bytes(b, n_heads, n_kv, head_dim, cap)
+        workspace = torch.empty((need,), dtype=torch.uint8, device=q.device) if need else None
+    _lib.check(_lib.lib().gbx_attn_decode_ws(q.data_ptr(), k.data_ptr(), v.data_ptr(), kcache.data_ptr(), vcache.data_ptr(),
+                                             inv_freq.data_ptr(), pos.data_ptr(), out.data_ptr(), b, n_heads, n_kv, head_dim,
                                                  cap, float(rope_scale), float(sm_scale), int(bool(traditional)),
                                                  q_norm_w.data_ptr() if q_norm_w is not None else None,
                                                  k_norm_w.data_ptr() if k_norm_w is not None else None, float(norm_eps),
                                                  q_bias.data_ptr() if q_bias is not None else None,
                                                  k_bias.data_ptr() if k_bias is not None else None,
                                                  v_bias.data_ptr() if v_bias is not None else None,
-                                                 _DT[q.dtype], _stream_ptr(q.device)))
+                                                 _DT[q.dtype], workspace.data_ptr() if workspace is not None else None,
+                                                 workspace.numel() if workspace is not None else 0, _stream_ptr(q.device)))
 
 
 def attn_cached(q: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, pos: torch.Tensor, scale: float) -> torch.Tensor:

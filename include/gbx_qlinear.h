@@ -234,6 +234,18 @@ int gbx_attn_decode_normed(const void* q, const void* k, const void* v, void* kc
                            const void* q_norm_weight, const void* k_norm_weight, float norm_eps, const void* q_bias,
                            const void* k_bias, const void* v_bias, int32_t act_dtype, void* hip_stream);
 
+/* gbx_attn_decode_normed with caller-owned scratch of gbx_attn_workspace_bytes(batch, n_heads, n_kv_heads, head_dim,
+ * capacity) bytes (16-byte aligned; 0 = no use for it): once the cache is long the cached positions of a (kv group,
+ * sequence) are split over several workgroups (flash-decoding) and a second launch merges their (max, sum, numerator)
+ * partials -- the per-head kernel reads a 2048-token context with 32 workgroups. */
+size_t gbx_attn_workspace_bytes(int32_t batch, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int32_t capacity);
+int gbx_attn_decode_ws(const void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
+                       const int64_t* pos, void* out, int32_t batch, int32_t n_heads, int32_t n_kv_heads,
+                       int32_t head_dim, int32_t capacity, float rope_scale, float sm_scale, int32_t traditional,
+                       const void* q_norm_weight, const void* k_norm_weight, float norm_eps, const void* q_bias,
+                       const void* k_bias, const void* v_bias, int32_t act_dtype, void* workspace, size_t workspace_bytes,
+                       void* hip_stream);
+
 /* Single-token attention over a cache that already holds the new token: out[b, h, :] = softmax(q[b, h, :] . K[b, kv(h), 0..*pos, :]^T
  * * sm_scale) V[b, kv(h), 0..*pos, :] with q [batch, n_heads, head_dim] already rotated, caches [batch, n_kv, capacity, head_dim],
  * `pos` a DEVICE int64.  mx.fast.scaled_dot_product_attention as every model graph calls it for L = 1 (models/base.py:65-92),

@@ -164,6 +164,33 @@ def test_attn_decode_with_qk_norm_matches_torch(B, hd, nh, nkv):
     assert torch.allclose(out.float().cpu(), want, atol=3e-2, rtol=3e-2)
 
 
+@pytest.mark.parametrize("B,nh,nkv,cap,pos", [(1, 32, 8, 4096, 3011), (1, 8, 2, 1536, 5), (2, 8, 2, 8192, 8000), (1, 4, 4, 2048, 1999)])
+def test_attn_decode_split_context_matches_torch(B, nh, nkv, cap, pos):
+    """Long caches: the grouped kernel with the cached positions split over workgroups + the merge launch
+    (gbx_attn_decode_ws) against torch; splits that receive no position (pos = 5 of 1024) must not disturb the merge."""
+    from gbx_lm_amd import ops, _lib
+    from gbx_lm_amd.models.rope_utils import RoPE, apply_rope
+    torch.manual_seed(pos)
+    hd = 128
+    assert _lib.lib().gbx_attn_workspace_bytes(B, nh, nkv, hd, cap) > 0
+    q = torch.randn(B, nh * hd).to(torch.bfloat16); k = torch.randn(B, nkv * hd).to(torch.bfloat16)
+    v = torch.randn(B, nkv * hd).to(torch.bfloat16)
+    kc = torch.randn(B, nkv, cap, hd).to(torch.bfloat16); vc = torch.randn(B, nkv, cap, hd).to(torch.bfloat16)
+    rope = RoPE(hd, base=500000.0)
+    kd, vd = kc.to(DEV), vc.to(DEV)
+    out = torch.zeros(B, nh * hd, dtype=torch.bfloat16, device=DEV)
+    ops.attn_decode_batched(q.to(DEV), k.to(DEV), v.to(DEV), kd, vd, rope.inv_freq.to(DEV), torch.tensor([pos], device=DEV), out,
+                            nh, nkv, hd, 1.0, hd ** -0.5, False)
+    qr = apply_rope(q.view(B, 1, nh, hd).transpose(1, 2), rope.inv_freq, pos, 1.0, False)
+    kr = apply_rope(k.view(B, 1, nkv, hd).transpose(1, 2), rope.inv_freq, pos, 1.0, False)
+    kc[:, :, pos:pos + 1] = kr; vc[:, :, pos:pos + 1] = v.view(B, nkv, 1, hd)
+    assert torch.allclose(kd.float().cpu(), kc.float(), atol=3e-2) and torch.equal(vd.cpu(), vc)
+    rep = nh // nkv
+    K = kc[:, :, :pos + 1].repeat_interleave(rep, 1).float(); V = vc[:, :, :pos + 1].repeat_interleave(rep, 1).float()
+    want = (torch.softmax((qr.float() @ K.transpose(-1, -2)) * hd ** -0.5, -1) @ V).reshape(B, -1)
+    assert torch.allclose(out.float().cpu(), want, atol=2e-2, rtol=2e-2)
+
+
 def test_attn_decode_with_qkv_bias_matches_torch():
     """Qwen2: the q / k / v projection biases ride in the attention launch (second rounding like the projection's own
     `+ bias`), B = 1 and B = 2."""
