@@ -338,6 +338,9 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
 #pragma unroll
   // (the speculative first positions belong to split 0; the other splits start their own slice below)
   for (int u = 0; u < UB0; ++u) consume(k0[u], v0[u], sp == 0 && wave * PPW + u * 4 * PPW + sub < te);
+  // Main loop: UB positions per lane group as ONE block of the online softmax -- UB independent dot / DPP chains, one
+  // rescale of the accumulators per block instead of per position (per position the chain dot -> DPP -> max -> exp ->
+  // acc * corr ran serially UB times with a single wave or two per SIMD to hide it: 1.2 TB/s of cache at long contexts).
   constexpr int UB = 4;
   for (int t0 = (sp == 0 ? UB0 * 4 * PPW : tb) + wave * PPW; t0 < te; t0 += 4 * PPW * UB) {
     u32x4 kv4[UB], vv4[UB];
@@ -350,8 +353,45 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
       kv4[u] = *reinterpret_cast<const u32x4*>(kbase + static_cast<size_t>(tc) * HD + d0);
       vv4[u] = *reinterpret_cast<const u32x4*>(vbase + static_cast<size_t>(tc) * HD + d0);
     }
+    float sc[REP][UB];
 #pragma unroll
-    for (int u = 0; u < UB; ++u) consume(kv4[u], vv4[u], valid[u]);
+    for (int u = 0; u < UB; ++u) {
+      const unsigned kw[4] = {kv4[u].x, kv4[u].y, kv4[u].z, kv4[u].w};
+#pragma unroll
+      for (int r = 0; r < REP; ++r) {
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d = fmaf(qr[r][2 * j], act_lo<BF16>(kw[j]), fmaf(qr[r][2 * j + 1], act_hi<BF16>(kw[j]), d));
+        d += dpp_f32<0xB1>(d);
+        d += dpp_f32<0x4E>(d);
+        d += dpp_f32<0x141>(d);
+        if constexpr (LP == 16) d += dpp_f32<0x140>(d);
+        sc[r][u] = valid[u] ? d : NEG;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < REP; ++r) {
+      float mn = m[r];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) mn = fmaxf(mn, sc[r][u]);
+      const float corr = __expf(m[r] - mn);
+      float pw[UB], ps = 0.f;
+#pragma unroll
+      for (int u = 0; u < UB; ++u) { pw[u] = valid[u] ? __expf(sc[r][u] - mn) : 0.f; ps += pw[u]; }
+      l[r] = l[r] * corr + ps;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[r][j] *= corr;
+      m[r] = mn;
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const unsigned vw[4] = {vv4[u].x, vv4[u].y, vv4[u].z, vv4[u].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[r][2 * j] = fmaf(pw[u], act_lo<BF16>(vw[j]), acc[r][2 * j]);
+          acc[r][2 * j + 1] = fmaf(pw[u], act_hi<BF16>(vw[j]), acc[r][2 * j + 1]);
+        }
+      }
+    }
   }
   // the new token itself (k, v in LDS)
   if (!STATIC && last_split && wave == 0 && sub == 0) {
@@ -402,22 +442,36 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
   }
 }
 
-// second launch of a split-context attention: out[b, head, :] = sum_s e^(M_s - M) num_s / sum_s e^(M_s - M) den_s
+// second launch of a split-context attention: out[b, head, :] = sum_s e^(M_s - M) num_s / sum_s e^(M_s - M) den_s.
+// The (max, den) pairs of the <= 64 slices are read by the first wave in parallel and the weights shared through LDS; the
+// numerator loop then has independent, coalesced loads (the first version walked the slices with dependent scalar-style
+// loads: 9.5 us per launch, as long as the attention itself).
 template <bool BF16, int HD>
 __global__ __launch_bounds__(HD) void attn_merge_kernel(const float* __restrict__ ws, unsigned short* __restrict__ out, int n_heads,
                                                         int nsplit) {
+  __shared__ float w_s[64];
+  __shared__ float den_s;
   const size_t bh = static_cast<size_t>(blockIdx.y) * n_heads + blockIdx.x;
   const float* p = ws + bh * nsplit * (HD + 2);
   const int f = threadIdx.x;
-  float M = -1e30f;
-  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, p[s * (HD + 2) + HD]);
-  float num = 0.f, den = 0.f;
-  for (int s = 0; s < nsplit; ++s) {
-    const float w = __expf(p[s * (HD + 2) + HD] - M);
-    num = fmaf(w, p[s * (HD + 2) + f], num);
-    den = fmaf(w, p[s * (HD + 2) + HD + 1], den);
+  if (f < 64) {
+    const float ml = f < nsplit ? p[f * (HD + 2) + HD] : -1e30f;
+    const float dl = f < nsplit ? p[f * (HD + 2) + HD + 1] : 0.f;
+    const float M = key2f(wave_max_u32(f2key(ml)));
+    const float w = f < nsplit ? __expf(ml - M) : 0.f;
+    w_s[f] = w;
+    const float den = wave_sum(w * dl);
+    if (f == 0) den_s = den;
   }
-  out[bh * HD + f] = f32_to_act<BF16>(num / den);
+  __syncthreads();
+  float num0 = 0.f, num1 = 0.f;
+  int s = 0;
+  for (; s + 1 < nsplit; s += 2) {
+    num0 = fmaf(w_s[s], p[s * (HD + 2) + f], num0);
+    num1 = fmaf(w_s[s + 1], p[(s + 1) * (HD + 2) + f], num1);
+  }
+  if (s < nsplit) num0 = fmaf(w_s[s], p[s * (HD + 2) + f], num0);
+  out[bh * HD + f] = f32_to_act<BF16>((num0 + num1) / den_s);
 }
 
 template <int HD, int REP>
@@ -473,7 +527,7 @@ hipError_t launch_attn_static(const void* q, const void* kcache, const void* vca
 // kv head (measured: 456 tok/s at context 2048 against 773 at 128).
 int attn_splits(int batch, int n_heads, int n_kv, int capacity) {
   const int rep = n_heads / n_kv;
-  const int R = rep % 4 == 0 ? 4 : rep % 3 == 0 ? 3 : rep % 2 == 0 ? 2 : 1;
+  const int R = rep % 2 == 0 ? 2 : 1;               // split launches serve 2 query heads per workgroup (see launch_attn_decode)
   const int wgs = n_kv * (rep / R) * batch;
   if (capacity < 1024) return 1;                    // short caches: the un-split kernels win (649 vs 774 tok/s at context 128)
   int s = std::min(std::min(512 / std::max(wgs, 1), capacity / 256), 32);   // (128-position slices measured no better)
@@ -501,7 +555,9 @@ hipError_t launch_attn_decode(const void* q, const void* k, const void* v, void*
   if (splits > 1) a.ws = ws;
   static const bool force_grouped = getenv("GBX_ATTN_GROUPED") != nullptr;    // tuning aid: grouped kernel at batch 1 too
   if (q_norm_w || q_bias || (batch > 1 && rep > 1) || (force_grouped && rep > 1) || splits > 1) {         // grouped kernel: batched decode, or q/k norms (any batch)
-    const int R = rep % 4 == 0 ? 4 : rep % 3 == 0 ? 3 : rep % 2 == 0 ? 2 : 1;
+    // 2 heads per workgroup when the context is split: 120 VGPRs -> two workgroups per CU, whose waves cover each other's
+    // dependent dot / DPP / exp chains (with 4 heads, 166 VGPRs, one wave per SIMD ran the cache at 1.2 TB/s)
+    const int R = splits > 1 ? (rep % 2 == 0 ? 2 : 1) : rep % 4 == 0 ? 4 : rep % 3 == 0 ? 3 : rep % 2 == 0 ? 2 : 1;
     if (head_dim == 128) {
       switch (R) {
         case 4: return launch_attn_gqa<128, 4>(a, batch, bf16, s, splits);
