@@ -529,7 +529,8 @@ int attn_splits(int batch, int n_heads, int n_kv, int capacity) {
   const int rep = n_heads / n_kv;
   const int R = rep % 2 == 0 ? 2 : 1;               // split launches serve 2 query heads per workgroup (see launch_attn_decode)
   const int wgs = n_kv * (rep / R) * batch;
-  if (capacity < 1024) return 1;                    // short caches: the un-split kernels win (649 vs 774 tok/s at context 128)
+  static const int min_cap = [] { const char* e = getenv("GBX_ATTN_SPLIT_MIN"); return e ? atoi(e) : 1024; }();   // tuning aid
+  if (capacity < min_cap) return 1;                    // short caches: the un-split kernels win (649 vs 774 tok/s at context 128)
   int s = std::min(std::min(512 / std::max(wgs, 1), capacity / 256), 32);   // (128-position slices measured no better)
   return s < 2 ? 1 : s;
 }
