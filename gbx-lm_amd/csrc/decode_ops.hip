@@ -523,7 +523,7 @@ hipError_t launch_attn_static(const void* q, const void* kcache, const void* vca
 }
 
 // Context splits of the grouped kernel (needs caller scratch): enough workgroups to fill the chip once the cache is long,
-// 256+ positions per slice.  The per-head batch-1 kernel gives a 2048-token context 32 workgroups that each re-read their
+// 128+ positions per slice (measured: 1024 -> 646, 2048 -> 645 tok/s against 629 / 614 with 256).  The per-head batch-1 kernel gives a 2048-token context 32 workgroups that each re-read their
 // kv head (measured: 456 tok/s at context 2048 against 773 at 128).
 int attn_splits(int batch, int n_heads, int n_kv, int capacity) {
   const int rep = n_heads / n_kv;
@@ -531,7 +531,8 @@ int attn_splits(int batch, int n_heads, int n_kv, int capacity) {
   const int wgs = n_kv * (rep / R) * batch;
   static const int min_cap = [] { const char* e = getenv("GBX_ATTN_SPLIT_MIN"); return e ? atoi(e) : 1024; }();   // tuning aid
   if (capacity < min_cap) return 1;                    // short caches: the un-split kernels win (649 vs 774 tok/s at context 128)
-  int s = std::min(std::min(512 / std::max(wgs, 1), capacity / 256), 32);   // (128-position slices measured no better)
+  static const int div = [] { const char* e = getenv("GBX_ATTN_SPLIT_DIV"); return e ? atoi(e) : 128; }();     // tuning aid
+  int s = std::min(std::min(512 / std::max(wgs, 1), capacity / div), 32);
   return s < 2 ? 1 : s;
 }
 
