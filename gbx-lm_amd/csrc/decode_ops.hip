@@ -525,9 +525,18 @@ hipError_t launch_attn_static(const void* q, const void* kcache, const void* vca
 // Context splits of the grouped kernel (needs caller scratch): enough workgroups to fill the chip once the cache is long,
 // 128+ positions per slice (measured: 1024 -> 646, 2048 -> 645 tok/s against 629 / 614 with 256).  The per-head batch-1 kernel gives a 2048-token context 32 workgroups that each re-read their
 // kv head (measured: 456 tok/s at context 2048 against 773 at 128).
+// Query heads per workgroup of a split launch: 2 (120 VGPRs, two workgroups per CU cover each other's dot / DPP / exp
+// chains; K/V read once per pair) -- but 1 while the cache is short and the batch small, where the extra workgroups matter
+// more than the re-read (context 900: 689 vs 654 tok/s; from 2048 on the pair wins: 650 vs 631, 563 vs 499 at 8192).
+static int split_heads(int batch, int n_heads, int rep, int capacity) {
+  if (rep % 2) return 1;
+  return (capacity <= 1536 && batch * n_heads <= 64) ? 1 : 2;
+}
+
 int attn_splits(int batch, int n_heads, int n_kv, int capacity) {
   const int rep = n_heads / n_kv;
-  const int R = rep % 2 == 0 ? 2 : 1;               // split launches serve 2 query heads per workgroup (see launch_attn_decode)
+  static const int force_r = [] { const char* e = getenv("GBX_ATTN_SPLIT_R"); return e ? atoi(e) : 0; }();   // tuning aid
+  const int R = force_r ? force_r : split_heads(batch, n_heads, rep, capacity);
   const int wgs = n_kv * (rep / R) * batch;
   static const int min_cap = [] { const char* e = getenv("GBX_ATTN_SPLIT_MIN"); return e ? atoi(e) : 1024; }();   // tuning aid
   if (capacity < min_cap) return 1;                    // short caches: the un-split kernels win (649 vs 774 tok/s at context 128)
@@ -559,7 +568,8 @@ hipError_t launch_attn_decode(const void* q, const void* k, const void* v, void*
   if (q_norm_w || q_bias || (batch > 1 && rep > 1) || (force_grouped && rep > 1) || splits > 1) {         // grouped kernel: batched decode, or q/k norms (any batch)
     // 2 heads per workgroup when the context is split: 120 VGPRs -> two workgroups per CU, whose waves cover each other's
     // dependent dot / DPP / exp chains (with 4 heads, 166 VGPRs, one wave per SIMD ran the cache at 1.2 TB/s)
-    const int R = splits > 1 ? (rep % 2 == 0 ? 2 : 1) : rep % 4 == 0 ? 4 : rep % 3 == 0 ? 3 : rep % 2 == 0 ? 2 : 1;
+    static const int force_r = [] { const char* e = getenv("GBX_ATTN_SPLIT_R"); return e ? atoi(e) : 0; }();
+    const int R = splits > 1 ? (force_r ? force_r : split_heads(batch, n_heads, rep, capacity)) : rep % 4 == 0 ? 4 : rep % 3 == 0 ? 3 : rep % 2 == 0 ? 2 : 1;
     if (head_dim == 128) {
       switch (R) {
         case 4: return launch_attn_gqa<128, 4>(a, batch, bf16, s, splits);
