@@ -74,6 +74,29 @@ def test_graph_decode_equals_eager_and_survives_cache_growth(tiny):
     assert c1[0].offset == c2[0].offset == len(prompt) + 22 and c2[0].capacity == 32
 
 
+def test_graph_decode_long_cache_split_attention(tiny):
+    """A 1000-token context crossing the 1024-position capacity step: the fused runner switches to the context-split
+    attention launch (gbx_attn_decode_ws) and is re-captured when the cache grows; logits stay equal to the eager forward."""
+    from gbx_lm_amd.models.cache import make_prompt_cache
+    model, _ = tiny
+    g = torch.Generator().manual_seed(1)
+    prompt = torch.randint(0, 500, (1000,), generator=g).to(DEV)
+    c1, c2 = make_prompt_cache(model), make_prompt_cache(model)
+    with torch.no_grad():
+        l1 = model(prompt[None], cache=c1)[:, -1, :]
+        l2 = model(prompt[None], cache=c2)[:, -1, :]
+        for t in range(40):                                   # positions 1000 .. 1039: capacity 1024 -> 1280 on the way
+            tok = torch.argmax(l2, -1)
+            l1 = model(tok[None], cache=c1)[:, -1, :]
+            l2 = model.decode_step(tok, c2).clone()
+            assert torch.allclose(l1.float(), l2.float(), atol=0.1, rtol=0.05), f"step {t}: {(l1.float() - l2.float()).abs().max().item()}"
+    assert c2[0].capacity == 1280 and c2[0].offset == 1040
+    from gbx_lm_amd import _lib
+    at = model.model.layers[0].self_attn                     # the launch at this capacity is the split one
+    assert _lib.lib().gbx_attn_workspace_bytes(1, at.n_heads, at.n_kv_heads, at.head_dim, 1280) > 0
+    assert model._decode_runner.graph is not None
+
+
 def test_load_and_generate_text(tmp_path):
     from gbx_lm_amd import synthetic as S, load, generate, stream_generate
     S.write_checkpoint(str(tmp_path), S.TINY, S.make_strategy("S22", 2), seed=11)
