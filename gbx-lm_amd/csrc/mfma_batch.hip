@@ -115,6 +115,11 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
   const int lrow = (tid & 255) >> 3, lpc = tid & 7;
   const unsigned short* xrow = a.x + static_cast<size_t>(min(lrow, M - 1)) * K + lpc * 16;
   const int xdst0 = lrow * XROW + lpc * 32;         // slab byte offset inside a chunk slot
+  // M <= 16: only the first 16 activation rows are staged (loader waves 10, 11 idle, half the x traffic -- the term that
+  // bounds this kernel) and the second 16-row tile is skipped; rows 16..31 of a 32x32 tile then multiply stale LDS
+  // contents whose results are never stored
+  const bool half_rows = M <= 16;
+  const bool lact = !half_rows || lrow < 16;
   auto xoff = [&](int cs) { return (cbase + (cs / NCHW) * cpk + (cs % NCHW)) * KC; };   // element offset of slot cs at step 0
 
   f32x16 acc32[TNW == 32 ? 1 : 1];
@@ -129,6 +134,7 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
   u32x4 xs[8][2];                                   // loader: activations of the step being staged
 
   auto load_x = [&](int step) {
+    if (!lact) return;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const unsigned short* p = xrow + xoff(it) + step * (NCHW * KC);
@@ -180,6 +186,7 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
   };
   // registers -> pair order of the packed fields -> slab; xsum of the piece, reduced over the 8 lanes of a row chunk
   auto store_x = [&](int buf) {
+    if (!lact) return;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const u32x4 lo = xs[it][0], hi = xs[it][1];
@@ -251,6 +258,7 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
         } else {
 #pragma unroll
           for (int i = 0; i < MT; ++i) {
+            if (i > 0 && half_rows) continue;       // (uniform)
             const u32x4 af = *reinterpret_cast<const u32x4*>(slab + (i * TNW + r) * XROW + aoff);
             g16[i] = mfma16<BF16>(af, bf, first ? f32x4v{0} : g16[i]);
           }
