@@ -14,6 +14,7 @@ _SO = os.environ.get("GBX_QLINEAR_LIB") or os.path.join(_CSRC, "libgbx_qlinear.s
 
 GBX_OK, GBX_ERR_INVALID, GBX_ERR_HIP, GBX_ERR_UNSUPPORTED = 0, 1, 2, 3
 GBX_F16, GBX_BF16, GBX_F32 = 0, 1, 2
+GBX_STREAM_OP_BYTES = 160
 
 _lib = None
 
@@ -74,6 +75,8 @@ def _declare_optional(L) -> None:
     i64, i32, p, f32 = ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_float
     table = {
         "gbx_qlinear_fused_forward": [ctypes.POINTER(FusedDesc), p],
+        "gbx_stream_encode": [ctypes.POINTER(FusedDesc), i32, p, ctypes.c_size_t],
+        "gbx_stream_run": [p, p, i32, i32, i32, p],
         "gbx_attn_decode": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, f32, f32, i32, i32, p],
         "gbx_attn_decode_batched": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, f32, i32, i32, p],
         "gbx_attn_decode_normed": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, f32, i32, p, p, f32, p, p, p, i32, p],

@@ -3,6 +3,7 @@
 // thread-local error text.  No allocation, no synchronisation: every call is graph-capturable.
 #include "gbx_qlinear.h"
 #include "gemv_impl.h"
+#include "gemv_stream.h"
 #include "kernels.h"
 
 #include <cstdarg>
@@ -170,6 +171,78 @@ int gbx_qlinear_fused_forward(const gbx_qlinear_fused* d, void* hip_stream) {
     default: e = gbx::launch_gemv<4>(a, 1, bf16, stream); break;
   }
   if (e != hipSuccess) return hip_fail(e, "gbx_qlinear_fused_forward launch");
+  return GBX_OK;
+}
+
+int gbx_stream_encode(const gbx_qlinear_fused* descs, int32_t n, void* out, size_t out_bytes) {
+  static_assert(sizeof(gbx::StOp) == GBX_STREAM_OP_BYTES, "public op size out of sync with the device format");
+  if (!descs || !out || n < 1) return fail(GBX_ERR_INVALID, "null descriptor table / output or n < 1");
+  if (out_bytes < static_cast<size_t>(n) * sizeof(gbx::StOp)) return fail(GBX_ERR_INVALID, "output buffer too small: %zu < %zu", out_bytes, static_cast<size_t>(n) * sizeof(gbx::StOp));
+  gbx::StOp* ops = static_cast<gbx::StOp*>(out);
+  for (int k = 0; k < n; ++k) {
+    const gbx_qlinear_fused* d = descs + k;
+    if (d->nseg < 1 || d->nseg > 3) return fail(GBX_ERR_INVALID, "op %d: nseg must be 1..3 (got %d)", k, d->nseg);
+    if (d->act_dtype != GBX_F16 && d->act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "op %d: act_dtype must be GBX_F16 or GBX_BF16", k);
+    int ntot = 0;
+    for (int i = 0; i < d->nseg; ++i) {
+      int rc = check_shape(1, d->N[i], d->K, d->bits, d->group_size);
+      if (rc) return rc;
+      if (!d->qweight[i] || !aligned(d->qweight[i], 16)) return fail(GBX_ERR_INVALID, "op %d: qweight of segment %d missing or not 16-byte aligned", k, i);
+      if (d->N[i] & 1) return fail(GBX_ERR_UNSUPPORTED, "op %d: the streamed path needs even row counts (segment %d has %d)", k, i, d->N[i]);
+      ntot += d->N[i];
+    }
+    if (!d->sz || !aligned(d->sz, 16)) return fail(GBX_ERR_UNSUPPORTED, "op %d: the streamed path needs the packed scale|zero companion (gbx_pack_scales_zeros), 16-byte aligned", k);
+    if ((d->K / d->group_size) & 1) return fail(GBX_ERR_UNSUPPORTED, "op %d: the streamed path needs an even number of groups per row (K / group_size = %d)", k, d->K / d->group_size);
+    if (!d->x || !aligned(d->x, 16) || !d->y[0]) return fail(GBX_ERR_INVALID, "op %d: x / y missing or x not 16-byte aligned", k);
+    if (d->swiglu && (d->nseg != 2 || d->N[0] != d->N[1])) return fail(GBX_ERR_INVALID, "op %d: swiglu needs two equal-sized segments", k);
+    if (!d->swiglu) for (int i = 0; i < d->nseg; ++i) if (!d->y[i]) return fail(GBX_ERR_INVALID, "op %d: null y in segment %d", k, i);
+    if (d->residual && (d->nseg != 1 || d->swiglu)) return fail(GBX_ERR_INVALID, "op %d: residual needs a single plain segment", k);
+    if (d->norm_weight && !aligned(d->norm_weight, 16)) return fail(GBX_ERR_INVALID, "op %d: norm_weight must be 16-byte aligned", k);
+    const int K = d->K, bits = d->bits, vpl = bits == 2 ? 64 : 32;
+    const int nslots = K / vpl;
+    if ((K % 128) != 0 || nslots > 512) return fail(GBX_ERR_UNSUPPORTED, "op %d: needs K %% 128 == 0 and K <= %d (K = %d)", k, 512 * vpl, K);
+    if (bits == 2 && d->group_size == 32) return fail(GBX_ERR_UNSUPPORTED, "op %d: 2-bit group_size 32 runs on gbx_qlinear_fused_forward", k);
+    if ((d->norm_weight || d->swiglu) && nslots > 128) return fail(GBX_ERR_UNSUPPORTED, "op %d: fused RMSNorm / SwiGLU need K <= %d at %d bits", k, 128 * vpl, bits);
+    gbx::StOp o{};
+    o.type = gbx::ST_GEMV;
+    o.bits = bits;
+    o.ks = nslots <= 128 ? 1 : 4;
+    o.P = (nslots <= 64 || (nslots > 128 && nslots <= 256)) ? 1 : 2;
+    o.K = K;
+    o.gshift = log2_group(d->group_size) - 5;
+    o.nseg = d->nseg;
+    o.flags = (d->swiglu ? gbx::ST_F_SWIGLU : 0) | (d->norm_weight ? gbx::ST_F_NORM : 0) | (d->residual ? gbx::ST_F_RESID : 0);
+    o.n0 = d->N[0];
+    o.n01 = d->N[0] + (d->nseg > 1 ? d->N[1] : 0);
+    o.N = d->swiglu ? d->N[0] : ntot;
+    o.nbatch = d->swiglu ? d->N[0] : ntot / 2;
+    o.W4 = K / 32 * bits * 4;
+    o.G8 = (K / d->group_size) * 8;
+    o.nslots = nslots;
+    const int owners = 1 * (o.ks == 1 ? gbx::ST_NW : gbx::ST_NW / 4);   /* per CU; the launch has >= 1 CU ... */
+    (void)owners;
+    for (int i = 0; i < 3; ++i) {
+      const int s = i < d->nseg ? i : 0;
+      o.qw[i] = d->qweight[s];
+      o.y[i] = static_cast<unsigned short*>(d->y[s]);
+    }
+    o.sz = d->sz;
+    o.x = static_cast<const unsigned short*>(d->x);
+    o.norm_w = static_cast<const unsigned short*>(d->norm_weight);
+    o.resid = static_cast<const unsigned short*>(d->residual);
+    o.eps = d->norm_eps;
+    ops[k] = o;
+  }
+  return GBX_OK;
+}
+
+int gbx_stream_run(const void* device_program, const void* host_program, int32_t begin, int32_t end, int32_t act_dtype, void* hip_stream) {
+  if (!device_program || !aligned(device_program, 16)) return fail(GBX_ERR_INVALID, "device program missing or not 16-byte aligned");
+  if (!host_program) return fail(GBX_ERR_INVALID, "host copy of the program missing (its first op of the range rides in the kernel arguments)");
+  if (begin < 0 || end <= begin) return fail(GBX_ERR_INVALID, "empty op range [%d, %d)", begin, end);
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  hipError_t e = gbx::launch_stream(device_program, static_cast<const gbx::StOp*>(host_program) + begin, begin, end, act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_stream_run launch");
   return GBX_OK;
 }
 

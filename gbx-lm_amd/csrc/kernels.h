@@ -64,6 +64,7 @@ hipError_t launch_logprobs_argmax(const void* logits, void* logprobs, void* part
                                   int V, bool bf16, hipStream_t s);
 hipError_t launch_add_rmsnorm(void* h, const void* d, const void* w, void* y, int M, int K, float eps, bool bf16, hipStream_t s);
 hipError_t launch_swiglu(const void* g, const void* u, void* y, long long n, bool bf16, hipStream_t s);
+hipError_t launch_stream(const void* dev_prog, const void* host_first_op, int op_begin, int op_end, bool bf16, hipStream_t s);
 hipError_t launch_rmsnorm(const void* x, const void* w, void* y, int M, int K, float eps, bool bf16, hipStream_t s);
 
 }  // namespace gbx

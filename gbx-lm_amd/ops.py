@@ -331,6 +331,31 @@ def qlinear_fused(desc, device) -> None:
     _lib.check(_lib.lib().gbx_qlinear_fused_forward(ctypes.byref(desc), _stream_ptr(device)))
 
 
+class StreamProgram:
+    """Device-resident program of the streamed decode GEMV / persistent engine (gbx_stream_encode / gbx_stream_run):
+    one entry per ``make_fused_desc`` descriptor.  ``run(begin, end)`` enqueues ONE launch that walks ops [begin, end)
+    with the packed rows of later ops streaming into LDS while earlier ones are consumed."""
+
+    def __init__(self, descs, device, dtype):
+        import ctypes
+        n = len(descs)
+        arr = (_lib.FusedDesc * n)(*descs)
+        host = (ctypes.c_uint8 * (n * _lib.GBX_STREAM_OP_BYTES))()
+        _lib.check(_lib.lib().gbx_stream_encode(arr, n, ctypes.addressof(host), len(host)))
+        self.n = n
+        self.dtype = dtype
+        self.device = torch.device(device)
+        self._host = host                  # op `begin` of a launch rides in the kernel arguments
+        self.blob = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(self.device)
+        self._keep = descs                 # the descriptors' tensors are owned by the caller (decode runner)
+
+    def run(self, begin: int = 0, end: Optional[int] = None) -> None:
+        end = self.n if end is None else end
+        import ctypes
+        _lib.check(_lib.lib().gbx_stream_run(self.blob.data_ptr(), ctypes.addressof(self._host), begin, end, _DT[self.dtype],
+                                             _stream_ptr(self.device)))
+
+
 def attn_decode(q, k, v, kcache, vcache, inv_freq, pos, out, n_heads: int, n_kv: int, head_dim: int, capacity: int,
                 rope_scale: float, sm_scale: float, traditional: bool) -> None:
     _lib.check(_lib.lib().gbx_attn_decode(q.data_ptr(), k.data_ptr(), v.data_ptr(), kcache.data_ptr(), vcache.data_ptr(),

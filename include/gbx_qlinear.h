@@ -325,6 +325,24 @@ int gbx_eminf_optimize(const void* logits, int32_t logits_dtype, float* best_log
 int gbx_rmsnorm(const void* x, const void* w, void* y, int64_t M, int32_t K, float eps, int32_t act_dtype,
                 void* hip_stream);
 
+/* ---- streamed decode GEMV / persistent decode engine (gbx-lm_amd/csrc/gemv_stream.hip) -------------------------------
+ * A PROGRAM is a device-resident array of encoded ops; one launch walks ops [begin, end) with one 8-wave workgroup per
+ * CU.  Every op is one gbx_qlinear_fused group (q|k|v, o, gate|up + SwiGLU, down: the QuantizedLinear calls of
+ * gbx_lm/models/qllama.py:76,96,115 at M = 1) with the same arithmetic, roundings and results as
+ * gbx_qlinear_fused_forward (bit-identical without the fused RMSNorm, whose fp32 sum order differs), but the packed
+ * rows reach the CU through a per-wave LDS ring filled by LDS-DMA that runs ahead of the activation prologue and, when
+ * a launch covers several ops, ahead of the next op's dependency (weights never depend on activations).
+ * Requirements per op: desc->sz present (gbx_pack_scales_zeros), group_size 64 or 128 (32 at 3/4 bits), K % 128 == 0,
+ * K / (64 values at 2 bits | 32 at 3/4 bits) <= 512, RMSNorm / SwiGLU only where that quotient is <= 128.
+ * gbx_stream_encode validates n descriptors and writes n * GBX_STREAM_OP_BYTES bytes of device-format ops into HOST
+ * memory `out`; the caller uploads them (the library never allocates) and keeps the host copy: gbx_stream_run enqueues one
+ * launch and passes op `begin` by value in the kernel arguments (no cold fetch of the program before the first load).
+ * Also needed per op: K / group_size even, sz 16-byte aligned. */
+#define GBX_STREAM_OP_BYTES 160
+int gbx_stream_encode(const gbx_qlinear_fused* descs, int32_t n, void* out, size_t out_bytes);
+int gbx_stream_run(const void* device_program, const void* host_program, int32_t begin, int32_t end, int32_t act_dtype,
+                   void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif
