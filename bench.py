@@ -3,8 +3,10 @@
 (2/3/4-bit, g128, raw 2.22 bpw -- BASELINE.json configs[2]), synthetic packed weights.
 
     python bench.py --gpus 1 --steps 64 --warmup 8
+    python bench.py --gpus N --steps K --warmup W         # spawns its own N ranks (one process per GPU) when WORLD_SIZE is unset
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W            # TP over N GPUs (RCCL all-reduce after o_proj / down_proj)
+    python bench.py --gpus 2 --dry-run                    # CPU / gloo rehearsal of the N > 1 control flow (no GPU, no model math)
 
 One "step" = one decoded token = one pass of the hot path (224 QuantizedLinear GEMVs) plus its callers (norms, RoPE,
 attention over the KV cache, bf16 lm_head, argmax) with every tensor resident in HBM.  Rank 0 prints ONE JSON line.
@@ -41,8 +43,10 @@ def token_bytes(model, context):
 
 
 def cpu_baseline(model, cfg, timeout=240.0):
-    """Oracle port timed on this box's host cores, in a CHILD process (no torch / GPU context, its own OpenMP pool):
-    oracle/cpu_baseline.py.  Reported baseline, never the product path."""
+    """The PyTorch-CPU re-expression of the identical GBA arithmetic (unpack -> dequant -> torch.matmul fp32,
+    plus the cached-dequant variant and a bf16 head), timed on this box's host cores in a CHILD process (its own thread
+    pools, no GPU context): oracle/cpu_baseline.py.  The C port of the oracle rides along as a second field.  Reported
+    baseline, never the product path."""
     import subprocess
     at = model.model.layers[0].self_attn
     spec = {"hidden": cfg["hidden_size"], "inter": cfg["intermediate_size"], "vocab": cfg["vocab_size"],
@@ -111,6 +115,178 @@ def kernel_leg(model, reps=20):
             "working_set_bytes": nbytes * len(descs)}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) BEFORE this process has
+    touched the GPU, forward rank 0's JSON line, exit with the worst return code.  Never re-executes a process."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for pr in procs[1:]:
+        try:
+            pr.wait(timeout=600 if rc == 0 else 20)
+        except subprocess.TimeoutExpired:
+            pr.kill()                                   # exactly the child we started
+        rc = rc or pr.returncode or (1 if pr.returncode is None else 0)
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    raise SystemExit(rc)
+
+
+def dry_run(args, world, rank):
+    """CPU rehearsal of the N > 1 control flow: gloo rendezvous, tp.shard_llama of the tiny model, the path's exchange
+    pattern (one all-reduce of [B, D] after o_proj and after down_proj per layer) timed with the same barrier / max-over-
+    ranks protocol, ONE JSON line from rank 0.  No QuantizedLinear math runs here (that needs the HIP extension)."""
+    from gbx_lm_amd import synthetic as S, tp
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    # tiny shapes that still shard 8 ways (K / 8 a multiple of 128 values, 8 KV heads)
+    cfg = dict(S.TINY, hidden_size=1024, intermediate_size=2048, num_attention_heads=8, num_key_value_heads=8)
+    model = S.build_model(cfg, S.make_strategy("S22", cfg["num_hidden_layers"]), device="cpu", seed=0)
+    if world > 1:
+        tp.shard_llama(model, rank, world)
+    h = torch.zeros((args.batch, cfg["hidden_size"]), dtype=torch.float32)
+
+    def step():
+        for _ in model.model.layers:
+            for _ in range(2):
+                if world > 1:
+                    tp.all_reduce_(h)
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ms = (time.perf_counter() - t0) * 1e3
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([ms], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item())
+    if rank == 0:
+        q = model.model.layers[0].self_attn.q_proj
+        print(json.dumps({"metric": "dry_run_exchange_steps_per_s", "value": args.steps * 1e3 / max(ms, 1e-9), "unit": "steps/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms / args.steps,
+                          "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+                          "dtype": "none", "data": "synthetic", "dry_run": True, "rccl_ranks": 0, "backend": "gloo",
+                          "config": {"workload": "tiny Llama, TP shard + all-reduce pattern only (CPU rehearsal)",
+                                     "parallelism": f"tp{world}", "q_rows_per_rank": q.output_dims}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def time_decode(runner, steps, warmup, batch, world=1, dev=None):
+    """EXACTLY `steps` greedy decode steps between a barrier + synchronize on both sides; HIP events on the launch stream
+    (N = 1) / max(events, host clock) then MAX over ranks (N > 1).  Returns ms for the `steps` steps."""
+    for _ in range(warmup):
+        runner.step_greedy()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t_host0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        runner.step_greedy()
+    e1.record()
+    torch.cuda.synchronize()
+    t_host = time.perf_counter() - t_host0
+    if world > 1:
+        dist.barrier()
+    ms = max(e0.elapsed_time(e1), t_host * 1e3) if world > 1 else e0.elapsed_time(e1)
+    if world > 1:
+        tms = torch.tensor([ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(tms, op=dist.ReduceOp.MAX)
+        ms = float(tms.item())
+    return ms
+
+
+def make_caches(model, batch, cap, dev):
+    from gbx_lm_amd.models.cache import KVCache
+    at = model.model.layers[0].self_attn
+    caches = []
+    for _ in model.model.layers:
+        c = KVCache(step=cap)
+        like = torch.empty((batch, at.n_kv_heads, 1, at.head_dim), dtype=torch.bfloat16, device=dev)
+        c.reserve(1, like, like)
+        caches.append(c)
+    return caches
+
+
+def decode_leg(model, cfg, dev, batch, context, steps, warmup):
+    """A secondary decode point of the metric on one GPU (same protocol as the headline leg)."""
+    from gbx_lm_amd.decode import DecodeRunner, FusedDecodeRunner, fused_eligible
+    cap = ((context + warmup + steps + 2 + 255) // 256) * 256
+    caches = make_caches(model, batch, cap, dev)
+    Runner = FusedDecodeRunner if (fused_eligible(model) and batch == 1) else DecodeRunner
+    runner = Runner(model, caches, use_graph=True)
+    for t in range(context):
+        runner.step(torch.full((batch,), t % cfg["vocab_size"], device=dev, dtype=torch.long))
+    runner.start_greedy(torch.argmax(runner.logits, -1))
+    ms = time_decode(runner, steps, warmup, batch) / steps
+    ql_b, head_b, kv_b = token_bytes(model, context + warmup + steps // 2)
+    nbytes = ql_b + head_b + kv_b * batch
+    return {"tok_s": batch * 1e3 / ms, "ms_per_step": ms, "steps": steps, "context": context, "batch": batch,
+            "bytes_per_step": nbytes, "achieved_GBps": nbytes / ms / 1e6, "frac_of_8TBps": nbytes / ms / 1e6 / HBM_PEAK_GBPS,
+            "decode_block": Runner.__name__}
+
+
+def prefill_leg(model, cfg, dev, B=8, T=4096):
+    """BASELINE.json configs[3]: prefill of B x T tokens through the model's own forward (chunks of 2048 like
+    generate_step), then the QuantizedLinear GEMMs alone at the same M (MFMA-bound: fraction of the 2.5 PFLOP/s dense
+    bf16 peak from the algorithmic flops 2 M N K)."""
+    from gbx_lm_amd.models.cache import make_prompt_cache
+    toks = (torch.arange(B * T, device=dev) % cfg["vocab_size"]).view(B, T)
+
+    def run():
+        cache = make_prompt_cache(model)
+        with torch.no_grad():
+            for s0 in range(0, T, 2048):
+                model.model(toks[:, s0:s0 + 2048], cache=cache)
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    mods = [m for blk in model.model.layers for m in (blk.self_attn.q_proj, blk.self_attn.k_proj, blk.self_attn.v_proj,
+                                                      blk.self_attn.o_proj, blk.mlp.gate_proj, blk.mlp.up_proj, blk.mlp.down_proj)]
+    flops = 2.0 * B * T * sum(m.input_dims * m.output_dims for m in mods)
+    x = {k: torch.randn(B * 2048, k, device=dev).to(torch.bfloat16) for k in {m.input_dims for m in mods}}
+    with torch.no_grad():
+        for m in mods[:7]:
+            m(x[m.input_dims])
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(T // 2048):
+            for m in mods:
+                m(x[m.input_dims])
+        e1.record()
+    torch.cuda.synchronize()
+    tg = e0.elapsed_time(e1)
+    return {"tok_s": B * T / ms * 1e3, "ms": ms, "batch": B, "seq_len": T, "qlinear_ms": tg, "qlinear_flops": flops,
+            "qlinear_TFLOPs": flops / tg / 1e9, "frac_of_2500_TFLOPs_dense_bf16": flops / tg / 1e9 / 2500.0,
+            "note": "whole forward incl. torch SDPA and glue; qlinear_* = the 224 dequant-GEMMs alone at M = B*2048 rows"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,23 +300,30 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-leg", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (bpw-4.0 decode, batch-32 decode, prefill)")
+    ap.add_argument("--dry-run", action="store_true", help="CPU / gloo rehearsal of the multi-rank control flow")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)                                     # never returns; nothing has touched the GPU yet
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs MI355X GPUs (the QuantizedLinear path has no CPU fallback)")
+    t_start = time.perf_counter()
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from gbx_lm_amd import synthetic as S, tp
     from gbx_lm_amd.decode import DecodeRunner, FusedDecodeRunner, fused_eligible
-    from gbx_lm_amd.models.cache import KVCache
 
     cfg = {"llama3-8b": S.LLAMA3_8B, "llama3.2-3b": S.LLAMA32_3B, "tiny": S.TINY}[args.model]
     strat = S.make_strategy(args.strategy, cfg["num_hidden_layers"], 128)
@@ -149,18 +332,12 @@ def main():
         tp.shard_llama(model, rank, world)
     torch.cuda.synchronize()
 
-    at = model.model.layers[0].self_attn
     total = args.context + args.warmup + args.steps + 2
     cap = ((total + 255) // 256) * 256
-    caches = []
-    for _ in model.model.layers:
-        c = KVCache(step=cap)
-        like = torch.empty((args.batch, at.n_kv_heads, 1, at.head_dim), dtype=torch.bfloat16, device=dev)
-        c.reserve(1, like, like)
-        caches.append(c)
+    caches = make_caches(model, args.batch, cap, dev)
 
-    # N > 1: the RCCL all-reduces are captured into the same HIP graph (verified capturable on this stack at
-    # world_size 1); GBX_TP_GRAPH=0 forces eager launches, and a failed capture falls back to them
+    # N > 1: the RCCL all-reduces are captured into the same HIP graph; GBX_TP_GRAPH=0 forces eager launches, and a capture
+    # that raises (before any collective has been enqueued for real) falls back to them on every rank alike
     use_graph = not args.no_graph and (world == 1 or os.environ.get("GBX_TP_GRAPH", "1") != "0")
     graph_note = "hipGraph replay"
     Runner = FusedDecodeRunner if (fused_eligible(model) and args.batch == 1) else DecodeRunner
@@ -181,28 +358,7 @@ def main():
     tok = torch.argmax(runner.logits, -1)
     runner.start_greedy(tok)                                        # greedy chain: argmax + next-token feed stay on the device
 
-    def decode(n):
-        for _ in range(n):
-            runner.step_greedy()
-
-    decode(args.warmup)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t_host0 = time.perf_counter()
-    e0.record()
-    decode(args.steps)
-    e1.record()
-    torch.cuda.synchronize()
-    t_host = time.perf_counter() - t_host0
-    if world > 1:
-        dist.barrier()
-    ms = max(e0.elapsed_time(e1), t_host * 1e3) if world > 1 else e0.elapsed_time(e1)   # HIP events on the launch stream
-    if world > 1:
-        tms = torch.tensor([ms], device=dev, dtype=torch.float64)
-        dist.all_reduce(tms, op=dist.ReduceOp.MAX)
-        ms = float(tms.item())
+    ms = time_decode(runner, args.steps, args.warmup, args.batch, world, dev)
     ms_per_step = ms / args.steps
     tok_s = args.batch * 1e3 / ms_per_step
 
@@ -212,8 +368,35 @@ def main():
 
     roof = None
     cpu = None
+    extra = None
     if rank == 0 and not args.no_kernel_leg:
         roof = kernel_leg(model)
+    if rank == 0 and world == 1 and not args.no_extra and args.model == "llama3-8b" and args.batch == 1:
+        # the rest of the metric (BASELINE.json: "bpw-2.2 & 4.0", configs[3], configs[4] at TP 1) in the same line, bounded
+        extra = {}
+        legs = []
+        if args.strategy == "S22":
+            legs.append(("b32_decode_S22", lambda: decode_leg(model, cfg, dev, 32, 128, 16, 2)))
+
+        def s40_legs():
+            m40 = S.build_model(cfg, S.make_strategy("S40", cfg["num_hidden_layers"], 128), device=dev, seed=0)
+            out = {"decode": decode_leg(m40, cfg, dev, 1, args.context, args.steps, args.warmup)}
+            try:
+                out["prefill_B8_T4096"] = prefill_leg(m40, cfg, dev)
+            except Exception as e:
+                out["prefill_B8_T4096"] = {"failed": f"{type(e).__name__}: {e}"[:200]}
+            return out
+        if args.strategy != "S40":
+            legs.append(("S40", s40_legs))
+        for name, fn in legs:
+            if time.perf_counter() - t_start > 240.0:
+                extra[name] = {"skipped": "time budget"}
+                continue
+            try:
+                extra[name] = fn()
+            except Exception as e:
+                extra[name] = {"failed": f"{type(e).__name__}: {e}"[:200]}
+            torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             cpu = cpu_baseline(model, cfg)
@@ -227,7 +410,7 @@ def main():
             "metric": "decode_tok_per_s", "value": tok_s, "unit": "tok/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "bf16",
-            "data": "synthetic",
+            "data": "synthetic", "rccl_ranks": world if world > 1 else 0,
             "config": {"workload": f"{args.model} layer-mix {args.strategy} greedy decode batch={args.batch} "
                                    f"context={args.context} (BASELINE.json configs[{2 if args.batch == 1 else 4}])",
                        "global_batch": args.batch, "seq_len": args.context, "parallelism": f"tp{world}",
@@ -237,6 +420,7 @@ def main():
             "e2e": {"bytes_per_token_per_gpu": per_gpu_bytes, "qlinear_bytes": ql_b, "lm_head_bytes": head_b,
                     "kv_bytes": kv_b, "achieved_GBps_per_gpu": e2e_gbps, "frac_of_8TBps": e2e_gbps / HBM_PEAK_GBPS,
                     "frac_of_measured_copy_6290": e2e_gbps / 6290.0},
+            "extra": extra,
         }
         print(json.dumps(out))
     if world > 1:

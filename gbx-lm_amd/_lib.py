@@ -75,6 +75,7 @@ def _declare_optional(L) -> None:
     i64, i32, p, f32 = ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_float
     table = {
         "gbx_qlinear_fused_forward": [ctypes.POINTER(FusedDesc), p],
+        "gbx_qlinear_kernel_id": [i64, i32, i32, i32, i32, i32],
         "gbx_stream_encode": [ctypes.POINTER(FusedDesc), i32, p, ctypes.c_size_t],
         "gbx_stream_run": [p, p, i32, i32, i32, p],
         "gbx_attn_decode": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, f32, f32, i32, i32, p],

@@ -61,6 +61,17 @@ size_t gbx_qlinear_workspace_bytes(int64_t M, int32_t N, int32_t K, int32_t bits
   return 0;
 }
 
+int gbx_qlinear_kernel_id(int64_t M, int32_t N, int32_t K, int32_t bits, int32_t group_size, int32_t has_workspace) {
+  if (check_shape(M, N, K, bits, group_size) != GBX_OK) return -1;
+  static const bool force_generic = getenv("GBX_FORCE_GENERIC") != nullptr;
+  const int max_k = bits == 2 ? gbx::gemv_max_k<2>() : bits == 3 ? gbx::gemv_max_k<3>() : gbx::gemv_max_k<4>();
+  if (M == 0) return 0;
+  if (!force_generic && M > 1 && M <= 64 && (K % 128) == 0 && K >= 512) return 20;               /* batched-decode kernels */
+  if (!force_generic && M > 1 && (K % 128) == 0) return 10 + gbx::prefill_tile_id(static_cast<int>(M), N, K, has_workspace != 0);
+  if (!force_generic && (K % 128) == 0 && K <= max_k) return 1;                                   /* decode GEMV */
+  return 2;                                                                                       /* generic kernel */
+}
+
 int gbx_qlinear_forward(const void* x, const uint32_t* qweight, const void* scales, const void* zeros,
                         const void* bias, void* y, int64_t M, int32_t N, int32_t K, int32_t bits,
                         int32_t group_size, int32_t act_dtype, void* hip_stream) {

@@ -21,6 +21,7 @@ hipError_t launch_qgemm_mfma(const void* x, const uint32_t* qw, const void* sc, 
                              int M, int N, int K, int bits, int log2g, bool bf16, hipStream_t s, float* ws = nullptr);
 size_t qgemm_batch_workspace_bytes(int M, int N, int K, int bits, int log2g);
 size_t qgemm_prefill_workspace_bytes(int M, int N, int K);
+int prefill_tile_id(int M, int N, int K, bool has_ws);
 hipError_t launch_qgemm_skinny(const void* x, const uint32_t* qw, const void* sc, const void* ze, const void* bias, void* y,
                                int M, int N, int K, int bits, int log2g, bool bf16, hipStream_t s, float* ws = nullptr);
 hipError_t launch_qgemm_skinny_multi(const void* x, int nseg, const uint32_t* const* qw, const void* const* sc, const void* const* ze,

@@ -277,6 +277,20 @@ size_t qgemm_prefill_workspace_bytes(int M, int N, int K) {
   return s > 1 ? static_cast<size_t>(s) * M * N * sizeof(float) : 0;
 }
 
+// Which workgroup tile a prefill-sized call (M > 64) runs on: 1 = 128 x 128, 2 = 256 x 128, 3 = 256 x 256 (8 waves),
+// 5 = 128 x 128 with k split over workgroups + summing launch (caller scratch).  The biggest tile that still gives every
+// CU a workgroup: LDS bytes per flop fall with the tile.  GBX_PREFILL_TILE=1..4 forces one (tuning aid).
+int prefill_tile_id(int M, int N, int K, bool has_ws) {
+  if (has_ws && prefill_ksplit(M, N, K) > 1) return 5;
+  static const int force = getenv("GBX_PREFILL_TILE") ? atoi(getenv("GBX_PREFILL_TILE")) : 0;
+  const long t256 = static_cast<long>((M + 255) / 256) * ((N + 255) / 256);
+  const long t128 = static_cast<long>((M + 255) / 256) * ((N + 127) / 128);
+  if (force == 4) return 4;
+  if (force == 3 || (force == 0 && t256 >= 256)) return 3;
+  if (force == 2 || (force == 0 && t128 >= 128 && M > 128)) return 2;
+  return 1;
+}
+
 template <int BITS>
 static hipError_t launch_prefill_bits(const MfmaArgs& a0, bool bf16, hipStream_t s) {
   MfmaArgs a = a0;
@@ -287,14 +301,12 @@ static hipError_t launch_prefill_bits(const MfmaArgs& a0, bool bf16, hipStream_t
     if (e != hipSuccess) return e;
     return launch_splitk_finish(a.ws, a.bias, a.y, a.ksplit, a.M, a.N, bf16, s);
   }
-  static const int force = getenv("GBX_PREFILL_TILE") ? atoi(getenv("GBX_PREFILL_TILE")) : 0;   // tuning aid: 1..4
-  // the biggest tile that still gives every CU a workgroup: LDS bytes per flop fall with the tile
-  const long t256 = static_cast<long>((a.M + 255) / 256) * ((a.N + 255) / 256);
-  const long t128 = static_cast<long>((a.M + 255) / 256) * ((a.N + 127) / 128);
-  if (force == 4) return launch_prefill_cfg<BITS, 4, 4, 4>(a, bf16, s);                                 // 256 x 256, 4 waves
-  if (force == 3 || (force == 0 && t256 >= 256)) return launch_prefill_cfg<BITS, 4, 2, 8>(a, bf16, s);   // 256 x 256, 8 waves
-  if (force == 2 || (force == 0 && t128 >= 128 && a.M > 128)) return launch_prefill_cfg<BITS, 4, 2, 4>(a, bf16, s);   // 256 x 128
-  return launch_prefill_cfg<BITS, 2, 2, 4>(a, bf16, s);                                                  // 128 x 128
+  switch (prefill_tile_id(a.M, a.N, a.K, false)) {
+    case 4: return launch_prefill_cfg<BITS, 4, 4, 4>(a, bf16, s);     // 256 x 256, 4 waves (tuning aid only)
+    case 3: return launch_prefill_cfg<BITS, 4, 2, 8>(a, bf16, s);     // 256 x 256, 8 waves
+    case 2: return launch_prefill_cfg<BITS, 4, 2, 4>(a, bf16, s);     // 256 x 128
+    default: return launch_prefill_cfg<BITS, 2, 2, 4>(a, bf16, s);    // 128 x 128
+  }
 }
 
 hipError_t launch_qgemm_mfma(const void* x, const uint32_t* qw, const void* sc, const void* ze, const void* bias, void* y,

@@ -325,6 +325,12 @@ int gbx_eminf_optimize(const void* logits, int32_t logits_dtype, float* best_log
 int gbx_rmsnorm(const void* x, const void* w, void* y, int64_t M, int32_t K, float eps, int32_t act_dtype,
                 void* hip_stream);
 
+/* Which kernel family a gbx_qlinear_forward[_ws] call of this shape dispatches to (introspection for tests and profiles):
+ * 0 nothing (M = 0), 1 decode GEMV, 2 generic kernel, 20 batched-decode matrix-core kernels (2 <= M <= 64),
+ * 11 / 12 / 13 prefill tile 128 x 128 / 256 x 128 / 256 x 256 (8 waves), 15 prefill with k split over workgroups
+ * (has_workspace != 0 and the shape qualifies); -1 invalid shape. */
+int gbx_qlinear_kernel_id(int64_t M, int32_t N, int32_t K, int32_t bits, int32_t group_size, int32_t has_workspace);
+
 /* ---- streamed decode GEMV / persistent decode engine (gbx-lm_amd/csrc/gemv_stream.hip) -------------------------------
  * A PROGRAM is a device-resident array of encoded ops; one launch walks ops [begin, end) with one 8-wave workgroup per
  * CU.  Every op is one gbx_qlinear_fused group (q|k|v, o, gate|up + SwiGLU, down: the QuantizedLinear calls of

@@ -1,11 +1,17 @@
-"""CPU baseline leg of bench.py (child process, no torch, no GPU).  TEST / MEASUREMENT INFRASTRUCTURE ONLY.
+"""CPU baseline leg of bench.py (child process, no GPU).  TEST / MEASUREMENT INFRASTRUCTURE ONLY.
 
-Times the oracle's C restatement (oracle/gba_oracle.c, OpenMP over output rows) of the hot path on this box's host
-cores for a BOUNDED sample of the bench workload and extrapolates to one decoded token:
+Times, on this box's host cores, a BOUNDED sample of the bench workload and extrapolates to one decoded token:
 
     sample  = the seven QuantizedLinear calls (M = 1) of one decoder layer at each bit width present in the strategy
-              + one bf16->fp32 lm_head matvec (numpy)
+              + one lm_head matvec
     t_token = sum_bits  n_layers(bits) * t_layer(bits)  +  t_head
+
+Three timings of the same sample:
+  * value                 -- the PyTorch-CPU re-expression of the identical GBA arithmetic: oracle unpack (numpy uint32
+                             bit-stream) -> w = q * scales + zeros (fp32) -> torch.matmul(x, w.T), bf16 head,
+                             torch.set_num_threads(os.cpu_count())
+  * cached_dequant_tok_s  -- the same with w kept dequantised (matmul only: separates unpack cost from GEMV cost)
+  * c_port_tok_s          -- the oracle's C restatement (oracle/gba_oracle.c, OpenMP over output rows, fused unpack + dot)
 
 Prints one JSON object.  Usage: python oracle/cpu_baseline.py '<json spec>'
 """
@@ -63,12 +69,57 @@ def main():
     t_head = (time.perf_counter() - t0) / 3
     t_token = sum(t_layer[b] for b in spec["layer_bits"]) + t_head
     threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    print(json.dumps({"value": 1.0 / t_token, "unit": "tok/s", "cores": threads, "kind": "port",
-                      "sample": "oracle/gba_oracle.c (fp32, OpenMP) timed on the 7 QuantizedLinear calls of one decoder "
-                                f"layer per bit width {sorted(t_layer)} (min of 3, ms: "
-                                f"{ {b: round(v * 1e3, 2) for b, v in t_layer.items()} }) + fp32 lm_head matvec "
-                                f"({t_head * 1e3:.2f} ms, numpy); token = sum over the {len(spec['layer_bits'])} layers "
-                                "+ head; norms/RoPE/attention excluded"}))
+
+    # ---- the PyTorch-CPU path (the baseline SURVEY.md 8d specifies) on the same sample ----
+    import torch
+    from oracle import gba_oracle as O
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    tt_full, tt_cached = {}, {}
+    budget_t0 = time.perf_counter()
+    for bits in sorted(set(spec["layer_bits"])):
+        full = cached = 0.0
+        for n, k in shapes:
+            qw = rng.integers(0, 2**32, size=(n, k * bits // 32), dtype=np.uint64).astype(np.uint32)
+            sc = torch.full((n, k // g), 0.01, dtype=torch.bfloat16)
+            ze = torch.full((n, k // g), -0.015, dtype=torch.bfloat16)
+            x = torch.randn(1, k, dtype=torch.bfloat16)
+            t0 = time.perf_counter()
+            q = torch.from_numpy(O.unpack(qw, bits).astype(np.float32))                   # [N, K]
+            w = (q.view(n, k // g, g) * sc.float()[:, :, None] + ze.float()[:, :, None]).view(n, k)
+            y = torch.matmul(x.float(), w.t())
+            full += time.perf_counter() - t0
+            torch.matmul(x.float(), w.t())
+            t0 = time.perf_counter()
+            for _ in range(3):
+                y = torch.matmul(x.float(), w.t())
+            cached += (time.perf_counter() - t0) / 3
+            del q, w, y
+        tt_full[bits], tt_cached[bits] = full, cached
+    hb = torch.randn(V, D, dtype=torch.float32).to(torch.bfloat16)
+    xb = torch.randn(D, dtype=torch.bfloat16)
+    torch.mv(hb, xb)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        torch.mv(hb, xb)
+    tt_head = (time.perf_counter() - t0) / 3
+    tok_full = sum(tt_full[b] for b in spec["layer_bits"]) + tt_head
+    tok_cached = sum(tt_cached[b] for b in spec["layer_bits"]) + tt_head
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+    except OSError:
+        cpu_model = "unknown"
+    print(json.dumps({"value": 1.0 / tok_full, "unit": "tok/s", "cores": ncores, "kind": "port",
+                      "cached_dequant_tok_s": 1.0 / tok_cached, "c_port_tok_s": 1.0 / t_token, "c_port_threads": threads,
+                      "cpu_model": cpu_model, "torch": torch.__version__, "sample_cpu_seconds": time.perf_counter() - budget_t0,
+                      "sample": "PyTorch-CPU re-expression (oracle unpack -> fp32 dequant -> torch.matmul, bf16 torch.mv head, "
+                                f"{ncores} threads) timed ONCE on the 7 QuantizedLinear calls (M = 1) of one decoder layer per bit "
+                                f"width {sorted(tt_full)} (s per layer: { {b: round(v, 3) for b, v in tt_full.items()} }; matmul only with "
+                                f"cached dequant, ms: { {b: round(v * 1e3, 2) for b, v in tt_cached.items()} }; head {tt_head * 1e3:.2f} ms); "
+                                f"token = sum over the {len(spec['layer_bits'])} layers + head; norms/RoPE/attention excluded.  "
+                                f"c_port_tok_s: oracle/gba_oracle.c (fp32, OpenMP x{threads}), ms per layer "
+                                f"{ {b: round(v * 1e3, 2) for b, v in t_layer.items()} } + fp32 numpy head {t_head * 1e3:.2f} ms"}))
 
 
 if __name__ == "__main__":
