@@ -1,0 +1,109 @@
+"""GPU: BASELINE.json configs[3] (prefill seq 4096 x batch 8 -> M = 32768 rows) through gbx_qlinear_forward, on the
+matrix-core dequant-GEMM tiles that M actually dispatches to (csrc/mfma_gemm.hip: 256 x 256 with 8 waves, 256 x 128,
+128 x 128, and 128 x 128 with k split over workgroups).  Every case asserts the dispatched tile
+(gbx_qlinear_kernel_id) and compares
+  (a) a strided subset of rows against the C oracle with fp64 accumulation (oracle.tolerance), and
+  (b) ALL rows against x . W^T in fp64 with W from gbx_dequantize (bit-exact vs the oracle, test_qlinear_gpu.py /
+      test_fullsize_gpu.py::test_dequantize_full_size_rows_vs_c_oracle).
+Reference op: mx.quantized_matmul at gbx_lm/models/quantized_linear_gba.py:195-205, called with M = B * L rows by the
+prefill of gbx_lm/utils.py:312-319."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TILE = {11: "128x128", 12: "256x128", 13: "256x256-8w", 15: "128x128 split-K"}
+
+
+def _layer(n, k, bits, g, seed, dtype=torch.bfloat16):
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(seed)
+    qw = torch.randint(0, 2**32, (n, k // 32 * bits), dtype=torch.int64, device=DEV, generator=gen).to(torch.int32).view(torch.uint32)
+    qmax = float((1 << bits) - 1)
+    sc = ((torch.rand((n, k // g), device=DEV, generator=gen) + 0.5) * (2.0 / qmax) * 0.02)
+    ze = -sc * qmax / 2 + torch.randn((n, k // g), device=DEV, generator=gen) * 0.1 * sc
+    return qw, sc.to(dtype), ze.to(dtype)
+
+
+def _check(oracle, c_oracle, m, n, k, bits, g, dtype, want_tile, bias=False, workspace=False, seed=0):
+    from gbx_lm_amd import _lib, ops
+    name = "bf16" if dtype == torch.bfloat16 else "fp16"
+    kid = _lib.lib().gbx_qlinear_kernel_id(m, n, k, bits, g, int(workspace))
+    assert kid == want_tile, f"M{m} N{n} K{k}: dispatched to {TILE.get(kid, kid)}, test expects {TILE[want_tile]}"
+    qw, sc, ze = _layer(n, k, bits, g, seed + m + n + bits, dtype)
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(seed + 1)
+    x = torch.randn((m, k), device=DEV, generator=gen).to(dtype)
+    b = (torch.randn((n,), device=DEV, generator=gen) * 0.5).to(dtype) if bias else None
+    L, dt = _lib.lib(), (_lib.GBX_BF16 if dtype == torch.bfloat16 else _lib.GBX_F16)
+    y = torch.empty((m, n), dtype=dtype, device=DEV)
+    stream = torch.cuda.current_stream().cuda_stream
+    if workspace:
+        need = L.gbx_qlinear_workspace_bytes(m, n, k, bits, g)
+        assert need > 0
+        ws = torch.empty((need,), dtype=torch.uint8, device=DEV)
+        _lib.check(L.gbx_qlinear_forward_ws(x.data_ptr(), qw.data_ptr(), sc.data_ptr(), ze.data_ptr(), b.data_ptr() if bias else None,
+                                            y.data_ptr(), m, n, k, bits, g, dt, ws.data_ptr(), need, stream))
+    else:                                                         # straight through the C-ABI, no scratch: one launch
+        _lib.check(L.gbx_qlinear_forward(x.data_ptr(), qw.data_ptr(), sc.data_ptr(), ze.data_ptr(), b.data_ptr() if bias else None,
+                                         y.data_ptr(), m, n, k, bits, g, dt, stream))
+    torch.cuda.synchronize()
+    assert y.shape == (m, n) and torch.isfinite(y.float()).all()
+    # (b) every row vs fp64 x . dequantised weights (+ bias, second rounding like the reference's separate add)
+    w = ops.dequantize(qw, sc, ze, group_size=g, bits=bits, dtype=torch.float32).double()
+    rtol, _ = oracle.tolerance(np.ones(1), name)
+    worst = 0.0
+    for r0 in range(0, m, 8192):                                  # fp64 reference in slabs (memory)
+        ref = x[r0:r0 + 8192].double() @ w.t()
+        if bias:
+            ref = ref + b.double()[None]
+        rms = ref.pow(2).mean().sqrt().item()
+        err = (y[r0:r0 + 8192].double() - ref).abs()
+        bound = rtol * rms + rtol * ref.abs()
+        assert (err <= bound).all(), (f"M{m} N{n} K{k} b{bits} g{g} {name} rows {r0}..: {(err > bound).sum().item()} outside "
+                                      f"tolerance, max err {err.max().item():.4g}, rms {rms:.4g}")
+        worst = max(worst, (err / bound).max().item())
+    # (a) strided row subset vs the C oracle (fp64 accumulation), the stated tolerance
+    rows = sorted({0, 1, m - 1, m // 2, *range(5, m, max(m // 11, 1))})[:16]
+    xs = x[rows].cpu()
+    y64 = c_oracle.qlinear(xs, qw.cpu().view(torch.int32).numpy().view(np.uint32), sc.cpu(), ze.cpu(), bits, g,
+                           bias=b.cpu() if bias else None, acc64=True)
+    oracle.assert_close(y[rows], y64, name, f"prefill M{m} N{n} K{k} b{bits} g{g} vs C oracle")
+    return worst
+
+
+# the four QuantizedLinear shapes of an 8B block at M = 32768 (4-bit = S40, the cfg4 strategy): 256 x 256 / 8 waves everywhere
+@pytest.mark.parametrize("n,k", [(4096, 4096), (1024, 4096), (14336, 4096), (4096, 14336)])
+def test_cfg4_full_m_4bit(oracle, c_oracle, n, k):
+    _check(oracle, c_oracle, 32768, n, k, 4, 128, torch.bfloat16, want_tile=13)
+
+
+@pytest.mark.parametrize("bits", [2, 3])
+def test_cfg4_full_m_other_widths(oracle, c_oracle, bits):
+    _check(oracle, c_oracle, 32768, 4096, 4096, bits, 128, torch.bfloat16, want_tile=13)
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_tile_256x256_8w(oracle, c_oracle, bits, dtype):
+    g = 64 if dtype == torch.float16 else 128
+    _check(oracle, c_oracle, 4096, 4096, 4096, bits, g, dtype, want_tile=13, bias=(bits == 3))
+    _check(oracle, c_oracle, 4096 - 37, 14336 - 24, 4096, bits, g, dtype, want_tile=13)          # ragged M and N
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_tile_256x128(oracle, c_oracle, bits, dtype):
+    g = 128 if dtype == torch.float16 else 64
+    _check(oracle, c_oracle, 4096, 1024, 4096, bits, g, dtype, want_tile=12)
+    _check(oracle, c_oracle, 1024, 4096, 14336, bits, g, dtype, want_tile=12, bias=(bits == 2))
+    _check(oracle, c_oracle, 1000, 14336 - 8, 4096, bits, g, dtype, want_tile=12)               # ragged
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+def test_tile_128x128_and_splitk(oracle, c_oracle, bits):
+    _check(oracle, c_oracle, 1024, 1024, 4096, bits, 128, torch.bfloat16, want_tile=11)
+    _check(oracle, c_oracle, 100, 4096 - 12, 4096, bits, 64, torch.float16, want_tile=11, bias=True)
+    _check(oracle, c_oracle, 1024, 1024, 4096, bits, 128, torch.bfloat16, want_tile=15, workspace=True)
+    _check(oracle, c_oracle, 300, 4096, 14336, bits, 128, torch.bfloat16, want_tile=15, workspace=True, bias=True)
