@@ -38,7 +38,7 @@ int check_shape(int64_t M, int32_t N, int32_t K, int32_t bits, int32_t group) {
   if (N <= 0 || K <= 0 || M < 0) return fail(GBX_ERR_INVALID, "non-positive dimension M=%lld N=%d K=%d", (long long)M, N, K);
   if (K % 32) return fail(GBX_ERR_INVALID, "input_dims (%d) must be a multiple of 32", K);
   if (K % group) return fail(GBX_ERR_INVALID, "input_dims (%d) must be a multiple of group_size (%d)", K, group);
-  if (M > 65535) return fail(GBX_ERR_INVALID, "M=%lld exceeds the launch limit of this entry point", (long long)M);
+  if (M > (1LL << 40)) return fail(GBX_ERR_INVALID, "M=%lld is not a plausible row count", (long long)M);
   return GBX_OK;
 }
 
@@ -90,6 +90,20 @@ int gbx_qlinear_forward_ws(const void* x, const uint32_t* qweight, const void* s
     return fail(GBX_ERR_INVALID, "x and qweight must be 16-byte aligned");
   if (!aligned(scales, 2) || !aligned(zeros, 2) || !aligned(y, 2) || (bias && !aligned(bias, 2)))
     return fail(GBX_ERR_INVALID, "scales/zeros/bias/y must be 2-byte aligned");
+  // The reference op has no row limit; a launch has (grid.y <= 65535 rows on the row-per-block kernels, 32-bit tile
+  // arithmetic on the matrix-core ones): longer inputs go in slabs of 61440 rows (a multiple of every row tile).
+  constexpr int64_t SLAB = 61440;
+  if (M > SLAB) {
+    if ((K % 8) != 0) return fail(GBX_ERR_UNSUPPORTED, "M > %lld needs K %% 8 == 0 (slab alignment)", (long long)SLAB);
+    for (int64_t m0 = 0; m0 < M; m0 += SLAB) {
+      const int64_t mm = M - m0 < SLAB ? M - m0 : SLAB;
+      rc = gbx_qlinear_forward_ws(static_cast<const unsigned short*>(x) + m0 * K, qweight, scales, zeros, bias,
+                                  static_cast<unsigned short*>(y) + m0 * N, mm, N, K, bits, group_size, act_dtype,
+                                  workspace, workspace_bytes, hip_stream);
+      if (rc) return rc;
+    }
+    return GBX_OK;
+  }
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   const bool bf16 = act_dtype == GBX_BF16;
   const int log2g = log2_group(group_size);

@@ -124,3 +124,20 @@ def test_fused_qkv_and_swiglu_full_size():
         wu = ops.dequantize(up.qweight, up.scales, up.zeros, group_size=128, bits=bits, dtype=torch.float32).double()
         gg, uu = xn[None].double() @ wg.t(), xn[None].double() @ wu.t()
         _close(act[None], gg / (1 + torch.exp(-gg)) * uu, f"fused swiglu b{bits}")
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("n,k", SHAPES_8B)
+def test_dequantize_full_size_rows_vs_c_oracle(c_oracle, bits, n, k):
+    """Chain of trust at the sizes it is used: gbx_dequantize (the reference weights of every full-size test here and in
+    test_prefill_gpu.py) against the C oracle's dequant on a strided subset of rows, bit for bit (fp32 fma of exact
+    integers and 16-bit scale/zero: one correctly rounded result), for g = 128 and 64."""
+    from gbx_lm_amd import ops
+    for g in (128, 64):
+        qw, sc, ze = _layer(n, k, bits, g, seed=3 * n + k + bits + g)
+        w = ops.dequantize(qw, sc, ze, group_size=g, bits=bits, dtype=torch.float32)
+        rows = sorted({0, 1, n - 1, n // 2, *range(3, n, max(n // 29, 1))})
+        ref = c_oracle.dequant(qw.view(torch.int32)[rows].cpu().numpy().view(np.uint32), sc[rows].cpu(), ze[rows].cpu(), bits, g)
+        got = w[rows].cpu().numpy()
+        assert got.shape == ref.shape and np.array_equal(got.view(np.uint32), ref.view(np.uint32)), \
+            f"dequantize N{n} K{k} b{bits} g{g}: {int((got != ref).sum())} elements differ"
