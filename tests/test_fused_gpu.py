@@ -652,3 +652,40 @@ def test_eminf_optimize_on_device(golden_dir, oracle):
     fixed, _ = eminf_optimize(torch.from_numpy(z["logits"]).to(DEV), num_steps=2)
     w2, _ = oracle.eminf_optimize(z["logits"], num_steps=2)
     assert np.abs(fixed.cpu().numpy() - w2).max() < 2e-3
+
+
+def test_eminf_generate_step_on_device(tmp_path):
+    """infer_opt.py:168-245 on the GPU: the generator form (prefill through the MFMA GEMMs, single-token steps through the
+    graph-replayed decode block, logits optimised by gbx_eminf_optimize) yields the tokens eminf_generate returns under the
+    same numpy stream, each with the logprob of the optimised distribution; a PromptCache hit feeds only the new tokens."""
+    from gbx_lm_amd import synthetic as S, utils as U
+    from gbx_lm_amd.infer_opt import eminf_generate, eminf_generate_step
+    from gbx_lm_amd.prompt_cache import PromptCache
+    S.write_checkpoint(str(tmp_path), S.TINY, S.make_strategy("S22", 2), seed=3)
+    model, tok = U.load(str(tmp_path))
+    model = model.to(DEV)
+    for blk in model.model.layers:
+        blk.self_attn.rope.to(DEV)
+    prompt = [5, 17, 42, 9, 100, 3]
+    ids = eminf_generate(model, tok, prompt, max_tokens=12, rng=np.random.default_rng(4))
+    steps = list(eminf_generate_step(model, tok, prompt, max_tokens=12, rng=np.random.default_rng(4)))
+    body = [t for t in ids if t not in tok.eos_token_ids]
+    assert [t for t, _, _ in steps] == body[:len(steps)] and len(steps) >= 1
+    for t, lp, hs in steps:
+        assert hs is None and lp.is_cuda and float(lp) <= 0.0 and 0 <= t < 512
+    pc = PromptCache()
+    conv1, conv2 = prompt, prompt + [33, 34, 35, 36]
+    eminf_generate(model, tok, conv1 + [4], conv1, max_tokens=2, prompt_cache=pc, rng=np.random.default_rng(5))
+    for c in pc.cache:
+        c.trim(c.offset - len(conv1))
+    # turn 2 extends the conversation: the hit feeds only the new tokens and reproduces the from-scratch logits
+    from gbx_lm_amd.infer_opt import get_input_ids
+    from gbx_lm_amd.models.cache import make_prompt_cache
+    todo, hit, cache = get_input_ids(pc, model, conv2 + [4], conv2, pc.model_key)
+    assert hit and todo == conv2[len(conv1):] + [4] and pc.tokens_no_gen == conv2
+    with torch.no_grad():
+        got = model(torch.tensor([todo], device=DEV), cache=cache)[:, -1, :].float()
+        want = model(torch.tensor([conv2 + [4]], device=DEV), cache=make_prompt_cache(model))[:, -1, :].float()
+    assert torch.allclose(got, want, atol=5e-2, rtol=5e-2)
+    steps2 = list(eminf_generate_step(model, tok, conv2 + [4, 7], conv2 + [4], max_tokens=4, prompt_cache=pc, rng=np.random.default_rng(6)))
+    assert all(0 <= t < 512 for t, _, _ in steps2)

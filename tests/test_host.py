@@ -171,7 +171,47 @@ def test_eminf_generate_loop(tmp_path, cpu_oracle_op):
     ids2 = eminf_generate(model, tok, [5, 17, 42], max_tokens=5, rng=np.random.default_rng(0))
     assert ids == ids2                                                                # seeded numpy sampling
     with pytest.raises(NotImplementedError):
-        eminf_generate(model, tok, [1], max_tokens=1, prompt_cache=object())
+        eminf_generate(model, tok, [1], max_tokens=1, max_kv_size=64)
+
+
+def test_eminf_generate_step_and_prompt_cache(tmp_path, cpu_oracle_op, capsys):
+    """infer_opt.py:10-28,168-245: the generator form yields (token, logprob of that token, None) and draws the same
+    tokens as eminf_generate under the same numpy stream; with a PromptCache the second request of a conversation feeds
+    only its new tokens and still reproduces the from-scratch tokens."""
+    from gbx_lm_amd.infer_opt import eminf_generate, eminf_generate_step, get_input_ids
+    from gbx_lm_amd.prompt_cache import PromptCache
+    from gbx_lm_amd.models.cache import make_prompt_cache
+    S.write_checkpoint(str(tmp_path), S.TINY, S.make_strategy("S22", 2), seed=3)
+    model, tok = U.load(str(tmp_path))
+    ids = eminf_generate(model, tok, [5, 17, 42], max_tokens=6, rng=np.random.default_rng(1))
+    steps = list(eminf_generate_step(model, tok, [5, 17, 42], max_tokens=6, rng=np.random.default_rng(1)))
+    assert [t for t, _, _ in steps] == [t for t in ids if t not in tok.eos_token_ids][:len(steps)] and len(steps) >= 1
+    for t, lp, hs in steps:
+        assert hs is None and lp.ndim == 0 and float(lp) <= 0.0
+    # get_input_ids: no cache / use_cache=False -> fresh cache + the whole prompt
+    todo, hit, cache = get_input_ids(None, model, [1, 2, 3], [1, 2], "k")
+    assert todo == [1, 2, 3] and not hit and cache[0].offset == 0
+    pc = PromptCache()
+    todo, hit, cache = get_input_ids(pc, model, [1, 2, 3], [1, 2], "k", use_cache=False)
+    assert todo == [1, 2, 3] and not hit and pc.cache is None
+    # a conversation through the prompt cache: turn 1 (miss), turn 2 extends it (hit: only the new tokens are fed)
+    conv1, conv2 = [5, 17, 42, 9], [5, 17, 42, 9, 33, 34, 35]
+    a1 = eminf_generate(model, tok, conv1 + [4], conv1, max_tokens=3, prompt_cache=pc, rng=np.random.default_rng(2))
+    assert pc.cache is not None and pc.tokens_no_gen == conv1
+    # the cache now also holds the generation prompt and the sampled tokens of turn 1: the reference's own bookkeeping
+    # (PromptCache.tokens_no_gen) decides what is reused, so mirror what its caller does and trim to the conversation
+    for c in pc.cache:
+        c.trim(c.offset - len(conv1))
+    capsys.readouterr()
+    a2 = eminf_generate(model, tok, conv2 + [4], conv2, max_tokens=4, prompt_cache=pc, rng=np.random.default_rng(3))
+    assert "Use input cache" in capsys.readouterr().out
+    want = eminf_generate(model, tok, conv2 + [4], conv2, max_tokens=4, rng=np.random.default_rng(3))
+    assert a2 == want and len(a1) >= 1
+    # identical request again: nothing new to process -> last token re-fed on a cache trimmed by one (no duplicate KV rows)
+    for c in pc.cache:
+        c.trim(c.offset - len(conv2))
+    todo, hit, cache = get_input_ids(pc, model, conv2, conv2, pc.model_key)
+    assert hit and todo == conv2[-1:] and cache[0].offset == len(conv2) - 1
 
 
 def test_load_gba_native_conversion_and_double_quant(tmp_path):
@@ -233,3 +273,72 @@ def test_load_gba_native_conversion_and_double_quant(tmp_path):
     want_z = -(((st & 0x0F).to(torch.float16) - 7.5) * 0.01).view(kg, N).t()          # negated by set_bias_and_weight
     assert torch.allclose(g2.scales.float(), want_s.float(), rtol=1e-2, atol=1e-6)
     assert torch.allclose(g2.zeros.float(), want_z.float(), rtol=1e-2, atol=1e-6)
+
+
+def _write_native(tmp_path, name, double_quant):
+    """A GBA-native twin of a runtime-layout tiny checkpoint: transposed qweight / scales / zeros, GBA-sign zeros in fp16,
+    or (double_quant) qstatistic + side tensors instead of scales / zeros."""
+    from safetensors.torch import save_file
+    strat = S.make_strategy("S22", 2, 64)
+    src = S.write_checkpoint(str(tmp_path / "mlx"), S.TINY, strat, seed=8)
+    sd = {}
+    gen = torch.Generator().manual_seed(0)
+    for k, v in S.state_dict_for_disk(src).items():
+        if k.endswith("qweight"):
+            sd[k] = v.view(torch.int32).t().contiguous()
+        elif k.endswith("scales"):
+            if not double_quant:
+                sd[k] = v.to(torch.float16).t().contiguous()
+        elif k.endswith("zeros"):
+            if not double_quant:
+                sd[k] = (-v.to(torch.float32)).to(torch.float16).t().contiguous()
+        else:
+            sd[k] = v
+    if double_quant:
+        for mname, m in src.named_modules():
+            if isinstance(m, QuantizedLinear):
+                kg, ng = m.input_dims // m.group_size, -(-m.output_dims // 32)
+                sd[mname + ".qstatistic"] = torch.randint(0, 256, (kg, ng, 32), dtype=torch.uint8, generator=gen)
+                sd[mname + ".qzeros_zeros"] = torch.full((kg, ng, 1), 7.5, dtype=torch.float16)
+                sd[mname + ".qzeros_scales"] = torch.full((kg, ng, 1), 0.004, dtype=torch.float16)
+                sd[mname + ".qscales_zeros"] = torch.full((kg, ng, 1), -1.0, dtype=torch.float16)
+                sd[mname + ".qscales_scales"] = torch.full((kg, ng, 1), 0.0008, dtype=torch.float16)
+    nat = tmp_path / name
+    os.makedirs(nat)
+    save_file(sd, str(nat / "model.safetensors"))
+    for f in ("config.json", "quant_strategy.json", "tokenizer.json", "tokenizer_config.json"):
+        open(nat / f, "w").write(open(tmp_path / "mlx" / f).read())
+    return nat
+
+
+@pytest.mark.parametrize("double_quant", [False, True])
+def test_convert_gba_native_repo(tmp_path, double_quant):
+    """gba2mlx.convert (gbx_lm/gba2mlx.py:93-161): GBA-native repo -> runtime layout on disk; plain load() of the result
+    holds exactly the tensors load_model(is_conversion=True) builds in memory."""
+    from gbx_lm_amd import gba2mlx
+    nat = _write_native(tmp_path, "tiny-w4-g64-native", double_quant)
+    out = tmp_path / "converted-mlx"
+    gba2mlx.convert(str(nat), str(out))
+    files = sorted(p.name for p in out.iterdir())
+    assert {"config.json", "quant_strategy.json", "model.safetensors", "model.safetensors.index.json", "tokenizer.json"} <= set(files)
+    cfg = json.load(open(out / "config.json"))
+    assert cfg["quantization"] == {"group_size": 64, "bits": 4} and list(cfg) == sorted(cfg)
+    idx = json.load(open(out / "model.safetensors.index.json"))
+    assert "model.layers.0.self_attn.q_proj.qweight" in idx["weight_map"] and idx["metadata"]["total_size"] > 0
+    direct, _ = U.load_model(nat, device="cpu", is_conversion=True)
+    conv, tok = U.load(str(out))
+    conv = conv.to("cpu")
+    a, b = S.state_dict_for_disk(direct), S.state_dict_for_disk(conv)
+    assert set(a) == set(b)
+    for k in a:
+        assert a[k].dtype == b[k].dtype and torch.equal(a[k].view(torch.int16) if a[k].dtype in (torch.bfloat16, torch.float16) else
+                                                        a[k].view(torch.int32) if a[k].dtype == torch.uint32 else a[k],
+                                                        b[k].view(torch.int16) if b[k].dtype in (torch.bfloat16, torch.float16) else
+                                                        b[k].view(torch.int32) if b[k].dtype == torch.uint32 else b[k]), k
+    assert not any("qstatistic" in k for k in b)
+    assert gba2mlx.extract_bits_and_group_size("GreenBitAI/Llama-3-8B-w3-g128") == (3, 128)
+    assert gba2mlx.extract_bits_and_group_size("plain-name") == (None, None)
+    with pytest.raises(NotImplementedError):
+        gba2mlx.convert(str(nat), str(out), upload_repo="a/b-mlx")
+    big = {f"t{i}": torch.zeros(1 << 20, dtype=torch.float32) for i in range(5)}      # 4 MiB each
+    assert [len(s) for s in gba2mlx.make_shards(big, max_file_size_gb=0)] == [0, 1, 1, 1, 1, 1] or len(gba2mlx.make_shards(big)) == 1

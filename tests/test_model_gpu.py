@@ -179,3 +179,36 @@ def test_free_running_128_steps_every_choice_is_an_oracle_argmax(golden_dir, mon
             strict += 1
             assert tok == int(np.argmax(lp_ref[t])), f"step {t}: argmax differs at oracle gap {gap[t]}"
     assert strict >= 3                                                    # (a random tiny model is mostly near-ties)
+
+
+@pytest.mark.parametrize("double_quant", [False, True])
+def test_gba_native_checkpoint_forwards_like_its_runtime_twin(tmp_path, double_quant):
+    """SURVEY 8f rank 2 on the GPU: a synthetic GBA-native checkpoint (transposed qweight, GBA-sign fp16 zeros, optionally
+    double-quantised statistics) goes through gba2mlx.convert -> load(); its logits over a prompt and a few graph-replayed
+    decode steps are bit-identical to the model load_model(is_conversion=True) builds in memory, and -- without double
+    quantisation, where the fp16 round trip of the bf16 scales is exact -- to the runtime-layout twin it was derived from."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_host import _write_native
+    from gbx_lm_amd import gba2mlx, utils as U
+    from gbx_lm_amd.models.cache import make_prompt_cache
+    nat = _write_native(tmp_path, "tiny-w4-g64-native", double_quant)
+    out = tmp_path / "converted-mlx"
+    gba2mlx.convert(str(nat), str(out))
+    conv, _ = U.load(str(out))
+    direct, _ = U.load_model(nat, is_conversion=True)
+    models = [conv, direct]
+    if not double_quant:
+        models.append(U.load(str(tmp_path / "mlx"))[0])
+    ids = torch.tensor([[5, 17, 42, 7, 99, 250, 3]], device=DEV)
+    outs = []
+    for m in models:
+        assert next(m.parameters()).is_cuda
+        cache = make_prompt_cache(m)
+        with torch.no_grad():
+            lg = [m(ids, cache=cache)[:, -1, :]]
+            for t in (11, 12, 13):
+                lg.append(m.decode_step(torch.tensor([t], device=DEV), cache))
+        outs.append(torch.stack([x.float() for x in lg]))
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
+    assert torch.isfinite(outs[0]).all()
