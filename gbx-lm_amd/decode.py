@@ -127,9 +127,15 @@ class DecodeRunner:
         self._next = torch.argmax(logits, -1)
         return logits
 
+    def _check_room(self, off: int) -> None:
+        # the attention / append kernels index the cache with the device-resident position and do no bounds check
+        if off >= self.capacity:
+            raise RuntimeError(f"KV cache is full ({off} of {self.capacity} positions): grow it (KVCache.reserve) and build a new runner")
+
     def step(self, token: torch.Tensor) -> torch.Tensor:
         """Consumes one token id per sequence (device tensor, shape [B]); returns logits [B, V] (a static buffer)."""
         off = self.caches[0].offset
+        self._check_room(off)
         self.tok.copy_(token.reshape(-1))
         self.pos.fill_(off)
         if self.use_graph:
@@ -184,6 +190,8 @@ class GraphDecodeRunner:
 
     def step(self, token: torch.Tensor) -> torch.Tensor:
         off = self.caches[0].offset
+        if off >= self.capacity:
+            raise RuntimeError(f"KV cache is full ({off} of {self.capacity} positions): grow it and build a new runner")
         self.tok.copy_(token.reshape(self.batch, 1))
         self.pos.fill_(off)
         self.graph.replay()
@@ -201,9 +209,20 @@ def graph_decode_step(model, y: torch.Tensor, prompt_cache: List[KVCache]) -> to
         for c in prompt_cache:
             c.reserve(1, c.keys[:, :, :1], c.values[:, :, :1])
     runner = getattr(model, "_decode_runner", None)
+    if getattr(model, "_graph_decode_unavailable", False):
+        return model(y[None], cache=prompt_cache)[:, -1, :]
     if runner is None or runner.caches is not prompt_cache or runner.capacity != c0.capacity \
             or c0.keys.data_ptr() != getattr(runner, "_kptr", None):
-        runner = GraphDecodeRunner(model, prompt_cache)
+        try:
+            runner = GraphDecodeRunner(model, prompt_cache)
+        except RuntimeError:
+            # a forward that cannot be captured (e.g. more (token, expert) pairs than the expert-indexed launch covers needs
+            # the host-grouped gather): this model decodes eagerly from here on
+            for c in prompt_cache:
+                c.static_active, c.static_pos = False, None
+            model._graph_decode_unavailable = True
+            torch.cuda.synchronize()
+            return model(y[None], cache=prompt_cache)[:, -1, :]
         runner._kptr = c0.keys.data_ptr()
         model._decode_runner = runner
     return runner.step(y)
@@ -354,6 +373,7 @@ class FusedDecodeRunner(DecodeRunner):
 
     def step_greedy(self) -> torch.Tensor:
         off = self.caches[0].offset
+        self._check_room(off)
         if self.use_graph:
             self.graph_chain.replay()
         else:

@@ -37,6 +37,18 @@ def _is_gba_linear_or_switch(m) -> bool:
     return isinstance(m, (QuantizedLinear, QuantizedSwitchLinear))
 
 
+def _mlx_named_modules(model: nn.Module):
+    """``(name, module)`` in the order MLX's ``Module.named_modules()`` yields them [external: mlx.nn.Module.apply_to_modules
+    is a stack -- pop the last pushed entry, push the children in attribute order], i.e. depth first with siblings visited
+    LAST to first.  Only the order matters here (the strategy loop's carry-over); names are torch's."""
+    stack = [("", model)]
+    while stack:
+        prefix, mod = stack.pop()
+        yield prefix, mod
+        for cname, child in mod.named_children():
+            stack.append((f"{prefix}.{cname}" if prefix else cname, child))
+
+
 class QuantizedLinear(nn.Module):
     """y = x @ dequant(qweight, scales, zeros)^T (+ bias), weights packed at 2/3/4 bits."""
 
@@ -136,7 +148,7 @@ class QuantizedLinear(nn.Module):
             return
         from .switch_layers import QuantizedSwitchLinear
         last_strg = None
-        for name, child in model.named_modules():
+        for name, child in _mlx_named_modules(model):
             if isinstance(child, QuantizedSwitchLinear):
                 # stacked experts: strategy["model.layers.<i>"]["moe_expert_<proj>"] over gate/up/down only (:236-252)
                 per_block = strategy["model.layers.{}".format(name.split('.')[2])]
@@ -173,9 +185,12 @@ class QuantizedLinear(nn.Module):
                         pass
             if strg is None:
                 # A name none of the keys matches -- the MoE router ``mlp.gate`` -- keeps the entry of the module visited
-                # just before it in the reference (its loop variable simply carries over, :256-272), i.e. o_proj's:
-                # checkpoints are laid out accordingly, so the carry-over is part of the format.
+                # just before it in the reference (its loop variable simply carries over, :256-272).  "Before it" is in
+                # MLX's traversal order (_mlx_named_modules): siblings last-to-first, so the router follows
+                # ``switch_mlp.gate_proj`` and inherits ``moe_expert_gate_proj``.  Checkpoints are laid out accordingly, so
+                # the carry-over is part of the format (load_model additionally reconciles it with the stored shapes).
                 strg = last_strg
+                child._strategy_carried_over = True
             if strg is None:
                 raise KeyError(f"quant strategy has no entry for {name}")
             last_strg = strg

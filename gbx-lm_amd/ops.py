@@ -208,6 +208,17 @@ def gather_quantized_matmul(x: torch.Tensor, w: torch.Tensor, scales: torch.Tens
         raise ValueError(f"x {tuple(x.shape)} does not broadcast against indices {tuple(rhs_indices.shape)}")
     shared = x.shape[-3] == 1
     pairs = rhs_indices.numel()
+    if x.dtype not in (torch.float16, torch.bfloat16):
+        raise ValueError(f"x must be float16 or bfloat16 (got {x.dtype})")
+    # scales / zeros / bias are read as the activation dtype by the kernels: cast here rather than reinterpret their bits
+    # (the loader aligns them once, so this is a no-op on the decode path)
+    if scales.dtype != x.dtype:
+        scales = scales.to(x.dtype)
+    if biases.dtype != x.dtype:
+        biases = biases.to(x.dtype)
+    if bias is not None and bias.dtype != x.dtype:
+        bias = bias.to(x.dtype)
+    w, scales, biases = w.contiguous(), scales.contiguous(), biases.contiguous()
     xr = x.reshape(-1, K).contiguous()                  # [tokens, K] (shared) or [pairs, K]
     idx = rhs_indices.reshape(-1)
     y = torch.empty((pairs, N), dtype=x.dtype, device=x.device)
@@ -219,6 +230,9 @@ def gather_quantized_matmul(x: torch.Tensor, w: torch.Tensor, scales: torch.Tens
             idx32.data_ptr(), y.data_ptr(), pairs, k if shared else 1, E, N, K, bits, group_size, _DT[x.dtype],
             _stream_ptr(x.device)))
     else:                                               # grouped by expert (one host sync for the expert list)
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError(f"gather_quantized_matmul: {pairs} (token, expert) pairs / K={K} need the host-grouped path, which "
+                               "cannot be captured into a HIP graph (the expert-indexed launch covers <= 64 pairs, K % 128 == 0)")
         ar = torch.arange(pairs, device=x.device)
         rows = ar // k if shared else ar
         for e in torch.unique(idx).tolist():

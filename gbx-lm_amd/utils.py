@@ -129,6 +129,29 @@ def load_weights(model: nn.Module, weights: dict, device=None) -> List[str]:
     return skipped
 
 
+def _reconcile_with_checkpoint(model, weights, use_double_quantization: bool, use_q_perm: bool) -> None:
+    """A module whose strategy entry was only CARRIED OVER by the reference's loop (a name no key matches: the MoE router)
+    gets whatever the traversal order happened to leave behind; the stored tensors are the ground truth there.  Where such a
+    module disagrees with the shapes in the checkpoint it is re-allocated from them -- ``qweight [N, K*bits/32]``,
+    ``scales [N, K/g]`` (``qstatistic [K/g, ...]`` when double-quantised).  Modules with a strategy entry of their own keep
+    the reference's behaviour: a mismatch is an error."""
+    for name, m in model.named_modules():
+        if not isinstance(m, QuantizedLinear) or not getattr(m, "_strategy_carried_over", False):
+            continue
+        qw = weights.get(name + ".qweight")
+        if qw is None or qw.dim() != 2 or qw.shape[0] != m.output_dims:
+            continue
+        k = m.input_dims
+        bits = qw.shape[1] * 32 // k if k else 0
+        gsrc = weights.get(name + ".qstatistic") if use_double_quantization else weights.get(name + ".scales")
+        groups = (gsrc.shape[0] if use_double_quantization else gsrc.shape[-1]) if gsrc is not None else 0
+        g = k // groups if groups else m.group_size
+        if bits in (2, 3, 4) and qw.shape[1] * 32 == k * bits and g in (32, 64, 128) and (bits, g) != (m.bits, m.group_size):
+            logging.warning(f"{name}: strategy says ({m.bits} bits, g{m.group_size}), checkpoint holds ({bits} bits, g{g}); using the checkpoint")
+            m.bits, m.group_size = bits, g
+            m.init_params(use_double_quantization, use_q_perm)
+
+
 def load_model(model_path: Path, lazy: bool = False, model_config: dict = {}, bits: int = 4, group_size: int = 64,
                is_conversion: bool = False,
                get_model_classes: Callable[[dict], Tuple[Type[nn.Module], Type]] = _get_classes,
@@ -196,6 +219,7 @@ def load_model(model_path: Path, lazy: bool = False, model_config: dict = {}, bi
 
     QuantizedLinear.reinit_module(model, **quantization, strategy=strategy,
                                   use_double_quantization=use_double_quantization, use_q_perm=use_q_perm)
+    _reconcile_with_checkpoint(model, weights, use_double_quantization, use_q_perm)
     load_weights(model, weights, device=device)
     model.to(device)
 

@@ -104,7 +104,8 @@ def moe_strategy():
     strat = S.make_strategy("S22", 2, 64)
     strat["model.layers.0"]["moe_expert_up_proj"] = {"bits": [2], "group_size": {"2": 32}}
     strat["model.layers.1"]["moe_expert_down_proj"] = {"bits": [4], "group_size": {"4": 128}}
-    strat["model.layers.1"]["o_proj"] = {"bits": [3], "group_size": {"3": 64}}      # the router of layer 1 inherits this
+    strat["model.layers.1"]["o_proj"] = {"bits": [3], "group_size": {"3": 64}}
+    # (the routers match no strategy key and inherit moe_expert_gate_proj: MLX visits switch_mlp.gate_proj just before mlp.gate)
     return strat
 
 
