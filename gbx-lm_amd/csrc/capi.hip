@@ -306,6 +306,23 @@ int gbx_qlinear_forward_multi(const void* x, int32_t nseg, const uint32_t* const
   return GBX_OK;
 }
 
+int gbx_qlinear_swiglu_forward(const void* x, const uint32_t* gate_qweight, const void* gate_scales, const void* gate_zeros,
+                               const uint32_t* up_qweight, const void* up_scales, const void* up_zeros, void* y, int64_t M,
+                               int32_t N, int32_t K, int32_t bits, int32_t group_size, int32_t act_dtype, void* hip_stream) {
+  int rc = check_shape(M, N, K, bits, group_size);
+  if (rc) return rc;
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  if (!x || !gate_qweight || !gate_scales || !gate_zeros || !up_qweight || !up_scales || !up_zeros || !y) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (!aligned(x, 16) || !aligned(gate_qweight, 16) || !aligned(up_qweight, 16)) return fail(GBX_ERR_INVALID, "x and qweight must be 16-byte aligned");
+  if (M < 2 || M > 64 || (N % 16) || (K % 1024))
+    return fail(GBX_ERR_UNSUPPORTED, "fused SwiGLU GEMM covers 2 <= M <= 64, N %% 16 == 0, K %% 1024 == 0 (M=%lld N=%d K=%d)", (long long)M, N, K);
+  hipError_t e = gbx::launch_qgemm_swiglu(x, gate_qweight, gate_scales, gate_zeros, up_qweight, up_scales, up_zeros, y, static_cast<int>(M), N, K,
+                                          bits, log2_group(group_size), act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));
+  if (e == hipErrorInvalidValue) return fail(GBX_ERR_UNSUPPORTED, "fused SwiGLU GEMM: (bits %d, group %d, N %d) is outside the batch kernel", bits, group_size, N);
+  if (e != hipSuccess) return hip_fail(e, "gbx_qlinear_swiglu_forward launch");
+  return GBX_OK;
+}
+
 int gbx_gather_qlinear_forward(const void* x, const uint32_t* qweight, const void* scales, const void* zeros,
                                const void* bias, const int32_t* indices, void* y, int32_t pairs, int32_t x_div,
                                int32_t num_experts, int32_t N, int32_t K, int32_t bits, int32_t group_size,
@@ -657,6 +674,39 @@ int gbx_add_rmsnorm(void* h, const void* delta, const void* w, void* y, int64_t 
   if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
   hipError_t e = gbx::launch_add_rmsnorm(h, delta, w, y, static_cast<int>(M), K, eps, act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));
   if (e != hipSuccess) return hip_fail(e, "gbx_add_rmsnorm launch");
+  return GBX_OK;
+}
+
+int gbx_qlinear_forward_partials(const void* x, const uint32_t* qweight, const void* scales, const void* zeros, void* workspace,
+                                 size_t workspace_bytes, int32_t* slices_out, int64_t M, int32_t N, int32_t K, int32_t bits,
+                                 int32_t group_size, int32_t act_dtype, void* hip_stream) {
+  int rc = check_shape(M, N, K, bits, group_size);
+  if (rc) return rc;
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  if (!x || !qweight || !scales || !zeros || !workspace || !slices_out) return fail(GBX_ERR_INVALID, "null pointer");
+  if (!aligned(x, 16) || !aligned(qweight, 16) || !aligned(workspace, 16)) return fail(GBX_ERR_INVALID, "x, qweight and workspace must be 16-byte aligned");
+  const int log2g = log2_group(group_size);
+  const int slices = (M >= 2 && M <= 32 && (K % 128) == 0 && K >= 512) ? gbx::qgemm_batch_slices(static_cast<int>(M), N, K, bits, log2g) : 1;
+  if (slices <= 1) return fail(GBX_ERR_UNSUPPORTED, "this shape does not split k across workgroups (M=%lld N=%d K=%d): use gbx_qlinear_forward", (long long)M, N, K);
+  const size_t need = static_cast<size_t>(slices) * M * N * sizeof(float);
+  if (workspace_bytes < need) return fail(GBX_ERR_INVALID, "workspace too small: %zu < %zu", workspace_bytes, need);
+  hipError_t e = gbx::launch_qgemm_partials(x, qweight, scales, zeros, static_cast<float*>(workspace), static_cast<int>(M), N, K, bits, log2g,
+                                            act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_qlinear_forward_partials launch");
+  *slices_out = slices;
+  return GBX_OK;
+}
+
+int gbx_add_rmsnorm_slices(void* h, const float* slices_ws, int32_t slices, const void* w, void* y, int64_t M, int32_t K, float eps,
+                           int32_t act_dtype, void* hip_stream) {
+  if (M == 0) return GBX_OK;
+  if (!h || !slices_ws || !w || !y) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (M < 0 || M > 65535 || K <= 0 || slices < 1) return fail(GBX_ERR_INVALID, "bad shape M=%lld K=%d slices=%d", (long long)M, K, slices);
+  if ((K % 8) || K > 8192 || !aligned(h, 16) || !aligned(slices_ws, 16) || !aligned(w, 16) || !aligned(y, 16))
+    return fail(GBX_ERR_UNSUPPORTED, "gbx_add_rmsnorm_slices needs K %% 8 == 0, K <= 8192 and 16-byte aligned tensors (K = %d)", K);
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  hipError_t e = gbx::launch_add_rmsnorm_slices(h, slices_ws, slices, w, y, static_cast<int>(M), K, eps, act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_add_rmsnorm_slices launch");
   return GBX_OK;
 }
 

@@ -916,13 +916,18 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const unsigned short* __re
   for (int i = tid; i < K; i += 256) yr[i] = f32_to_act<BF16>(act_to_f32<BF16>(xr[i]) * rstd * act_to_f32<BF16>(w[i]));
 }
 
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+
 // Residual add + RMSNorm in one pass (batched decode glue): h <- round(h + d) (the activation-dtype add the model graph
 // does, qllama.py:138-140), y = RMSNorm(h) * w.  h is updated in place.
 // Rows up to 8192 values stay in registers between the two passes: 16-byte loads, one barrier.
-template <bool BF16, bool ADD>
+// ADD == 2: the addend is the sum of `slices` fp32 partial tiles ws[s][M][K] of a k-split GEMM, rounded once to the
+// activation dtype exactly like the summing launch it replaces (batch_finish_kernel: v = ws[0]; v += ws[s], s = 1..).
+template <bool BF16, int ADD>
 __global__ __launch_bounds__(256) void rmsnorm_vec_kernel(unsigned short* __restrict__ h, const unsigned short* __restrict__ d,
                                                           const unsigned short* __restrict__ w, unsigned short* __restrict__ y,
-                                                          int K, float eps) {
+                                                          int K, float eps, const float* __restrict__ ws = nullptr, int slices = 0,
+                                                          long long mn = 0) {
   __shared__ float red[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t row = static_cast<size_t>(blockIdx.x) * K;
@@ -934,8 +939,22 @@ __global__ __launch_bounds__(256) void rmsnorm_vec_kernel(unsigned short* __rest
     const int p = it * 256 + tid;
     if (p < n8) {
       u32x4 hv = reinterpret_cast<const u32x4*>(h + row)[p];
-      if constexpr (ADD) {
-        const u32x4 dv = reinterpret_cast<const u32x4*>(d + row)[p];
+      if constexpr (ADD != 0) {
+        u32x4 dv;
+        if constexpr (ADD == 2) {
+          const float* src = ws + row + static_cast<size_t>(p) * 8;
+          f32x4s a0 = *reinterpret_cast<const f32x4s*>(src), a1 = *reinterpret_cast<const f32x4s*>(src + 4);
+          for (int sl = 1; sl < slices; ++sl) {
+            a0 += *reinterpret_cast<const f32x4s*>(src + sl * mn);
+            a1 += *reinterpret_cast<const f32x4s*>(src + sl * mn + 4);
+          }
+          dv = u32x4{static_cast<unsigned>(f32_to_act<BF16>(a0.x)) | (static_cast<unsigned>(f32_to_act<BF16>(a0.y)) << 16),
+                     static_cast<unsigned>(f32_to_act<BF16>(a0.z)) | (static_cast<unsigned>(f32_to_act<BF16>(a0.w)) << 16),
+                     static_cast<unsigned>(f32_to_act<BF16>(a1.x)) | (static_cast<unsigned>(f32_to_act<BF16>(a1.y)) << 16),
+                     static_cast<unsigned>(f32_to_act<BF16>(a1.z)) | (static_cast<unsigned>(f32_to_act<BF16>(a1.w)) << 16)};
+        } else {
+          dv = reinterpret_cast<const u32x4*>(d + row)[p];
+        }
         const unsigned hw[4] = {hv.x, hv.y, hv.z, hv.w}, dw[4] = {dv.x, dv.y, dv.z, dv.w};
         unsigned o[4];
 #pragma unroll
@@ -1005,12 +1024,25 @@ hipError_t launch_add_rmsnorm(void* h, const void* d, const void* w, void* y, in
   auto W = static_cast<const unsigned short*>(w);
   auto Y = static_cast<unsigned short*>(y);
   if (vec_ok(h, d, w, y, K)) {
-    if (bf16) hipLaunchKernelGGL((rmsnorm_vec_kernel<true, true>), dim3(M), dim3(256), 0, s, H, D, W, Y, K, eps);
-    else hipLaunchKernelGGL((rmsnorm_vec_kernel<false, true>), dim3(M), dim3(256), 0, s, H, D, W, Y, K, eps);
+    if (bf16) hipLaunchKernelGGL((rmsnorm_vec_kernel<true, 1>), dim3(M), dim3(256), 0, s, H, D, W, Y, K, eps);
+    else hipLaunchKernelGGL((rmsnorm_vec_kernel<false, 1>), dim3(M), dim3(256), 0, s, H, D, W, Y, K, eps);
     return hipGetLastError();
   }
   if (bf16) hipLaunchKernelGGL((add_rmsnorm_kernel<true>), dim3(M), dim3(256), 0, s, H, D, W, Y, K, eps);
   else hipLaunchKernelGGL((add_rmsnorm_kernel<false>), dim3(M), dim3(256), 0, s, H, D, W, Y, K, eps);
+  return hipGetLastError();
+}
+
+// h += round(sum of the fp32 slices of a k-split GEMM), y = RMSNorm(h) * w: the summing launch of the down projection folded
+// into the next block's add + norm (K % 8 == 0, K <= 8192, 16-byte aligned rows: the callers' decode shapes)
+hipError_t launch_add_rmsnorm_slices(void* h, const float* ws, int slices, const void* w, void* y, int M, int K, float eps, bool bf16,
+                                     hipStream_t s) {
+  auto H = static_cast<unsigned short*>(h);
+  auto W = static_cast<const unsigned short*>(w);
+  auto Y = static_cast<unsigned short*>(y);
+  const long long mn = static_cast<long long>(M) * K;
+  if (bf16) hipLaunchKernelGGL((rmsnorm_vec_kernel<true, 2>), dim3(M), dim3(256), 0, s, H, nullptr, W, Y, K, eps, ws, slices, mn);
+  else hipLaunchKernelGGL((rmsnorm_vec_kernel<false, 2>), dim3(M), dim3(256), 0, s, H, nullptr, W, Y, K, eps, ws, slices, mn);
   return hipGetLastError();
 }
 
@@ -1075,8 +1107,8 @@ hipError_t launch_rmsnorm(const void* x, const void* w, void* y, int M, int K, f
   }
   if (vec_ok(x, x, w, y, K)) {                      // one pass, rows in registers
     auto Xm = const_cast<unsigned short*>(X);
-    if (bf16) hipLaunchKernelGGL((rmsnorm_vec_kernel<true, false>), dim3(M), dim3(256), 0, s, Xm, X, W, Y, K, eps);
-    else hipLaunchKernelGGL((rmsnorm_vec_kernel<false, false>), dim3(M), dim3(256), 0, s, Xm, X, W, Y, K, eps);
+    if (bf16) hipLaunchKernelGGL((rmsnorm_vec_kernel<true, 0>), dim3(M), dim3(256), 0, s, Xm, X, W, Y, K, eps);
+    else hipLaunchKernelGGL((rmsnorm_vec_kernel<false, 0>), dim3(M), dim3(256), 0, s, Xm, X, W, Y, K, eps);
     return hipGetLastError();
   }
   if (bf16) hipLaunchKernelGGL((rmsnorm_kernel<true>), dim3(M), dim3(256), 0, s, X, W, Y, K, eps);

@@ -27,6 +27,12 @@ hipError_t launch_qgemm_skinny(const void* x, const uint32_t* qw, const void* sc
 hipError_t launch_qgemm_skinny_multi(const void* x, int nseg, const uint32_t* const* qw, const void* const* sc, const void* const* ze,
                                      const void* const* bias, void* const* y, const int* n, int M, int K, int bits, int log2g,
                                      bool bf16, hipStream_t s);
+hipError_t launch_qgemm_swiglu(const void* x, const uint32_t* gq, const void* gs, const void* gz, const uint32_t* uq, const void* us,
+                               const void* uz, void* y, int M, int N, int K, int bits, int log2g, bool bf16, hipStream_t s);
+hipError_t launch_qgemm_partials(const void* x, const uint32_t* qw, const void* sc, const void* ze, float* ws, int M, int N, int K,
+                                 int bits, int log2g, bool bf16, hipStream_t s);
+int qgemm_batch_slices(int M, int N, int K, int bits, int log2g);
+hipError_t launch_add_rmsnorm_slices(void* h, const float* ws, int slices, const void* w, void* y, int M, int K, float eps, bool bf16, hipStream_t s);
 hipError_t launch_prepack_tiles(const uint32_t* qw, const void* sc, const void* ze, const uint32_t* qw2, const void* sc2,
                                 const void* ze2, uint32_t* wt, uint32_t* szt, int N, int K, hipStream_t s);
 hipError_t launch_gemv_mfma(const void* x, const uint32_t* wt, const uint32_t* szt, void* y, int N, int K, const void* norm_w,

@@ -96,7 +96,13 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
   const unsigned short* bs = a.bias;
   unsigned short* yo = a.y;
   int nl0 = nwg, NL = a.N;
-  if (a.nseg > 1) {
+  const bool swiglu = a.swiglu != 0;               // (uniform) row groups [0, NG/2) = gate rows, [NG/2, NG) = the same rows of up
+  int ngl = ng;                                     // row group inside the workgroup's row range of ONE matrix
+  if (swiglu) {
+    nl0 = blockIdx.x * (NG * TNW / 2);
+    NL = a.n_seg[0];
+    if (ng >= NG / 2) { qw = a.qweight_x[0]; sc = a.scales_x[0]; ze = a.zeros_x[0]; ngl = ng - NG / 2; }
+  } else if (a.nseg > 1) {
     const int sg = (nwg >= a.n_seg[0]) + (nwg >= a.n_seg[0] + a.n_seg[1]);
     NL = a.n_seg[sg];
     if (sg > 0) {
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
       qw = a.qweight_x[sg - 1]; sc = a.scales_x[sg - 1]; ze = a.zeros_x[sg - 1]; bs = a.bias_x[sg - 1]; yo = a.y_x[sg - 1];
     }
   }
-  const int nrow = min(nl0 + ng * TNW + r, NL - 1);
+  const int nrow = min(nl0 + ngl * TNW + r, NL - 1);
   const uint32_t* wrow = qw + static_cast<size_t>(nrow) * W + (IL ? 0 : h * WL) + static_cast<size_t>(cbase + kg * cpk) * WPC;
   const unsigned short* srow = sc + static_cast<size_t>(nrow) * G + (cbase + kg * cpk) * NF;
   const unsigned short* zrow = ze + static_cast<size_t>(nrow) * G + (cbase + kg * cpk) * NF;
@@ -361,6 +367,28 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
       red[((kg * NG + ng) * TE + i * AE + e) * 64 + lane] = v;
     }
   __syncthreads();
+  if (swiglu) {
+    if constexpr (NG >= 2) {
+      for (int idx = tid; idx < (NG / 2) * TE * 64; idx += 768) {
+        const int g = idx / (TE * 64), ie = (idx / 64) % TE, ln = idx & 63;
+        float gt = 0.f, up = 0.f;
+#pragma unroll
+        for (int w = 0; w < KG; ++w) {
+          gt += red[((w * NG + g) * TE + ie) * 64 + ln];
+          up += red[((w * NG + g + NG / 2) * TE + ie) * 64 + ln];
+        }
+        const int i = ie / AE, e = ie % AE;
+        const int n = nl0 + g * TNW + (ln & (TNW - 1));
+        const int m = i * TNW + (TNW == 32 ? (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5) : 4 * (ln >> 4) + e);
+        if (n < NL && m < M) {       // activation-dtype gate, up, silu(gate), product: the unfused graph's four roundings
+          const float g0 = act_to_f32<BF16>(f32_to_act<BF16>(gt)), u0 = act_to_f32<BF16>(f32_to_act<BF16>(up));
+          const float sl = act_to_f32<BF16>(f32_to_act<BF16>(g0 / (1.f + __expf(-g0))));
+          a.y[static_cast<size_t>(m) * NL + n] = f32_to_act<BF16>(sl * u0);
+        }
+      }
+    }
+    return;
+  }
   for (int idx = tid; idx < NG * TE * 64; idx += 768) {
     const int g = idx / (TE * 64), ie = (idx / 64) % TE, ln = idx & 63;
     float v = 0.f;
@@ -434,7 +462,7 @@ static hipError_t launch_batch_grp(const MfmaArgs& a, bool bf16, hipStream_t s) 
     if (e != hipSuccess) return e;
     done[bf16] = true;
   }
-  dim3 grid((a.N + ROWS - 1) / ROWS, a.ws ? a.ksplit : 1), block(768);
+  dim3 grid(a.swiglu ? (a.n_seg[0] + ROWS / 2 - 1) / (ROWS / 2) : (a.N + ROWS - 1) / ROWS, a.ws ? a.ksplit : 1), block(768);
 #ifdef BX_STAMPS
   long long* sp = reinterpret_cast<long long*>(strtoull(getenv("GBX_STAMP_PTR") ? getenv("GBX_STAMP_PTR") : "0", nullptr, 0));
   (void)hipMemcpyToSymbol(HIP_SYMBOL(bx_stamp_ptr), &sp, sizeof(sp));
@@ -463,6 +491,11 @@ size_t qgemm_batch_workspace_bytes(int M, int N, int K, int bits, int log2g) {
   return s > 1 ? static_cast<size_t>(s) * M * N * sizeof(float) : 0;
 }
 
+int qgemm_batch_slices(int M, int N, int K, int bits, int log2g) {
+  if (log2g != 7 || !qgemm_batch_supported(M < 32 ? M : 32, K, bits, log2g)) return 1;
+  return batch_ksplit(N, K, 1);
+}
+
 // workgroup rows: as many as still give ~200 workgroups (256 CUs, one workgroup each), and never across a segment
 template <int BITS>
 static hipError_t launch_batch_bits(const MfmaArgs& a0, bool bf16, hipStream_t s) {
@@ -471,13 +504,19 @@ static hipError_t launch_batch_bits(const MfmaArgs& a0, bool bf16, hipStream_t s
   if (a.ksplit <= 1) a.ws = nullptr;
   if (a.ws) {                                       // 128-row workgroups x ksplit slices, then the summing launch
     hipError_t e = launch_batch_cfg<BITS, 32, 4, 2>(a, bf16, s);
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess || a.partials_only) return e;
     return launch_splitk_finish(a.ws, a.bias, a.y, a.ksplit, a.M, a.N, bf16, s);
   }
   int rows = a.N >= 128 * 192 ? 128 : a.N >= 64 * 192 ? 64 : a.N >= 32 * 160 ? 32 : 16;
   static const int forced = [] { const char* e = getenv("GBX_BATCH_ROWS"); return e ? atoi(e) : 0; }();
   if (forced) rows = forced;
   if (a.log2g < 7 && rows == 128) rows = 64;        // small groups: twice the packed words per lane -- the 128-row shape spills
+  if (a.swiglu) {                                   // half of a workgroup's rows come from each matrix: rows / 2 must tile n_seg[0]
+    if (a.nseg != 2 || a.n_seg[0] != a.n_seg[1] || a.ws) return hipErrorInvalidValue;
+    if (rows < 32) rows = 32;
+    while (rows >= 32 && a.n_seg[0] % (rows / 2)) rows >>= 1;
+    if (rows < 32) return hipErrorInvalidValue;
+  } else
   for (int i = 0; i < (a.nseg > 1 ? a.nseg : 0); ++i)
     while (a.n_seg[i] % rows) rows >>= 1;
   if (rows < 16) return hipErrorInvalidValue;

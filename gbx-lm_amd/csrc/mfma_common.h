@@ -29,6 +29,12 @@ struct MfmaArgs {
   // partial tile to ws[s][M][N] (caller-owned workspace) and a second launch sums the slices
   float* ws;
   int ksplit;
+  // batch kernel only: nseg == 2 (gate_proj, up_proj of one block), every workgroup takes rows [n0, n0 + R/2) of BOTH and
+  // writes y[m, n] = silu(gate[m, n]) * up[m, n] (the reference's op-by-op roundings, qllama.py:115) to y [M, n_seg[0]]
+  int swiglu;
+  // batch kernel only, with ws: leave the fp32 slices in ws and skip the summing launch (the consumer folds the sum in:
+  // gbx_add_rmsnorm_slices)
+  int partials_only;
 #ifdef GBX_PSTAMPS
   long long* stamps;            // diagnostic build only: [workgroup][wave][4] s_memtime totals
 #endif
@@ -44,6 +50,8 @@ hipError_t launch_splitk_finish(const float* ws, const unsigned short* bias, uns
 size_t qgemm_prefill_workspace_bytes(int M, int N, int K);
 // fp32 workspace bytes with which launch_qgemm_batch splits k across workgroups (0: it would not)
 size_t qgemm_batch_workspace_bytes(int M, int N, int K, int bits, int log2g);
+// k slices launch_qgemm_batch writes with a workspace of that size (1: it does not split)
+int qgemm_batch_slices(int M, int N, int K, int bits, int log2g);
 
 constexpr int KC = 128;                 // k-values per chunk (one LDS stage of activations)
 constexpr int XROW = KC * 2 + 16;       // LDS bytes per activation row: 256 B + 16 B pad (conflict-free ds_read_b128)

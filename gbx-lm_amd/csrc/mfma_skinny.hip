@@ -260,7 +260,7 @@ static hipError_t launch_batch_rows(const MfmaArgs& a, int bits, bool bf16, hipS
   MfmaArgs hi = a;
   hi.M = a.M - 32;
   hi.x = a.x + static_cast<size_t>(32) * a.K;
-  const bool multi = a.nseg > 1;
+  const bool multi = a.nseg > 1;          // (SwiGLU launches write ONE [M, n_seg[0]] output: the same offset rule)
   hi.y = a.y + static_cast<size_t>(32) * (multi ? a.n_seg[0] : a.N);
   for (int i = 1; i < a.nseg; ++i) hi.y_x[i - 1] = a.y_x[i - 1] + static_cast<size_t>(32) * a.n_seg[i];
   return launch_qgemm_batch(hi, bits, bf16, s);
@@ -290,6 +290,32 @@ hipError_t launch_qgemm_skinny_multi(const void* x, int nseg, const uint32_t* co
     case 4: return launch_skinny_bits<4>(a, bf16, s);
     default: return hipErrorInvalidValue;
   }
+}
+
+// gate_proj | up_proj + SwiGLU in one launch of the no-dequant batch kernel (2 <= M <= 64); hipErrorInvalidValue when the
+// shape is outside it (the caller then runs the three ops)
+hipError_t launch_qgemm_swiglu(const void* x, const uint32_t* gq, const void* gs, const void* gz, const uint32_t* uq, const void* us,
+                               const void* uz, void* y, int M, int N, int K, int bits, int log2g, bool bf16, hipStream_t s) {
+  MfmaArgs a{};
+  a.x = static_cast<const unsigned short*>(x);
+  a.qweight = gq; a.scales = static_cast<const unsigned short*>(gs); a.zeros = static_cast<const unsigned short*>(gz);
+  a.qweight_x[0] = uq; a.scales_x[0] = static_cast<const unsigned short*>(us); a.zeros_x[0] = static_cast<const unsigned short*>(uz);
+  a.y = static_cast<unsigned short*>(y);
+  a.M = M; a.K = K; a.log2g = log2g; a.nseg = 2; a.n_seg[0] = a.n_seg[1] = N; a.N = 2 * N; a.swiglu = 1;
+  if (M < 2 || M > 64 || !qgemm_batch_supported(M <= 32 ? M : 32, K, bits, log2g)) return hipErrorInvalidValue;
+  return launch_batch_rows(a, bits, bf16, s);
+}
+
+// k-split batch GEMM that stops at the fp32 slices ws[slices][M][N] (2 <= M <= 32; hipErrorInvalidValue when this shape does
+// not split): the summing launch is folded into the consumer (gbx_add_rmsnorm_slices)
+hipError_t launch_qgemm_partials(const void* x, const uint32_t* qw, const void* sc, const void* ze, float* ws, int M, int N, int K,
+                                 int bits, int log2g, bool bf16, hipStream_t s) {
+  MfmaArgs a{};
+  a.x = static_cast<const unsigned short*>(x); a.qweight = qw; a.scales = static_cast<const unsigned short*>(sc);
+  a.zeros = static_cast<const unsigned short*>(ze); a.M = M; a.N = N; a.K = K; a.log2g = log2g;
+  a.ws = ws; a.partials_only = 1;
+  if (M < 2 || M > 32 || qgemm_batch_slices(M, N, K, bits, log2g) <= 1) return hipErrorInvalidValue;
+  return launch_qgemm_batch(a, bits, bf16, s);
 }
 
 hipError_t launch_qgemm_skinny(const void* x, const uint32_t* qw, const void* sc, const void* ze, const void* bias, void* y,

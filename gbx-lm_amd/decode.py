@@ -55,7 +55,12 @@ class DecodeRunner:
             at = layer.self_attn
             norm = layer.input_layernorm
             # residual add of the previous block fused with this norm (gbx_add_rmsnorm); plain norm for the first layer
-            x = ops.rmsnorm(h, norm.weight, norm.eps) if delta is None else ops.add_rmsnorm(h, delta, norm.weight, norm.eps)
+            if delta is None:
+                x = ops.rmsnorm(h, norm.weight, norm.eps)
+            elif isinstance(delta, tuple):           # fp32 slices of the previous block's k-split down projection
+                x = ops.add_rmsnorm_slices(h, delta[0], delta[1], norm.weight, norm.eps)
+            else:
+                x = ops.add_rmsnorm(h, delta, norm.weight, norm.eps)
             q, k, v = (t.reshape(B, -1) for t in ops.quantized_matmul_multi(x, (at.q_proj, at.k_proj, at.v_proj)))
             full_rope = at.rope.inv_freq.numel() * 2 == self.hd and c.keys.is_contiguous() and c.values.is_contiguous()
             qn, kn = getattr(at, "q_norm", None), getattr(at, "k_norm", None)       # Qwen3: per-head norms before RoPE
@@ -93,12 +98,21 @@ class DecodeRunner:
             x = ops.add_rmsnorm(h, o.reshape(h.shape).contiguous(), norm.weight, norm.eps)
             mlp = layer.mlp
             if B > 1 and getattr(mlp, "tp_world", 1) == 1 and hasattr(mlp, "gate_proj"):
-                g, u = ops.quantized_matmul_multi(x, (mlp.gate_proj, mlp.up_proj))     # one launch for gate and up
-                delta = mlp.down_proj(ops.swiglu(g, u)).reshape(h.shape)
+                act = ops.quantized_swiglu(x, mlp.gate_proj, mlp.up_proj)              # gate | up + SwiGLU: one launch
+                if act is None:
+                    g, u = ops.quantized_matmul_multi(x, (mlp.gate_proj, mlp.up_proj))
+                    act = ops.swiglu(g, u)
+                # long rows: k split across workgroups; the summing launch is folded into the next add + norm
+                delta = ops.quantized_matmul_partials(act, mlp.down_proj)
+                if delta is None:
+                    delta = mlp.down_proj(act).reshape(h.shape)
             else:
                 delta = mlp(x).reshape(h.shape).contiguous()
-        h = h + delta
-        out = ops.rmsnorm(h, m.norm.weight, m.norm.eps)
+        if isinstance(delta, tuple):
+            out = ops.add_rmsnorm_slices(h, delta[0], delta[1], m.norm.weight, m.norm.eps)
+        else:
+            h = h + delta
+            out = ops.rmsnorm(h, m.norm.weight, m.norm.eps)
         return F.linear(out, self.model.head_weight())[:, -1, :]   # [B, V]
 
     def _capture(self):

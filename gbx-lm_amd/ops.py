@@ -264,6 +264,62 @@ def gather_swiglu(x: torch.Tensor, gate, up, rhs_indices: torch.Tensor):
     return y.reshape(*rhs_indices.shape[:-1], k, 1, N)
 
 
+def quantized_swiglu(x: torch.Tensor, gate, up) -> Optional[torch.Tensor]:
+    """``silu(gate_proj(x)) * up_proj(x)`` for a decode-sized batch (2..64 rows) in ONE launch (gbx_qlinear_swiglu_forward:
+    the no-dequant matrix-core GEMM with the SwiGLU in its epilogue).  Returns None when the shapes are outside that launch
+    (the caller then runs the three ops)."""
+    k, n = gate.input_dims, gate.output_dims
+    x2 = x.reshape(-1, k)
+    m = x2.shape[0]
+    if not (x.is_cuda and x.dtype in _DT and 2 <= m <= 64 and k % 1024 == 0 and n % 16 == 0 and gate.bias is None and up.bias is None
+            and (gate.bits, gate.group_size, gate.input_dims, gate.output_dims) == (up.bits, up.group_size, up.input_dims, up.output_dims)
+            and (gate.group_size == 128 or gate.bits == 2) and gate.scales.dtype == x.dtype and up.scales.dtype == x.dtype):
+        return None
+    x2 = x2.contiguous()
+    y = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    rc = _lib.lib().gbx_qlinear_swiglu_forward(x2.data_ptr(), gate.qweight.data_ptr(), gate.scales.data_ptr(), gate.zeros.data_ptr(),
+                                               up.qweight.data_ptr(), up.scales.data_ptr(), up.zeros.data_ptr(), y.data_ptr(), m, n, k,
+                                               gate.bits, gate.group_size, _DT[x.dtype], _stream_ptr(x.device))
+    if rc == _lib.GBX_ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc)
+    return y.reshape(*x.shape[:-1], n)
+
+
+def quantized_matmul_partials(x: torch.Tensor, mod):
+    """The k-split batched-decode GEMM of ``mod`` WITHOUT its summing launch: ``(slices_ws fp32 [slices, M, N], slices)`` or
+    None when this shape does not split k across workgroups (then call the module).  The consumer folds the sum in
+    (``add_rmsnorm_slices``)."""
+    import ctypes
+    k, n = mod.input_dims, mod.output_dims
+    x2 = x.reshape(-1, k)
+    m = x2.shape[0]
+    if not (x.is_cuda and x.dtype in _DT and 2 <= m <= 32 and mod.bias is None and mod.scales is not None and mod.scales.dtype == x.dtype):
+        return None
+    need = _lib.lib().gbx_qlinear_workspace_bytes(m, n, k, mod.bits, mod.group_size)
+    if not need:
+        return None
+    ws = torch.empty((need // 4,), dtype=torch.float32, device=x.device)
+    slices = ctypes.c_int32(0)
+    rc = _lib.lib().gbx_qlinear_forward_partials(x2.contiguous().data_ptr(), mod.qweight.data_ptr(), mod.scales.data_ptr(), mod.zeros.data_ptr(),
+                                                 ws.data_ptr(), need, ctypes.byref(slices), m, n, k, mod.bits, mod.group_size,
+                                                 _DT[x.dtype], _stream_ptr(x.device))
+    if rc == _lib.GBX_ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc)
+    return ws, int(slices.value)
+
+
+def add_rmsnorm_slices(h: torch.Tensor, ws: torch.Tensor, slices: int, w: torch.Tensor, eps: float) -> torch.Tensor:
+    """h += round(sum of the fp32 slices) in place, returns RMSNorm(h) * w -- one launch (gbx_add_rmsnorm_slices)."""
+    k = h.shape[-1]
+    assert h.is_contiguous() and ws.numel() >= slices * h.numel()
+    y = torch.empty_like(h)
+    _lib.check(_lib.lib().gbx_add_rmsnorm_slices(h.data_ptr(), ws.data_ptr(), slices, w.data_ptr(), y.data_ptr(), h.numel() // k, k,
+                                                 float(eps), _DT[h.dtype], _stream_ptr(h.device)))
+    return y
+
+
 def prepack_tiles(mod, mod_up=None):
     """Load-time tiled form of a 2-bit / group-128 QuantizedLinear for the matrix-core decode GEMV
     (gbx_qlinear_prepack_tiles): returns ``(wt, szt)`` int32 tensors.  With ``mod_up`` the pair (gate_proj, up_proj) is

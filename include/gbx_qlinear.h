@@ -143,6 +143,29 @@ int gbx_qlinear_forward_multi(const void* x, int32_t nseg, const uint32_t* const
                               const void* const* zeros, const void* const* bias, void* const* y, const int32_t* N,
                               int64_t M, int32_t K, int32_t bits, int32_t group_size, int32_t act_dtype, void* hip_stream);
 
+/* gate_proj, up_proj and SwiGLU of one decoder block for a decode-sized batch in ONE launch of the no-dequant matrix-core
+ * kernel: y[m, n] = silu(x . gate^T)[m, n] * (x . up^T)[m, n], x [M, K], both matrices [N, K] of one (bits, group_size),
+ * y [M, N]; the four activation-dtype roundings of the unfused graph (gbx_lm/models/qllama.py:115: gate, up, silu, product).
+ * 2 <= M <= 64, K % 1024 == 0, N % 16 == 0, (bits, group_size) as the batch kernel takes them (2/3/4 bits at 128, 2 bits
+ * also at 64 / 32); GBX_ERR_UNSUPPORTED otherwise (run gbx_qlinear_forward_multi + gbx_swiglu). */
+int gbx_qlinear_swiglu_forward(const void* x, const uint32_t* gate_qweight, const void* gate_scales, const void* gate_zeros,
+                               const uint32_t* up_qweight, const void* up_scales, const void* up_zeros, void* y, int64_t M,
+                               int32_t N, int32_t K, int32_t bits, int32_t group_size, int32_t act_dtype, void* hip_stream);
+
+/* The k-split batched-decode GEMM without its summing launch: writes `*slices_out` fp32 partial tiles
+ * workspace[s][M][N] (s < *slices_out; size from gbx_qlinear_workspace_bytes) and no y.  For the long-row projection of
+ * a decoder block (down_proj, 2 <= M <= 32) whose consumer -- the next block's residual add + RMSNorm -- folds the sum in
+ * (gbx_add_rmsnorm_slices): one launch and one pass over [M, N] less per layer.  GBX_ERR_UNSUPPORTED when this shape does
+ * not split (use gbx_qlinear_forward); no bias. */
+int gbx_qlinear_forward_partials(const void* x, const uint32_t* qweight, const void* scales, const void* zeros, void* workspace,
+                                 size_t workspace_bytes, int32_t* slices_out, int64_t M, int32_t N, int32_t K, int32_t bits,
+                                 int32_t group_size, int32_t act_dtype, void* hip_stream);
+
+/* h[M,K] += round(sum_s slices_ws[s][M][K]) (the one rounding the summing launch would have applied), y = RMSNorm(h) * w.
+ * K % 8 == 0, K <= 8192, 16-byte aligned tensors.  gbx_add_rmsnorm with the k-split GEMM's slices as the addend. */
+int gbx_add_rmsnorm_slices(void* h, const float* slices_ws, int32_t slices, const void* w, void* y, int64_t M, int32_t K, float eps,
+                           int32_t act_dtype, void* hip_stream);
+
 /* Expert-indexed QuantizedLinear for a few (token, expert-slot) pairs -- the decode case of
  * mx.gather_qmm(x, qweight[E,N,W], scales[E,N,G], zeros[E,N,G], rhs_indices=indices, transpose=True) + bias[indices]
  * (QuantizedSwitchLinear.__call__, gbx_lm/models/switch_layers.py:78-92):

@@ -689,3 +689,54 @@ def test_eminf_generate_step_on_device(tmp_path):
     assert torch.allclose(got, want, atol=5e-2, rtol=5e-2)
     steps2 = list(eminf_generate_step(model, tok, conv2 + [4, 7], conv2 + [4], max_tokens=4, prompt_cache=pc, rng=np.random.default_rng(6)))
     assert all(0 <= t < 512 for t, _, _ in steps2)
+
+
+@pytest.mark.parametrize("bits,g", [(2, 128), (3, 128), (4, 128), (2, 64), (2, 32)])
+@pytest.mark.parametrize("m", [2, 16, 32, 48])
+def test_batched_swiglu_gemm(oracle, bits, g, m):
+    """gbx_qlinear_swiglu_forward (gate | up + SwiGLU in the epilogue of the no-dequant batch GEMM) against the three unfused
+    ops (same four roundings: equal up to one activation-dtype ulp) and against the oracle."""
+    from gbx_lm_amd import ops
+    for n, k in ((14336, 4096), (1024, 2048), (8192, 3072)):
+        (gate, dg), (up, du) = _mk(oracle, n, k, bits, g, seed=bits + m), _mk(oracle, n, k, bits, g, seed=bits + m + 77)
+        x = torch.randn(m, k).to(torch.bfloat16).to(DEV)
+        act = ops.quantized_swiglu(x, gate, up)
+        assert act is not None and act.shape == (m, n)
+        gg, uu = ops.quantized_matmul_multi(x, (gate, up))
+        want = ops.swiglu(gg.contiguous(), uu.contiguous())
+        # (not bit-identical: a workgroup starts its k walk at step blockIdx.x % steps, and the fused launch tiles the rows
+        # differently, so the fp32 sums differ in their last bits and ~0.3 % of the outputs round the other way)
+        d = (act.float() - want.float()).abs()
+        rms = want.float().pow(2).mean().sqrt().item()
+        # (rows beyond 32 of narrow matrices: the unfused path runs the dequantising kernel -- different arithmetic throughout)
+        assert (d <= 2e-2 * want.float().abs() + (2e-2 if m > 32 else 2e-3) * rms).all() and ((d > 0).float().mean().item() < 0.02 or m > 32), \
+            f"N{n} K{k}: max diff {d.max().item()}, differing {(d > 0).float().mean().item():.4f}"
+        rows = [0, m - 1]
+        g64 = oracle.qlinear_ref(x[rows].cpu(), dg["qweight"], dg["scales"], dg["zeros"], bits, g, acc=np.float64)
+        u64 = oracle.qlinear_ref(x[rows].cpu(), du["qweight"], du["scales"], du["zeros"], bits, g, acc=np.float64)
+        oracle.assert_close(act[rows], (g64 / (1 + np.exp(-g64))) * u64, "bf16", f"batched swiglu b{bits} g{g} M{m}")
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("m", [2, 9, 32])
+def test_partials_gemm_and_slice_folding_norm(oracle, bits, m):
+    """gbx_qlinear_forward_partials + gbx_add_rmsnorm_slices (the summing launch of the k-split down projection folded into
+    the next residual add + RMSNorm) against gbx_qlinear_forward_ws + gbx_add_rmsnorm: bit-identical h and y."""
+    from gbx_lm_amd import ops
+    n, k = 4096, 14336
+    mod, d = _mk(oracle, n, k, bits, 128, seed=bits * 3 + m)
+    x = torch.randn(m, k).to(torch.bfloat16).to(DEV)
+    w = (1 + 0.1 * torch.randn(n)).to(torch.bfloat16).to(DEV)
+    h0 = torch.randn(m, n).to(torch.bfloat16).to(DEV)
+    parts = ops.quantized_matmul_partials(x, mod)
+    assert parts is not None and parts[1] > 1
+    h1 = h0.clone()
+    y1 = ops.add_rmsnorm_slices(h1, parts[0], parts[1], w, 1e-5)
+    h2 = h0.clone()
+    delta = mod(x)
+    y2 = ops.add_rmsnorm(h2, delta.contiguous(), w, 1e-5)
+    assert torch.equal(h1, h2) and torch.equal(y1, y2)
+    y64 = oracle.qlinear_ref(x[:1].cpu(), d["qweight"], d["scales"], d["zeros"], bits, 128, acc=np.float64)
+    oracle.assert_close((h1[:1].float() - h0[:1].float()), y64, "bf16", "partials row 0")
+    small, _ = _mk(oracle, 512, 4096, bits, 128, seed=1)
+    assert ops.quantized_matmul_partials(torch.randn(4, 4096).to(torch.bfloat16).to(DEV), small) is None     # short rows do not split
