@@ -51,6 +51,9 @@ def lib() -> ctypes.CDLL:
         L.gbx_unpack.argtypes = [p, p, i32, i32, i32, p]
         L.gbx_dequantize.argtypes = [p, p, p, p, i32, i32, i32, i32, i32, i32, p]
         L.gbx_logprobs_workspace_bytes.restype = ctypes.c_size_t
+        if hasattr(L, 'gbx_qlinear_partials_bytes'):
+            L.gbx_qlinear_partials_bytes.argtypes = [i64, i32, i32, i32, i32]
+            L.gbx_qlinear_partials_bytes.restype = ctypes.c_size_t
         L.gbx_attn_workspace_bytes.restype = ctypes.c_size_t
         _declare_optional(L)
         _lib = L

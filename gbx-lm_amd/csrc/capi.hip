@@ -677,6 +677,12 @@ int gbx_add_rmsnorm(void* h, const void* delta, const void* w, void* y, int64_t 
   return GBX_OK;
 }
 
+size_t gbx_qlinear_partials_bytes(int64_t M, int32_t N, int32_t K, int32_t bits, int32_t group_size) {
+  if (check_shape(M, N, K, bits, group_size) != GBX_OK || M < 2 || M > 32 || (K % 128) != 0 || K < 512) return 0;
+  const int slices = gbx::qgemm_batch_slices(static_cast<int>(M), N, K, bits, log2_group(group_size));
+  return slices > 1 ? static_cast<size_t>(slices) * M * N * sizeof(float) : 0;
+}
+
 int gbx_qlinear_forward_partials(const void* x, const uint32_t* qweight, const void* scales, const void* zeros, void* workspace,
                                  size_t workspace_bytes, int32_t* slices_out, int64_t M, int32_t N, int32_t K, int32_t bits,
                                  int32_t group_size, int32_t act_dtype, void* hip_stream) {
@@ -688,7 +694,7 @@ int gbx_qlinear_forward_partials(const void* x, const uint32_t* qweight, const v
   const int log2g = log2_group(group_size);
   const int slices = (M >= 2 && M <= 32 && (K % 128) == 0 && K >= 512) ? gbx::qgemm_batch_slices(static_cast<int>(M), N, K, bits, log2g) : 1;
   if (slices <= 1) return fail(GBX_ERR_UNSUPPORTED, "this shape does not split k across workgroups (M=%lld N=%d K=%d): use gbx_qlinear_forward", (long long)M, N, K);
-  const size_t need = static_cast<size_t>(slices) * M * N * sizeof(float);
+  const size_t need = static_cast<size_t>(slices) * M * N * sizeof(float);      /* (not gbx_qlinear_workspace_bytes: short rows split here only) */
   if (workspace_bytes < need) return fail(GBX_ERR_INVALID, "workspace too small: %zu < %zu", workspace_bytes, need);
   hipError_t e = gbx::launch_qgemm_partials(x, qweight, scales, zeros, static_cast<float*>(workspace), static_cast<int>(M), N, K, bits, log2g,
                                             act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));

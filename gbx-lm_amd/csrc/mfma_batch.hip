@@ -475,9 +475,11 @@ static hipError_t launch_batch_grp(const MfmaArgs& a, bool bf16, hipStream_t s) 
 // k split across workgroups (needs the caller's fp32 workspace): worth it where the rows are long and few -- the down
 // projection, N = 4096 x K = 14336 -- because every workgroup stages the activations of its whole k range: 16-row
 // workgroups pull 256 x 917 KB of x through the CUs, 128-row workgroups x 7 slices pull 224 x 131 KB.
-static int batch_ksplit(int N, int K, int nseg) {
+static int batch_ksplit(int N, int K, int nseg, bool partials = false) {
   static const int min_k = [] { const char* e = getenv("GBX_BATCH_KSPLIT_MINK"); return e ? atoi(e) : 8192; }();   // tuning aid
-  if (nseg > 1 || N % 4 || N > 8192 || K < min_k) return 1;
+  // with the summing launch folded into the consumer (partials) the split also pays on the short rows of o_proj: every
+  // workgroup then stages 1/s of the activation tile -- the traffic that bounds this kernel
+  if (nseg > 1 || N % 4 || N > 8192 || K < (partials ? 2048 : min_k)) return 1;
   const int tiles = (N + 127) / 128, nchunks = K / KC;
   int best = 1;
   for (int s = 2; s <= 16; ++s)
@@ -493,17 +495,19 @@ size_t qgemm_batch_workspace_bytes(int M, int N, int K, int bits, int log2g) {
 
 int qgemm_batch_slices(int M, int N, int K, int bits, int log2g) {
   if (log2g != 7 || !qgemm_batch_supported(M < 32 ? M : 32, K, bits, log2g)) return 1;
-  return batch_ksplit(N, K, 1);
+  return batch_ksplit(N, K, 1, true);
 }
 
 // workgroup rows: as many as still give ~200 workgroups (256 CUs, one workgroup each), and never across a segment
 template <int BITS>
 static hipError_t launch_batch_bits(const MfmaArgs& a0, bool bf16, hipStream_t s) {
   MfmaArgs a = a0;
-  a.ksplit = (a.ws && a.log2g == 7) ? batch_ksplit(a.N, a.K, a.nseg) : 1;
+  a.ksplit = (a.ws && a.log2g == 7) ? batch_ksplit(a.N, a.K, a.nseg, a.partials_only != 0) : 1;
   if (a.ksplit <= 1) a.ws = nullptr;
   if (a.ws) {                                       // 128-row workgroups x ksplit slices, then the summing launch
-    hipError_t e = launch_batch_cfg<BITS, 32, 4, 2>(a, bf16, s);
+    // (few tiles even after the split -- o_proj: 32 x 4 -- : 64-row workgroups put one on every CU)
+    const bool narrow = a.partials_only && ((a.N + 127) / 128) * a.ksplit <= 128 && a.N % 64 == 0;
+    hipError_t e = narrow ? launch_batch_cfg<BITS, 32, 2, 4>(a, bf16, s) : launch_batch_cfg<BITS, 32, 4, 2>(a, bf16, s);
     if (e != hipSuccess || a.partials_only) return e;
     return launch_splitk_finish(a.ws, a.bias, a.y, a.ksplit, a.M, a.N, bf16, s);
   }

@@ -91,11 +91,15 @@ class DecodeRunner:
                 qg = q.reshape(B, self.n_kv, rep, self.hd)
                 sc = torch.matmul(qg, c.keys.transpose(-1, -2)).float() * at.scale + mask
                 o = torch.matmul(torch.softmax(sc, dim=-1).to(self.dtype), c.values)     # [B, n_kv, rep, hd]
-            o = at.o_proj(o.reshape(B, 1, -1))
-            if self.tp_world > 1:
-                all_reduce_(o, at.tp_group)
             norm = layer.post_attention_layernorm
-            x = ops.add_rmsnorm(h, o.reshape(h.shape).contiguous(), norm.weight, norm.eps)
+            parts = ops.quantized_matmul_partials(o.reshape(B, -1), at.o_proj) if (B > 1 and self.tp_world == 1) else None
+            if parts is not None:                    # k split across workgroups, summed inside the add + norm launch
+                x = ops.add_rmsnorm_slices(h, parts[0], parts[1], norm.weight, norm.eps)
+            else:
+                o = at.o_proj(o.reshape(B, 1, -1))
+                if self.tp_world > 1:
+                    all_reduce_(o, at.tp_group)
+                x = ops.add_rmsnorm(h, o.reshape(h.shape).contiguous(), norm.weight, norm.eps)
             mlp = layer.mlp
             if B > 1 and getattr(mlp, "tp_world", 1) == 1 and hasattr(mlp, "gate_proj"):
                 act = ops.quantized_swiglu(x, mlp.gate_proj, mlp.up_proj)              # gate | up + SwiGLU: one launch

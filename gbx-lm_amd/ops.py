@@ -296,7 +296,7 @@ def quantized_matmul_partials(x: torch.Tensor, mod):
     m = x2.shape[0]
     if not (x.is_cuda and x.dtype in _DT and 2 <= m <= 32 and mod.bias is None and mod.scales is not None and mod.scales.dtype == x.dtype):
         return None
-    need = _lib.lib().gbx_qlinear_workspace_bytes(m, n, k, mod.bits, mod.group_size)
+    need = _lib.lib().gbx_qlinear_partials_bytes(m, n, k, mod.bits, mod.group_size)
     if not need:
         return None
     ws = torch.empty((need // 4,), dtype=torch.float32, device=x.device)

@@ -153,10 +153,11 @@ int gbx_qlinear_swiglu_forward(const void* x, const uint32_t* gate_qweight, cons
                                int32_t N, int32_t K, int32_t bits, int32_t group_size, int32_t act_dtype, void* hip_stream);
 
 /* The k-split batched-decode GEMM without its summing launch: writes `*slices_out` fp32 partial tiles
- * workspace[s][M][N] (s < *slices_out; size from gbx_qlinear_workspace_bytes) and no y.  For the long-row projection of
+ * workspace[s][M][N] (s < *slices_out; size from gbx_qlinear_partials_bytes) and no y.  For the long-row projection of
  * a decoder block (down_proj, 2 <= M <= 32) whose consumer -- the next block's residual add + RMSNorm -- folds the sum in
  * (gbx_add_rmsnorm_slices): one launch and one pass over [M, N] less per layer.  GBX_ERR_UNSUPPORTED when this shape does
  * not split (use gbx_qlinear_forward); no bias. */
+size_t gbx_qlinear_partials_bytes(int64_t M, int32_t N, int32_t K, int32_t bits, int32_t group_size);   /* 0: this shape does not split */
 int gbx_qlinear_forward_partials(const void* x, const uint32_t* qweight, const void* scales, const void* zeros, void* workspace,
                                  size_t workspace_bytes, int32_t* slices_out, int64_t M, int32_t N, int32_t K, int32_t bits,
                                  int32_t group_size, int32_t act_dtype, void* hip_stream);

@@ -738,5 +738,14 @@ def test_partials_gemm_and_slice_folding_norm(oracle, bits, m):
     assert torch.equal(h1, h2) and torch.equal(y1, y2)
     y64 = oracle.qlinear_ref(x[:1].cpu(), d["qweight"], d["scales"], d["zeros"], bits, 128, acc=np.float64)
     oracle.assert_close((h1[:1].float() - h0[:1].float()), y64, "bf16", "partials row 0")
-    small, _ = _mk(oracle, 512, 4096, bits, 128, seed=1)
-    assert ops.quantized_matmul_partials(torch.randn(4, 4096).to(torch.bfloat16).to(DEV), small) is None     # short rows do not split
+    # o_proj-sized rows split too when the consumer folds the sum in; against the unsplit launch: equal up to the output rounding
+    om, od = _mk(oracle, 4096, 4096, bits, 128, seed=bits + 40)
+    xo = torch.randn(m, 4096).to(torch.bfloat16).to(DEV)
+    po = ops.quantized_matmul_partials(xo, om)
+    assert po is not None and po[1] > 1
+    hz = torch.zeros(m, 4096, dtype=torch.bfloat16, device=DEV)
+    ops.add_rmsnorm_slices(hz, po[0], po[1], w, 1e-5)
+    y64 = oracle.qlinear_ref(xo.cpu(), od["qweight"], od["scales"], od["zeros"], bits, 128, acc=np.float64)
+    oracle.assert_close(hz, y64, "bf16", "o_proj partials")
+    small, _ = _mk(oracle, 512, 1024, bits, 128, seed=1)
+    assert ops.quantized_matmul_partials(torch.randn(4, 1024).to(torch.bfloat16).to(DEV), small) is None     # short rows do not split
