@@ -35,6 +35,10 @@ struct MfmaArgs {
   // batch kernel only, with ws: leave the fp32 slices in ws and skip the summing launch (the consumer folds the sum in:
   // gbx_add_rmsnorm_slices)
   int partials_only;
+  // prefill kernel, BITS == 16 instantiation: the weights already dequantised to the activation dtype, [N, K] row-major
+  // (one gbx_dequantize pass per call into the caller's workspace, shared by all M / 256 row tiles instead of being redone
+  // by every one of them)
+  const unsigned short* wdense;
 #ifdef GBX_PSTAMPS
   long long* stamps;            // diagnostic build only: [workgroup][wave][4] s_memtime totals
 #endif

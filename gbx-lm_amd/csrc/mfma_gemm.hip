@@ -36,9 +36,12 @@ __global__ __launch_bounds__(WV * 64) void qgemm_prefill_kernel(const MfmaArgs a
   constexpr int NTH = WV * 64, WN = WV / 2;
   constexpr int BM = 64 * MT;                     // activation rows per workgroup
   constexpr int PBN = 32 * NT * WN;               // weight rows (output columns) per workgroup
+  constexpr bool DENSE = BITS == 16;              // weights pre-dequantised (a.wdense): the B tile is staged like the A tile
+  constexpr int WB = DENSE ? 1 : BITS;            // packed words per 32-value unit
   constexpr int NU = PBN * 2 / NTH;               // 32-value units of the B tile per thread and chunk
   constexpr int AP = BM * 8 / NTH;                // 16-byte activation pieces per thread per chunk
-  static_assert(NU >= 1 && AP >= 4, "tile too small for the thread count");
+  constexpr int BP = DENSE ? PBN * 8 / NTH : 4;   // dense: 16-byte weight pieces per thread per chunk
+  static_assert(NU >= 1 && AP >= 4 && BP % 4 == 0, "tile too small for the thread count");
   constexpr int ABYTES = BM * PROW, BBYTES = PBN * PROW, STAGE = ABYTES + BBYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 stages of [A tile | B tile]
 
@@ -67,7 +70,15 @@ __global__ __launch_bounds__(WV * 64) void qgemm_prefill_kernel(const MfmaArgs a
   // B loader: unit u = tid*NU + j -> row u/2 of the tile, 32-value half u%2 of the chunk (NU = 2: the whole row chunk)
   const int brow = (tid * NU) >> 1, bhalf = (tid * NU) & 1;
   const int bn = min(n0 + brow, N - 1);
-  const uint32_t* wsrc = a.qweight + static_cast<size_t>(bn) * W + bhalf * BITS;
+  const uint32_t* wsrc = a.qweight + static_cast<size_t>(bn) * W + bhalf * WB;
+  const unsigned short* bsrc[BP];                 // dense: piece p = tid + NTH*i -> weight row p/8, 16-byte column p%8
+  int bdstd[BP];
+#pragma unroll
+  for (int i = 0; i < BP; ++i) {
+    const int p = tid + NTH * i, row = p >> 3, col = p & 7;
+    bsrc[i] = (DENSE ? a.wdense : a.x) + static_cast<size_t>(min(n0 + row, N - 1)) * K + col * 8;
+    bdstd[i] = ABYTES + row * PROW + col * 16;
+  }
   const unsigned short* ssrc = a.scales + static_cast<size_t>(bn) * G;
   const unsigned short* zsrc = a.zeros + static_cast<size_t>(bn) * G;
   const int bdst = ABYTES + brow * PROW + bhalf * 64;
@@ -90,7 +101,8 @@ __global__ __launch_bounds__(WV * 64) void qgemm_prefill_kernel(const MfmaArgs a
   // Two register sets: chunk c+2 is requested while chunk c is on the matrix cores and chunk c+1 moves from registers
   // to LDS, so a global load has a whole iteration (>= 1000 MFMA cycles) before its first use.
   u32x4 areg[2][AP];
-  unsigned wreg[2][NU * BITS];
+  u32x4 breg[2][DENSE ? BP : 1];
+  unsigned wreg[2][NU * WB];
   unsigned short sreg[2][NU], zreg[2][NU];
 
   // global -> registers, in four parts so that the requests of a chunk spread over the k-steps of the chunk before it
@@ -99,6 +111,10 @@ __global__ __launch_bounds__(WV * 64) void qgemm_prefill_kernel(const MfmaArgs a
   // activation pieces.  Clamped: late prefetches re-read the final chunk.
   auto load_part = [&](int set, int c, int t) {
     const int kc = kbase + min(c, nchunks - 1) * PKC;
+    if constexpr (DENSE) {
+#pragma unroll
+      for (int i = t * (BP / 4); i < (t + 1) * (BP / 4); ++i) breg[set][i] = *reinterpret_cast<const u32x4*>(bsrc[i] + kc);
+    } else
     if (t == 0) {
 #pragma unroll
       for (int j = 0; j < NU; ++j) {
@@ -106,22 +122,22 @@ __global__ __launch_bounds__(WV * 64) void qgemm_prefill_kernel(const MfmaArgs a
         sreg[set][j] = ssrc[g];
         zreg[set][j] = zsrc[g];
       }
-      const uint32_t* src = wsrc + (kc / 32) * BITS;
-      if constexpr (NU * BITS % 4 == 0) {
+      const uint32_t* src = wsrc + (kc / 32) * WB;
+      if constexpr (NU * WB % 4 == 0) {
 #pragma unroll
-        for (int q = 0; q < NU * BITS; q += 4) {
+        for (int q = 0; q < NU * WB; q += 4) {
           const u32x4 v = *reinterpret_cast<const u32x4*>(src + q);
           wreg[set][q] = v.x; wreg[set][q + 1] = v.y; wreg[set][q + 2] = v.z; wreg[set][q + 3] = v.w;
         }
-      } else if constexpr (NU * BITS % 2 == 0) {
+      } else if constexpr (NU * WB % 2 == 0) {
 #pragma unroll
-        for (int q = 0; q < NU * BITS; q += 2) {
+        for (int q = 0; q < NU * WB; q += 2) {
           const u32x2 v = *reinterpret_cast<const u32x2*>(src + q);
           wreg[set][q] = v.x; wreg[set][q + 1] = v.y;
         }
       } else {
 #pragma unroll
-        for (int q = 0; q < NU * BITS; ++q) wreg[set][q] = src[q];
+        for (int q = 0; q < NU * WB; ++q) wreg[set][q] = src[q];
       }
     }
 #pragma unroll
@@ -136,9 +152,13 @@ __global__ __launch_bounds__(WV * 64) void qgemm_prefill_kernel(const MfmaArgs a
     unsigned char* base = lds + stage * STAGE;
 #pragma unroll
     for (int i = t * (AP / 4); i < (t + 1) * (AP / 4); ++i) *reinterpret_cast<u32x4*>(base + adst[i]) = areg[set][i];
+    if constexpr (DENSE) {
+#pragma unroll
+      for (int i = t * (BP / 4); i < (t + 1) * (BP / 4); ++i) *reinterpret_cast<u32x4*>(base + bdstd[i]) = breg[set][i];
+    } else
 #pragma unroll
     for (int j = 0; j < NU; ++j) {                // octet t of every unit this thread owns
-      const unsigned* wu = wreg[set] + j * BITS;
+      const unsigned* wu = wreg[set] + j * WB;
       unsigned win;
       if constexpr (BITS == 4) win = wu[t];
       else if constexpr (BITS == 2) win = (t & 1) ? (wu[t >> 1] >> 16) : wu[t >> 1];
@@ -147,7 +167,7 @@ __global__ __launch_bounds__(WV * 64) void qgemm_prefill_kernel(const MfmaArgs a
         win = __builtin_amdgcn_alignbit(wu[w + 1 <= 2 ? w + 1 : 2], wu[w], b & 31);
       }
       float q[8];
-      decode8<BITS>(win, q);
+      decode8<DENSE ? 4 : BITS>(win, q);
       const float s = act_to_f32<BF16>(sreg[set][j]), z = act_to_f32<BF16>(zreg[set][j]);
       u32x4 v;
       v.x = pack2<BF16>(fmaf(s, q[0], z), fmaf(s, q[1], z));
@@ -307,6 +327,21 @@ static hipError_t launch_prefill_bits(const MfmaArgs& a0, bool bf16, hipStream_t
     case 2: return launch_prefill_cfg<BITS, 4, 2, 4>(a, bf16, s);     // 256 x 128
     default: return launch_prefill_cfg<BITS, 2, 2, 4>(a, bf16, s);    // 128 x 128
   }
+}
+
+// Long prompts (M >= GBX_DENSE_MIN_M rows): dequantise ONCE per call into the caller's workspace (fields -> fp32, w = s*q + z,
+// one rounding: the arithmetic of the fused kernel's staging pass, shared by all M / 256 row tiles instead of being redone by
+// each of them), then the same tile kernel with the weight tile staged like the activation tile (no VALU work per element).
+hipError_t launch_qgemm_dense(const void* x, const uint32_t* qw, const void* sc, const void* ze, const void* bias, void* y, int M,
+                              int N, int K, int bits, int log2g, bool bf16, hipStream_t s, void* wdense) {
+  hipError_t e = launch_dequant(qw, sc, ze, wdense, N, K, bits, log2g, bf16, bf16 ? 1 : 0, s);
+  if (e != hipSuccess) return e;
+  MfmaArgs a{};
+  a.x = static_cast<const unsigned short*>(x); a.wdense = static_cast<const unsigned short*>(wdense);
+  a.qweight = qw; a.scales = static_cast<const unsigned short*>(sc); a.zeros = static_cast<const unsigned short*>(ze);
+  a.bias = static_cast<const unsigned short*>(bias); a.y = static_cast<unsigned short*>(y);
+  a.M = M; a.N = N; a.K = K; a.log2g = log2g;
+  return launch_prefill_bits<16>(a, bf16, s);
 }
 
 hipError_t launch_qgemm_mfma(const void* x, const uint32_t* qw, const void* sc, const void* ze, const void* bias, void* y,

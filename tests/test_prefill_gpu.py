@@ -13,7 +13,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-TILE = {11: "128x128", 12: "256x128", 13: "256x256-8w", 15: "128x128 split-K"}
+TILE = {11: "128x128", 12: "256x128", 13: "256x256-8w", 15: "128x128 split-K", 31: "dense 128x128", 32: "dense 256x128",
+        33: "dense 256x256-8w"}
 
 
 def _layer(n, k, bits, g, seed, dtype=torch.bfloat16):
@@ -107,3 +108,38 @@ def test_tile_128x128_and_splitk(oracle, c_oracle, bits):
     _check(oracle, c_oracle, 100, 4096 - 12, 4096, bits, 64, torch.float16, want_tile=11, bias=True)
     _check(oracle, c_oracle, 1024, 1024, 4096, bits, 128, torch.bfloat16, want_tile=15, workspace=True)
     _check(oracle, c_oracle, 300, 4096, 14336, bits, 128, torch.bfloat16, want_tile=15, workspace=True, bias=True)
+
+
+# M >= 8192 with caller scratch: the weights are dequantised ONCE per call into the workspace and the same tiles run on them
+# (what gbx_lm_amd.ops.quantized_matmul does for every long prompt)
+@pytest.mark.parametrize("n,k", [(4096, 4096), (1024, 4096), (14336, 4096), (4096, 14336)])
+def test_cfg4_full_m_4bit_dense(oracle, c_oracle, n, k):
+    _check(oracle, c_oracle, 32768, n, k, 4, 128, torch.bfloat16, want_tile=33, workspace=True)
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_dense_tiles(oracle, c_oracle, bits, dtype):
+    g = 64 if dtype == torch.float16 else 128
+    _check(oracle, c_oracle, 8192, 4096, 4096, bits, g, dtype, want_tile=33, workspace=True, bias=(bits == 3))
+    _check(oracle, c_oracle, 8192 + 19, 14336 - 24, 4096, bits, g, dtype, want_tile=33, workspace=True)      # ragged M and N
+    _check(oracle, c_oracle, 8192, 512, 4096, bits, g, dtype, want_tile=32, workspace=True)
+
+
+def test_dense_equals_fused_tiles_bit_for_bit(oracle):
+    """same weights rounded the same way, same tile and k order: the dequantise-once path must reproduce the fused kernel exactly"""
+    from gbx_lm_amd import _lib
+    L = _lib.lib()
+    m, n, k, bits, g = 8192, 4096, 4096, 4, 128
+    qw, sc, ze = _layer(n, k, bits, g, 5)
+    x = torch.randn((m, k), device=DEV).to(torch.bfloat16)
+    y0, y1 = torch.empty((m, n), dtype=torch.bfloat16, device=DEV), torch.empty((m, n), dtype=torch.bfloat16, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(L.gbx_qlinear_forward(x.data_ptr(), qw.data_ptr(), sc.data_ptr(), ze.data_ptr(), None, y0.data_ptr(), m, n, k, bits, g, _lib.GBX_BF16, st))
+    need = L.gbx_qlinear_workspace_bytes(m, n, k, bits, g)
+    assert need == n * k * 2
+    ws = torch.empty((need,), dtype=torch.uint8, device=DEV)
+    _lib.check(L.gbx_qlinear_forward_ws(x.data_ptr(), qw.data_ptr(), sc.data_ptr(), ze.data_ptr(), None, y1.data_ptr(), m, n, k, bits, g, _lib.GBX_BF16,
+                                        ws.data_ptr(), need, st))
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
