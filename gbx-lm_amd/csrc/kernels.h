@@ -20,7 +20,9 @@ hipError_t launch_qlinear_generic(const void* x, const uint32_t* qw, const void*
 hipError_t launch_qgemm_mfma(const void* x, const uint32_t* qw, const void* sc, const void* ze, const void* bias, void* y,
                              int M, int N, int K, int bits, int log2g, bool bf16, hipStream_t s, float* ws = nullptr);
 size_t qgemm_batch_workspace_bytes(int M, int N, int K, int bits, int log2g);
-constexpr int GBX_DENSE_MIN_M = 8192;      // (measured: at M = 4096 the extra pass costs more than the lighter tiles save)
+bool gemm_dense_supported(int M, int N, int K);
+hipError_t launch_gemm_dense(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, bool bf16, hipStream_t s);
+constexpr int GBX_DENSE_MIN_M = 4096;
 hipError_t launch_qgemm_dense(const void* x, const uint32_t* qw, const void* sc, const void* ze, const void* bias, void* y, int M,
                               int N, int K, int bits, int log2g, bool bf16, hipStream_t s, void* wdense);
 size_t qgemm_prefill_workspace_bytes(int M, int N, int K);

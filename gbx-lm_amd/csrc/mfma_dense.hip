@@ -1,0 +1,236 @@
+// Dense y[M,N] = x[M,K] . w[N,K]^T on the matrix cores for LONG prompts: the second half of the "dequantise once per call"
+// prefill path (mfma_gemm.hip: launch_qgemm_dense).  The weights arrive already dequantised to the activation dtype
+// (gbx_dequantize arithmetic: fields -> fp32, w = s*q + z, one rounding), so this is a plain 16-bit GEMM and the kernel can
+// spend everything on keeping the matrix pipe fed:
+//   * workgroup tile 256 x 256, K tiles of 64, 8 waves as 2 (M) x 4 (N), a wave owns 128 x 64 = 8 x 4 accumulators of
+//     v_mfma_f32_16x16x32 (128 VGPRs) -- the 256^2 "8-phase" structure of cdna_hip_programming.md section 5;
+//   * both operands go HBM/L2 -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, no VGPR staging, no ds_write pass), four
+//     16 KB half-tiles per K tile (A rows 0-127 / 128-255, B rows 0-127 / 128-255), two K tiles of LDS (128 KB);
+//     the LDS image is lane-linear, the st_16x32 XOR swizzle (conflict-free ds_read_b128 fragments) is applied to the
+//     SOURCE column of every lane;
+//   * four phases per K tile, one C quadrant (16 MFMAs) each, fragments of the whole K tile are in registers after phase 2,
+//     so the tile's LDS slots are restaged from phase 3 on: the four half-tiles of tile t+2 are requested in phases 3, 4 of
+//     tile t and 1, 2 of tile t+1 and waited for ONCE per K tile with a counted vmcnt(4) (never 0 in the loop);
+//   * the two wave groups (waves 0-3 / 4-7: one wave of each on every SIMD) run one barrier interval apart, so one group's
+//     MFMA segment covers the other's ds_read / DMA-issue segment.
+// Ordering rules this schedule obeys (MI355X_MICROARCH.md, cdna_hip_programming.md section 5): a staged buffer is read one
+// phase after the counted wait + barrier that retire it (RAW); a buffer is restaged only after a barrier that follows the
+// lgkmcnt(0) retiring its last ds_read in every wave (WAR); raw s_barrier, never __syncthreads() (which would drain vmcnt).
+#include "mfma_common.h"
+#include "kernels.h"
+
+namespace gbx {
+
+namespace {
+
+constexpr int DT = 256;            // tile edge (M and N)
+constexpr int DK = 64;             // K tile
+constexpr int HALF = 128 * DK * 2; // bytes of one half-tile (128 rows x 64 k)
+constexpr int TILE_LDS = 4 * HALF; // A-lo | A-hi | B-lo | B-hi
+constexpr int DENSE_LDS = 8 * 128 * 144;   // 2 K tiles (131072 B) during the loop; 8 wave-private 128 x 144 B output tiles in the epilogue
+
+#define DLDSP(p) ((__attribute__((address_space(3))) void*)(p))
+__device__ __forceinline__ constexpr int wc_vm(int n) { return (n & 0xF) | ((n >> 4) << 14) | (0x7 << 4) | (0xF << 8); }
+__device__ __forceinline__ void bar() { asm volatile("s_barrier" ::: "memory"); }
+
+struct DenseArgs2 {
+  const unsigned short* x;     // [M, K]
+  const unsigned short* w;     // [N, K]
+  const unsigned short* bias;  // [N] or null
+  unsigned short* y;           // [M, N]
+  int M, N, K;
+};
+
+template <bool BF16>
+__global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseArgs2 a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wcn = wave & 3;          // wave row (M half) / wave column (64 of the 256 N)
+  const int M = a.M, N = a.N, K = a.K;
+  const int nk = K / DK;
+
+  // XCD-aware tile order (as mfma_gemm.hip): every XCD walks a contiguous run of tiles, M-tile major
+  const int tiles_n = (N + DT - 1) / DT, tiles_m = (M + DT - 1) / DT, tiles = tiles_m * tiles_n;
+  const int per_xcd = (tiles + 7) / 8;
+  const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (tile >= tiles) return;
+  const int m0 = (tile / tiles_n) * DT, n0 = (tile % tiles_n) * DT;
+
+  // ---- DMA side: piece p = tid + 512 i (i = 0, 1) of a half-tile = (row p >> 3, 16-byte column p & 7); LDS linear, the
+  // swizzle on the source column: slot (row, c) holds logical column c ^ (((row >> 2) & 1) << 1)
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x), 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.w), 0, 0x7FFFFFFF, 0x00020000);
+  int voa[2][2], vob[2][2];                          // [half][i] byte offsets of this lane's pieces at k = 0
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = tid + 512 * i, row = p >> 3, c = (p & 7) ^ (((row >> 2) & 1) << 1);
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      voa[hf][i] = (min(m0 + hf * 128 + row, M - 1) * K + c * 8) * 2;
+      vob[hf][i] = (min(n0 + hf * 128 + row, N - 1) * K + c * 8) * 2;
+    }
+  }
+  const int dma_lds = wave * 1024;                   // + 8192 i: this wave's 1 KiB run inside a half-tile slot
+  // half-tile h (0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi) of K tile kt -> LDS buffer kt & 1
+  auto stage = [&](int kt, int h) {
+    const int ktc = min(kt, nk - 1);                 // past the end: re-request the last tile (keeps the vmcnt arithmetic uniform)
+    unsigned char* dst = lds + (kt & 1) * TILE_LDS + h * HALF + dma_lds;
+    const int koff = ktc * (DK * 2);
+    if (h < 2) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, DLDSP(dst), 16, voa[h][0], koff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, DLDSP(dst + 8192), 16, voa[h][1], koff, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, DLDSP(dst), 16, vob[h - 2][0], koff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, DLDSP(dst + 8192), 16, vob[h - 2][1], koff, 0, 0);
+    }
+  };
+
+  // ---- fragment side: lane = (row l & 15, k block l >> 4) of a 16 x 32 operand; swizzled column
+  const int fr = lane & 15, fk = lane >> 4;
+  const int sw = ((fr >> 2) & 1) << 1;
+  const int fa_off = wr * HALF + fr * 128;                          // + rt * 2048 + ((ks * 4 + fk) ^ sw) * 16
+  const int fb_off = (2 + (wcn >> 1)) * HALF + ((wcn & 1) * 64 + fr) * 128;
+  const int c0 = (fk ^ sw) * 16, c1 = ((4 + fk) ^ sw) * 16;         // k-step 0 / 1 column bytes
+  u32x4 fa[8][2], fb[4][2];
+  auto read_a = [&](const unsigned char* buf, int half) {           // row tiles 4 half .. 4 half + 3
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      fa[half * 4 + rt][0] = *reinterpret_cast<const u32x4*>(buf + fa_off + (half * 4 + rt) * 2048 + c0);
+      fa[half * 4 + rt][1] = *reinterpret_cast<const u32x4*>(buf + fa_off + (half * 4 + rt) * 2048 + c1);
+    }
+  };
+  auto read_b = [&](const unsigned char* buf, int half) {           // column tiles 2 half, 2 half + 1
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      fb[half * 2 + ct][0] = *reinterpret_cast<const u32x4*>(buf + fb_off + (half * 2 + ct) * 2048 + c0);
+      fb[half * 2 + ct][1] = *reinterpret_cast<const u32x4*>(buf + fb_off + (half * 2 + ct) * 2048 + c1);
+    }
+  };
+  f32x4v acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0};
+  auto quadrant = [&](int ah, int bh) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        acc[ah * 4 + rt][bh * 2 + ct] = mfma16<BF16>(fa[ah * 4 + rt][0], fb[bh * 2 + ct][0], acc[ah * 4 + rt][bh * 2 + ct]);
+        acc[ah * 4 + rt][bh * 2 + ct] = mfma16<BF16>(fa[ah * 4 + rt][1], fb[bh * 2 + ct][1], acc[ah * 4 + rt][bh * 2 + ct]);
+      }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- prologue: K tile 0 whole, the first two half-tiles of K tile 1
+#pragma unroll
+  for (int h = 0; h < 4; ++h) stage(0, h);
+  stage(1, 0);
+  stage(1, 1);
+  __builtin_amdgcn_s_waitcnt(wc_vm(4));              // K tile 0 has landed (this wave's share); tile 1's two may fly
+  bar();
+  if (wr == 1) bar();                                // the second wave group runs one barrier interval behind the first
+
+  for (int t = 0; t < nk; ++t) {
+    const unsigned char* buf = lds + (t & 1) * TILE_LDS;
+    // phase 1: B0 + A0 -> quadrant (A0, B0); request half-tile 2 of K tile t+1
+    read_b(buf, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(buf, 0);
+    stage(t + 1, 2);
+    bar();
+    quadrant(0, 0);
+    bar();
+    // phase 2: B1 + A1 (the K tile is in registers afterwards) -> quadrant (A0, B1); request half-tile 3 of K tile t+1
+    read_b(buf, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(buf, 1);
+    stage(t + 1, 3);
+    __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): every fragment read of this buffer retired before the barrier
+    bar();
+    quadrant(0, 1);
+    bar();
+    // phase 3: quadrant (A1, B1); buffer t & 1 is free: request half-tile 0 of K tile t+2 into it
+    stage(t + 2, 0);
+    bar();
+    quadrant(1, 1);
+    bar();
+    // phase 4: quadrant (A1, B0); request half-tile 1 of K tile t+2; K tile t+1 must have landed: all but the 4 youngest DMAs
+    stage(t + 2, 1);
+    __builtin_amdgcn_s_waitcnt(wc_vm(4));
+    bar();
+    quadrant(1, 0);
+    bar();
+  }
+  if (wr == 0) bar();                                // barrier counts of the two groups match again
+  __builtin_amdgcn_s_waitcnt(wc_vm(0));              // no LDS-DMA may outlive the workgroup
+
+  // ---- epilogue: one rounding to the activation dtype (+ bias as a second rounding, like the reference's x + bias).
+  // A lane holds 4 consecutive ROWS of one column per 16x16 tile: stored from the registers that is 128 two-byte stores per
+  // lane in 32-byte segments (measured: ~30 us per workgroup, a quarter of the K = 4096 tile).  The wave's 128 x 64 tile
+  // goes through its own LDS region instead (rows of 128 B + 16 B pad) and leaves as 16-byte row-contiguous stores.
+  bar();                                             // every wave is past its last fragment read / DMA wait: LDS is free
+  constexpr int EROW = 144;
+  unsigned char* et = lds + wave * (128 * EROW);
+  const int nb = n0 + wcn * 64, mb = m0 + wr * 128;
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    const int n = min(nb + ct * 16 + fr, N - 1);
+    const float b = a.bias ? act_to_f32<BF16>(a.bias[n]) : 0.f;
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {                  // C/D layout of the 16x16 tile: row = 4 (lane >> 4) + e, column = lane & 15
+        float v = acc[rt][ct][e];
+        if (a.bias) v = act_to_f32<BF16>(f32_to_act<BF16>(v)) + b;
+        *reinterpret_cast<unsigned short*>(et + (rt * 16 + 4 * fk + e) * EROW + (ct * 16 + fr) * 2) = f32_to_act<BF16>(v);
+      }
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);                // the wave's own LDS writes (no other wave touches this region)
+  const bool full_n = (nb + 64 <= N) && (N % 8 == 0);
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int p = it * 64 + lane, row = p >> 3, c = p & 7;       // 16-byte piece c of row `row`
+    const int m = mb + row;
+    if (m >= M) continue;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(et + row * EROW + c * 16);
+    unsigned short* dst = a.y + static_cast<size_t>(m) * N + nb + c * 8;
+    if (full_n) {
+      *reinterpret_cast<u32x4*>(dst) = v;
+    } else {
+      const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (nb + c * 8 + q < N) dst[q] = static_cast<unsigned short>(wv[q >> 1] >> (16 * (q & 1)));
+    }
+  }
+}
+
+}  // namespace
+
+// K % 64 == 0; x and w 16-byte aligned rows (K % 8 == 0).  Byte offsets inside the kernel are 32-bit: M * K and N * K * 2 < 2^31.
+bool gemm_dense_supported(int M, int N, int K) {
+  return K % DK == 0 && K >= DK && static_cast<long long>(M) * K * 2 < (1LL << 31) && static_cast<long long>(N) * K * 2 < (1LL << 31);
+}
+
+hipError_t launch_gemm_dense(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, bool bf16, hipStream_t s) {
+  static bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dense_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dense_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_LDS);
+    if (e != hipSuccess) return e;
+    done = true;
+  }
+  DenseArgs2 a{static_cast<const unsigned short*>(x), static_cast<const unsigned short*>(w), static_cast<const unsigned short*>(bias),
+               static_cast<unsigned short*>(y), M, N, K};
+  const int tiles = ((N + DT - 1) / DT) * ((M + DT - 1) / DT);
+  dim3 grid(8 * ((tiles + 7) / 8)), block(512);
+  if (bf16) hipLaunchKernelGGL((gemm_dense_kernel<true>), grid, block, DENSE_LDS, s, a);
+  else hipLaunchKernelGGL((gemm_dense_kernel<false>), grid, block, DENSE_LDS, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace gbx

@@ -336,6 +336,8 @@ hipError_t launch_qgemm_dense(const void* x, const uint32_t* qw, const void* sc,
                               int N, int K, int bits, int log2g, bool bf16, hipStream_t s, void* wdense) {
   hipError_t e = launch_dequant(qw, sc, ze, wdense, N, K, bits, log2g, bf16, bf16 ? 1 : 0, s);
   if (e != hipSuccess) return e;
+  static const bool no8p = getenv("GBX_DENSE_NO_8PHASE") != nullptr;      // tuning aid: the register-staged tiles on dense weights
+  if (!no8p && gemm_dense_supported(M, N, K)) return launch_gemm_dense(x, wdense, bias, y, M, N, K, bf16, s);   // mfma_dense.hip
   MfmaArgs a{};
   a.x = static_cast<const unsigned short*>(x); a.wdense = static_cast<const unsigned short*>(wdense);
   a.qweight = qw; a.scales = static_cast<const unsigned short*>(sc); a.zeros = static_cast<const unsigned short*>(ze);

@@ -74,7 +74,7 @@ def quantized_matmul(x: torch.Tensor, w: torch.Tensor, scales: torch.Tensor, bia
     elif out.shape != (m, n) or out.dtype != x.dtype or not out.is_contiguous():
         raise ValueError("out must be a contiguous [M, N] tensor of the activation dtype")
     L = _lib.lib()
-    need = L.gbx_qlinear_workspace_bytes(m, n, k, bits, group_size) if (2 <= m <= 32 or 64 < m <= 2048 or m >= 8192) else 0
+    need = L.gbx_qlinear_workspace_bytes(m, n, k, bits, group_size) if (2 <= m <= 32 or 64 < m <= 2048 or m >= 4096) else 0
     if need:                                            # decode batches / short prompts: k split across workgroups; long prompts: dequantise once
         ws = torch.empty((need,), dtype=torch.uint8, device=x.device)      # caller-owned scratch (caching allocator: no sync)
         rc = L.gbx_qlinear_forward_ws(

@@ -353,7 +353,7 @@ int gbx_rmsnorm(const void* x, const void* w, void* y, int64_t M, int32_t K, flo
  * 0 nothing (M = 0), 1 decode GEMV, 2 generic kernel, 20 batched-decode matrix-core kernels (2 <= M <= 64),
  * 11 / 12 / 13 prefill tile 128 x 128 / 256 x 128 / 256 x 256 (8 waves), 15 prefill with k split over workgroups
  * (has_workspace != 0 and the shape qualifies), 31 / 32 / 33 the same tiles on weights dequantised once per call into the
- * workspace (M >= 8192 and has_workspace != 0); -1 invalid shape. */
+ * workspace (M >= 4096 and has_workspace != 0); -1 invalid shape. */
 int gbx_qlinear_kernel_id(int64_t M, int32_t N, int32_t K, int32_t bits, int32_t group_size, int32_t has_workspace);
 
 /* ---- streamed decode GEMV / persistent decode engine (gbx-lm_amd/csrc/gemv_stream.hip) -------------------------------

@@ -110,7 +110,7 @@ def test_tile_128x128_and_splitk(oracle, c_oracle, bits):
     _check(oracle, c_oracle, 300, 4096, 14336, bits, 128, torch.bfloat16, want_tile=15, workspace=True, bias=True)
 
 
-# M >= 8192 with caller scratch: the weights are dequantised ONCE per call into the workspace and the same tiles run on them
+# M >= 4096 with caller scratch: the weights are dequantised ONCE per call into the workspace and the same tiles run on them
 # (what gbx_lm_amd.ops.quantized_matmul does for every long prompt)
 @pytest.mark.parametrize("n,k", [(4096, 4096), (1024, 4096), (14336, 4096), (4096, 14336)])
 def test_cfg4_full_m_4bit_dense(oracle, c_oracle, n, k):
@@ -123,11 +123,12 @@ def test_dense_tiles(oracle, c_oracle, bits, dtype):
     g = 64 if dtype == torch.float16 else 128
     _check(oracle, c_oracle, 8192, 4096, 4096, bits, g, dtype, want_tile=33, workspace=True, bias=(bits == 3))
     _check(oracle, c_oracle, 8192 + 19, 14336 - 24, 4096, bits, g, dtype, want_tile=33, workspace=True)      # ragged M and N
-    _check(oracle, c_oracle, 8192, 512, 4096, bits, g, dtype, want_tile=32, workspace=True)
+    _check(oracle, c_oracle, 4096, 1024, 4096, bits, g, dtype, want_tile=32, workspace=True)
 
 
-def test_dense_equals_fused_tiles_bit_for_bit(oracle):
-    """same weights rounded the same way, same tile and k order: the dequantise-once path must reproduce the fused kernel exactly"""
+def test_dense_path_close_to_fused_tiles(oracle):
+    """same weights rounded the same way (one gbx_dequantize rounding either way); the dense kernel accumulates in another
+    order (16x16x32 tiles), so equality holds up to the fp32 accumulation -> output-dtype rounding: a few ulps at most"""
     from gbx_lm_amd import _lib
     L = _lib.lib()
     m, n, k, bits, g = 8192, 4096, 4096, 4, 128
@@ -142,4 +143,13 @@ def test_dense_equals_fused_tiles_bit_for_bit(oracle):
     _lib.check(L.gbx_qlinear_forward_ws(x.data_ptr(), qw.data_ptr(), sc.data_ptr(), ze.data_ptr(), None, y1.data_ptr(), m, n, k, bits, g, _lib.GBX_BF16,
                                         ws.data_ptr(), need, st))
     torch.cuda.synchronize()
-    assert torch.equal(y0, y1)
+    d = (y0.float() - y1.float()).abs()
+    rms = y0.float().pow(2).mean().sqrt().item()
+    assert (d <= 2.0 ** -7 * y0.float().abs() + 1e-3 * rms).all(), f"max diff {d.max().item()} (rms {rms})"
+    # repeated launches are deterministic (no race between the DMA stages and the fragment reads shows up as a diff here)
+    for _ in range(5):
+        y2 = torch.empty_like(y1)
+        _lib.check(L.gbx_qlinear_forward_ws(x.data_ptr(), qw.data_ptr(), sc.data_ptr(), ze.data_ptr(), None, y2.data_ptr(), m, n, k, bits, g,
+                                            _lib.GBX_BF16, ws.data_ptr(), need, st))
+        torch.cuda.synchronize()
+        assert torch.equal(y1, y2)
