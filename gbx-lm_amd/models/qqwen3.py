@@ -101,6 +101,17 @@ class Model(nn.Module):
             weights.pop("lm_head.weight", None)
         return weights
 
+    def prefill(self, inputs, cache) -> None:
+        """Fill the KV cache for a prompt chunk whose logits nobody reads (generate_step's chunk loop, gbx_lm/utils.py:312-319:
+        the reference never evaluates those logits): the decoder body only, no output head."""
+        self.model(inputs, None, cache)
+
+    def last_logits(self, inputs, cache) -> torch.Tensor:
+        """``self(inputs, cache=cache)[:, -1, :]`` (gbx_lm/utils.py:291-294) with the output head applied to the last
+        position only -- at a 4096-token prompt the full head is 2 x 4096 x vocab x hidden flops of discarded work."""
+        hidden = self.model(inputs, None, cache)
+        return F.linear(hidden[:, -1:, :], self.head_weight())[:, -1, :]
+
     def decode_step(self, y: torch.Tensor, prompt_cache) -> torch.Tensor:
         """Single-token fast path: the hand-fused five-launch block of the Llama graph when the checkpoint qualifies (the
         per-head q / k norms run inside the attention launch), else this model's own forward captured once and replayed

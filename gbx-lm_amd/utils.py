@@ -294,6 +294,8 @@ def generate_step(prompt: torch.Tensor, model: nn.Module, *, max_tokens: int = 2
         elif hidden_states:
             logits, prompt_hidden_states = model(y[None], cache=prompt_cache, hidden_states=True)
             logits = logits[:, -1, :]
+        elif hasattr(model, "last_logits"):
+            logits = model.last_logits(y[None], prompt_cache)          # output head on the last position only
         else:
             logits = model(y[None], cache=prompt_cache)[:, -1, :]
         if logits_processors:
@@ -312,7 +314,10 @@ def generate_step(prompt: torch.Tensor, model: nn.Module, *, max_tokens: int = 2
         total_prompt_tokens = y.numel()
         prompt_processed_tokens = 0
         while y.numel() > prefill_step_size:
-            model(y[:prefill_step_size][None], cache=prompt_cache)
+            if hasattr(model, "prefill"):
+                model.prefill(y[:prefill_step_size][None], prompt_cache)    # these logits are never read: body only
+            else:
+                model(y[:prefill_step_size][None], cache=prompt_cache)
             prompt_progress_callback(prompt_processed_tokens, total_prompt_tokens)
             prompt_processed_tokens += prefill_step_size
             y = y[prefill_step_size:]
