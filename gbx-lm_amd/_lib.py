@@ -82,6 +82,7 @@ def _declare_optional(L) -> None:
         "gbx_qlinear_swiglu_forward": [p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, p],
         "gbx_qlinear_forward_partials": [p, p, p, p, p, ctypes.c_size_t, ctypes.POINTER(i32), i64, i32, i32, i32, i32, i32, p],
         "gbx_add_rmsnorm_slices": [p, p, i32, p, p, i64, i32, f32, i32, p],
+        "gbx_dense_forward": [p, p, p, p, i64, i32, i32, i32, p],
         "gbx_stream_encode": [ctypes.POINTER(FusedDesc), i32, p, ctypes.c_size_t],
         "gbx_stream_run": [p, p, i32, i32, i32, p],
         "gbx_attn_decode": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, f32, f32, i32, i32, p],

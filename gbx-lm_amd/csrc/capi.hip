@@ -721,6 +721,20 @@ int gbx_add_rmsnorm_slices(void* h, const float* slices_ws, int32_t slices, cons
   return GBX_OK;
 }
 
+int gbx_dense_forward(const void* x, const void* w, const void* bias, void* y, int64_t M, int32_t N, int32_t K, int32_t act_dtype,
+                      void* hip_stream) {
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  if (M < 0 || N <= 0 || K <= 0) return fail(GBX_ERR_INVALID, "bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+  if (M == 0) return GBX_OK;
+  if (!x || !w || !y) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (!aligned(x, 16) || !aligned(w, 16) || !aligned(y, 2)) return fail(GBX_ERR_INVALID, "x and w must be 16-byte aligned");
+  if (M > 2147483647LL || !gbx::gemm_dense_supported(static_cast<int>(M), N, K))
+    return fail(GBX_ERR_UNSUPPORTED, "dense matrix-core GEMM needs K %% 64 == 0 and M*K, N*K < 2^30 elements (M=%lld N=%d K=%d)", (long long)M, N, K);
+  hipError_t e = gbx::launch_gemm_dense(x, w, bias, y, static_cast<int>(M), N, K, act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_dense_forward launch");
+  return GBX_OK;
+}
+
 int gbx_swiglu(const void* gate, const void* up, void* y, int64_t n, int32_t act_dtype, void* hip_stream) {
   if (n == 0) return GBX_OK;
   if (!gate || !up || !y) return fail(GBX_ERR_INVALID, "null device pointer");

@@ -113,7 +113,9 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseArgs2 a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0};
   auto quadrant = [&](int ah, int bh) {
+#ifndef DENSE_NOPRIO
     __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
@@ -121,7 +123,9 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseArgs2 a) {
         acc[ah * 4 + rt][bh * 2 + ct] = mfma16<BF16>(fa[ah * 4 + rt][0], fb[bh * 2 + ct][0], acc[ah * 4 + rt][bh * 2 + ct]);
         acc[ah * 4 + rt][bh * 2 + ct] = mfma16<BF16>(fa[ah * 4 + rt][1], fb[bh * 2 + ct][1], acc[ah * 4 + rt][bh * 2 + ct]);
       }
+#ifndef DENSE_NOPRIO
     __builtin_amdgcn_s_setprio(0);
+#endif
   };
 
   // ---- prologue: K tile 0 whole, the first two half-tiles of K tile 1

@@ -117,7 +117,7 @@ class DecodeRunner:
         else:
             h = h + delta
             out = ops.rmsnorm(h, m.norm.weight, m.norm.eps)
-        return F.linear(out, self.model.head_weight())[:, -1, :]   # [B, V]
+        return ops.dense_linear(out, self.model.head_weight())[:, -1, :]   # [B, V]: the head streamed once for the whole batch
 
     def _capture(self):
         chain = getattr(self, "chain", False)

@@ -320,6 +320,21 @@ def add_rmsnorm_slices(h: torch.Tensor, ws: torch.Tensor, slices: int, w: torch.
     return y
 
 
+def dense_linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``x @ w.T (+ bias)`` for unquantised 16-bit weights ``w [N, K]`` on the hand-written matrix-core GEMM
+    (gbx_dense_forward): the output head of a decode batch.  Falls back to ``F.linear`` for shapes outside it."""
+    k, n = w.shape[1], w.shape[0]
+    x2 = x.reshape(-1, k)
+    if not (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and w.dtype == x.dtype and w.is_contiguous() and k % 64 == 0
+            and (bias is None or bias.dtype == x.dtype) and n * k < (1 << 30) and x2.shape[0] * k < (1 << 30)):
+        return torch.nn.functional.linear(x, w, bias)
+    x2 = x2.contiguous()
+    y = torch.empty((x2.shape[0], n), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().gbx_dense_forward(x2.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                                            x2.shape[0], n, k, _DT[x.dtype], _stream_ptr(x.device)))
+    return y.reshape(*x.shape[:-1], n)
+
+
 def prepack_tiles(mod, mod_up=None):
     """Load-time tiled form of a 2-bit / group-128 QuantizedLinear for the matrix-core decode GEMV
     (gbx_qlinear_prepack_tiles): returns ``(wt, szt)`` int32 tensors.  With ``mod_up`` the pair (gate_proj, up_proj) is

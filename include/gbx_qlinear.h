@@ -167,6 +167,13 @@ int gbx_qlinear_forward_partials(const void* x, const uint32_t* qweight, const v
 int gbx_add_rmsnorm_slices(void* h, const float* slices_ws, int32_t slices, const void* w, void* y, int64_t M, int32_t K, float eps,
                            int32_t act_dtype, void* hip_stream);
 
+/* y[M,N] = x[M,K] . w[N,K]^T (+ bias[N] as a second rounding) for UNQUANTISED 16-bit weights on the matrix cores
+ * (csrc/mfma_dense.hip: 256 x 256 tiles, LDS-DMA staging): the output head of a batch of decode rows (`nn.Linear lm_head` /
+ * `embed_tokens.as_linear`, gbx_lm/models/qllama.py:194-198, M = batch: the weight matrix is streamed once for all rows)
+ * and the GEMM stage of the dequantise-once prefill path.  K % 64 == 0; x, w 16-byte aligned. */
+int gbx_dense_forward(const void* x, const void* w, const void* bias, void* y, int64_t M, int32_t N, int32_t K, int32_t act_dtype,
+                      void* hip_stream);
+
 /* Expert-indexed QuantizedLinear for a few (token, expert-slot) pairs -- the decode case of
  * mx.gather_qmm(x, qweight[E,N,W], scales[E,N,G], zeros[E,N,G], rhs_indices=indices, transpose=True) + bias[indices]
  * (QuantizedSwitchLinear.__call__, gbx_lm/models/switch_layers.py:78-92):

@@ -749,3 +749,21 @@ def test_partials_gemm_and_slice_folding_norm(oracle, bits, m):
     oracle.assert_close(hz, y64, "bf16", "o_proj partials")
     small, _ = _mk(oracle, 512, 1024, bits, 128, seed=1)
     assert ops.quantized_matmul_partials(torch.randn(4, 1024).to(torch.bfloat16).to(DEV), small) is None     # short rows do not split
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,n,k", [(32, 128256, 4096), (2, 1000, 512), (300, 4096 + 40, 3072), (1, 256, 64)])
+def test_dense_forward_matches_fp64(dtype, m, n, k):
+    """gbx_dense_forward (the B > 1 output head / the GEMM stage of the long-prompt path) against an fp64 matmul of the same
+    16-bit operands, incl. ragged M / N and a bias."""
+    from gbx_lm_amd import ops
+    x = torch.randn(m, k, device=DEV).to(dtype)
+    w = (torch.randn(n, k, device=DEV) * 0.02).to(dtype)
+    b = torch.randn(n, device=DEV).to(dtype) if n % 3 == 1 else None
+    y = ops.dense_linear(x, w, b)
+    ref = x.double() @ w.double().t()
+    if b is not None:
+        ref = ref + b.double()
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    rms = ref.pow(2).mean().sqrt().item()
+    assert y.shape == (m, n) and ((y.double() - ref).abs() <= tol * rms + tol * ref.abs()).all()
