@@ -6,8 +6,9 @@
 //     v_mfma_f32_16x16x32 (128 VGPRs) -- the 256^2 "8-phase" structure of cdna_hip_programming.md section 5;
 //   * both operands go HBM/L2 -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, no VGPR staging, no ds_write pass), four
 //     16 KB half-tiles per K tile (A rows 0-127 / 128-255, B rows 0-127 / 128-255), two K tiles of LDS (128 KB);
-//     the LDS image is lane-linear, the st_16x32 XOR swizzle (conflict-free ds_read_b128 fragments) is applied to the
-//     SOURCE column of every lane;
+//     the LDS image is lane-linear, an XOR swizzle of the 16-byte column with (row >> 1) & 7 is applied to the SOURCE column
+//     of every lane: a 16 x 32 fragment read (lane = row l & 15, k block l >> 4) then hits 16 different bank quads in each of
+//     ds_read_b128's four lane groups (PMC: the guide's st_16x32 swizzle left 49 % of the LDS cycles as bank conflicts here);
 //   * four phases per K tile, one C quadrant (16 MFMAs) each, fragments of the whole K tile are in registers after phase 2,
 //     so the tile's LDS slots are restaged from phase 3 on: the four half-tiles of tile t+2 are requested in phases 3, 4 of
 //     tile t and 1, 2 of tile t+1 and waited for ONCE per K tile with a counted vmcnt(4) (never 0 in the loop);
@@ -58,13 +59,13 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseArgs2 a) {
   const int m0 = (tile / tiles_n) * DT, n0 = (tile % tiles_n) * DT;
 
   // ---- DMA side: piece p = tid + 512 i (i = 0, 1) of a half-tile = (row p >> 3, 16-byte column p & 7); LDS linear, the
-  // swizzle on the source column: slot (row, c) holds logical column c ^ (((row >> 2) & 1) << 1)
+  // swizzle on the source column: slot (row, c) holds logical column c ^ ((row >> 1) & 7)
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x), 0, 0x7FFFFFFF, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.w), 0, 0x7FFFFFFF, 0x00020000);
   int voa[2][2], vob[2][2];                          // [half][i] byte offsets of this lane's pieces at k = 0
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int p = tid + 512 * i, row = p >> 3, c = (p & 7) ^ (((row >> 2) & 1) << 1);
+    const int p = tid + 512 * i, row = p >> 3, c = (p & 7) ^ ((row >> 1) & 7);
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       voa[hf][i] = (min(m0 + hf * 128 + row, M - 1) * K + c * 8) * 2;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseArgs2 a) {
 
   // ---- fragment side: lane = (row l & 15, k block l >> 4) of a 16 x 32 operand; swizzled column
   const int fr = lane & 15, fk = lane >> 4;
-  const int sw = ((fr >> 2) & 1) << 1;
+  const int sw = (fr >> 1) & 7;
   const int fa_off = wr * HALF + fr * 128;                          // + rt * 2048 + ((ks * 4 + fk) ^ sw) * 16
   const int fb_off = (2 + (wcn >> 1)) * HALF + ((wcn & 1) * 64 + fr) * 128;
   const int c0 = (fk ^ sw) * 16, c1 = ((4 + fk) ^ sw) * 16;         // k-step 0 / 1 column bytes
