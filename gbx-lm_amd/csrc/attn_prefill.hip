@@ -1,0 +1,209 @@
+// Causal self-attention over a prompt chunk (L > 1 query positions against S = offset + L cached keys) on the matrix cores:
+// softmax(q k^T * scale + causal mask) v without materialising the L x S scores.  Replaces the
+// mx.fast.scaled_dot_product_attention call of the prefill (gbx_lm/models/base.py:101-122 via qllama.py:84-95; mask of
+// base.py:27-62: query i of the chunk sees keys 0 .. offset + i), grouped-query heads read the shared K / V head directly
+// (no repeated copies).  The caller of the QuantizedLinear path, not the path itself: what it has to be is not slower than
+// the library it displaces (torch SDPA: 250 TFLOP/s at B = 8, T = 4096 with an explicit mask tensor).
+//
+// Structure: one workgroup = 4 waves = 128 query rows of one (sequence, head); a wave owns 32 query rows.  K / V tiles of 64
+// keys go global -> registers (while the previous tile is on the matrix cores) -> LDS, both row-major; the V^T operand is
+// gathered by ds_read_b64_tr_b16 (hardware transposed read).
+// Both products are computed "swapped" so that a lane owns ONE query and the softmax is lane-local:
+//   S^T[key, q]  = mfma(K rows, Q rows)   -> lane (q = lane & 31) holds 16 keys per 32-key sub-tile (the other 16 in lane ^ 32)
+//   O^T[d, q]   += mfma(V^T rows, P^T)    -> the P^T operand of step t is exactly the lane's own p[8t .. 8t+7] (no shuffle),
+//                                            the accumulator column is the lane's query: rescaling by alpha is per lane
+// Online softmax in base 2 (scores scaled by scale * log2 e), fp32 statistics, P rounded to the activation dtype for P V
+// (as every fused attention does), one division at the end.
+#include "mfma_common.h"
+#include "kernels.h"
+
+namespace gbx {
+
+namespace {
+
+struct PrefillAttnArgs {
+  const unsigned short* q;     // [B, Hq, L, D] through strides (elements): qs_b, qs_h, qs_l; D contiguous
+  const unsigned short* k;     // [B, Hkv, S.., D]: ks_b, ks_h, row stride D
+  const unsigned short* v;
+  unsigned short* out;         // [B, L, Hq * D] contiguous
+  long long qs_b, qs_h, qs_l, ks_b, ks_h, vs_b, vs_h;
+  int B, Hq, Hkv, L, S, offset;
+  float scale_log2;            // sm_scale * log2(e)
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+// ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block of 16-bit elements, delivered column-major (lane i of the
+// group: column i, rows 0..3); lane 4q+p of the group supplies the address of row q, columns 4p .. 4p+3.  EXEC must be full.
+__device__ __forceinline__ u32x2 lds_read_tr(const unsigned char* p) {
+  return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (s16x4 __attribute__((address_space(3)))*)(__attribute__((address_space(3))) unsigned char*)p));
+}
+
+template <bool BF16, int HD>
+__global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillAttnArgs a) {
+  constexpr int KT = 64;                       // keys per tile
+  constexpr int KROW = HD * 2 + 16;            // K tile row bytes (+16: conflict-free 16-byte fragment reads)
+  constexpr int VROW = HD * 2 + 64;            // V tile row bytes: pitch = 16 dwords mod 64, the 4 rows of a transposed block
+                                               // (16 banks each per 32-lane half) land on disjoint banks
+  constexpr int KS = HD / 16;                  // k-steps of q k^T
+  constexpr int DT = HD / 32;                  // 32-row tiles of O^T
+  constexpr int PPT = KT * HD / 8 / 256;       // 16-byte pieces of a K (or V) tile per thread
+  __shared__ __attribute__((aligned(16))) unsigned char lds[KT * KROW + KT * VROW];
+  unsigned char* kl = lds;
+  unsigned char* vl = lds + KT * KROW;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z, kvh = head / (a.Hq / a.Hkv);
+  const int qb = (gridDim.x - 1 - blockIdx.x) * 128;                     // longest key sweeps are dispatched first
+  const int qi = qb + wave * 32 + r;                                     // this lane's query (both halves of the wave)
+  const int L = a.L, S = a.S;
+  const unsigned short* kg = a.k + b * a.ks_b + kvh * a.ks_h;
+  const unsigned short* vg = a.v + b * a.vs_b + kvh * a.vs_h;
+
+  // Q fragments (second MFMA operand: column = query, 8 d-values per half and k-step), kept for the whole key sweep
+  u32x4 qf[KS];
+  {
+    const unsigned short* qp = a.q + b * a.qs_b + head * a.qs_h + static_cast<long long>(min(qi, L - 1)) * a.qs_l + h * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qp + ks * 16);
+  }
+  f32x16 o[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) o[i] = f32x16{0};
+  // running maximum in RAW score units (the scale is folded into the exponent's fma), partial sum of this lane's 32 keys/tile
+  float m_run = -INFINITY, l_run = 0.f;
+  const float c = a.scale_log2;
+
+  // keys this workgroup needs: 0 .. offset + (last query of the block), at most S
+  const int kmax = min(S, a.offset + min(qb + 128, L));
+  const int ntiles = (kmax + KT - 1) / KT;
+  u32x4 kr[PPT], vr[PPT];
+  auto load_tile = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int p = tid + 256 * i, key = min(t * KT + p / (HD / 8), S - 1), cc = p % (HD / 8);
+      kr[i] = *reinterpret_cast<const u32x4*>(kg + static_cast<long long>(key) * HD + cc * 8);
+      vr[i] = *reinterpret_cast<const u32x4*>(vg + static_cast<long long>(key) * HD + cc * 8);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int p = tid + 256 * i, key = p / (HD / 8), cc = p % (HD / 8);
+      *reinterpret_cast<u32x4*>(kl + key * KROW + cc * 16) = kr[i];
+      *reinterpret_cast<u32x4*>(vl + key * VROW + cc * 16) = vr[i];
+    }
+  };
+  // transposed-read base of this lane: row 4h + q, columns 16 * (second 16-lane group of the half) + 4p
+  const unsigned char* vbase = vl + (4 * h + ((lane >> 2) & 3)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  const unsigned char* kbase = kl + r * KROW + h * 16;
+
+  if (ntiles > 0) load_tile(0);
+  for (int t = 0; t < ntiles; ++t) {
+    __syncthreads();                                                      // the previous tile's fragment reads are done
+    store_tile();
+    __syncthreads();
+    if (t + 1 < ntiles) load_tile(t + 1);                                 // in flight under this tile's MFMAs
+
+    // ---- S^T = K Q^T for the two 32-key sub-tiles
+    f32x16 st[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      st[u] = f32x16{0};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        st[u] = mfma<BF16>(*reinterpret_cast<const u32x4*>(kbase + u * 32 * KROW + ks * 32), qf[ks], st[u]);
+    }
+    // ---- causal / length mask on the tiles that reach past some query's last key (wave-uniform test)
+    if ((t + 1) * KT - 1 > min(a.offset + qb + wave * 32, S - 1)) {
+      const int klim = min(a.offset + qi, S - 1) - t * KT - 4 * h;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st[u][e] = (u * 32 + (e & 3) + 8 * (e >> 2)) <= klim ? st[u][e] : -INFINITY;
+    }
+    float mx = st[0][0];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[u][e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));                                   // the other 32 keys of this query
+    // ---- rescale only when some query's maximum grew by more than 2^8 in exponent units (P <= 256 otherwise: exact
+    //      softmax either way, the factor cancels in the final division)
+    if (__builtin_amdgcn_ballot_w64((mx - m_run) * c > 8.f) != 0) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);    // (m_new is finite: key 0 is visible to every query)
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+    }
+    const float mc = -m_run * c;
+    float ls = 0.f;
+    u32x4 pf[2][2];                                                       // P^T operands: [sub-tile][k-step]
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float p[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { p[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[u][e], c, mc)); ls += p[e]; }
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+        pf[u][tt] = u32x4{pack2<BF16>(p[8 * tt], p[8 * tt + 1]), pack2<BF16>(p[8 * tt + 2], p[8 * tt + 3]),
+                          pack2<BF16>(p[8 * tt + 4], p[8 * tt + 5]), pack2<BF16>(p[8 * tt + 6], p[8 * tt + 7])};
+    }
+    l_run += ls;
+    // ---- O^T += V^T P^T; the V^T operand (row d, 8 keys) comes out of the row-major V tile through transposed reads:
+    //      keys 32u + 16tt + 4h + {0..3} and the same + 8
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const u32x2 v0 = lds_read_tr(vbase + (u * 32 + tt * 16) * VROW + dt * 64);
+          const u32x2 v1 = lds_read_tr(vbase + (u * 32 + tt * 16 + 8) * VROW + dt * 64);
+          o[dt] = mfma<BF16>(u32x4{v0.x, v0.y, v1.x, v1.y}, pf[u][tt], o[dt]);
+        }
+  }
+
+  // ---- normalise and store: lane (q, h) holds d = 32 dt + (e & 3) + 8 (e >> 2) + 4 h of its query
+  const float lt = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.f / lt;
+  if (qi < L) {
+    unsigned short* op = a.out + (static_cast<long long>(b) * L + qi) * (a.Hq * HD) + head * HD;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = dt * 32 + 8 * g + 4 * h;
+        *reinterpret_cast<u32x2*>(op + d) = u32x2{pack2<BF16>(o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv),
+                                                pack2<BF16>(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv)};
+      }
+  }
+}
+
+}  // namespace
+
+hipError_t launch_attn_prefill(const void* q, const void* k, const void* v, void* out, int B, int Hq, int Hkv, int L, int S, int D,
+                               long long qs_b, long long qs_h, long long qs_l, long long ks_b, long long ks_h, long long vs_b,
+                               long long vs_h, int offset, float sm_scale, bool bf16, hipStream_t s) {
+  PrefillAttnArgs a{static_cast<const unsigned short*>(q), static_cast<const unsigned short*>(k), static_cast<const unsigned short*>(v),
+                    static_cast<unsigned short*>(out), qs_b, qs_h, qs_l, ks_b, ks_h, vs_b, vs_h, B, Hq, Hkv, L, S, offset,
+                    sm_scale * 1.4426950408889634f};
+  dim3 grid((L + 127) / 128, Hq, B), block(256);
+  if (D == 128) {
+    if (bf16) hipLaunchKernelGGL((attn_prefill_kernel<true, 128>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((attn_prefill_kernel<false, 128>), grid, block, 0, s, a);
+  } else if (D == 64) {
+    if (bf16) hipLaunchKernelGGL((attn_prefill_kernel<true, 64>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((attn_prefill_kernel<false, 64>), grid, block, 0, s, a);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace gbx

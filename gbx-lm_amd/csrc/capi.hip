@@ -611,6 +611,28 @@ int gbx_attn_cached(const void* q, const void* kcache, const void* vcache, const
   return GBX_OK;
 }
 
+int gbx_attn_prefill(const void* q, const void* k, const void* v, void* out, int32_t batch, int32_t n_heads, int32_t n_kv_heads,
+                     int32_t L, int32_t S, int32_t head_dim, int64_t q_stride_b, int64_t q_stride_h, int64_t q_stride_l,
+                     int64_t k_stride_b, int64_t k_stride_h, int64_t v_stride_b, int64_t v_stride_h, int32_t offset, float sm_scale,
+                     int32_t act_dtype, void* hip_stream) {
+  if (batch == 0 || L == 0) return GBX_OK;
+  if (!q || !k || !v || !out) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (batch < 0 || batch > 65535) return fail(GBX_ERR_INVALID, "batch must be in [0, 65535] (got %d)", batch);
+  if (head_dim != 64 && head_dim != 128) return fail(GBX_ERR_UNSUPPORTED, "head_dim must be 64 or 128 (got %d)", head_dim);
+  if (n_heads <= 0 || n_heads > 65535 || n_kv_heads <= 0 || n_heads % n_kv_heads)
+    return fail(GBX_ERR_INVALID, "n_heads must be a multiple of n_kv_heads");
+  if (L < 0 || offset < 0 || S < offset + L) return fail(GBX_ERR_INVALID, "need S >= offset + L (L %d, S %d, offset %d)", L, S, offset);
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  if (!aligned(q, 16) || !aligned(k, 16) || !aligned(v, 16) || !aligned(out, 8)) return fail(GBX_ERR_INVALID, "q / k / v must be 16-byte aligned");
+  if ((q_stride_b | q_stride_h | q_stride_l | k_stride_b | k_stride_h | v_stride_b | v_stride_h) & 7)
+    return fail(GBX_ERR_INVALID, "strides must be multiples of 8 elements");
+  hipError_t e = gbx::launch_attn_prefill(q, k, v, out, batch, n_heads, n_kv_heads, L, S, head_dim, q_stride_b, q_stride_h, q_stride_l,
+                                          k_stride_b, k_stride_h, v_stride_b, v_stride_h, offset, sm_scale, act_dtype == GBX_BF16,
+                                          static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_attn_prefill launch");
+  return GBX_OK;
+}
+
 int gbx_moe_route(const void* logits, int32_t* indices, void* scores, int64_t tokens, int32_t num_experts, int32_t top_k,
                   int32_t mode, int32_t renormalize, int32_t act_dtype, void* hip_stream) {
   if (tokens == 0) return GBX_OK;

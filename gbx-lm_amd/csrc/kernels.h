@@ -25,6 +25,10 @@ size_t qgemm_batch_workspace_bytes(int M, int N, int K, int bits, int log2g);
 bool gemm_dense_supported(int M, int N, int K);
 hipError_t launch_gemm_dense(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, bool bf16, hipStream_t s);
 constexpr int GBX_DENSE_MIN_M = 4096;
+// attn_prefill.hip: causal attention of L query rows at positions offset .. offset + L - 1 against S keys (strides in elements)
+hipError_t launch_attn_prefill(const void* q, const void* k, const void* v, void* out, int B, int Hq, int Hkv, int L, int S, int D,
+                               long long qs_b, long long qs_h, long long qs_l, long long ks_b, long long ks_h, long long vs_b,
+                               long long vs_h, int offset, float sm_scale, bool bf16, hipStream_t s);
 hipError_t launch_qgemm_dense(const void* x, const uint32_t* qw, const void* sc, const void* ze, const void* bias, void* y, int M,
                               int N, int K, int bits, int log2g, bool bf16, hipStream_t s, void* wdense);
 size_t qgemm_prefill_workspace_bytes(int M, int N, int K);

@@ -44,8 +44,10 @@ def create_attention_mask(h: torch.Tensor, cache: Optional[Any] = None) -> Optio
                 window_size = c.max_size
             else:
                 offset = c.offset
-        mask = create_causal_mask(T, offset, window_size=window_size, device=h.device)
-        return mask.to(h.dtype)
+        mask = create_causal_mask(T, offset, window_size=window_size, device=h.device).to(h.dtype)
+        if window_size is None:             # plain causal: the HIP prefill attention rebuilds it from the offset alone
+            mask._gbx_causal_offset = offset
+        return mask
     return None
 
 
@@ -106,6 +108,12 @@ def scaled_dot_product_attention(queries, keys, values, cache, scale: float, mas
         cap = keys.shape[2]
         live = torch.arange(cap, device=keys.device)[None, None, None, :] <= cache.static_pos
         mask = torch.where(live, 0.0, float("-inf")).to(queries.dtype)
+    off = getattr(mask, "_gbx_causal_offset", None)
+    if off is not None and queries.shape[2] > 1 and keys.shape[2] == off + queries.shape[2]:
+        from .. import ops                         # one launch on the matrix cores, no mask tensor, no repeated K / V heads
+        if ops.attn_prefill_supported(queries, keys, values):
+            b, hq, l, d = queries.shape
+            return ops.attn_prefill(queries, keys, values, off, scale).view(b, l, hq, d).permute(0, 2, 1, 3)
     n_q, n_kv = queries.shape[1], keys.shape[1]
     if n_q != n_kv:
         rep = n_q // n_kv

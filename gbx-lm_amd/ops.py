@@ -483,6 +483,27 @@ def attn_cached(q: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, pos
     return out
 
 
+def attn_prefill_supported(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> bool:
+    """shapes / layouts gbx_attn_prefill takes without a copy: head_dim 64 / 128 contiguous, key rows head_dim apart"""
+    d = q.shape[3]
+    return (q.is_cuda and q.dtype in (torch.bfloat16, torch.float16) and k.dtype == q.dtype and v.dtype == q.dtype and d in (64, 128)
+            and k.shape[3] == d and v.shape[3] == d and q.shape[1] % k.shape[1] == 0 and k.shape[1] == v.shape[1]
+            and q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1 and k.stride(2) == d and v.stride(2) == d
+            and all(t.stride(i) % 8 == 0 for t in (q, k, v) for i in (0, 1, 2)) and all(t.data_ptr() % 16 == 0 for t in (q, k, v)))
+
+
+def attn_prefill(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, offset: int, scale: float) -> torch.Tensor:
+    """Causal attention of a prompt chunk (gbx_attn_prefill): q [B, Hq, L, D] at positions offset .. offset + L - 1, k / v
+    [B, Hkv, S, D] with S >= offset + L (any batch / head strides) -> context [B, L, Hq * D] (what o_proj consumes)."""
+    _require_cuda(q, "q")
+    b, hq, l, d = q.shape
+    out = torch.empty((b, l, hq * d), dtype=q.dtype, device=q.device)
+    _lib.check(_lib.lib().gbx_attn_prefill(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), b, hq, k.shape[1], l, k.shape[2], d,
+                                           q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+                                           int(offset), float(scale), _DT[q.dtype], _stream_ptr(q.device)))
+    return out
+
+
 def moe_route(logits: torch.Tensor, top_k: int, mode: int = 0, renormalize: bool = True):
     """Router logits [..., E] -> (indices int32 [..., k], scores [..., k]) in one launch (gbx_moe_route)."""
     _require_cuda(logits, "logits")

@@ -285,6 +285,18 @@ int gbx_attn_cached(const void* q, const void* kcache, const void* vcache, const
                     int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int32_t capacity, float sm_scale, int32_t act_dtype,
                     void* hip_stream);
 
+/* Causal attention of a prompt chunk: L query rows (positions offset .. offset + L - 1) of every head against the S >= offset + L
+ * cached keys; query i sees keys 0 .. offset + i.  out[b, i, h, :] = softmax(q[b, h, i, :] . K[b, kv(h), :, :]^T * sm_scale + mask) V,
+ * written as [batch, L, n_heads * head_dim] (the layout o_proj consumes).  q / k / v are addressed through element strides
+ * (head_dim contiguous, key rows head_dim apart): q[b, h, i] at q + b * q_stride_b + h * q_stride_h + i * q_stride_l,
+ * K[b, g, j] at k + b * k_stride_b + g * k_stride_h + j * head_dim, V likewise.  Replaces the L > 1 call of
+ * mx.fast.scaled_dot_product_attention with the mask of create_causal_mask (gbx_lm/models/base.py:27-62, :101-122); grouped-query
+ * heads read the shared K / V head.  head_dim 64 or 128; no sliding window. */
+int gbx_attn_prefill(const void* q, const void* k, const void* v, void* out, int32_t batch, int32_t n_heads, int32_t n_kv_heads,
+                     int32_t L, int32_t S, int32_t head_dim, int64_t q_stride_b, int64_t q_stride_h, int64_t q_stride_l,
+                     int64_t k_stride_b, int64_t k_stride_h, int64_t v_stride_b, int64_t v_stride_h, int32_t offset, float sm_scale,
+                     int32_t act_dtype, void* hip_stream);
+
 /* Expert routing of `tokens` rows of router logits[tokens, num_experts] on the device: indices[tokens, top_k] (int32, best
  * first, ties to the lowest expert) and mixing weights scores[tokens, top_k] in the activation dtype.
  * mode 0: softmax over all experts (fp32, rounded), top_k largest, divided by their sum if `renormalize`
