@@ -284,7 +284,7 @@ def prefill_leg(model, cfg, dev, B=8, T=4096):
     tg = e0.elapsed_time(e1)
     return {"tok_s": B * T / ms * 1e3, "ms": ms, "batch": B, "seq_len": T, "qlinear_ms": tg, "qlinear_flops": flops,
             "qlinear_TFLOPs": flops / tg / 1e9, "frac_of_2500_TFLOPs_dense_bf16": flops / tg / 1e9 / 2500.0,
-            "note": "whole forward incl. torch SDPA and glue; qlinear_* = the 224 dequant-GEMMs alone at M = B*2048 rows"}
+            "note": "whole forward incl. gbx_attn_prefill (HIP causal attention) and glue (RoPE, norms, cache writes); qlinear_* = the 224 dequant-GEMMs alone at M = B*2048 rows"}
 
 
 def main():
