@@ -328,6 +328,37 @@ int gbx_qlinear_swiglu_forward(const void* x, const uint32_t* gate_qweight, cons
   return GBX_OK;
 }
 
+size_t gbx_qlinear_swiglu_workspace_bytes(int64_t M, int32_t N, int32_t K) {
+  if (M < gbx::GBX_DENSE_MIN_M || N <= 0 || K <= 0 || (N % 128) || !gbx::gemm_dense_supported(static_cast<int>(std::min<int64_t>(M, 61440)), 2 * N, K)) return 0;
+  return static_cast<size_t>(2) * N * K * 2;
+}
+
+int gbx_qlinear_swiglu_forward_ws(const void* x, const uint32_t* gate_qweight, const void* gate_scales, const void* gate_zeros,
+                                  const uint32_t* up_qweight, const void* up_scales, const void* up_zeros, void* y, int64_t M,
+                                  int32_t N, int32_t K, int32_t bits, int32_t group_size, int32_t act_dtype, void* workspace,
+                                  size_t workspace_bytes, void* hip_stream) {
+  const size_t need = gbx_qlinear_swiglu_workspace_bytes(M, N, K);
+  if (need == 0 || !workspace || workspace_bytes < need)       // decode-sized batches (and callers without scratch): the one-launch batch kernel
+    return gbx_qlinear_swiglu_forward(x, gate_qweight, gate_scales, gate_zeros, up_qweight, up_scales, up_zeros, y, M, N, K, bits, group_size,
+                                      act_dtype, hip_stream);
+  int rc = check_shape(M, N, K, bits, group_size);
+  if (rc) return rc;
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  if (!x || !gate_qweight || !gate_scales || !gate_zeros || !up_qweight || !up_scales || !up_zeros || !y) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (!aligned(x, 16) || !aligned(gate_qweight, 16) || !aligned(up_qweight, 16) || !aligned(workspace, 16) || !aligned(y, 16))
+    return fail(GBX_ERR_INVALID, "x, qweight, y and workspace must be 16-byte aligned");
+  const size_t esz = 2;
+  for (int64_t m0 = 0; m0 < M; m0 += 61440) {                  // 32-bit byte offsets inside the kernel: rows in slabs
+    const int mm = static_cast<int>(std::min<int64_t>(M - m0, 61440));
+    hipError_t e = gbx::launch_qgemm_dense_swiglu(static_cast<const char*>(x) + m0 * K * esz, gate_qweight, gate_scales, gate_zeros, up_qweight,
+                                                  up_scales, up_zeros, static_cast<char*>(y) + m0 * N * esz, mm, N, K, bits,
+                                                  log2_group(group_size), act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream), workspace);
+    if (e == hipErrorInvalidValue) return fail(GBX_ERR_UNSUPPORTED, "dense SwiGLU GEMM: shape outside the kernel (N %d, K %d)", N, K);
+    if (e != hipSuccess) return hip_fail(e, "gbx_qlinear_swiglu_forward_ws launch");
+  }
+  return GBX_OK;
+}
+
 int gbx_gather_qlinear_forward(const void* x, const uint32_t* qweight, const void* scales, const void* zeros,
                                const void* bias, const int32_t* indices, void* y, int32_t pairs, int32_t x_div,
                                int32_t num_experts, int32_t N, int32_t K, int32_t bits, int32_t group_size,

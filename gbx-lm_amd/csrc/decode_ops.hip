@@ -1122,6 +1122,17 @@ hipError_t launch_rmsnorm(const void* x, const void* w, void* y, int M, int K, f
 // (2i, 2i+1), else (i, i + dims/2); input scaled by `mscale` first (su / YaRN); fp32 math, one rounding.  The offset is
 // an immediate or, for graph-replayed decode, read from device memory.  Features past `dims` are copied.  x is a
 // strided [B, H, L, D] view (element strides sb, sh, sl; unit feature stride), y is contiguous and must not alias x.
+// one rotation, the SAME instruction sequence in both kernels below (a contraction picked by the compiler per call site would
+// round differently)
+// ... and the same sincosf body (not inlined: two inlined copies were scheduled / contracted differently and disagreed by one
+// fp32 ulp on rare angles)
+__device__ __noinline__ void rope_sincos(float ang, float* sn, float* cs) { sincosf(ang, sn, cs); }
+
+__device__ __forceinline__ void rope_rot(float x1, float x2, float sn, float cs, float& o1, float& o2) {
+  o1 = __fmaf_rn(x1, cs, -__fmul_rn(x2, sn));
+  o2 = __fmaf_rn(x1, sn, __fmul_rn(x2, cs));
+}
+
 template <bool BF16>
 __global__ __launch_bounds__(256) void rope_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
                                                    const float* __restrict__ inv_freq, const long long* __restrict__ posp,
@@ -1141,9 +1152,11 @@ __global__ __launch_bounds__(256) void rope_kernel(const unsigned short* __restr
     const float x1 = act_to_f32<BF16>(xr[i1]) * mscale, x2 = act_to_f32<BF16>(xr[i2]) * mscale;
     const float ang = static_cast<float>(base + t) * scale * inv_freq[i];
     float sn, cs;
-    sincosf(ang, &sn, &cs);
-    y[row * D + i1] = f32_to_act<BF16>(x1 * cs - x2 * sn);
-    y[row * D + i2] = f32_to_act<BF16>(x1 * sn + x2 * cs);
+    rope_sincos(ang, &sn, &cs);
+    float o1, o2;
+    rope_rot(x1, x2, sn, cs, o1, o2);
+    y[row * D + i1] = f32_to_act<BF16>(o1);
+    y[row * D + i2] = f32_to_act<BF16>(o2);
   }
   if (dims < D) {
     const int tail = D - dims;
@@ -1156,9 +1169,81 @@ __global__ __launch_bounds__(256) void rope_kernel(const unsigned short* __restr
   }
 }
 
+// Prompt-sized calls (many rows of one position share the angles): one workgroup per token (b, t); the dims / 2 (sin, cos)
+// pairs of the position are computed ONCE (64 threads, same sincosf as above) and applied to all H heads with 16-byte loads and
+// stores -- the generic kernel above computes them per (head, pair) with 2-byte accesses (100 us for a 2048 x 8 x 32 x 128
+// chunk, 2.7 TB/s).  dims == D, D % 16 == 0 (non-traditional: 8-element chunk c pairs with chunk c + D / 16), D <= 256.
+template <bool BF16>
+__global__ __launch_bounds__(256) void rope_tokens_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
+                                                          const float* __restrict__ inv_freq, const long long* __restrict__ posp,
+                                                          long long offset, int H, int L, int D, long long sb, long long sh,
+                                                          long long sl, float scale, float mscale, int traditional) {
+  __shared__ float sn_s[128], cs_s[128];
+  const int t = blockIdx.x, b = blockIdx.y, half = D / 2;
+  const long long base = posp ? *posp : offset;
+  if (threadIdx.x < half) {
+    const float ang = static_cast<float>(base + t) * scale * inv_freq[threadIdx.x];
+    float sn, cs;
+    rope_sincos(ang, &sn, &cs);
+    sn_s[threadIdx.x] = sn;
+    cs_s[threadIdx.x] = cs;
+  }
+  __syncthreads();
+  const int cph = D / 16;                                 // chunk pairs per head
+  for (int w = threadIdx.x; w < H * cph; w += 256) {
+    const int h = w / cph, c = w % cph;
+    const unsigned short* xr = x + b * sb + h * sh + t * sl;
+    unsigned short* yr = y + ((static_cast<long long>(b) * H + h) * L + t) * D;
+    if (traditional) {                                    // pairs (2i, 2i+1): both 16-byte chunks of this work item are self-contained
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int e0 = (2 * c + q) * 8;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(xr + e0);
+        const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+        unsigned o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = e0 / 2 + j;
+          const float x1 = act_lo<BF16>(wv[j]) * mscale, x2 = act_hi<BF16>(wv[j]) * mscale;
+          float o1, o2;
+          rope_rot(x1, x2, sn_s[i], cs_s[i], o1, o2);
+          o[j] = static_cast<unsigned>(f32_to_act<BF16>(o1)) | (static_cast<unsigned>(f32_to_act<BF16>(o2)) << 16);
+        }
+        *reinterpret_cast<u32x4*>(yr + e0) = u32x4{o[0], o[1], o[2], o[3]};
+      }
+    } else {
+      const u32x4 va = *reinterpret_cast<const u32x4*>(xr + c * 8), vb = *reinterpret_cast<const u32x4*>(xr + half + c * 8);
+      const unsigned wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+      unsigned oa[4], ob[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = c * 8 + 2 * j;
+        const float a0 = act_lo<BF16>(wa[j]) * mscale, a1 = act_hi<BF16>(wa[j]) * mscale;
+        const float b0 = act_lo<BF16>(wb[j]) * mscale, b1 = act_hi<BF16>(wb[j]) * mscale;
+        float p0, q0, p1, q1;
+        rope_rot(a0, b0, sn_s[i], cs_s[i], p0, q0);
+        rope_rot(a1, b1, sn_s[i + 1], cs_s[i + 1], p1, q1);
+        oa[j] = static_cast<unsigned>(f32_to_act<BF16>(p0)) | (static_cast<unsigned>(f32_to_act<BF16>(p1)) << 16);
+        ob[j] = static_cast<unsigned>(f32_to_act<BF16>(q0)) | (static_cast<unsigned>(f32_to_act<BF16>(q1)) << 16);
+      }
+      *reinterpret_cast<u32x4*>(yr + c * 8) = u32x4{oa[0], oa[1], oa[2], oa[3]};
+      *reinterpret_cast<u32x4*>(yr + half + c * 8) = u32x4{ob[0], ob[1], ob[2], ob[3]};
+    }
+  }
+}
+
 hipError_t launch_rope(const void* x, void* y, const float* inv_freq, const long long* posp, long long offset, long long B,
                        int H, int L, int D, int dims, long long sb, long long sh, long long sl, float scale, float mscale,
                        int traditional, bool bf16, hipStream_t s) {
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (L >= 16 && dims == D && D % 16 == 0 && D <= 256 && B <= 65535 && al16(x) && al16(y) && sb % 8 == 0 && sh % 8 == 0 && sl % 8 == 0) {
+    dim3 grid(L, static_cast<unsigned>(B));
+    auto X = static_cast<const unsigned short*>(x);
+    auto Y = static_cast<unsigned short*>(y);
+    if (bf16) hipLaunchKernelGGL((rope_tokens_kernel<true>), grid, dim3(256), 0, s, X, Y, inv_freq, posp, offset, H, L, D, sb, sh, sl, scale, mscale, traditional);
+    else hipLaunchKernelGGL((rope_tokens_kernel<false>), grid, dim3(256), 0, s, X, Y, inv_freq, posp, offset, H, L, D, sb, sh, sl, scale, mscale, traditional);
+    return hipGetLastError();
+  }
   const long long nrows = B * H * L, total = nrows * (dims / 2);
   const unsigned blocks = static_cast<unsigned>(std::min<long long>((total + 255) / 256, 16384));
   auto X = static_cast<const unsigned short*>(x);

@@ -15,7 +15,7 @@ hipError_t launch_unpack(const uint32_t* qw, int32_t* q, int N, int K, int bits,
 hipError_t launch_dequant(const uint32_t* qw, const void* sc, const void* ze, void* w, int N, int K, int bits,
                           int log2g, bool sz_bf16, int out, hipStream_t s);
 hipError_t launch_dequant_units(const uint32_t* qw, const void* sc, const void* ze, void* w, int N, int K, int bits, int log2g,
-                                bool bf16, hipStream_t s);
+                                bool bf16, hipStream_t s, int blk = 0, int which = 0);
 hipError_t launch_qlinear_generic(const void* x, const uint32_t* qw, const void* sc, const void* ze, const void* bias,
                                   void* y, int M, int N, int K, int bits, int log2g, bool bf16, hipStream_t s);
 
@@ -23,7 +23,13 @@ hipError_t launch_qgemm_mfma(const void* x, const uint32_t* qw, const void* sc, 
                              int M, int N, int K, int bits, int log2g, bool bf16, hipStream_t s, float* ws = nullptr);
 size_t qgemm_batch_workspace_bytes(int M, int N, int K, int bits, int log2g);
 bool gemm_dense_supported(int M, int N, int K);
-hipError_t launch_gemm_dense(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, bool bf16, hipStream_t s);
+hipError_t launch_gemm_dense(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, bool bf16, hipStream_t s,
+                             bool swiglu = false);
+// long-prompt SwiGLU: gate and up dequantised into ONE dense matrix (blocks of 128 rows alternating), one GEMM over its 2 N rows
+// whose epilogue writes silu(gate) * up [M, N]; wdense: 2 * N * K * 2 bytes
+hipError_t launch_qgemm_dense_swiglu(const void* x, const uint32_t* gq, const void* gs, const void* gz, const uint32_t* uq, const void* us,
+                                     const void* uz, void* y, int M, int N, int K, int bits, int log2g, bool bf16, hipStream_t s,
+                                     void* wdense);
 constexpr int GBX_DENSE_MIN_M = 4096;
 // attn_prefill.hip: causal attention of L query rows at positions offset .. offset + L - 1 against S keys (strides in elements)
 hipError_t launch_attn_prefill(const void* q, const void* k, const void* v, void* out, int B, int Hq, int Hkv, int L, int S, int D,

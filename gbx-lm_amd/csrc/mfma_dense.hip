@@ -38,8 +38,9 @@ struct DenseArgs2 {
   const unsigned short* x;     // [M, K]
   const unsigned short* w;     // [N, K]
   const unsigned short* bias;  // [N] or null
-  unsigned short* y;           // [M, N]
+  unsigned short* y;           // [M, N] ([M, N / 2] with swiglu)
   int M, N, K;
+  int swiglu;                  // w rows alternate in blocks of 128: gate rows | up rows; y = silu(gate) * up
 };
 
 template <bool BF16>
@@ -194,6 +195,36 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseArgs2 a) {
       }
   }
   __builtin_amdgcn_s_waitcnt(0xC07F);                // the wave's own LDS writes (no other wave touches this region)
+  if (a.swiglu) {
+    // Tile columns 0-127 are gate rows j, columns 128-255 the up rows of the SAME j (waves wcn and wcn + 2 of one wave row):
+    // y[m, n0 / 2 + j] = round(round(silu(gate)) * up) on the already rounded GEMM outputs -- the reference's op-by-op
+    // roundings (qllama.py:115), what gbx_swiglu computes from the two tensors this epilogue never writes.
+    bar();
+    const int NO = N >> 1;
+    const unsigned char* gt = lds + (wr * 4 + (wcn & 1)) * (128 * EROW);
+    const unsigned char* ut = lds + (wr * 4 + 2 + (wcn & 1)) * (128 * EROW);
+    const int ob = (n0 >> 1) + (wcn & 1) * 64;       // output column of this wave's piece 0
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int p = it * 64 + lane, row = (wcn >> 1) * 64 + (p >> 3), c = p & 7;
+      const int m = mb + row;
+      if (m >= M) continue;
+      const u32x4 gv = *reinterpret_cast<const u32x4*>(gt + row * EROW + c * 16);
+      const u32x4 uv = *reinterpret_cast<const u32x4*>(ut + row * EROW + c * 16);
+      const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, uw[4] = {uv.x, uv.y, uv.z, uv.w};
+      unsigned o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float g0 = act_lo<BF16>(gw[j]), g1 = act_hi<BF16>(gw[j]);
+        const float s0 = act_to_f32<BF16>(f32_to_act<BF16>(g0 / (1.f + __expf(-g0))));
+        const float s1 = act_to_f32<BF16>(f32_to_act<BF16>(g1 / (1.f + __expf(-g1))));
+        o[j] = static_cast<unsigned>(f32_to_act<BF16>(s0 * act_lo<BF16>(uw[j]))) |
+               (static_cast<unsigned>(f32_to_act<BF16>(s1 * act_hi<BF16>(uw[j]))) << 16);
+      }
+      *reinterpret_cast<u32x4*>(a.y + static_cast<size_t>(m) * NO + ob + c * 8) = u32x4{o[0], o[1], o[2], o[3]};
+    }
+    return;
+  }
   const bool full_n = (nb + 64 <= N) && (N % 8 == 0);
 #pragma unroll
   for (int it = 0; it < 16; ++it) {
@@ -220,7 +251,9 @@ bool gemm_dense_supported(int M, int N, int K) {
   return K % DK == 0 && K >= DK && static_cast<long long>(M) * K * 2 < (1LL << 31) && static_cast<long long>(N) * K * 2 < (1LL << 31);
 }
 
-hipError_t launch_gemm_dense(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, bool bf16, hipStream_t s) {
+hipError_t launch_gemm_dense(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, bool bf16, hipStream_t s,
+                             bool swiglu) {
+  if (swiglu && (N % 256 || bias)) return hipErrorInvalidValue;
   static bool done = false;
   if (!done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dense_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_LDS);
@@ -230,7 +263,7 @@ hipError_t launch_gemm_dense(const void* x, const void* w, const void* bias, voi
     done = true;
   }
   DenseArgs2 a{static_cast<const unsigned short*>(x), static_cast<const unsigned short*>(w), static_cast<const unsigned short*>(bias),
-               static_cast<unsigned short*>(y), M, N, K};
+               static_cast<unsigned short*>(y), M, N, K, swiglu ? 1 : 0};
   const int tiles = ((N + DT - 1) / DT) * ((M + DT - 1) / DT);
   dim3 grid(8 * ((tiles + 7) / 8)), block(512);
   if (bf16) hipLaunchKernelGGL((gemm_dense_kernel<true>), grid, block, DENSE_LDS, s, a);

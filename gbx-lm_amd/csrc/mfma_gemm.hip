@@ -346,6 +346,17 @@ hipError_t launch_qgemm_dense(const void* x, const uint32_t* qw, const void* sc,
   return launch_prefill_bits<16>(a, bf16, s);
 }
 
+hipError_t launch_qgemm_dense_swiglu(const void* x, const uint32_t* gq, const void* gs, const void* gz, const uint32_t* uq, const void* us,
+                                     const void* uz, void* y, int M, int N, int K, int bits, int log2g, bool bf16, hipStream_t s,
+                                     void* wdense) {
+  if (N % 128 || !gemm_dense_supported(M, 2 * N, K)) return hipErrorInvalidValue;
+  hipError_t e = launch_dequant_units(gq, gs, gz, wdense, N, K, bits, log2g, bf16, s, 128, 0);
+  if (e != hipSuccess) return e;
+  e = launch_dequant_units(uq, us, uz, wdense, N, K, bits, log2g, bf16, s, 128, 1);
+  if (e != hipSuccess) return e;
+  return launch_gemm_dense(x, wdense, nullptr, y, M, 2 * N, K, bf16, s, true);
+}
+
 hipError_t launch_qgemm_mfma(const void* x, const uint32_t* qw, const void* sc, const void* ze, const void* bias, void* y,
                              int M, int N, int K, int bits, int log2g, bool bf16, hipStream_t s, float* ws) {
   MfmaArgs a{};

@@ -86,10 +86,12 @@ hipError_t launch_dequant(const uint32_t* qw, const void* sc, const void* ze, vo
 template <int BITS, bool BF16>
 __global__ __launch_bounds__(256) void dequant_units_kernel(const uint32_t* __restrict__ qw, const unsigned short* __restrict__ sc,
                                                             const unsigned short* __restrict__ ze, unsigned short* __restrict__ w,
-                                                            long long units, int upr, int log2g) {
+                                                            long long units, int upr, int log2g, int blk, int which) {
   for (long long u = blockIdx.x * 256LL + threadIdx.x; u < units; u += static_cast<long long>(gridDim.x) * 256) {
     const long long n = u / upr;
     const int ur = static_cast<int>(u - n * upr);
+    // blk > 0: two matrices interleaved in blocks of blk rows (this one is matrix `which`): gate | up of a fused SwiGLU GEMM
+    const long long no = blk ? (n / blk) * (2 * blk) + which * blk + n % blk : n;
     const uint32_t* src = qw + u * BITS;
     unsigned wv[BITS];
 #pragma unroll
@@ -109,22 +111,22 @@ __global__ __launch_bounds__(256) void dequant_units_kernel(const uint32_t* __re
       }
       o[j >> 1] = static_cast<unsigned>(h[0]) | (static_cast<unsigned>(h[1]) << 16);
     }
-    u32x4* dst = reinterpret_cast<u32x4*>(w + u * 32);
+    u32x4* dst = reinterpret_cast<u32x4*>(w + (no * upr + ur) * 32);
 #pragma unroll
     for (int i = 0; i < 4; ++i) dst[i] = u32x4{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]};
   }
 }
 
 hipError_t launch_dequant_units(const uint32_t* qw, const void* sc, const void* ze, void* w, int N, int K, int bits, int log2g,
-                                bool bf16, hipStream_t s) {
+                                bool bf16, hipStream_t s, int blk, int which) {
   const long long units = static_cast<long long>(N) * (K / 32);
   const int blocks = static_cast<int>(std::min<long long>((units + 255) / 256, 16384));
   auto S = static_cast<const unsigned short*>(sc);
   auto Z = static_cast<const unsigned short*>(ze);
   auto Wd = static_cast<unsigned short*>(w);
 #define GBX_DU(B)                                                                                                        \
-  if (bf16) hipLaunchKernelGGL((dequant_units_kernel<B, true>), dim3(blocks), dim3(256), 0, s, qw, S, Z, Wd, units, K / 32, log2g); \
-  else hipLaunchKernelGGL((dequant_units_kernel<B, false>), dim3(blocks), dim3(256), 0, s, qw, S, Z, Wd, units, K / 32, log2g);
+  if (bf16) hipLaunchKernelGGL((dequant_units_kernel<B, true>), dim3(blocks), dim3(256), 0, s, qw, S, Z, Wd, units, K / 32, log2g, blk, which); \
+  else hipLaunchKernelGGL((dequant_units_kernel<B, false>), dim3(blocks), dim3(256), 0, s, qw, S, Z, Wd, units, K / 32, log2g, blk, which);
   switch (bits) {
     case 2: GBX_DU(2) break;
     case 3: GBX_DU(3) break;

@@ -129,7 +129,13 @@ class MLP(nn.Module):
         self.tp_world, self.tp_group = 1, None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        out = self.down_proj(swiglu(self.gate_proj(x), self.up_proj(x)))
+        act = None
+        if x.is_cuda and x.numel() // x.shape[-1] >= 4096 and type(self.gate_proj) is QuantizedLinear and type(self.up_proj) is QuantizedLinear:
+            from .. import ops                       # long prompt: both projections and the SwiGLU as one dense matrix-core GEMM
+            act = ops.quantized_swiglu(x, self.gate_proj, self.up_proj)
+        if act is None:
+            act = swiglu(self.gate_proj(x), self.up_proj(x))
+        out = self.down_proj(act)
         if self.tp_world > 1:
             from ..tp import all_reduce_
             all_reduce_(out, self.tp_group)
@@ -171,9 +177,33 @@ class LlamaModel(nn.Module):
         if mask is None:
             mask = create_attention_mask(h, cache)
         caches = cache if cache is not None else [None] * len(self.layers)
+        if self._fused_residuals(h):
+            return self._forward_fused_residuals(h, mask, caches)
         for block, c in zip(self.layers, caches):
             h = block(h, mask, cache=c)
         return self.norm(h)
+
+    def _fused_residuals(self, h: torch.Tensor) -> bool:
+        """prompt-sized CUDA calls of the plain Llama block: every residual add runs inside the following RMSNorm launch"""
+        return (h.is_cuda and h.shape[1] > 1 and h.dtype in (torch.bfloat16, torch.float16) and h.shape[-1] % 8 == 0
+                and h.shape[-1] <= 8192 and self.norm.weight.dtype == h.dtype and len(self.layers) > 0
+                and all(type(b) is TransformerBlock for b in self.layers))
+
+    def _forward_fused_residuals(self, h, mask, caches):
+        """Same graph as the loop above (TransformerBlock.forward: h = x + attn(norm(x)); out = h + mlp(norm(h))) with each
+        ``a + b`` folded into the norm that consumes it (gbx_add_rmsnorm: the add rounded to the activation dtype in place, then
+        the norm -- the op-by-op roundings), 2 launches per block instead of 4."""
+        from .. import ops
+        resid = h.contiguous()                      # the embedding output: owned here, updated in place
+        delta = None
+        for block, c in zip(self.layers, caches):
+            ln = block.input_layernorm
+            n = ln(resid) if delta is None else ops.add_rmsnorm(resid, delta, ln.weight, ln.eps)
+            r = block.self_attn(n, mask, c)
+            ln = block.post_attention_layernorm
+            n = ops.add_rmsnorm(resid, r.contiguous(), ln.weight, ln.eps)
+            delta = block.mlp(n).contiguous()
+        return ops.add_rmsnorm(resid, delta, self.norm.weight, self.norm.eps)
 
 
 class Model(nn.Module):

@@ -266,11 +266,25 @@ def gather_swiglu(x: torch.Tensor, gate, up, rhs_indices: torch.Tensor):
 
 def quantized_swiglu(x: torch.Tensor, gate, up) -> Optional[torch.Tensor]:
     """``silu(gate_proj(x)) * up_proj(x)`` for a decode-sized batch (2..64 rows) in ONE launch (gbx_qlinear_swiglu_forward:
-    the no-dequant matrix-core GEMM with the SwiGLU in its epilogue).  Returns None when the shapes are outside that launch
-    (the caller then runs the three ops)."""
+    the no-dequant matrix-core GEMM with the SwiGLU in its epilogue) or for a long prompt (>= 4096 rows:
+    gbx_qlinear_swiglu_forward_ws).  Returns None when the shapes are outside both (the caller then runs the three ops)."""
     k, n = gate.input_dims, gate.output_dims
     x2 = x.reshape(-1, k)
     m = x2.shape[0]
+    same = ((gate.bits, gate.group_size, gate.input_dims, gate.output_dims) == (up.bits, up.group_size, up.input_dims, up.output_dims)
+            and gate.bias is None and up.bias is None and gate.scales is not None and up.scales is not None)
+    if x.is_cuda and x.dtype in _DT and m >= 4096 and same and gate.scales.dtype == x.dtype and up.scales.dtype == x.dtype:
+        # long prompt: gate | up dequantised once into one dense matrix, one matrix-core GEMM with the SwiGLU in its epilogue
+        need = _lib.lib().gbx_qlinear_swiglu_workspace_bytes(m, n, k)
+        if need:
+            x2 = x2.contiguous()
+            ws = torch.empty((need,), dtype=torch.uint8, device=x.device)
+            y = torch.empty((m, n), dtype=x.dtype, device=x.device)
+            _lib.check(_lib.lib().gbx_qlinear_swiglu_forward_ws(
+                x2.data_ptr(), gate.qweight.data_ptr(), gate.scales.data_ptr(), gate.zeros.data_ptr(), up.qweight.data_ptr(),
+                up.scales.data_ptr(), up.zeros.data_ptr(), y.data_ptr(), m, n, k, gate.bits, gate.group_size, _DT[x.dtype], ws.data_ptr(),
+                need, _stream_ptr(x.device)))
+            return y.reshape(*x.shape[:-1], n)
     if not (x.is_cuda and x.dtype in _DT and 2 <= m <= 64 and k % 1024 == 0 and n % 16 == 0 and gate.bias is None and up.bias is None
             and (gate.bits, gate.group_size, gate.input_dims, gate.output_dims) == (up.bits, up.group_size, up.input_dims, up.output_dims)
             and (gate.group_size == 128 or gate.bits == 2) and gate.scales.dtype == x.dtype and up.scales.dtype == x.dtype):

@@ -152,6 +152,16 @@ int gbx_qlinear_swiglu_forward(const void* x, const uint32_t* gate_qweight, cons
                                const uint32_t* up_qweight, const void* up_scales, const void* up_zeros, void* y, int64_t M,
                                int32_t N, int32_t K, int32_t bits, int32_t group_size, int32_t act_dtype, void* hip_stream);
 
+/* The same op with caller scratch for long prompts: M >= 4096 rows and a workspace of gbx_qlinear_swiglu_workspace_bytes
+ * (2 * N * K * 2 bytes; 0 = this shape has no scratch path) dequantise gate and up ONCE into one dense matrix and run one
+ * matrix-core GEMM whose epilogue applies the SwiGLU (same roundings: each GEMM output to the activation dtype, silu rounded,
+ * product rounded); without enough scratch, or for smaller M, it forwards to gbx_qlinear_swiglu_forward. */
+size_t gbx_qlinear_swiglu_workspace_bytes(int64_t M, int32_t N, int32_t K);
+int gbx_qlinear_swiglu_forward_ws(const void* x, const uint32_t* gate_qweight, const void* gate_scales, const void* gate_zeros,
+                                  const uint32_t* up_qweight, const void* up_scales, const void* up_zeros, void* y, int64_t M,
+                                  int32_t N, int32_t K, int32_t bits, int32_t group_size, int32_t act_dtype, void* workspace,
+                                  size_t workspace_bytes, void* hip_stream);
+
 /* The k-split batched-decode GEMM without its summing launch: writes `*slices_out` fp32 partial tiles
  * workspace[s][M][N] (s < *slices_out; size from gbx_qlinear_partials_bytes) and no y.  For the long-row projection of
  * a decoder block (down_proj, 2 <= M <= 32) whose consumer -- the next block's residual add + RMSNorm -- folds the sum in

@@ -104,3 +104,18 @@ def test_model_prefill_uses_it_and_agrees_with_sdpa(monkeypatch):
     assert len(calls) == 2 * n_layers
     rms = b.pow(2).mean().sqrt().item()
     assert (a - b).abs().max().item() <= 0.05 * rms, f"max diff {(a - b).abs().max().item()} (rms {rms})"
+
+
+def test_prompt_pass_residual_adds_inside_the_norms(monkeypatch):
+    """LlamaModel's prompt-sized forward folds every residual add into the next RMSNorm launch (gbx_add_rmsnorm): same
+    roundings as the op-by-op loop, so the hidden states are identical bit for bit"""
+    from gbx_lm_amd import synthetic as S
+    from gbx_lm_amd.models import qllama
+    from gbx_lm_amd.models.cache import make_prompt_cache
+    cfg = dict(S.TINY, num_hidden_layers=3)
+    model = S.build_model(cfg, S.make_strategy("S22", 3, 64), device=torch.device(DEV), seed=3)
+    toks = torch.randint(0, cfg["vocab_size"], (2, 70), device=DEV)
+    a = model.model(toks, None, make_prompt_cache(model))
+    monkeypatch.setattr(qllama.LlamaModel, "_fused_residuals", lambda self, h: False)
+    b = model.model(toks, None, make_prompt_cache(model))
+    assert torch.equal(a, b)

@@ -603,7 +603,7 @@ def test_rope_kernel_matches_torch_fp32(traditional, dt):
     from gbx_lm_amd import ops
     from gbx_lm_amd.models.rope_utils import apply_rope
     g = torch.Generator().manual_seed(3)
-    for (B, H, L, D, dims, off, scale) in ((2, 8, 17, 128, 128, 0, 1.0), (1, 4, 1, 64, 32, 4099, 0.25), (3, 2, 5, 96, 96, 120000, 1.0)):
+    for (B, H, L, D, dims, off, scale) in ((2, 8, 17, 128, 128, 0, 1.0), (2, 6, 300, 64, 64, 2048, 1.0), (1, 4, 1, 64, 32, 4099, 0.25), (3, 2, 5, 96, 96, 120000, 1.0)):
         x = torch.randn(B, L, H, D, generator=g).to(dt)
         inv = 1.0 / (10000.0 ** (torch.arange(0, dims, 2, dtype=torch.float32) / dims))
         want = apply_rope(x.transpose(1, 2), inv, off, scale, traditional)
@@ -617,6 +617,11 @@ def test_rope_kernel_matches_torch_fp32(traditional, dt):
         assert torch.equal(got, got_dev)
         if dims < D:
             assert torch.equal(got[..., dims:].cpu(), x.transpose(1, 2)[..., dims:])
+        if L >= 16:             # prompt-sized calls run rope_tokens_kernel (angles once per position) -- against the per-pair kernel:
+            for t in (0, 7, L - 1):     # the same fp32 formula; the compiled sequences differ by an fp32 ulp on rare elements
+                a, b = got[:, :, t:t + 1].float(), ops.rope(xd[:, :, t:t + 1], inv.to(DEV), off + t, scale, traditional).float()
+                ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+                assert ((a - b).abs() <= ulp * b.abs().clamp_min(2.0 ** -14)).all() and (a != b).float().mean().item() < 2e-3
 
 
 def test_rmsnorm_short_rows():

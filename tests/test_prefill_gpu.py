@@ -153,3 +153,48 @@ def test_dense_path_close_to_fused_tiles(oracle):
                                             _lib.GBX_BF16, ws.data_ptr(), need, st))
         torch.cuda.synchronize()
         assert torch.equal(y1, y2)
+
+
+@pytest.mark.parametrize("bits,dtype,m,n", [(4, torch.bfloat16, 16384, 14336), (2, torch.float16, 4096 + 77, 1024), (3, torch.bfloat16, 4096, 256)])
+def test_dense_swiglu_epilogue(bits, dtype, m, n):
+    """gbx_qlinear_swiglu_forward_ws at M >= 4096 (gate | up dequantised into one dense matrix, SwiGLU in the GEMM epilogue)
+    == gbx_swiglu(gate GEMM, up GEMM) through the same dense path, bit for bit: every output element accumulates over k in the
+    same order whichever tile column it sits in, and the epilogue applies the same roundings to the rounded GEMM outputs"""
+    from gbx_lm_amd import _lib, ops
+    L = _lib.lib()
+    k, g = 4096, 128
+    dt = _lib.GBX_BF16 if dtype == torch.bfloat16 else _lib.GBX_F16
+    gq, gs, gz = _layer(n, k, bits, g, 11, dtype)
+    uq, us, uz = _layer(n, k, bits, g, 12, dtype)
+    x = torch.randn((m, k), device=DEV).to(dtype)
+    st = torch.cuda.current_stream().cuda_stream
+    need = L.gbx_qlinear_swiglu_workspace_bytes(m, n, k)
+    assert need == 2 * n * k * 2
+    ws = torch.empty((need,), dtype=torch.uint8, device=DEV)
+    y = torch.empty((m, n), dtype=dtype, device=DEV)
+    _lib.check(L.gbx_qlinear_swiglu_forward_ws(x.data_ptr(), gq.data_ptr(), gs.data_ptr(), gz.data_ptr(), uq.data_ptr(), us.data_ptr(),
+                                               uz.data_ptr(), y.data_ptr(), m, n, k, bits, g, dt, ws.data_ptr(), need, st))
+    outs = []
+    for (q, s, z) in ((gq, gs, gz), (uq, us, uz)):
+        o = torch.empty((m, n), dtype=dtype, device=DEV)
+        nd = L.gbx_qlinear_workspace_bytes(m, n, k, bits, g)
+        w1 = torch.empty((nd,), dtype=torch.uint8, device=DEV)
+        _lib.check(L.gbx_qlinear_forward_ws(x.data_ptr(), q.data_ptr(), s.data_ptr(), z.data_ptr(), None, o.data_ptr(), m, n, k, bits, g, dt,
+                                            w1.data_ptr(), nd, st))
+        outs.append(o)
+    ref = ops.swiglu(outs[0], outs[1])
+    torch.cuda.synchronize()
+    assert torch.isfinite(y.float()).all()
+    assert torch.equal(y, ref), f"{(y != ref).sum().item()} of {y.numel()} elements differ, max {(y.float() - ref.float()).abs().max().item()}"
+
+
+def test_mlp_long_prompt_uses_the_fused_path(monkeypatch):
+    from gbx_lm_amd import ops, synthetic as S
+    cfg = dict(S.TINY, hidden_size=1024, intermediate_size=1024, num_attention_heads=8, num_key_value_heads=2)
+    model = S.build_model(cfg, S.make_strategy("S40", cfg["num_hidden_layers"], 128), device=torch.device(DEV), seed=2)
+    mlp = model.model.layers[0].mlp
+    x = torch.randn((2, 2048, 1024), device=DEV).to(torch.bfloat16)
+    a = mlp(x)
+    monkeypatch.setattr(ops, "quantized_swiglu", lambda *a, **k: None)
+    b = mlp(x)
+    assert torch.equal(a, b)
