@@ -6,8 +6,9 @@
 // the library it displaces (torch SDPA: 250 TFLOP/s at B = 8, T = 4096 with an explicit mask tensor).
 //
 // Structure: one workgroup = 4 waves = 128 query rows of one (sequence, head); a wave owns 32 query rows.  K / V tiles of 64
-// keys go global -> registers (while the previous tile is on the matrix cores) -> LDS, both row-major; the V^T operand is
-// gathered by ds_read_b64_tr_b16 (hardware transposed read).
+// keys go global -> registers -> LDS (two buffers each, K two tiles ahead, V one), both row-major; the V^T operand is
+// gathered by ds_read_b64_tr_b16 (hardware transposed read).  One barrier per key tile; the S^T MFMAs of tile t+1 are issued
+// before the softmax of tile t, so the vector ALU and the matrix pipe of a wave overlap.
 // Both products are computed "swapped" so that a lane owns ONE query and the softmax is lane-local:
 //   S^T[key, q]  = mfma(K rows, Q rows)   -> lane (q = lane & 31) holds 16 keys per 32-key sub-tile (the other 16 in lane ^ 32)
 //   O^T[d, q]   += mfma(V^T rows, P^T)    -> the P^T operand of step t is exactly the lane's own p[8t .. 8t+7] (no shuffle),
@@ -48,9 +49,10 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillAttnA
   constexpr int KS = HD / 16;                  // k-steps of q k^T
   constexpr int DT = HD / 32;                  // 32-row tiles of O^T
   constexpr int PPT = KT * HD / 8 / 256;       // 16-byte pieces of a K (or V) tile per thread
-  __shared__ __attribute__((aligned(16))) unsigned char lds[KT * KROW + KT * VROW];
+  constexpr int KBUF = KT * KROW, VBUF = KT * VROW;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * KBUF + 2 * VBUF];   // K ping | K pong | V ping | V pong
   unsigned char* kl = lds;
-  unsigned char* vl = lds + KT * KROW;
+  unsigned char* vl = lds + 2 * KBUF;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -79,42 +81,86 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillAttnA
   const int kmax = min(S, a.offset + min(qb + 128, L));
   const int ntiles = (kmax + KT - 1) / KT;
   u32x4 kr[PPT], vr[PPT];
-  auto load_tile = [&](int t) {
+  // tiles past the sweep are requested at clamped addresses and never consumed (keeps the loop branch-free)
+  auto load_k = [&](int t) {
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
       const int p = tid + 256 * i, key = min(t * KT + p / (HD / 8), S - 1), cc = p % (HD / 8);
       kr[i] = *reinterpret_cast<const u32x4*>(kg + static_cast<long long>(key) * HD + cc * 8);
+    }
+  };
+  auto load_v = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int p = tid + 256 * i, key = min(t * KT + p / (HD / 8), S - 1), cc = p % (HD / 8);
       vr[i] = *reinterpret_cast<const u32x4*>(vg + static_cast<long long>(key) * HD + cc * 8);
     }
   };
-  auto store_tile = [&]() {
+  auto store_k = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-      const int p = tid + 256 * i, key = p / (HD / 8), cc = p % (HD / 8);
-      *reinterpret_cast<u32x4*>(kl + key * KROW + cc * 16) = kr[i];
-      *reinterpret_cast<u32x4*>(vl + key * VROW + cc * 16) = vr[i];
+      const int p = tid + 256 * i;
+      *reinterpret_cast<u32x4*>(kl + buf * KBUF + (p / (HD / 8)) * KROW + (p % (HD / 8)) * 16) = kr[i];
+    }
+  };
+  auto store_v = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int p = tid + 256 * i;
+      *reinterpret_cast<u32x4*>(vl + buf * VBUF + (p / (HD / 8)) * VROW + (p % (HD / 8)) * 16) = vr[i];
     }
   };
   // transposed-read base of this lane: row 4h + q, columns 16 * (second 16-lane group of the half) + 4p
   const unsigned char* vbase = vl + (4 * h + ((lane >> 2) & 3)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
   const unsigned char* kbase = kl + r * KROW + h * 16;
 
-  if (ntiles > 0) load_tile(0);
+  // ONE barrier per key tile: at the top of iteration t (after the barrier) tile t is in buffer t & 1 and tile t+1 is in
+  // registers (requested an iteration ago); it is parked in the other buffer -- whose readers all passed the barrier -- and
+  // tile t+2 is requested.  LDS fragment reads are issued in bulk ahead of the MFMAs that consume them (the compiler's own
+  // order was read-two / wait / multiply, every LDS latency exposed): the K fragments of the second sub-tile refill the
+  // registers of the first as its MFMAs retire, the first half of the V^T fragments is requested BEFORE the softmax.
+  if (ntiles > 0) {
+    load_k(0); load_v(0);
+    store_k(0); store_v(0);
+    load_k(1); load_v(1);
+  }
   for (int t = 0; t < ntiles; ++t) {
-    __syncthreads();                                                      // the previous tile's fragment reads are done
-    store_tile();
     __syncthreads();
-    if (t + 1 < ntiles) load_tile(t + 1);                                 // in flight under this tile's MFMAs
+    store_k((t + 1) & 1);
+    store_v((t + 1) & 1);
+    load_k(t + 2);
+    load_v(t + 2);
 
     // ---- S^T = K Q^T for the two 32-key sub-tiles
     f32x16 st[2];
+    st[0] = f32x16{0};
+    st[1] = f32x16{0};
+    const unsigned char* kb = kbase + (t & 1) * KBUF;
+    u32x4 fr[KS];                                                         // 8 fragments in flight (K, then V^T)
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      st[u] = f32x16{0};
+    for (int ks = 0; ks < KS; ++ks) fr[ks] = *reinterpret_cast<const u32x4*>(kb + ks * 32);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-        st[u] = mfma<BF16>(*reinterpret_cast<const u32x4*>(kbase + u * 32 * KROW + ks * 32), qf[ks], st[u]);
+    for (int ks = 0; ks < KS; ++ks) {
+      st[0] = mfma<BF16>(fr[ks], qf[ks], st[0]);
+      fr[ks] = *reinterpret_cast<const u32x4*>(kb + 32 * KROW + ks * 32);
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) st[1] = mfma<BF16>(fr[ks], qf[ks], st[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    // V^T fragments of d-tiles 0 .. DT/2-1 (keys 32u + 16tt + 4h + {0..3} and the same + 8): in flight under the softmax
+    const unsigned char* vb = vbase + (t & 1) * VBUF;
+    auto vfrag = [&](int dt, int j) {                                     // j = 2u + tt
+      const u32x2 v0 = lds_read_tr(vb + ((j >> 1) * 32 + (j & 1) * 16) * VROW + dt * 64);
+      const u32x2 v1 = lds_read_tr(vb + ((j >> 1) * 32 + (j & 1) * 16 + 8) * VROW + dt * 64);
+      return u32x4{v0.x, v0.y, v1.x, v1.y};
+    };
+    constexpr int NF = KS;                                                // fragments held: (DT / 2) d-tiles x 4 = 8 at HD 128
+#pragma unroll
+    for (int i = 0; i < NF; ++i) fr[i] = vfrag(i >> 2, i & 3);
+    __builtin_amdgcn_sched_barrier(0);
+
     // ---- causal / length mask on the tiles that reach past some query's last key (wave-uniform test)
     if ((t + 1) * KT - 1 > min(a.offset + qb + wave * 32, S - 1)) {
       const int klim = min(a.offset + qi, S - 1) - t * KT - 4 * h;
@@ -143,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillAttnA
     }
     const float mc = -m_run * c;
     float ls = 0.f;
-    u32x4 pf[2][2];                                                       // P^T operands: [sub-tile][k-step]
+    u32x4 pf[4];                                                          // P^T operands: index 2u + tt
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       float p[16];
@@ -151,22 +197,17 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillAttnA
       for (int e = 0; e < 16; ++e) { p[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[u][e], c, mc)); ls += p[e]; }
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
-        pf[u][tt] = u32x4{pack2<BF16>(p[8 * tt], p[8 * tt + 1]), pack2<BF16>(p[8 * tt + 2], p[8 * tt + 3]),
-                          pack2<BF16>(p[8 * tt + 4], p[8 * tt + 5]), pack2<BF16>(p[8 * tt + 6], p[8 * tt + 7])};
+        pf[2 * u + tt] = u32x4{pack2<BF16>(p[8 * tt], p[8 * tt + 1]), pack2<BF16>(p[8 * tt + 2], p[8 * tt + 3]),
+                               pack2<BF16>(p[8 * tt + 4], p[8 * tt + 5]), pack2<BF16>(p[8 * tt + 6], p[8 * tt + 7])};
     }
     l_run += ls;
-    // ---- O^T += V^T P^T; the V^T operand (row d, 8 keys) comes out of the row-major V tile through transposed reads:
-    //      keys 32u + 16tt + 4h + {0..3} and the same + 8
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- O^T += V^T P^T: the held fragments first, each slot refilled with the fragment NF positions later as it retires
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-          const u32x2 v0 = lds_read_tr(vbase + (u * 32 + tt * 16) * VROW + dt * 64);
-          const u32x2 v1 = lds_read_tr(vbase + (u * 32 + tt * 16 + 8) * VROW + dt * 64);
-          o[dt] = mfma<BF16>(u32x4{v0.x, v0.y, v1.x, v1.y}, pf[u][tt], o[dt]);
-        }
+    for (int i = 0; i < DT * 4; ++i) {
+      o[i >> 2] = mfma<BF16>(fr[i % NF], pf[i & 3], o[i >> 2]);
+      if (i + NF < DT * 4) fr[i % NF] = vfrag((i + NF) >> 2, i & 3);
+    }
   }
 
   // ---- normalise and store: lane (q, h) holds d = 32 dt + (e & 3) + 8 (e >> 2) + 4 h of its query
