@@ -15,6 +15,11 @@
 //                                            the accumulator column is the lane's query: rescaling by alpha is per lane
 // Online softmax in base 2 (scores scaled by scale * log2 e), fp32 statistics, P rounded to the activation dtype for P V
 // (as every fused attention does), one division at the end.
+// Measured variants (cfg4 shape, TFLOP/s of causal flops): V transposed by 2-byte LDS stores, 1 workgroup / CU 174; transposed
+// reads + 2 workgroups / CU 547; one barrier per tile + bulk fragment reads (this file) 590-611; forced to 1 workgroup / CU 375;
+// S^T of tile t+1 issued before the softmax of tile t 519, softmax per 32-key sub-tile with the other sub-tile's MFMAs issued
+// first 588 (a wave issues in order: a dependent MFMA chain ahead of the VALU block holds it back until the chain has ISSUED, so
+// only an instruction-level interleave would overlap them); V pitch without the bank-spreading pad 563.
 #include "mfma_common.h"
 #include "kernels.h"
 
@@ -81,20 +86,19 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillAttnA
   const int kmax = min(S, a.offset + min(qb + 128, L));
   const int ntiles = (kmax + KT - 1) / KT;
   u32x4 kr[PPT], vr[PPT];
-  // tiles past the sweep are requested at clamped addresses and never consumed (keeps the loop branch-free)
+  // K / V tiles by buffer loads: one instruction per 16 bytes, the tile offset in an SGPR, nothing recomputed per tile on the
+  // vector ALU; rows past S (last tile, and the tiles requested past the sweep) read as zeros -- masked by the key limit
+  const unsigned nrec = static_cast<unsigned>(min(static_cast<long long>(S) * HD * 2, 0xFFFFFFFFLL));
+  const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(kg), 0, nrec, 0x00020000);
+  const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(vg), 0, nrec, 0x00020000);
+  const int voff = tid * 16;                                              // piece p = tid + 256 i of a tile: byte offset 16 p
   auto load_k = [&](int t) {
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      const int p = tid + 256 * i, key = min(t * KT + p / (HD / 8), S - 1), cc = p % (HD / 8);
-      kr[i] = *reinterpret_cast<const u32x4*>(kg + static_cast<long long>(key) * HD + cc * 8);
-    }
+    for (int i = 0; i < PPT; ++i) kr[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, voff + i * 4096, t * (KT * HD * 2), 0);
   };
   auto load_v = [&](int t) {
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      const int p = tid + 256 * i, key = min(t * KT + p / (HD / 8), S - 1), cc = p % (HD / 8);
-      vr[i] = *reinterpret_cast<const u32x4*>(vg + static_cast<long long>(key) * HD + cc * 8);
-    }
+    for (int i = 0; i < PPT; ++i) vr[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, voff + i * 4096, t * (KT * HD * 2), 0);
   };
   auto store_k = [&](int buf) {
 #pragma unroll
