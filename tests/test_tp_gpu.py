@@ -12,14 +12,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, batch=1):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from gbx_lm_amd import synthetic as S, tp
-        from gbx_lm_amd.decode import FusedDecodeRunner, fused_eligible
+        from gbx_lm_amd.decode import DecodeRunner, FusedDecodeRunner, fused_eligible
         from gbx_lm_amd.models.cache import KVCache
         dev = "cuda:0"
         cfg = dict(S.TINY, num_hidden_layers=3, hidden_size=512, intermediate_size=1024, num_attention_heads=4,
@@ -32,9 +32,12 @@ def _worker(rank, world, port, out):
             caches = []
             for _ in model.model.layers:
                 c = KVCache(step=64)
-                like = torch.empty((1, at.n_kv_heads, 1, at.head_dim), dtype=torch.bfloat16, device=dev)
+                like = torch.empty((batch, at.n_kv_heads, 1, at.head_dim), dtype=torch.bfloat16, device=dev)
                 c.reserve(1, like, like)
                 caches.append(c)
+            if batch > 1:                # the B > 1 runner: batch GEMMs, batched attention, all-reduce after o_proj / the MLP
+                r = DecodeRunner(model, caches, use_graph=False)
+                return [r.step(torch.tensor([(t + 37 * b) % 512 for b in range(batch)], device=dev)).float().cpu().clone() for t in toks]
             r = FusedDecodeRunner(model, caches, use_graph=False)
             return [r.step(torch.tensor([t], device=dev)).float().cpu().clone() for t in toks]
 
@@ -57,6 +60,20 @@ def test_tp2_fused_decode_matches_unsharded():
     mgr = mp.get_context("spawn").Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    assert len(out) == world
+    for k, v in out.items():
+        assert v < 0.05, f"rank {k}: relative max |dlogit| = {v}"
+
+
+def test_tp2_batched_decode_runner_matches_unsharded():
+    """DecodeRunner (B = 4) on two tensor-parallel ranks: the `tp_world > 1` branches of decode.py (_forward: all-reduce after
+    o_proj, the sharded MLP with its own all-reduce) against the unsharded runner (k-split partial slices, fused SwiGLU GEMM)"""
+    assert torch.cuda.is_available()
+    world = 2
+    port = 29900 + (os.getpid() % 1000)
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out, 4), nprocs=world, join=True)
     assert len(out) == world
     for k, v in out.items():
         assert v < 0.05, f"rank {k}: relative max |dlogit| = {v}"
