@@ -32,6 +32,15 @@
 // the loaders' 64 (19.6 -> 23.4 us: the phase then starts late for the loaders).  What the numbers fit is a fill-rate
 // limit per CU of ~24 KB/us from L2 or HBM alike (256 CUs x 24 GB/s = the 6.2 TB/s copy ceiling of the chip): a workgroup
 // here pulls 256 KB of x + 128 KB of weights = 16 us.
+// Round 2, two more measured negatives (M = 32, 2 bits, scratch/bench_skinny32.py):
+//   * TWO steps of activations in flight per loader thread (second register set, 168 VGPRs + 15 spilled dwords):
+//     28672x4096 22.0 -> 27.4 us, 4096x14336 18.0 -> 20.5 us -- more bulk requests queued in the CU's in-order vector-memory
+//     path only delay the weight loads the compute waves wait for;
+//   * 256-row workgroups (NG = 8, KG = 1: x staged once per 256 weight rows, half the activation traffic per CU) with the k
+//     range split over two workgroups and the fp32 slices summed by the second launch: 28672x4096 21.0 -> 29.4 us (the GEMM
+//     launch alone ~25 us): with 2 steps per workgroup the ramp / drain of the staging pipeline outweighs the bytes saved.
+// In-kernel stamps of this kernel (compute waves, 4096-value rows = 4 steps): a step is ~8k cycles of which the MFMAs are
+// ~2.5k; ISSUING the next step's 6 weight loads takes 3-5k (they queue behind the loaders' 64 requests in the in-order path).
 // -DBX_STAMPS: diagnostic build with s_memtime phase stamps (scratch/stamps_batch.py).
 #include "mfma_common.h"
 #include "kernels.h"
