@@ -185,8 +185,10 @@ class LlamaModel(nn.Module):
 
     def _fused_residuals(self, h: torch.Tensor) -> bool:
         """prompt-sized CUDA calls of the plain Llama block: every residual add runs inside the following RMSNorm launch"""
+        # (rows of 512 values or fewer: the stand-alone norm is the wave-per-row kernel, whose sum of squares is ordered
+        # differently from gbx_add_rmsnorm's -- keep the op-by-op loop there so both routes stay bit-identical)
         return (h.is_cuda and h.shape[1] > 1 and h.dtype in (torch.bfloat16, torch.float16) and h.shape[-1] % 8 == 0
-                and h.shape[-1] <= 8192 and self.norm.weight.dtype == h.dtype and len(self.layers) > 0
+                and 512 < h.shape[-1] <= 8192 and self.norm.weight.dtype == h.dtype and len(self.layers) > 0
                 and all(type(b) is TransformerBlock for b in self.layers))
 
     def _forward_fused_residuals(self, h, mask, caches):

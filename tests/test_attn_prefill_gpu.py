@@ -112,9 +112,10 @@ def test_prompt_pass_residual_adds_inside_the_norms(monkeypatch):
     from gbx_lm_amd import synthetic as S
     from gbx_lm_amd.models import qllama
     from gbx_lm_amd.models.cache import make_prompt_cache
-    cfg = dict(S.TINY, num_hidden_layers=3)
+    cfg = dict(S.TINY, num_hidden_layers=3, hidden_size=1024, intermediate_size=1024, num_attention_heads=8, num_key_value_heads=2)
     model = S.build_model(cfg, S.make_strategy("S22", 3, 64), device=torch.device(DEV), seed=3)
-    toks = torch.randint(0, cfg["vocab_size"], (2, 70), device=DEV)
+    assert model.model._fused_residuals(torch.empty((2, 70, 1024), dtype=torch.bfloat16, device=DEV))
+    toks = torch.randint(0, cfg["vocab_size"], (2, 70), device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
     a = model.model(toks, None, make_prompt_cache(model))
     monkeypatch.setattr(qllama.LlamaModel, "_fused_residuals", lambda self, h: False)
     b = model.model(toks, None, make_prompt_cache(model))
