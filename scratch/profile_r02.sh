@@ -7,8 +7,6 @@ timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- 
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_b32 -- python3 $R/bench.py --batch 32 --no-cpu-baseline --no-kernel-leg --no-extra --steps 16 --warmup 2 --context 128 > $O/stats_b32.log 2>&1
 timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 $R/scratch/one_fused.py > $O/fetch.log 2>&1
 timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 $R/scratch/one_fused.py > $O/write.log 2>&1
-timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAVES --kernel-trace --output-format csv -d $O/p1 -- python3 $R/scratch/one_prefill.py 16384 4096 4096 4 > $O/p1.log 2>&1
-timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/p2 -- python3 $R/scratch/one_prefill.py 16384 4096 4096 4 > $O/p2.log 2>&1
 cd $R
 python3 profiles/summarize.py $(ls $O/stats/*/*_kernel_stats.csv | head -1) 24 > $O/kernel_stats.txt 2>&1
 python3 profiles/summarize.py $(ls $O/stats_b32/*/*_kernel_stats.csv | head -1) 24 > $O/b32_kernel_stats.txt 2>&1
@@ -21,7 +19,7 @@ for name in ("fetch","write"):
     if not f: print(name,"missing"); continue
     vals=[float(r["Counter_Value"]) for r in csv.DictReader(open(f[0])) if "gemv_kernel" in r["Kernel_Name"]]
     print(name, "gemv_kernel dispatches", len(vals), "mean", sum(vals)/max(1,len(vals)), "min", min(vals), "max", max(vals))
-for name in ("p1","p2"):
+for name in ():
     f=glob.glob(f"{O}/{name}/*/*_counter_collection.csv")
     if not f: print(name,"missing"); continue
     acc=collections.defaultdict(lambda: collections.defaultdict(list))
@@ -42,5 +40,5 @@ for name in ("p1","p2"):
             if kk: d[kk].append((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3)
         for kk,v in d.items(): print(f"{name} {kk:22s} duration_us mean {sum(v)/len(v):.1f} n {len(v)}")
 PY
-rm -rf $O/stats $O/stats_b32 $O/fetch $O/write $O/p1 $O/p2
+rm -rf $O/stats $O/stats_b32 $O/fetch $O/write
 ls -la $O
