@@ -195,6 +195,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
   }
 }
 
+// (Round 2, measured and not kept: the sweep below on the matrix cores -- S^T = mfma(K rows from the cache in operand layout,
+// Q^T), O^T += mfma(V^T by transposed LDS reads of a wave-private V tile, P^T), the REP heads as REP of the 16 columns of a
+// 16x16x32 tile, 472 GPU tests green -- B = 32: 2.60 -> 2.56 ms/step at context 128, 3.37 -> 3.32 at 1024; batch 1 at context
+// 2048: 648 -> 640 tok/s.  The kernel is a latency chain (projection loads -> RoPE -> barrier -> K / V round trip -> merge),
+// not vector-ALU work: the arithmetic it removed was not on the critical path.)
 // Batched decode variant: one workgroup per (kv head, sequence) serves all REP query heads of the group, so every cached
 // K / V row is read ONCE per group instead of once per query head (at B = 32 the per-head kernel moved 4x the cache
 // bytes: 67 MB per layer at context 128).  Same arithmetic and layout as attn_decode_kernel.
@@ -980,6 +985,9 @@ __global__ __launch_bounds__(256) void rmsnorm_vec_kernel(unsigned short* __rest
       for (int j = 0; j < 4; ++j) { const float a0 = act_lo<BF16>(hw[j]), a1 = act_hi<BF16>(hw[j]); ssq = fmaf(a0, a0, fmaf(a1, a1, ssq)); }
     }
   }
+  u32x4 wq[4];                                      // the norm weights are requested before the reduction, not after it
+#pragma unroll
+  for (int it = 0; it < 4; ++it) wq[it] = reinterpret_cast<const u32x4*>(w)[min(it * 256 + tid, n8 - 1)];
   ssq = wave_sum(ssq);
   if (lane == 63) red[wave] = ssq;
   __syncthreads();
@@ -988,7 +996,7 @@ __global__ __launch_bounds__(256) void rmsnorm_vec_kernel(unsigned short* __rest
   for (int it = 0; it < 4; ++it) {
     const int p = it * 256 + tid;
     if (p < n8) {
-      const u32x4 wv = reinterpret_cast<const u32x4*>(w)[p];
+      const u32x4 wv = wq[it];
       const unsigned hw[4] = {v[it].x, v[it].y, v[it].z, v[it].w}, ww[4] = {wv.x, wv.y, wv.z, wv.w};
       unsigned o[4];
 #pragma unroll
