@@ -320,7 +320,9 @@ def main():
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        import datetime
+        # a rank that dies must not leave the others waiting for the default 10 minutes
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=240))
 
     from gbx_lm_amd import synthetic as S, tp
     from gbx_lm_amd.decode import DecodeRunner, FusedDecodeRunner, fused_eligible
@@ -388,6 +390,12 @@ def main():
             return out
         if args.strategy != "S40":
             legs.append(("S40", s40_legs))
+
+        def cfg2_leg():                                             # BASELINE.json configs[1]: Llama-3.2-3B shapes, all 4-bit, batch 1
+            c3 = S.LLAMA32_3B
+            m3 = S.build_model(c3, S.make_strategy("S40", c3["num_hidden_layers"], 128), device=dev, seed=0)
+            return decode_leg(m3, c3, dev, 1, args.context, args.steps, args.warmup)
+        legs.append(("llama3.2-3b_S40_decode", cfg2_leg))
         for name, fn in legs:
             if time.perf_counter() - t_start > 240.0:
                 extra[name] = {"skipped": "time budget"}
