@@ -788,6 +788,22 @@ int gbx_dense_forward(const void* x, const void* w, const void* bias, void* y, i
   return GBX_OK;
 }
 
+int gbx_dense_swiglu_forward(const void* x, const void* w_gate_up, void* y, int64_t M, int32_t N, int32_t K, int32_t act_dtype,
+                             void* hip_stream) {
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  if (M < 0 || N <= 0 || K <= 0) return fail(GBX_ERR_INVALID, "bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+  if (M == 0) return GBX_OK;
+  if (!x || !w_gate_up || !y) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (!aligned(x, 16) || !aligned(w_gate_up, 16) || !aligned(y, 16)) return fail(GBX_ERR_INVALID, "x, w and y must be 16-byte aligned");
+  if ((N % 128) || M > 2147483647LL || N > (1 << 29) || !gbx::gemm_dense_supported(static_cast<int>(M), 2 * N, K))
+    return fail(GBX_ERR_UNSUPPORTED, "dense SwiGLU GEMM needs N %% 128 == 0, K %% 64 == 0 and M*K, 2*N*K < 2^30 elements (M=%lld N=%d K=%d)",
+                (long long)M, N, K);
+  hipError_t e = gbx::launch_gemm_dense(x, w_gate_up, nullptr, y, static_cast<int>(M), 2 * N, K, act_dtype == GBX_BF16,
+                                        static_cast<hipStream_t>(hip_stream), true);
+  if (e != hipSuccess) return hip_fail(e, "gbx_dense_swiglu_forward launch");
+  return GBX_OK;
+}
+
 int gbx_swiglu(const void* gate, const void* up, void* y, int64_t n, int32_t act_dtype, void* hip_stream) {
   if (n == 0) return GBX_OK;
   if (!gate || !up || !y) return fail(GBX_ERR_INVALID, "null device pointer");

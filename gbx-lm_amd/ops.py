@@ -6,6 +6,7 @@ gbx_lm/models/quantized_linear_gba.py:195-203): same argument names and meaning.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -24,6 +25,65 @@ def _require_cuda(t: torch.Tensor, name: str) -> None:
         raise RuntimeError(
             f"gbx_lm_amd: `{name}` lives on {t.device}; the GBA QuantizedLinear path runs only as HIP kernels on an "
             "MI355X (no CPU fallback).")
+
+
+class _DenseCache:
+    """Dequantised copies of packed weights that long prompts (M >= 4096 rows) left in their workspace, kept resident and reused
+    by the next long call on the same tensors -- the second chunk of a prompt, the next request -- instead of being rebuilt
+    (25 us per 4096 x 4096 matrix, 11 ms of an 8 x 4096-token prompt pass).  288 GB of HBM per GPU make the 16 GB an 8B model's
+    bf16 image takes a fair trade; ``GBX_DENSE_CACHE_GB`` bounds it (default 32, 0 disables), least recently used entries go
+    first.  An entry is valid only for the very tensor OBJECTS it was built from (weak references + their in-place version
+    counters), so reloaded, re-created or modified weights never see a stale image."""
+
+    def __init__(self):
+        import collections
+        self.budget = int(float(os.environ.get("GBX_DENSE_CACHE_GB", "32")) * (1 << 30))
+        self.entries = collections.OrderedDict()
+        self.nbytes = 0
+
+    @staticmethod
+    def _key(tensors, extra):
+        return tuple(id(t) for t in tensors) + tuple(extra)
+
+    def get(self, tensors, extra):
+        ent = self.entries.get(self._key(tensors, extra))
+        if ent is None:
+            return None
+        refs, versions, dense = ent
+        if any(r() is not t for r, t in zip(refs, tensors)) or versions != tuple(t._version for t in tensors):
+            self.drop(tensors, extra)
+            return None
+        self.entries.move_to_end(self._key(tensors, extra))
+        return dense
+
+    def drop(self, tensors, extra):
+        ent = self.entries.pop(self._key(tensors, extra), None)
+        if ent is not None:
+            self.nbytes -= ent[2].numel() * ent[2].element_size()
+
+    def put(self, tensors, extra, dense):
+        import weakref
+        size = dense.numel() * dense.element_size()
+        if size > self.budget or torch.cuda.is_current_stream_capturing():
+            return
+        self.drop(tensors, extra)
+        while self.entries and self.nbytes + size > self.budget:
+            _, (_, _, old) = self.entries.popitem(last=False)
+            self.nbytes -= old.numel() * old.element_size()
+        self.entries[self._key(tensors, extra)] = (tuple(weakref.ref(t) for t in tensors), tuple(t._version for t in tensors), dense)
+        self.nbytes += size
+
+    def clear(self):
+        self.entries.clear()
+        self.nbytes = 0
+
+
+_dense_cache = _DenseCache()
+
+
+def dense_cache_clear() -> None:
+    """Free the resident dequantised weight images (see ``_DenseCache``)."""
+    _dense_cache.clear()
 
 
 def quantized_matmul(x: torch.Tensor, w: torch.Tensor, scales: torch.Tensor, biases: torch.Tensor,
@@ -66,6 +126,7 @@ def quantized_matmul(x: torch.Tensor, w: torch.Tensor, scales: torch.Tensor, bia
         bias = bias.contiguous()
     x2 = x.reshape(-1, k).contiguous()
     m = x2.shape[0]
+    src = (w, scales, biases)                           # the caller's tensor objects: identity of a resident dense image
     w = w.contiguous()
     scales = scales.contiguous()
     biases = biases.contiguous()
@@ -75,12 +136,23 @@ def quantized_matmul(x: torch.Tensor, w: torch.Tensor, scales: torch.Tensor, bia
         raise ValueError("out must be a contiguous [M, N] tensor of the activation dtype")
     L = _lib.lib()
     need = L.gbx_qlinear_workspace_bytes(m, n, k, bits, group_size) if (2 <= m <= 32 or 64 < m <= 2048 or m >= 4096) else 0
+    cacheable = m >= 4096 and need == n * k * 2 and _dense_cache.budget > 0 and (w, scales, biases) == src
+    ckey = (n, k, bits, group_size, x.dtype, x.device.index)
+    if cacheable:
+        dense = _dense_cache.get(src, ckey)
+        if dense is not None:                           # long prompt, weights already dequantised by an earlier call: the GEMM alone
+            rc = L.gbx_dense_forward(x2.data_ptr(), dense.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(),
+                                     m, n, k, _DT[x.dtype], _stream_ptr(x.device))
+            if rc == _lib.GBX_OK:
+                return out.reshape(*x.shape[:-1], n)
     if need:                                            # decode batches / short prompts: k split across workgroups; long prompts: dequantise once
         ws = torch.empty((need,), dtype=torch.uint8, device=x.device)      # caller-owned scratch (caching allocator: no sync)
         rc = L.gbx_qlinear_forward_ws(
             x2.data_ptr(), w.data_ptr(), scales.data_ptr(), biases.data_ptr(),
             bias.data_ptr() if bias is not None else None, out.data_ptr(),
             m, n, k, bits, group_size, _DT[x.dtype], ws.data_ptr(), need, _stream_ptr(x.device))
+        if cacheable and rc == _lib.GBX_OK:
+            _dense_cache.put(src, ckey, ws)             # the workspace now IS the [N, K] image in the activation dtype
     else:
         rc = L.gbx_qlinear_forward(
             x2.data_ptr(), w.data_ptr(), scales.data_ptr(), biases.data_ptr(),
@@ -278,12 +350,22 @@ def quantized_swiglu(x: torch.Tensor, gate, up) -> Optional[torch.Tensor]:
         need = _lib.lib().gbx_qlinear_swiglu_workspace_bytes(m, n, k)
         if need:
             x2 = x2.contiguous()
-            ws = torch.empty((need,), dtype=torch.uint8, device=x.device)
             y = torch.empty((m, n), dtype=x.dtype, device=x.device)
+            src = (gate.qweight, gate.scales, gate.zeros, up.qweight, up.scales, up.zeros)
+            ckey = ("swiglu", n, k, gate.bits, gate.group_size, x.dtype, x.device.index)
+            dense = _dense_cache.get(src, ckey) if _dense_cache.budget > 0 else None
+            if dense is not None:                       # the interleaved gate | up image of an earlier call: the GEMM alone
+                rc = _lib.lib().gbx_dense_swiglu_forward(x2.data_ptr(), dense.data_ptr(), y.data_ptr(), m, n, k, _DT[x.dtype],
+                                                         _stream_ptr(x.device))
+                if rc == _lib.GBX_OK:
+                    return y.reshape(*x.shape[:-1], n)
+            ws = torch.empty((need,), dtype=torch.uint8, device=x.device)
             _lib.check(_lib.lib().gbx_qlinear_swiglu_forward_ws(
                 x2.data_ptr(), gate.qweight.data_ptr(), gate.scales.data_ptr(), gate.zeros.data_ptr(), up.qweight.data_ptr(),
                 up.scales.data_ptr(), up.zeros.data_ptr(), y.data_ptr(), m, n, k, gate.bits, gate.group_size, _DT[x.dtype], ws.data_ptr(),
                 need, _stream_ptr(x.device)))
+            if all(t.is_contiguous() for t in src):
+                _dense_cache.put(src, ckey, ws)
             return y.reshape(*x.shape[:-1], n)
     if not (x.is_cuda and x.dtype in _DT and 2 <= m <= 64 and k % 1024 == 0 and n % 16 == 0 and gate.bias is None and up.bias is None
             and (gate.bits, gate.group_size, gate.input_dims, gate.output_dims) == (up.bits, up.group_size, up.input_dims, up.output_dims)

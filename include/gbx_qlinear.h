@@ -184,6 +184,13 @@ int gbx_add_rmsnorm_slices(void* h, const float* slices_ws, int32_t slices, cons
 int gbx_dense_forward(const void* x, const void* w, const void* bias, void* y, int64_t M, int32_t N, int32_t K, int32_t act_dtype,
                       void* hip_stream);
 
+/* The same GEMM over TWO matrices in one dense image with the SwiGLU in its epilogue: w_gate_up [2 * N, K] holds gate rows and up
+ * rows in alternating blocks of 128 (rows [256 t, 256 t + 128) = gate rows [128 t, +128), the next 128 = the same up rows -- the
+ * image gbx_qlinear_swiglu_forward_ws leaves in its workspace, which a caller may keep and reuse); y [M, N] = silu(x . gate^T) *
+ * (x . up^T) with each GEMM output, the silu and the product rounded to the activation dtype (qllama.py:115). */
+int gbx_dense_swiglu_forward(const void* x, const void* w_gate_up, void* y, int64_t M, int32_t N, int32_t K, int32_t act_dtype,
+                             void* hip_stream);
+
 /* Expert-indexed QuantizedLinear for a few (token, expert-slot) pairs -- the decode case of
  * mx.gather_qmm(x, qweight[E,N,W], scales[E,N,G], zeros[E,N,G], rhs_indices=indices, transpose=True) + bias[indices]
  * (QuantizedSwitchLinear.__call__, gbx_lm/models/switch_layers.py:78-92):

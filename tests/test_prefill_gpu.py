@@ -198,3 +198,50 @@ def test_mlp_long_prompt_uses_the_fused_path(monkeypatch):
     monkeypatch.setattr(ops, "quantized_swiglu", lambda *a, **k: None)
     b = mlp(x)
     assert torch.equal(a, b)
+
+
+def test_resident_dense_images():
+    """ops.quantized_matmul / quantized_swiglu at M >= 4096 keep the dequantised image of a call and reuse it for the next call
+    on the SAME tensor objects (bit-identical output); a modified or re-created tensor never sees a stale image"""
+    from gbx_lm_amd import ops
+    from gbx_lm_amd.models.quantized_linear_gba import QuantizedLinear
+    ops.dense_cache_clear()
+    m, n, k, bits, g = 4096, 1024, 4096, 4, 128
+    qw, sc, ze = _layer(n, k, bits, g, 21)
+    x = torch.randn((m, k), device=DEV).to(torch.bfloat16)
+    y0 = ops.quantized_matmul(x, qw, sc, ze, group_size=g, bits=bits)
+    assert len(ops._dense_cache.entries) == 1 and ops._dense_cache.nbytes == n * k * 2
+    assert ops._dense_cache.get((qw, sc, ze), (n, k, bits, g, x.dtype, 0)) is not None
+    y1 = ops.quantized_matmul(x, qw, sc, ze, group_size=g, bits=bits)            # served from the resident image
+    assert torch.equal(y0, y1)
+    sc.mul_(2.0)                                                                  # in place: the version counter invalidates the image
+    y2 = ops.quantized_matmul(x, qw, sc, ze, group_size=g, bits=bits)
+    w2 = ops.dequantize(qw, sc, ze, group_size=g, bits=bits, dtype=torch.float32)
+    ref = x.float() @ w2.t()
+    assert (y2.float() - ref).abs().max().item() <= 0.02 * ref.abs().max().item()
+    assert not torch.equal(y2, y0)
+    qw2, sc2, ze2 = qw.clone(), (sc * 0.5).clone(), ze.clone()                     # other objects: a miss, not a stale hit
+    y3 = ops.quantized_matmul(x, qw2, sc2, ze2, group_size=g, bits=bits)
+    assert torch.equal(y3, ops.quantized_matmul(x, qw, sc2, ze, group_size=g, bits=bits))
+    # gate | up image
+    ops.dense_cache_clear()
+    gate, up = QuantizedLinear(k, n, bias=False, group_size=g, bits=bits), QuantizedLinear(k, n, bias=False, group_size=g, bits=bits)
+    for mod, seed in ((gate, 31), (up, 32)):
+        q_, s_, z_ = _layer(n, k, bits, g, seed)
+        mod._set("qweight", q_), mod._set("scales", s_), mod._set("zeros", z_)
+    a0 = ops.quantized_swiglu(x, gate, up)
+    assert len(ops._dense_cache.entries) == 1
+    a1 = ops.quantized_swiglu(x, gate, up)
+    assert torch.equal(a0, a1)
+    want = ops.swiglu(ops.quantized_matmul(x, gate.qweight, gate.scales, gate.zeros, group_size=g, bits=bits),
+                      ops.quantized_matmul(x, up.qweight, up.scales, up.zeros, group_size=g, bits=bits))
+    assert torch.equal(a0, want)
+    old = ops._dense_cache.budget
+    try:                                                                          # a budget of 0 disables it
+        ops._dense_cache.budget = 0
+        ops.dense_cache_clear()
+        ops.quantized_matmul(x, qw, sc, ze, group_size=g, bits=bits)
+        assert len(ops._dense_cache.entries) == 0
+    finally:
+        ops._dense_cache.budget = old
+        ops.dense_cache_clear()
