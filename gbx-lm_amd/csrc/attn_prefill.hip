@@ -20,6 +20,13 @@
 // S^T of tile t+1 issued before the softmax of tile t 519, softmax per 32-key sub-tile with the other sub-tile's MFMAs issued
 // first 588 (a wave issues in order: a dependent MFMA chain ahead of the VALU block holds it back until the chain has ISSUED, so
 // only an instruction-level interleave would overlap them); V pitch without the bank-spreading pad 563.
+// That interleave was then built and measured (round 2, not kept): TWO 32-query tiles per wave at one wave per SIMD (493
+// registers), the S^T MFMAs of tile B issued one per ~12 VALU instructions of tile A's exponentials, P V of A between B's
+// exponentials, every K / V fragment feeding two MFMAs, 11 tests green: 405-410 TFLOP/s.  PMC: MFMA pipe busy 19 %, VALU 28 % --
+// with ONE wave per SIMD every LDS / barrier / dependency bubble is exposed (half the SIMD time is neither), and the register
+// allocator parks the 128 accumulator registers in AGPRs with a copy to VGPRs per key tile; moving the accumulations to inline
+// asm with AGPR constraints removed those copies, not the bubbles (and forfeits the compiler's MFMA hazard handling).
+// Two waves per SIMD from two independent workgroups -- this kernel -- remain the better trade in HIP source.
 #include "mfma_common.h"
 #include "kernels.h"
 
