@@ -101,15 +101,19 @@ class DecodeRunner:
                     all_reduce_(o, at.tp_group)
                 x = ops.add_rmsnorm(h, o.reshape(h.shape).contiguous(), norm.weight, norm.eps)
             mlp = layer.mlp
-            if B > 1 and getattr(mlp, "tp_world", 1) == 1 and hasattr(mlp, "gate_proj"):
+            if B > 1 and hasattr(mlp, "gate_proj"):
                 act = ops.quantized_swiglu(x, mlp.gate_proj, mlp.up_proj)              # gate | up + SwiGLU: one launch
                 if act is None:
                     g, u = ops.quantized_matmul_multi(x, (mlp.gate_proj, mlp.up_proj))
                     act = ops.swiglu(g, u)
-                # long rows: k split across workgroups; the summing launch is folded into the next add + norm
-                delta = ops.quantized_matmul_partials(act, mlp.down_proj)
-                if delta is None:
-                    delta = mlp.down_proj(act).reshape(h.shape)
+                if getattr(mlp, "tp_world", 1) > 1:  # row-sharded gate / up need no exchange; the K-split down_proj partials meet here
+                    delta = mlp.down_proj(act).reshape(h.shape).contiguous()
+                    all_reduce_(delta, mlp.tp_group)
+                else:
+                    # long rows: k split across workgroups; the summing launch is folded into the next add + norm
+                    delta = ops.quantized_matmul_partials(act, mlp.down_proj)
+                    if delta is None:
+                        delta = mlp.down_proj(act).reshape(h.shape)
             else:
                 delta = mlp(x).reshape(h.shape).contiguous()
         if isinstance(delta, tuple):
