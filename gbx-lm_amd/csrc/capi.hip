@@ -57,7 +57,7 @@ int gbx_qlinear_check(int64_t M, int32_t N, int32_t K, int32_t bits, int32_t gro
 size_t gbx_qlinear_workspace_bytes(int64_t M, int32_t N, int32_t K, int32_t bits, int32_t group_size) {
   if (check_shape(M, N, K, bits, group_size) != GBX_OK || M < 2) return 0;
   if (M <= 32) return gbx::qgemm_batch_workspace_bytes(static_cast<int>(M), N, K, bits, log2_group(group_size));
-  if (M >= gbx::GBX_DENSE_MIN_M && (K % 128) == 0) return static_cast<size_t>(N) * K * 2;   /* the weights, dequantised once per call */
+  if (gbx::dense_path_wanted(M, N, K)) return static_cast<size_t>(N) * K * 2;   /* the weights, dequantised once per call */
   if (M > 64 && (K % 128) == 0) return gbx::qgemm_prefill_workspace_bytes(static_cast<int>(M), N, K);
   return 0;
 }
@@ -68,7 +68,7 @@ int gbx_qlinear_kernel_id(int64_t M, int32_t N, int32_t K, int32_t bits, int32_t
   const int max_k = bits == 2 ? gbx::gemv_max_k<2>() : bits == 3 ? gbx::gemv_max_k<3>() : gbx::gemv_max_k<4>();
   if (M == 0) return 0;
   if (!force_generic && M > 1 && M <= 64 && (K % 128) == 0 && K >= 512) return 20;               /* batched-decode kernels */
-  if (!force_generic && M >= gbx::GBX_DENSE_MIN_M && (K % 128) == 0 && has_workspace) return 30 + gbx::prefill_tile_id(static_cast<int>(M), N, K, false);
+  if (!force_generic && gbx::dense_path_wanted(M, N, K) && has_workspace) return 30 + gbx::prefill_tile_id(static_cast<int>(M), N, K, false);
   if (!force_generic && M > 1 && (K % 128) == 0) return 10 + gbx::prefill_tile_id(static_cast<int>(M), N, K, has_workspace != 0);
   if (!force_generic && (K % 128) == 0 && K <= max_k) return 1;                                   /* decode GEMV */
   return 2;                                                                                       /* generic kernel */
@@ -119,7 +119,7 @@ int gbx_qlinear_forward_ws(const void* x, const uint32_t* qweight, const void* s
     const size_t need = M <= 32 ? gbx::qgemm_batch_workspace_bytes(static_cast<int>(M), N, K, bits, log2g) : 0;
     if (workspace && need && workspace_bytes >= need && aligned(workspace, 16)) ws = static_cast<float*>(workspace);
     e = gbx::launch_qgemm_skinny(x, qweight, scales, zeros, bias, y, static_cast<int>(M), N, K, bits, log2g, bf16, stream, ws);
-  } else if (!force_generic && M >= gbx::GBX_DENSE_MIN_M && (K % 128) == 0 && workspace && aligned(workspace, 16) &&
+  } else if (!force_generic && gbx::dense_path_wanted(M, N, K) && workspace && aligned(workspace, 16) &&
              workspace_bytes >= static_cast<size_t>(N) * K * 2) {
     e = gbx::launch_qgemm_dense(x, qweight, scales, zeros, bias, y, static_cast<int>(M), N, K, bits, log2g, bf16, stream, workspace);
   } else if (!force_generic && M > 1 && (K % 128) == 0) {
@@ -329,7 +329,7 @@ int gbx_qlinear_swiglu_forward(const void* x, const uint32_t* gate_qweight, cons
 }
 
 size_t gbx_qlinear_swiglu_workspace_bytes(int64_t M, int32_t N, int32_t K) {
-  if (M < gbx::GBX_DENSE_MIN_M || N <= 0 || K <= 0 || (N % 128) || !gbx::gemm_dense_supported(static_cast<int>(std::min<int64_t>(M, 61440)), 2 * N, K)) return 0;
+  if (N <= 0 || K <= 0 || (N % 128) || !gbx::dense_path_wanted(M, 2 * N, K) || !gbx::gemm_dense_supported(static_cast<int>(std::min<int64_t>(M, 61440)), 2 * N, K)) return 0;
   return static_cast<size_t>(2) * N * K * 2;
 }
 

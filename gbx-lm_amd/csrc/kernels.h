@@ -31,6 +31,15 @@ hipError_t launch_qgemm_dense_swiglu(const void* x, const uint32_t* gq, const vo
                                      const void* uz, void* y, int M, int N, int K, int bits, int log2g, bool bf16, hipStream_t s,
                                      void* wdense);
 constexpr int GBX_DENSE_MIN_M = 4096;
+// Prompt-sized calls with caller scratch: dequantise once + the 256 x 256 dense GEMM wherever its tiles fill the chip --
+// always from 4096 rows, from 1024 rows when the 256 x 256 tiles make at least ~0.7 of a round over the 256 CUs (measured,
+// 4 bits: M 3072 x N 4096: 161 -> 96 us, M 1024 x N 14336: 172 -> 96, M 2048 x N 14336: 268 -> 190; below that the fused tiles
+// with their finer shapes / k split win, e.g. M 2048 x N 4096: 89 vs 96)
+inline bool dense_path_wanted(long long M, int N, int K) {
+  if ((K % 128) != 0) return false;
+  if (M >= GBX_DENSE_MIN_M) return true;
+  return M >= 1024 && ((M + 255) / 256) * ((N + 255) / 256) >= 176;
+}
 // attn_prefill.hip: causal attention of L query rows at positions offset .. offset + L - 1 against S keys (strides in elements)
 hipError_t launch_attn_prefill(const void* q, const void* k, const void* v, void* out, int B, int Hq, int Hkv, int L, int S, int D,
                                long long qs_b, long long qs_h, long long qs_l, long long ks_b, long long ks_h, long long vs_b,

@@ -130,7 +130,7 @@ class MLP(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         act = None
-        if x.is_cuda and x.numel() // x.shape[-1] >= 4096 and type(self.gate_proj) is QuantizedLinear and type(self.up_proj) is QuantizedLinear:
+        if x.is_cuda and x.numel() // x.shape[-1] >= 1024 and type(self.gate_proj) is QuantizedLinear and type(self.up_proj) is QuantizedLinear:
             from .. import ops                       # long prompt: both projections and the SwiGLU as one dense matrix-core GEMM
             act = ops.quantized_swiglu(x, self.gate_proj, self.up_proj)
         if act is None:

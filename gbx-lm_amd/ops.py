@@ -28,7 +28,8 @@ def _require_cuda(t: torch.Tensor, name: str) -> None:
 
 
 class _DenseCache:
-    """Dequantised copies of packed weights that long prompts (M >= 4096 rows) left in their workspace, kept resident and reused
+    """Dequantised copies of packed weights that prompt-sized calls on the dense path (M >= 4096 rows, or >= 1024 with enough tiles)
+    left in their workspace, kept resident and reused
     by the next long call on the same tensors -- the second chunk of a prompt, the next request -- instead of being rebuilt
     (25 us per 4096 x 4096 matrix, 11 ms of an 8 x 4096-token prompt pass).  288 GB of HBM per GPU make the 16 GB an 8B model's
     bf16 image takes a fair trade; ``GBX_DENSE_CACHE_GB`` bounds it (default 32, 0 disables), least recently used entries go
@@ -135,8 +136,9 @@ def quantized_matmul(x: torch.Tensor, w: torch.Tensor, scales: torch.Tensor, bia
     elif out.shape != (m, n) or out.dtype != x.dtype or not out.is_contiguous():
         raise ValueError("out must be a contiguous [M, N] tensor of the activation dtype")
     L = _lib.lib()
-    need = L.gbx_qlinear_workspace_bytes(m, n, k, bits, group_size) if (2 <= m <= 32 or 64 < m <= 2048 or m >= 4096) else 0
-    cacheable = m >= 4096 and need == n * k * 2 and _dense_cache.budget > 0 and (w, scales, biases) == src
+    need = L.gbx_qlinear_workspace_bytes(m, n, k, bits, group_size) if (2 <= m <= 32 or m > 64) else 0
+    dense_path = m >= 1024 and need == n * k * 2 and 31 <= L.gbx_qlinear_kernel_id(m, n, k, bits, group_size, 1) <= 33
+    cacheable = dense_path and _dense_cache.budget > 0 and all(a is b for a, b in zip((w, scales, biases), src))
     ckey = (n, k, bits, group_size, x.dtype, x.device.index)
     if cacheable:
         dense = _dense_cache.get(src, ckey)
@@ -338,14 +340,14 @@ def gather_swiglu(x: torch.Tensor, gate, up, rhs_indices: torch.Tensor):
 
 def quantized_swiglu(x: torch.Tensor, gate, up) -> Optional[torch.Tensor]:
     """``silu(gate_proj(x)) * up_proj(x)`` for a decode-sized batch (2..64 rows) in ONE launch (gbx_qlinear_swiglu_forward:
-    the no-dequant matrix-core GEMM with the SwiGLU in its epilogue) or for a long prompt (>= 4096 rows:
+    the no-dequant matrix-core GEMM with the SwiGLU in its epilogue) or for a long prompt (the dense path of >= 1024 / 4096 rows:
     gbx_qlinear_swiglu_forward_ws).  Returns None when the shapes are outside both (the caller then runs the three ops)."""
     k, n = gate.input_dims, gate.output_dims
     x2 = x.reshape(-1, k)
     m = x2.shape[0]
     same = ((gate.bits, gate.group_size, gate.input_dims, gate.output_dims) == (up.bits, up.group_size, up.input_dims, up.output_dims)
             and gate.bias is None and up.bias is None and gate.scales is not None and up.scales is not None)
-    if x.is_cuda and x.dtype in _DT and m >= 4096 and same and gate.scales.dtype == x.dtype and up.scales.dtype == x.dtype:
+    if x.is_cuda and x.dtype in _DT and m >= 1024 and same and gate.scales.dtype == x.dtype and up.scales.dtype == x.dtype:
         # long prompt: gate | up dequantised once into one dense matrix, one matrix-core GEMM with the SwiGLU in its epilogue
         need = _lib.lib().gbx_qlinear_swiglu_workspace_bytes(m, n, k)
         if need:

@@ -152,7 +152,7 @@ int gbx_qlinear_swiglu_forward(const void* x, const uint32_t* gate_qweight, cons
                                const uint32_t* up_qweight, const void* up_scales, const void* up_zeros, void* y, int64_t M,
                                int32_t N, int32_t K, int32_t bits, int32_t group_size, int32_t act_dtype, void* hip_stream);
 
-/* The same op with caller scratch for long prompts: M >= 4096 rows and a workspace of gbx_qlinear_swiglu_workspace_bytes
+/* The same op with caller scratch for long prompts: M >= 4096 rows (or >= 1024 rows whose 256 x 256 tiles fill the chip) and a workspace of gbx_qlinear_swiglu_workspace_bytes
  * (2 * N * K * 2 bytes; 0 = this shape has no scratch path) dequantise gate and up ONCE into one dense matrix and run one
  * matrix-core GEMM whose epilogue applies the SwiGLU (same roundings: each GEMM output to the activation dtype, silu rounded,
  * product rounded); without enough scratch, or for smaller M, it forwards to gbx_qlinear_swiglu_forward. */
@@ -389,7 +389,7 @@ int gbx_rmsnorm(const void* x, const void* w, void* y, int64_t M, int32_t K, flo
  * 0 nothing (M = 0), 1 decode GEMV, 2 generic kernel, 20 batched-decode matrix-core kernels (2 <= M <= 64),
  * 11 / 12 / 13 prefill tile 128 x 128 / 256 x 128 / 256 x 256 (8 waves), 15 prefill with k split over workgroups
  * (has_workspace != 0 and the shape qualifies), 31 / 32 / 33 the same tiles on weights dequantised once per call into the
- * workspace (M >= 4096 and has_workspace != 0); -1 invalid shape. */
+ * workspace (M >= 4096, or M >= 1024 with at least 176 tiles of 256 x 256, and has_workspace != 0); -1 invalid shape. */
 int gbx_qlinear_kernel_id(int64_t M, int32_t N, int32_t K, int32_t bits, int32_t group_size, int32_t has_workspace);
 
 /* ---- streamed decode GEMV / persistent decode engine (gbx-lm_amd/csrc/gemv_stream.hip) -------------------------------
