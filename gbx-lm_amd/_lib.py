@@ -56,6 +56,9 @@ def lib() -> ctypes.CDLL:
             L.gbx_qlinear_partials_bytes.restype = ctypes.c_size_t
         L.gbx_attn_workspace_bytes.restype = ctypes.c_size_t
         L.gbx_dense_swiglu_forward.argtypes = [p, p, p, i64, i32, i32, i32, p]
+        L.gbx_dense_workspace_bytes.argtypes = [i64, i32, i32]
+        L.gbx_dense_workspace_bytes.restype = ctypes.c_size_t
+        L.gbx_dense_forward_ws.argtypes = [p, p, p, p, i64, i32, i32, i32, p, ctypes.c_size_t, p]
         L.gbx_qlinear_swiglu_workspace_bytes.argtypes = [i64, i32, i32]
         L.gbx_qlinear_swiglu_workspace_bytes.restype = ctypes.c_size_t
         L.gbx_qlinear_swiglu_forward_ws.argtypes = [p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, p, ctypes.c_size_t, p]

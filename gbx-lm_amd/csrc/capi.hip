@@ -57,7 +57,11 @@ int gbx_qlinear_check(int64_t M, int32_t N, int32_t K, int32_t bits, int32_t gro
 size_t gbx_qlinear_workspace_bytes(int64_t M, int32_t N, int32_t K, int32_t bits, int32_t group_size) {
   if (check_shape(M, N, K, bits, group_size) != GBX_OK || M < 2) return 0;
   if (M <= 32) return gbx::qgemm_batch_workspace_bytes(static_cast<int>(M), N, K, bits, log2_group(group_size));
-  if (gbx::dense_path_wanted(M, N, K)) return static_cast<size_t>(N) * K * 2;   /* the weights, dequantised once per call */
+  if (gbx::dense_path_wanted(M, N, K)) {            /* the weights, dequantised once per call (+ fp32 slices of a k-split dense GEMM) */
+    const size_t img = (static_cast<size_t>(N) * K * 2 + 255) & ~static_cast<size_t>(255);
+    const size_t part = M <= 61440 ? gbx::gemm_dense_workspace_bytes(static_cast<int>(M), N, K) : 0;
+    return part ? img + part : static_cast<size_t>(N) * K * 2;
+  }
   if (M > 64 && (K % 128) == 0) return gbx::qgemm_prefill_workspace_bytes(static_cast<int>(M), N, K);
   return 0;
 }
@@ -113,15 +117,26 @@ int gbx_qlinear_forward_ws(const void* x, const uint32_t* qweight, const void* s
   static const bool force_generic = getenv("GBX_FORCE_GENERIC") != nullptr;
   const int max_k = bits == 2 ? gbx::gemv_max_k<2>() : bits == 3 ? gbx::gemv_max_k<3>() : gbx::gemv_max_k<4>();
   hipError_t e;
+  // dense path: the image always fits when the caller sized the workspace with gbx_qlinear_workspace_bytes; a few-tile shape takes
+  // it only together with the scratch of its k split (the un-split dense GEMM would leave most CUs idle)
+  float* dense_part = nullptr;
+  bool use_dense = !force_generic && gbx::dense_path_wanted(M, N, K) && workspace && aligned(workspace, 16) &&
+                   workspace_bytes >= static_cast<size_t>(N) * K * 2;
+  if (use_dense) {
+    const size_t img = (static_cast<size_t>(N) * K * 2 + 255) & ~static_cast<size_t>(255);
+    const size_t part = gbx::gemm_dense_workspace_bytes(static_cast<int>(M), N, K);
+    if (part && workspace_bytes >= img + part) dense_part = reinterpret_cast<float*>(static_cast<char*>(workspace) + img);
+    const long long tiles = ((M + 255) / 256) * ((N + 255) / 256);
+    if (!dense_part && M < gbx::GBX_DENSE_MIN_M && tiles < 176) use_dense = false;
+  }
   if (!force_generic && M > 1 && M <= 64 && (K % 128) == 0 && K >= 512) {
     // a sufficient, 16-byte aligned workspace lets the batched-decode kernel split k across workgroups
     float* ws = nullptr;
     const size_t need = M <= 32 ? gbx::qgemm_batch_workspace_bytes(static_cast<int>(M), N, K, bits, log2g) : 0;
     if (workspace && need && workspace_bytes >= need && aligned(workspace, 16)) ws = static_cast<float*>(workspace);
     e = gbx::launch_qgemm_skinny(x, qweight, scales, zeros, bias, y, static_cast<int>(M), N, K, bits, log2g, bf16, stream, ws);
-  } else if (!force_generic && gbx::dense_path_wanted(M, N, K) && workspace && aligned(workspace, 16) &&
-             workspace_bytes >= static_cast<size_t>(N) * K * 2) {
-    e = gbx::launch_qgemm_dense(x, qweight, scales, zeros, bias, y, static_cast<int>(M), N, K, bits, log2g, bf16, stream, workspace);
+  } else if (use_dense) {
+    e = gbx::launch_qgemm_dense(x, qweight, scales, zeros, bias, y, static_cast<int>(M), N, K, bits, log2g, bf16, stream, workspace, dense_part);
   } else if (!force_generic && M > 1 && (K % 128) == 0) {
     float* ws = nullptr;                            // short prompts: k split across workgroups when the caller brought scratch
     const size_t need = gbx::qgemm_prefill_workspace_bytes(static_cast<int>(M), N, K);
@@ -774,6 +789,28 @@ int gbx_add_rmsnorm_slices(void* h, const float* slices_ws, int32_t slices, cons
   return GBX_OK;
 }
 
+size_t gbx_dense_workspace_bytes(int64_t M, int32_t N, int32_t K) {
+  if (M <= 0 || M > 2147483647LL || N <= 0 || K <= 0 || (N % 4) || !gbx::gemm_dense_supported(static_cast<int>(M), N, K)) return 0;
+  return gbx::gemm_dense_workspace_bytes(static_cast<int>(M), N, K);
+}
+
+int gbx_dense_forward_ws(const void* x, const void* w, const void* bias, void* y, int64_t M, int32_t N, int32_t K, int32_t act_dtype,
+                         void* workspace, size_t workspace_bytes, void* hip_stream) {
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  if (M < 0 || N <= 0 || K <= 0) return fail(GBX_ERR_INVALID, "bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+  if (M == 0) return GBX_OK;
+  if (!x || !w || !y) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (!aligned(x, 16) || !aligned(w, 16) || !aligned(y, 2)) return fail(GBX_ERR_INVALID, "x and w must be 16-byte aligned");
+  if (M > 2147483647LL || !gbx::gemm_dense_supported(static_cast<int>(M), N, K))
+    return fail(GBX_ERR_UNSUPPORTED, "dense matrix-core GEMM needs K %% 64 == 0 and M*K, N*K < 2^30 elements (M=%lld N=%d K=%d)", (long long)M, N, K);
+  const size_t need = gbx_dense_workspace_bytes(M, N, K);
+  float* part = (need && workspace && workspace_bytes >= need && aligned(workspace, 16) && aligned(y, 8)) ? static_cast<float*>(workspace) : nullptr;
+  hipError_t e = gbx::launch_gemm_dense(x, w, bias, y, static_cast<int>(M), N, K, act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream),
+                                        false, part);
+  if (e != hipSuccess) return hip_fail(e, "gbx_dense_forward_ws launch");
+  return GBX_OK;
+}
+
 int gbx_dense_forward(const void* x, const void* w, const void* bias, void* y, int64_t M, int32_t N, int32_t K, int32_t act_dtype,
                       void* hip_stream) {
   if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
@@ -831,8 +868,13 @@ int gbx_dequantize(const uint32_t* qweight, const void* scales, const void* zero
   if (!qweight || !scales || !zeros || !w) return fail(GBX_ERR_INVALID, "null device pointer");
   if (sz_dtype != GBX_F16 && sz_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "sz_dtype must be GBX_F16 or GBX_BF16");
   if (out_dtype < 0 || out_dtype > GBX_F32) return fail(GBX_ERR_INVALID, "out_dtype must be GBX_F16, GBX_BF16 or GBX_F32");
-  hipError_t e = gbx::launch_dequant(qweight, scales, zeros, w, N, K, bits, log2_group(group_size), sz_dtype == GBX_BF16,
-                                     out_dtype, static_cast<hipStream_t>(hip_stream));
+  hipError_t e;
+  if (out_dtype == sz_dtype && aligned(w, 16) && aligned(qweight, 4))      // 16-bit image: a 32-value unit per thread, 16-byte stores (same arithmetic)
+    e = gbx::launch_dequant_units(qweight, scales, zeros, w, N, K, bits, log2_group(group_size), sz_dtype == GBX_BF16,
+                                  static_cast<hipStream_t>(hip_stream));
+  else
+    e = gbx::launch_dequant(qweight, scales, zeros, w, N, K, bits, log2_group(group_size), sz_dtype == GBX_BF16,
+                            out_dtype, static_cast<hipStream_t>(hip_stream));
   if (e != hipSuccess) return hip_fail(e, "gbx_dequantize launch");
   return GBX_OK;
 }

@@ -24,7 +24,10 @@ hipError_t launch_qgemm_mfma(const void* x, const uint32_t* qw, const void* sc, 
 size_t qgemm_batch_workspace_bytes(int M, int N, int K, int bits, int log2g);
 bool gemm_dense_supported(int M, int N, int K);
 hipError_t launch_gemm_dense(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, bool bf16, hipStream_t s,
-                             bool swiglu = false);
+                             bool swiglu = false, float* part = nullptr);
+// k split of the dense GEMM for few-tile shapes (fp32 slices in caller scratch + the summing launch): slices (1: none) and scratch bytes
+int gemm_dense_ksplit(int M, int N, int K);
+size_t gemm_dense_workspace_bytes(int M, int N, int K);
 // long-prompt SwiGLU: gate and up dequantised into ONE dense matrix (blocks of 128 rows alternating), one GEMM over its 2 N rows
 // whose epilogue writes silu(gate) * up [M, N]; wdense: 2 * N * K * 2 bytes
 hipError_t launch_qgemm_dense_swiglu(const void* x, const uint32_t* gq, const void* gs, const void* gz, const uint32_t* uq, const void* us,
@@ -35,17 +38,21 @@ constexpr int GBX_DENSE_MIN_M = 4096;
 // always from 4096 rows, from 1024 rows when the 256 x 256 tiles make at least ~0.7 of a round over the 256 CUs (measured,
 // 4 bits: M 3072 x N 4096: 161 -> 96 us, M 1024 x N 14336: 172 -> 96, M 2048 x N 14336: 268 -> 190; below that the fused tiles
 // with their finer shapes / k split win, e.g. M 2048 x N 4096: 89 vs 96)
+// ... and, with its k range split over workgroups (gemm_dense_ksplit, fp32 slices + a summing launch), the few-tile shapes of a
+// 1024..4095-row chunk too (M 1024 x N 4096: 83 -> 45 us, K 14336: 256 -> 104)
+int gemm_dense_ksplit(int M, int N, int K);
 inline bool dense_path_wanted(long long M, int N, int K) {
   if ((K % 128) != 0) return false;
   if (M >= GBX_DENSE_MIN_M) return true;
-  return M >= 1024 && ((M + 255) / 256) * ((N + 255) / 256) >= 176;
+  if (M < 1024) return false;
+  return ((M + 255) / 256) * ((N + 255) / 256) >= 176 || (N % 4 == 0 && gemm_dense_ksplit(static_cast<int>(M), N, K) > 1);
 }
 // attn_prefill.hip: causal attention of L query rows at positions offset .. offset + L - 1 against S keys (strides in elements)
 hipError_t launch_attn_prefill(const void* q, const void* k, const void* v, void* out, int B, int Hq, int Hkv, int L, int S, int D,
                                long long qs_b, long long qs_h, long long qs_l, long long ks_b, long long ks_h, long long vs_b,
                                long long vs_h, int offset, float sm_scale, bool bf16, hipStream_t s);
 hipError_t launch_qgemm_dense(const void* x, const uint32_t* qw, const void* sc, const void* ze, const void* bias, void* y, int M,
-                              int N, int K, int bits, int log2g, bool bf16, hipStream_t s, void* wdense);
+                              int N, int K, int bits, int log2g, bool bf16, hipStream_t s, void* wdense, float* part = nullptr);
 size_t qgemm_prefill_workspace_bytes(int M, int N, int K);
 int prefill_tile_id(int M, int N, int K, bool has_ws);
 hipError_t launch_qgemm_skinny(const void* x, const uint32_t* qw, const void* sc, const void* ze, const void* bias, void* y,

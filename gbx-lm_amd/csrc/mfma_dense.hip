@@ -41,6 +41,10 @@ struct DenseArgs2 {
   unsigned short* y;           // [M, N] ([M, N / 2] with swiglu)
   int M, N, K;
   int swiglu;                  // w rows alternate in blocks of 128: gate rows | up rows; y = silu(gate) * up
+  // few-tile shapes: the k range split over `ksplit` workgroups per tile, slice s writes its fp32 partial tile to part[s][M][N]
+  // (caller scratch) and a second launch sums the slices, adds the bias and rounds (launch_splitk_finish)
+  float* part;
+  int ksplit;
 };
 
 template <bool BF16>
@@ -50,14 +54,17 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseArgs2 a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wcn = wave & 3;          // wave row (M half) / wave column (64 of the 256 N)
   const int M = a.M, N = a.N, K = a.K;
-  const int nk = K / DK;
+  const int ksplit = a.part ? a.ksplit : 1;
+  const int nk = K / DK / ksplit;                    // K tiles of this workgroup's slice
 
-  // XCD-aware tile order (as mfma_gemm.hip): every XCD walks a contiguous run of tiles, M-tile major
-  const int tiles_n = (N + DT - 1) / DT, tiles_m = (M + DT - 1) / DT, tiles = tiles_m * tiles_n;
+  // XCD-aware tile order (as mfma_gemm.hip): every XCD walks a contiguous run of (tile, k slice) units, M-tile major
+  const int tiles_n = (N + DT - 1) / DT, tiles_m = (M + DT - 1) / DT, tiles = tiles_m * tiles_n * ksplit;
   const int per_xcd = (tiles + 7) / 8;
-  const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (tile >= tiles) return;
+  const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (unit >= tiles) return;
+  const int tile = unit / ksplit, kslice = unit % ksplit;
   const int m0 = (tile / tiles_n) * DT, n0 = (tile % tiles_n) * DT;
+  const int kbase = kslice * nk * (DK * 2);          // byte offset of the slice inside a row
 
   // ---- DMA side: piece p = tid + 512 i (i = 0, 1) of a half-tile = (row p >> 3, 16-byte column p & 7); LDS linear, the
   // swizzle on the source column: slot (row, c) holds logical column c ^ ((row >> 1) & 7)
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseArgs2 a) {
   auto stage = [&](int kt, int h) {
     const int ktc = min(kt, nk - 1);                 // past the end: re-request the last tile (keeps the vmcnt arithmetic uniform)
     unsigned char* dst = lds + (kt & 1) * TILE_LDS + h * HALF + dma_lds;
-    const int koff = ktc * (DK * 2);
+    const int koff = kbase + ktc * (DK * 2);
     if (h < 2) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, DLDSP(dst), 16, voa[h][0], koff, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, DLDSP(dst + 8192), 16, voa[h][1], koff, 0, 0);
@@ -178,6 +185,44 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseArgs2 a) {
   // lane in 32-byte segments (measured: ~30 us per workgroup, a quarter of the K = 4096 tile).  The wave's 128 x 64 tile
   // goes through its own LDS region instead (rows of 128 B + 16 B pad) and leaves as 16-byte row-contiguous stores.
   bar();                                             // every wave is past its last fragment read / DMA wait: LDS is free
+  if (ksplit > 1) {
+    // fp32 partial tile of this k slice, through the wave's own LDS region in two passes of 64 rows (rows of 256 B + 16 B pad)
+    // so that it leaves as 16-byte row-contiguous stores
+    constexpr int PROW = 64 * 4 + 16;
+    unsigned char* pt = lds + wave * (64 * PROW);
+    float* dst0 = a.part + (static_cast<size_t>(kslice) * M) * N;
+    const int nbp = n0 + wcn * 64, mbp = m0 + wr * 128;
+    const bool full = (nbp + 64 <= N) && (N % 4 == 0);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            *reinterpret_cast<float*>(pt + (rt * 16 + 4 * fk + e) * PROW + (ct * 16 + fr) * 4) = acc[half * 4 + rt][ct][e];
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int p = it * 64 + lane, row = p >> 4, c = p & 15;    // 16-byte piece c (4 floats) of row `row`
+        const int m = mbp + half * 64 + row;
+        if (m >= M) continue;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(pt + row * PROW + c * 16);
+        float* dst = dst0 + static_cast<size_t>(m) * N + nbp + c * 4;
+        if (full) {
+          *reinterpret_cast<u32x4*>(dst) = v;
+        } else {
+          const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (nbp + c * 4 + q < N) dst[q] = __builtin_bit_cast(float, wv[q]);
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);              // this pass's reads retired before the next pass overwrites the region
+    }
+    return;
+  }
   constexpr int EROW = 144;
   unsigned char* et = lds + wave * (128 * EROW);
   const int nb = n0 + wcn * 64, mb = m0 + wr * 128;
@@ -251,9 +296,26 @@ bool gemm_dense_supported(int M, int N, int K) {
   return K % DK == 0 && K >= DK && static_cast<long long>(M) * K * 2 < (1LL << 31) && static_cast<long long>(N) * K * 2 < (1LL << 31);
 }
 
+// k slices for a shape whose 256 x 256 tiles leave most CUs idle: as many as still give every slice >= 8 K tiles and at most one
+// round of workgroups (1: no split)
+int gemm_dense_ksplit(int M, int N, int K) {
+  const int tiles = ((N + DT - 1) / DT) * ((M + DT - 1) / DT), nk = K / DK;
+  if (tiles >= 176) return 1;
+  int best = 1;
+  for (int sp = 2; sp <= 8; ++sp)
+    if (nk % sp == 0 && nk / sp >= 8 && tiles * sp <= 256) best = sp;
+  return best;
+}
+
+size_t gemm_dense_workspace_bytes(int M, int N, int K) {
+  const int sp = gemm_dense_ksplit(M, N, K);
+  return sp > 1 ? static_cast<size_t>(sp) * M * N * sizeof(float) : 0;
+}
+
 hipError_t launch_gemm_dense(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, bool bf16, hipStream_t s,
-                             bool swiglu) {
+                             bool swiglu, float* part) {
   if (swiglu && (N % 256 || bias)) return hipErrorInvalidValue;
+  const int ksplit = (part && !swiglu && N % 4 == 0) ? gemm_dense_ksplit(M, N, K) : 1;
   static bool done = false;
   if (!done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dense_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_LDS);
@@ -263,12 +325,14 @@ hipError_t launch_gemm_dense(const void* x, const void* w, const void* bias, voi
     done = true;
   }
   DenseArgs2 a{static_cast<const unsigned short*>(x), static_cast<const unsigned short*>(w), static_cast<const unsigned short*>(bias),
-               static_cast<unsigned short*>(y), M, N, K, swiglu ? 1 : 0};
-  const int tiles = ((N + DT - 1) / DT) * ((M + DT - 1) / DT);
+               static_cast<unsigned short*>(y), M, N, K, swiglu ? 1 : 0, ksplit > 1 ? part : nullptr, ksplit};
+  const int tiles = ((N + DT - 1) / DT) * ((M + DT - 1) / DT) * ksplit;
   dim3 grid(8 * ((tiles + 7) / 8)), block(512);
   if (bf16) hipLaunchKernelGGL((gemm_dense_kernel<true>), grid, block, DENSE_LDS, s, a);
   else hipLaunchKernelGGL((gemm_dense_kernel<false>), grid, block, DENSE_LDS, s, a);
-  return hipGetLastError();
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || ksplit <= 1) return e;
+  return launch_splitk_finish(part, static_cast<const unsigned short*>(bias), static_cast<unsigned short*>(y), ksplit, M, N, bf16, s);
 }
 
 }  // namespace gbx

@@ -333,11 +333,11 @@ static hipError_t launch_prefill_bits(const MfmaArgs& a0, bool bf16, hipStream_t
 // one rounding: the arithmetic of the fused kernel's staging pass, shared by all M / 256 row tiles instead of being redone by
 // each of them), then the same tile kernel with the weight tile staged like the activation tile (no VALU work per element).
 hipError_t launch_qgemm_dense(const void* x, const uint32_t* qw, const void* sc, const void* ze, const void* bias, void* y, int M,
-                              int N, int K, int bits, int log2g, bool bf16, hipStream_t s, void* wdense) {
+                              int N, int K, int bits, int log2g, bool bf16, hipStream_t s, void* wdense, float* part) {
   hipError_t e = launch_dequant_units(qw, sc, ze, wdense, N, K, bits, log2g, bf16, s);
   if (e != hipSuccess) return e;
   static const bool no8p = getenv("GBX_DENSE_NO_8PHASE") != nullptr;      // tuning aid: the register-staged tiles on dense weights
-  if (!no8p && gemm_dense_supported(M, N, K)) return launch_gemm_dense(x, wdense, bias, y, M, N, K, bf16, s);   // mfma_dense.hip
+  if (!no8p && gemm_dense_supported(M, N, K)) return launch_gemm_dense(x, wdense, bias, y, M, N, K, bf16, s, false, part);   // mfma_dense.hip
   MfmaArgs a{};
   a.x = static_cast<const unsigned short*>(x); a.wdense = static_cast<const unsigned short*>(wdense);
   a.qweight = qw; a.scales = static_cast<const unsigned short*>(sc); a.zeros = static_cast<const unsigned short*>(ze);

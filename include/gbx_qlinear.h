@@ -184,6 +184,13 @@ int gbx_add_rmsnorm_slices(void* h, const float* slices_ws, int32_t slices, cons
 int gbx_dense_forward(const void* x, const void* w, const void* bias, void* y, int64_t M, int32_t N, int32_t K, int32_t act_dtype,
                       void* hip_stream);
 
+/* The same GEMM with caller scratch: shapes whose 256 x 256 tiles would leave most compute units idle (a 1024..4095-row prompt
+ * chunk against a 4096-row matrix) split the k range over workgroups, fp32 partial tiles go to the workspace
+ * (gbx_dense_workspace_bytes; 0 = this shape does not split) and a second launch sums them in slice order, adds the bias and rounds once. */
+size_t gbx_dense_workspace_bytes(int64_t M, int32_t N, int32_t K);
+int gbx_dense_forward_ws(const void* x, const void* w, const void* bias, void* y, int64_t M, int32_t N, int32_t K, int32_t act_dtype,
+                         void* workspace, size_t workspace_bytes, void* hip_stream);
+
 /* The same GEMM over TWO matrices in one dense image with the SwiGLU in its epilogue: w_gate_up [2 * N, K] holds gate rows and up
  * rows in alternating blocks of 128 (rows [256 t, 256 t + 128) = gate rows [128 t, +128), the next 128 = the same up rows -- the
  * image gbx_qlinear_swiglu_forward_ws leaves in its workspace, which a caller may keep and reuse); y [M, N] = silu(x . gate^T) *

@@ -106,7 +106,7 @@ def test_tile_256x128(oracle, c_oracle, bits, dtype):
 def test_tile_128x128_and_splitk(oracle, c_oracle, bits):
     _check(oracle, c_oracle, 1024, 1024, 4096, bits, 128, torch.bfloat16, want_tile=11)
     _check(oracle, c_oracle, 100, 4096 - 12, 4096, bits, 64, torch.float16, want_tile=11, bias=True)
-    _check(oracle, c_oracle, 1024, 1024, 4096, bits, 128, torch.bfloat16, want_tile=15, workspace=True)
+    _check(oracle, c_oracle, 1000, 1024, 4096, bits, 128, torch.bfloat16, want_tile=15, workspace=True)
     _check(oracle, c_oracle, 300, 4096, 14336, bits, 128, torch.bfloat16, want_tile=15, workspace=True, bias=True)
 
 
@@ -124,6 +124,19 @@ def test_dense_tiles(oracle, c_oracle, bits, dtype):
     _check(oracle, c_oracle, 8192, 4096, 4096, bits, g, dtype, want_tile=33, workspace=True, bias=(bits == 3))
     _check(oracle, c_oracle, 8192 + 19, 14336 - 24, 4096, bits, g, dtype, want_tile=33, workspace=True)      # ragged M and N
     _check(oracle, c_oracle, 4096, 1024, 4096, bits, g, dtype, want_tile=32, workspace=True)
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+def test_dense_ksplit_mid_prompts(oracle, c_oracle, bits):
+    """1024..4095-row chunks whose 256 x 256 tiles leave most CUs idle: the dense GEMM with its k range split over workgroups
+    (fp32 slices in the workspace tail + the summing launch), through gbx_qlinear_forward_ws"""
+    from gbx_lm_amd import _lib
+    L = _lib.lib()
+    assert L.gbx_dense_workspace_bytes(2048, 4096, 4096) == 2 * 2048 * 4096 * 4 and L.gbx_dense_workspace_bytes(8192, 4096, 4096) == 0
+    _check(oracle, c_oracle, 2048, 4096, 4096, bits, 128, torch.bfloat16, want_tile=32, workspace=True)
+    _check(oracle, c_oracle, 1024, 4096, 14336, bits, 64, torch.float16, want_tile=32, workspace=True, bias=True)
+    _check(oracle, c_oracle, 1500, 4096 - 12, 4096, bits, 128, torch.bfloat16, want_tile=32, workspace=True)      # ragged M and N
+    _check(oracle, c_oracle, 1024 + 77, 1024, 4096, bits, 128, torch.bfloat16, want_tile=31, workspace=True)
 
 
 def test_dense_path_close_to_fused_tiles(oracle):
@@ -185,7 +198,12 @@ def test_dense_swiglu_epilogue(bits, dtype, m, n):
     ref = ops.swiglu(outs[0], outs[1])
     torch.cuda.synchronize()
     assert torch.isfinite(y.float()).all()
-    assert torch.equal(y, ref), f"{(y != ref).sum().item()} of {y.numel()} elements differ, max {(y.float() - ref.float()).abs().max().item()}"
+    if L.gbx_dense_workspace_bytes(m, n, k) == 0:
+        assert torch.equal(y, ref), f"{(y != ref).sum().item()} of {y.numel()} elements differ, max {(y.float() - ref.float()).abs().max().item()}"
+    else:       # the single GEMMs of this few-tile shape split k over workgroups (another summation order): equal up to output ulps
+        d = (y.float() - ref.float()).abs()
+        rms = ref.float().pow(2).mean().sqrt().item()
+        assert (d <= 2.0 ** -6 * ref.float().abs() + 2e-3 * rms).all() and (d > 0).float().mean().item() < 0.1
 
 
 def test_mlp_long_prompt_uses_the_fused_path(monkeypatch):
@@ -197,7 +215,10 @@ def test_mlp_long_prompt_uses_the_fused_path(monkeypatch):
     a = mlp(x)
     monkeypatch.setattr(ops, "quantized_swiglu", lambda *a, **k: None)
     b = mlp(x)
-    assert torch.equal(a, b)
+    # (the separate GEMMs of this small shape split k over workgroups: another summation order, so a few activations differ by an
+    # output ulp and the down projection -- a 1024-term sum with cancellation -- spreads that over its outputs)
+    d = (a.float() - b.float()).abs()
+    assert (d <= 2.0 ** -5 * b.float().abs() + 3e-2 * b.float().pow(2).mean().sqrt()).all()
 
 
 def test_resident_dense_images():
@@ -235,7 +256,8 @@ def test_resident_dense_images():
     assert torch.equal(a0, a1)
     want = ops.swiglu(ops.quantized_matmul(x, gate.qweight, gate.scales, gate.zeros, group_size=g, bits=bits),
                       ops.quantized_matmul(x, up.qweight, up.scales, up.zeros, group_size=g, bits=bits))
-    assert torch.equal(a0, want)
+    d = (a0.float() - want.float()).abs()           # (the single GEMMs of this few-tile shape split k: equal up to output ulps)
+    assert (d <= 2.0 ** -6 * want.float().abs() + 2e-3 * want.float().pow(2).mean().sqrt()).all()
     old = ops._dense_cache.budget
     try:                                                                          # a budget of 0 disables it
         ops._dense_cache.budget = 0
