@@ -6,7 +6,7 @@ from gbx_lm_amd import synthetic as S
 from gbx_lm_amd.models.cache import make_prompt_cache
 dev = torch.device("cuda:0")
 cfg = S.LLAMA3_8B
-B, T = 8, 4096
+B, T = int(os.environ.get('B', 8)), int(os.environ.get('T', 4096))
 model = S.build_model(cfg, S.make_strategy("S40", cfg["num_hidden_layers"], 128), device=dev, seed=0)
 toks = (torch.arange(B * T, device=dev) % cfg["vocab_size"]).view(B, T)
 def run():
