@@ -34,7 +34,7 @@ class _DenseCache:
     (25 us per 4096 x 4096 matrix, 11 ms of an 8 x 4096-token prompt pass).  288 GB of HBM per GPU make the 16 GB an 8B model's
     bf16 image takes a fair trade; ``GBX_DENSE_CACHE_GB`` bounds it (default 32, 0 disables), least recently used entries go
     first.  An entry is valid only for the very tensor OBJECTS it was built from (weak references + their in-place version
-    counters), so reloaded, re-created or modified weights never see a stale image."""
+    counters and storage addresses), so reloaded, re-created or modified weights never see a stale image."""
 
     def __init__(self):
         import collections
@@ -51,7 +51,7 @@ class _DenseCache:
         if ent is None:
             return None
         refs, versions, dense = ent
-        if any(r() is not t for r, t in zip(refs, tensors)) or versions != tuple(t._version for t in tensors):
+        if any(r() is not t for r, t in zip(refs, tensors)) or versions != tuple((t._version, t.data_ptr()) for t in tensors):
             self.drop(tensors, extra)
             return None
         self.entries.move_to_end(self._key(tensors, extra))
@@ -71,7 +71,8 @@ class _DenseCache:
         while self.entries and self.nbytes + size > self.budget:
             _, (_, _, old) = self.entries.popitem(last=False)
             self.nbytes -= old.numel() * old.element_size()
-        self.entries[self._key(tensors, extra)] = (tuple(weakref.ref(t) for t in tensors), tuple(t._version for t in tensors), dense)
+        self.entries[self._key(tensors, extra)] = (tuple(weakref.ref(t) for t in tensors),
+                                                   tuple((t._version, t.data_ptr()) for t in tensors), dense)
         self.nbytes += size
 
     def clear(self):
