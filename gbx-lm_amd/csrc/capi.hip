@@ -344,7 +344,9 @@ int gbx_qlinear_swiglu_forward(const void* x, const uint32_t* gate_qweight, cons
 }
 
 size_t gbx_qlinear_swiglu_workspace_bytes(int64_t M, int32_t N, int32_t K) {
-  if (N <= 0 || K <= 0 || (N % 128) || !gbx::dense_path_wanted(M, 2 * N, K) || !gbx::gemm_dense_supported(static_cast<int>(std::min<int64_t>(M, 61440)), 2 * N, K)) return 0;
+  // (the SwiGLU epilogue needs whole tiles: no k split here, so the few-tile shapes stay with the unfused ops)
+  if (M < gbx::GBX_DENSE_MIN_M && (M < 1024 || ((M + 255) / 256) * ((2LL * N + 255) / 256) < 176)) return 0;
+  if (N <= 0 || K <= 0 || (N % 128) || (K % 128) || !gbx::gemm_dense_supported(static_cast<int>(std::min<int64_t>(M, 61440)), 2 * N, K)) return 0;
   return static_cast<size_t>(2) * N * K * 2;
 }
 
