@@ -323,16 +323,41 @@ def generate_step(prompt: torch.Tensor, model: nn.Module, *, max_tokens: int = 2
             y = y[prefill_step_size:]
         y, logprobs, h_states = _step(y, hidden_states=with_hidden_states)
 
+    # One-token lookahead like the reference's mx.async_eval (utils.py:323-338): step n+1 is enqueued BEFORE token n is read on the
+    # host.  On one in-order stream a plain ``y.item()`` would queue its copy behind step n+1 and wait for it, so the id goes to a
+    # pinned host word right after its own step (async copy + event) and the host waits for that event only.
+    ring, slot = [], [0]
+
+    def _to_host(t):
+        if not t.is_cuda:
+            return t, None
+        if not ring:
+            ring.extend(torch.empty((1,), dtype=torch.long, pin_memory=True) for _ in range(3))   # (two ids are in flight at most)
+        pinned = ring[slot[0] % 3]
+        slot[0] += 1
+        pinned.copy_(t.reshape(-1)[:1], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(t.device))
+        return pinned, ev
+
+    def _read(pending):
+        host, ev = pending
+        if ev is not None:
+            ev.synchronize()
+        return int(host.item())
+
     n = 0
+    pending = _to_host(y)
     while True:
         if n != max_tokens:
             next_y, next_logprobs, _ = _step(y)
+            next_pending = _to_host(next_y)
         if n == 0:
             prompt_progress_callback(total_prompt_tokens, total_prompt_tokens)
         if n == max_tokens:
             break
-        yield int(y.item()), logprobs, h_states
-        y, logprobs = next_y, next_logprobs
+        yield _read(pending), logprobs, h_states
+        y, logprobs, pending = next_y, next_logprobs, next_pending
         n += 1
 
 
