@@ -76,6 +76,34 @@ def test_glue_entry_points_validate_arguments_on_the_host(lib):
         _lib.check(lib.gbx_attn_decode_batched(*args, 2, 8, 2, 96, 64, 1.0, 0.1, 0, _lib.GBX_BF16, None))
 
 
+def test_round2_entry_points_validate_arguments_on_the_host(lib):
+    """The prompt-pass entry points added in round 2: sizes / shapes are answered and malformed calls refused before any HIP call."""
+    from gbx_lm_amd import _lib
+    one = ctypes.c_void_p(256)
+    # dense path dispatch: always from 4096 rows; from 1024 rows when the 256 x 256 tiles fill the chip or the k range can be split
+    assert lib.gbx_qlinear_workspace_bytes(32768, 4096, 4096, 4, 128) == 4096 * 4096 * 2
+    assert lib.gbx_qlinear_workspace_bytes(1024, 14336, 4096, 4, 128) == 14336 * 4096 * 2            # 224 tiles: one round
+    assert lib.gbx_qlinear_workspace_bytes(2048, 4096, 4096, 4, 128) == 4096 * 4096 * 2 + 2 * 2048 * 4096 * 4   # + 2 fp32 k slices
+    assert lib.gbx_qlinear_kernel_id(2048, 4096, 4096, 4, 128, 1) in (31, 32, 33) and lib.gbx_qlinear_kernel_id(2048, 4096, 4096, 4, 128, 0) in (11, 12, 13)
+    assert lib.gbx_qlinear_kernel_id(1000, 4096, 4096, 4, 128, 1) == 12 and lib.gbx_qlinear_kernel_id(1000, 1024, 4096, 4, 128, 1) == 15
+    assert lib.gbx_dense_workspace_bytes(2048, 4096, 4096) == 2 * 2048 * 4096 * 4 and lib.gbx_dense_workspace_bytes(16384, 4096, 4096) == 0
+    assert lib.gbx_qlinear_swiglu_workspace_bytes(16384, 14336, 4096) == 2 * 14336 * 4096 * 2
+    assert lib.gbx_qlinear_swiglu_workspace_bytes(1024, 14336, 4096) == 2 * 14336 * 4096 * 2
+    assert lib.gbx_qlinear_swiglu_workspace_bytes(1024, 1024, 4096) == 0 and lib.gbx_qlinear_swiglu_workspace_bytes(16384, 1000, 4096) == 0
+    # refusals
+    assert lib.gbx_dense_forward_ws(one, one, None, one, 4096, 4096, 4100, _lib.GBX_BF16, None, 0, None) == _lib.GBX_ERR_UNSUPPORTED      # K % 64
+    assert lib.gbx_dense_forward_ws(one, None, None, one, 4096, 4096, 4096, _lib.GBX_BF16, None, 0, None) == _lib.GBX_ERR_INVALID
+    assert lib.gbx_dense_forward_ws(None, None, None, None, 0, 4096, 4096, _lib.GBX_BF16, None, 0, None) == _lib.GBX_OK
+    assert lib.gbx_dense_swiglu_forward(one, one, one, 4096, 1000, 4096, _lib.GBX_BF16, None) == _lib.GBX_ERR_UNSUPPORTED                  # N % 128
+    assert lib.gbx_dense_swiglu_forward(one, one, one, 4096, 1024, 4096, _lib.GBX_F32, None) == _lib.GBX_ERR_INVALID
+    a = (one, one, one, one)
+    assert lib.gbx_attn_prefill(*a, 0, 8, 2, 16, 16, 128, 0, 0, 128, 0, 0, 0, 0, 0, 0.1, _lib.GBX_BF16, None) == _lib.GBX_OK               # empty batch
+    assert lib.gbx_attn_prefill(*a, 1, 8, 2, 16, 16, 96, 0, 0, 96, 0, 0, 0, 0, 0, 0.1, _lib.GBX_BF16, None) == _lib.GBX_ERR_UNSUPPORTED     # head_dim
+    assert lib.gbx_attn_prefill(*a, 1, 8, 3, 16, 16, 128, 0, 0, 128, 0, 0, 0, 0, 0, 0.1, _lib.GBX_BF16, None) == _lib.GBX_ERR_INVALID       # heads
+    assert lib.gbx_attn_prefill(*a, 1, 8, 2, 16, 8, 128, 0, 0, 128, 0, 0, 0, 0, 0, 0.1, _lib.GBX_BF16, None) == _lib.GBX_ERR_INVALID        # S < offset + L
+    assert lib.gbx_attn_prefill(*a, 1, 8, 2, 16, 16, 128, 0, 0, 132, 0, 0, 0, 0, 0, 0.1, _lib.GBX_BF16, None) == _lib.GBX_ERR_INVALID       # stride % 8
+
+
 def test_product_path_never_imports_oracle():
     """The shipped package must not reference oracle/ (a product path through the oracle voids parity)."""
     pkg = os.path.join(ROOT, "gbx-lm_amd")
