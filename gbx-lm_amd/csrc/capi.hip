@@ -605,6 +605,26 @@ int gbx_rope(const void* x, void* y, const float* inv_freq, const int64_t* pos, 
   return GBX_OK;
 }
 
+int gbx_rope_kv_write(const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq, int64_t pos0, int64_t B,
+                      int32_t H, int32_t L, int32_t D, int64_t k_stride_b, int64_t k_stride_h, int64_t k_stride_l, int64_t v_stride_b,
+                      int64_t v_stride_h, int64_t v_stride_l, int32_t capacity, int32_t t0, float scale, int32_t traditional,
+                      int32_t act_dtype, void* hip_stream) {
+  if (B == 0 || H == 0 || L == 0) return GBX_OK;
+  if (!k || !v || !kcache || !vcache || !inv_freq) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (B < 0 || B > 65535 || H <= 0 || L < 0 || t0 < 0 || capacity < t0 + L)
+    return fail(GBX_ERR_INVALID, "bad shape B=%lld H=%d L=%d capacity=%d t0=%d", (long long)B, H, L, capacity, t0);
+  if (D % 16 || D <= 0 || D > 256) return fail(GBX_ERR_UNSUPPORTED, "head_dim must be a multiple of 16 up to 256 (got %d)", D);
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  if (!aligned(k, 16) || !aligned(v, 16) || !aligned(kcache, 16) || !aligned(vcache, 16) ||
+      ((k_stride_b | k_stride_h | k_stride_l | v_stride_b | v_stride_h | v_stride_l) & 7))
+    return fail(GBX_ERR_INVALID, "k / v / caches must be 16-byte aligned with strides that are multiples of 8 elements");
+  hipError_t e = gbx::launch_rope_kv_write(k, v, kcache, vcache, inv_freq, pos0, B, H, L, D, k_stride_b, k_stride_h, k_stride_l,
+                                           v_stride_b, v_stride_h, v_stride_l, capacity, t0, scale, traditional, act_dtype == GBX_BF16,
+                                           static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_rope_kv_write launch");
+  return GBX_OK;
+}
+
 int gbx_rope_append(void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
                     const int64_t* pos, int32_t batch, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int32_t capacity,
                     float rope_scale, int32_t traditional, int32_t act_dtype, void* hip_stream) {

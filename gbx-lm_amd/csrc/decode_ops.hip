@@ -1191,9 +1191,15 @@ template <bool BF16>
 __global__ __launch_bounds__(256) void rope_tokens_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
                                                           const float* __restrict__ inv_freq, const long long* __restrict__ posp,
                                                           long long offset, int H, int L, int D, long long sb, long long sh,
-                                                          long long sl, float scale, float mscale, int traditional) {
+                                                          long long sl, float scale, float mscale, int traditional,
+                                                          long long yrows = 0, int yt0 = 0, const unsigned short* __restrict__ v = nullptr,
+                                                          unsigned short* __restrict__ vy = nullptr, long long vsb = 0,
+                                                          long long vsh = 0, long long vsl = 0) {
+  // yrows > 0: y is a KV-cache buffer [B, H, yrows, D] written at rows yt0 + t (else the contiguous [B, H, L, D]); v / vy: the value
+  // rows of the same tokens copied into their cache in the same launch (cache.update_and_fetch of a prompt chunk)
   __shared__ float sn_s[128], cs_s[128];
   const int t = blockIdx.x, b = blockIdx.y, half = D / 2;
+  const long long yr_rows = yrows ? yrows : L;
   const long long base = posp ? *posp : offset;
   if (threadIdx.x < half) {
     const float ang = static_cast<float>(base + t) * scale * inv_freq[threadIdx.x];
@@ -1207,7 +1213,13 @@ __global__ __launch_bounds__(256) void rope_tokens_kernel(const unsigned short* 
   for (int w = threadIdx.x; w < H * cph; w += 256) {
     const int h = w / cph, c = w % cph;
     const unsigned short* xr = x + b * sb + h * sh + t * sl;
-    unsigned short* yr = y + ((static_cast<long long>(b) * H + h) * L + t) * D;
+    unsigned short* yr = y + ((static_cast<long long>(b) * H + h) * yr_rows + yt0 + t) * D;
+    if (v) {                                              // the value chunk pair of this work item
+      const unsigned short* vr = v + b * vsb + h * vsh + t * vsl;
+      unsigned short* vd = vy + ((static_cast<long long>(b) * H + h) * yr_rows + yt0 + t) * D;
+      *reinterpret_cast<u32x4*>(vd + c * 8) = *reinterpret_cast<const u32x4*>(vr + c * 8);
+      *reinterpret_cast<u32x4*>(vd + half + c * 8) = *reinterpret_cast<const u32x4*>(vr + half + c * 8);
+    }
     if (traditional) {                                    // pairs (2i, 2i+1): both 16-byte chunks of this work item are self-contained
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -1264,6 +1276,25 @@ hipError_t launch_rope(const void* x, void* y, const float* inv_freq, const long
   auto Y = static_cast<unsigned short*>(y);
   if (bf16) hipLaunchKernelGGL((rope_kernel<true>), dim3(blocks), dim3(256), 0, s, X, Y, inv_freq, posp, offset, nrows, H, L, D, dims, sb, sh, sl, scale, mscale, traditional);
   else hipLaunchKernelGGL((rope_kernel<false>), dim3(blocks), dim3(256), 0, s, X, Y, inv_freq, posp, offset, nrows, H, L, D, dims, sb, sh, sl, scale, mscale, traditional);
+  return hipGetLastError();
+}
+
+// RoPE(k) of a prompt chunk written straight into the key cache + the value rows copied into theirs: rope(k, offset) followed by
+// cache.update_and_fetch(k, v) (qllama.py:88-91, cache.py:222-244) as ONE launch.  k / v: strided [B, H, L, D] views of the
+// projection outputs; caches [B, H, capacity, D]; rows t0 .. t0 + L - 1 are written, angles from position pos0 + t.
+hipError_t launch_rope_kv_write(const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq, long long pos0,
+                                long long B, int H, int L, int D, long long ksb, long long ksh, long long ksl, long long vsb,
+                                long long vsh, long long vsl, int capacity, int t0, float scale, int traditional, bool bf16,
+                                hipStream_t s) {
+  dim3 grid(L, static_cast<unsigned>(B));
+  auto K = static_cast<const unsigned short*>(k);
+  auto V = static_cast<const unsigned short*>(v);
+  auto KC = static_cast<unsigned short*>(kcache);
+  auto VC = static_cast<unsigned short*>(vcache);
+  if (bf16) hipLaunchKernelGGL((rope_tokens_kernel<true>), grid, dim3(256), 0, s, K, KC, inv_freq, nullptr, pos0, H, L, D, ksb, ksh, ksl, scale, 1.f,
+                               traditional, static_cast<long long>(capacity), t0, V, VC, vsb, vsh, vsl);
+  else hipLaunchKernelGGL((rope_tokens_kernel<false>), grid, dim3(256), 0, s, K, KC, inv_freq, nullptr, pos0, H, L, D, ksb, ksh, ksl, scale, 1.f,
+                          traditional, static_cast<long long>(capacity), t0, V, VC, vsb, vsh, vsl);
   return hipGetLastError();
 }
 

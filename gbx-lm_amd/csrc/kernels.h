@@ -47,6 +47,10 @@ inline bool dense_path_wanted(long long M, int N, int K) {
   if (M < 1024) return false;
   return ((M + 255) / 256) * ((N + 255) / 256) >= 176 || (N % 4 == 0 && gemm_dense_ksplit(static_cast<int>(M), N, K) > 1);
 }
+hipError_t launch_rope_kv_write(const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq, long long pos0,
+                                long long B, int H, int L, int D, long long ksb, long long ksh, long long ksl, long long vsb,
+                                long long vsh, long long vsl, int capacity, int t0, float scale, int traditional, bool bf16,
+                                hipStream_t s);
 // attn_prefill.hip: causal attention of L query rows at positions offset .. offset + L - 1 against S keys (strides in elements)
 hipError_t launch_attn_prefill(const void* q, const void* k, const void* v, void* out, int B, int Hq, int Hkv, int L, int S, int D,
                                long long qs_b, long long qs_h, long long qs_l, long long ks_b, long long ks_h, long long vs_b,

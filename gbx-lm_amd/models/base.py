@@ -87,6 +87,32 @@ def fused_decode_attention(q, k, v, cache, rope, scale: float, n_heads: int, n_k
     return out.reshape(bsz, 1, -1)
 
 
+def rope_keys_and_update_cache(rope, k: torch.Tensor, v: torch.Tensor, cache, start):
+    """``k = rope(k, offset=start); k, v = cache.update_and_fetch(k, v)`` (qllama.py:88-91).  A prompt chunk on the GPU with a plain
+    full-width RoPE and a plain KVCache does both in ONE launch: the rotated keys go straight into the cache (gbx_rope_kv_write:
+    the same arithmetic as the stand-alone RoPE launch, so the cache contents are bit-identical), no temporary, no copy launches."""
+    from .cache import KVCache
+    from .rope_utils import RoPE, Llama3RoPE
+    L, D = k.shape[2], k.shape[3]
+    if (type(cache) is KVCache and not cache.static_active and k.is_cuda and L >= 16 and type(rope) in (RoPE, Llama3RoPE)
+            and isinstance(start, int) and rope.inv_freq.numel() * 2 == D and D % 16 == 0 and D <= 256 and v.shape[3] == D
+            and k.dtype in (torch.bfloat16, torch.float16) and v.dtype == k.dtype and k.stride(3) == 1 and v.stride(3) == 1
+            and all(t.stride(i) % 8 == 0 for t in (k, v) for i in (0, 1, 2)) and k.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0
+            and rope.inv_freq.is_cuda and rope.inv_freq.dtype == torch.float32):
+        prev = cache.offset
+        cache.reserve(L, k, v)
+        if (cache.keys.dtype == k.dtype and cache.values.dtype == k.dtype and cache.keys.is_contiguous() and cache.values.is_contiguous()
+                and cache.keys.shape[3] == D and cache.values.shape[3] == D):
+            from .. import ops
+            ops.rope_kv_write(k, v, cache.keys, cache.values, rope.inv_freq, start, prev, getattr(rope, "scale", 1.0), rope.traditional)
+            cache.offset = prev + L
+            return cache.keys[..., :cache.offset, :], cache.values[..., :cache.offset, :]
+    k = rope(k, offset=start)
+    if cache is not None:
+        k, v = cache.update_and_fetch(k, v)
+    return k, v
+
+
 def cache_offset(cache):
     """Position of the next token: the cache's host-side ``offset``, or -- inside a graph-replayed decode step -- its
     device-resident ``static_pos`` (RoPE then reads the position from device memory)."""

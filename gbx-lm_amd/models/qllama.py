@@ -16,8 +16,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .base import (BaseModelArgs, cache_offset, create_attention_mask, fused_decode_attention, scaled_dot_product_attention,
-                   swiglu)
+from .base import (BaseModelArgs, cache_offset, create_attention_mask, fused_decode_attention, rope_keys_and_update_cache,
+                   scaled_dot_product_attention, swiglu)
 from .quantized_linear_gba import QuantizedLinear
 from .rope_utils import initialize_rope
 
@@ -106,9 +106,8 @@ class Attention(nn.Module):
             return out
         q, k, v = _heads(q, self.n_heads), _heads(k, self.n_kv_heads), _heads(v, self.n_kv_heads)
         start = cache_offset(cache)
-        q, k = self.rope(q, offset=start), self.rope(k, offset=start)
-        if cache is not None:
-            k, v = cache.update_and_fetch(k, v)
+        q = self.rope(q, offset=start)
+        k, v = rope_keys_and_update_cache(self.rope, k, v, cache, start)
         ctx = scaled_dot_product_attention(q, k, v, cache=cache, scale=self.scale, mask=mask)
         out = self.o_proj(ctx.permute(0, 2, 1, 3).reshape(b, l, -1))
         if self.tp_world > 1:                       # K-split layer: partial sums meet here (gbx_lm_amd/tp.py)

@@ -15,7 +15,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .base import BaseModelArgs, cache_offset, create_attention_mask, scaled_dot_product_attention, swiglu
+from .base import (BaseModelArgs, cache_offset, create_attention_mask, rope_keys_and_update_cache, scaled_dot_product_attention,
+                   swiglu)
 from .qllama import RMSNorm
 from .quantized_linear_gba import QuantizedLinear
 from .rope_utils import RoPE, SuScaledRotaryEmbedding
@@ -83,9 +84,8 @@ class Attention(nn.Module):
         k = k.reshape(b, l, self.n_kv_heads, -1).permute(0, 2, 1, 3)
         v = v.reshape(b, l, self.n_kv_heads, -1).permute(0, 2, 1, 3)
         start = cache_offset(cache)
-        q, k = self.rope(q, offset=start), self.rope(k, offset=start)
-        if cache is not None:
-            k, v = cache.update_and_fetch(k, v)
+        q = self.rope(q, offset=start)
+        k, v = rope_keys_and_update_cache(self.rope, k, v, cache, start)
         ctx = scaled_dot_product_attention(q, k, v, cache=cache, scale=self.scale, mask=mask)
         return self.o_proj(ctx.permute(0, 2, 1, 3).reshape(b, l, -1))
 

@@ -756,6 +756,18 @@ def rope(x: torch.Tensor, inv_freq: torch.Tensor, offset, scale: float = 1.0, tr
     return y
 
 
+def rope_kv_write(k: torch.Tensor, v: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, inv_freq: torch.Tensor,
+                  pos0: int, t0: int, scale: float = 1.0, traditional: bool = False) -> None:
+    """RoPE(k) of a prompt chunk written into rows t0.. of the key cache and v copied into the value cache, one launch
+    (gbx_rope_kv_write).  k / v: [B, H, L, D] views with a unit feature stride; caches [B, H, capacity, D] contiguous."""
+    _require_cuda(k, "k")
+    B, H, L, D = k.shape
+    _lib.check(_lib.lib().gbx_rope_kv_write(k.data_ptr(), v.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), inv_freq.data_ptr(),
+                                            int(pos0), B, H, L, D, k.stride(0), k.stride(1), k.stride(2), v.stride(0), v.stride(1),
+                                            v.stride(2), kcache.shape[2], int(t0), float(scale), int(bool(traditional)), _DT[k.dtype],
+                                            _stream_ptr(k.device)))
+
+
 def rope_append(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor,
                 inv_freq: torch.Tensor, pos: torch.Tensor, n_heads: int, n_kv: int, head_dim: int,
                 rope_scale: float, traditional: bool) -> None:

@@ -371,6 +371,16 @@ int gbx_rope(const void* x, void* y, const float* inv_freq, const int64_t* pos, 
              int32_t D, int32_t dims, int64_t stride_b, int64_t stride_h, int64_t stride_l, float scale, float mscale,
              int32_t traditional, int32_t act_dtype, void* hip_stream);
 
+/* RoPE of the keys of a prompt chunk written straight into the key cache, the values copied into theirs -- ``rope(k, offset)``
+ * followed by ``cache.update_and_fetch(k, v)`` (qllama.py:88-91, models/cache.py:222-244) for L > 1 tokens in ONE launch.
+ * k / v: [B, H, L, D] addressed through element strides (D contiguous: the transposed view of a projection output); caches
+ * [B, H, capacity, D] contiguous; rows t0 .. t0 + L - 1 are written, row t rotated by (pos0 + t) * scale * inv_freq[i] with the
+ * arithmetic of gbx_rope (full-width RoPE, pairs (i, i + D/2) or, traditional, (2i, 2i+1)). */
+int gbx_rope_kv_write(const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq, int64_t pos0, int64_t B,
+                      int32_t H, int32_t L, int32_t D, int64_t k_stride_b, int64_t k_stride_h, int64_t k_stride_l, int64_t v_stride_b,
+                      int64_t v_stride_h, int64_t v_stride_l, int32_t capacity, int32_t t0, float scale, int32_t traditional,
+                      int32_t act_dtype, void* hip_stream);
+
 /* Synchronous batched decode step, every sequence at position *pos (device int64): q[batch, n_heads*head_dim] is rotated
  * in place, k[batch, n_kv*head_dim] is rotated into kcache[b, kvh, *pos, :], v copied into vcache[b, kvh, *pos, :]
  * (caches [batch, n_kv, capacity, head_dim]).  rope(q), rope(k), cache.update_and_fetch of qllama.py:84-91 for one new

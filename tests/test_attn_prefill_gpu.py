@@ -120,3 +120,31 @@ def test_prompt_pass_residual_adds_inside_the_norms(monkeypatch):
     monkeypatch.setattr(qllama.LlamaModel, "_fused_residuals", lambda self, h: False)
     b = model.model(toks, None, make_prompt_cache(model))
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("traditional", [False, True])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_rope_keys_written_straight_into_the_cache(traditional, dtype):
+    """rope(k) + cache.update_and_fetch(k, v) of a prompt chunk as one launch (gbx_rope_kv_write) against the two-step route: the
+    same cache contents and returned views bit for bit, over two chunks with a cache growth in between"""
+    from gbx_lm_amd.models.base import rope_keys_and_update_cache
+    from gbx_lm_amd.models.cache import KVCache
+    from gbx_lm_amd.models.rope_utils import RoPE
+    B, H, D = 2, 4, 128
+    rope = RoPE(D, traditional=traditional, base=10000.0).to(DEV)
+    fused, plain = KVCache(step=64), KVCache(step=64)
+    start = 0
+    for L in (40, 24, 300):
+        k = torch.randn((B, L, H, D), device=DEV).to(dtype).permute(0, 2, 1, 3)          # the _heads view of a projection output
+        v = torch.randn((B, L, H, D), device=DEV).to(dtype).permute(0, 2, 1, 3)
+        kf, vf = rope_keys_and_update_cache(rope, k, v, fused, start)
+        kp, vp = plain.update_and_fetch(rope(k, offset=start), v)
+        start += L
+        assert fused.offset == plain.offset == start and kf.shape == kp.shape == (B, H, start, D)
+        assert torch.equal(kf, kp) and torch.equal(vf, vp)
+    # shapes the launch does not take (a short chunk) go through the two steps and stay consistent
+    k = torch.randn((B, 3, H, D), device=DEV).to(dtype).permute(0, 2, 1, 3)
+    v = torch.randn((B, 3, H, D), device=DEV).to(dtype).permute(0, 2, 1, 3)
+    kf, vf = rope_keys_and_update_cache(rope, k, v, fused, start)
+    kp, vp = plain.update_and_fetch(rope(k, offset=start), v)
+    assert torch.equal(kf, kp) and torch.equal(vf, vp)
