@@ -44,6 +44,21 @@ int check_shape(int64_t M, int32_t N, int32_t K, int32_t bits, int32_t group) {
 
 }  // namespace
 
+#ifdef GBX_STAMPS
+namespace gbx {
+static unsigned long long g_stamp_launch = 0;
+unsigned long long* stamp_region() {
+  const char* p = getenv("GBX_STAMP_PTR");
+  if (!p) return nullptr;
+  unsigned long long* base = reinterpret_cast<unsigned long long*>(strtoull(p, nullptr, 0));
+  const char* n = getenv("GBX_STAMP_SLOTS");
+  const unsigned long long slots = n ? strtoull(n, nullptr, 0) : 1;
+  return base + (g_stamp_launch++ % slots) * STAMP_REGION_WORDS;
+}
+}  // namespace gbx
+extern "C" void gbx_debug_stamp_reset(void) { gbx::g_stamp_launch = 0; }
+#endif
+
 extern "C" {
 
 int gbx_version(void) { return 1000; }
@@ -149,7 +164,7 @@ int gbx_qlinear_forward_ws(const void* x, const uint32_t* qweight, const void* s
                             static_cast<unsigned short*>(y), N};
     a.nseg = 1; a.N = N; a.K = K; a.log2g = log2g; a.bias = bias;
 #ifdef GBX_STAMPS
-    a.stamps = reinterpret_cast<unsigned long long*>(strtoull(getenv("GBX_STAMP_PTR") ? getenv("GBX_STAMP_PTR") : "0", nullptr, 0));
+    a.stamps = gbx::stamp_region();
 #endif
     switch (bits) {
       case 2: e = gbx::launch_gemv<2>(a, static_cast<int>(M), bf16, stream); break;
@@ -205,7 +220,7 @@ int gbx_qlinear_fused_forward(const gbx_qlinear_fused* d, void* hip_stream) {
   a.residual = static_cast<const unsigned short*>(d->residual);
   a.swiglu = d->swiglu ? 1 : 0;
 #ifdef GBX_STAMPS
-  a.stamps = reinterpret_cast<unsigned long long*>(strtoull(getenv("GBX_STAMP_PTR") ? getenv("GBX_STAMP_PTR") : "0", nullptr, 0));
+  a.stamps = gbx::stamp_region();
 #endif
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   const bool bf16 = d->act_dtype == GBX_BF16;

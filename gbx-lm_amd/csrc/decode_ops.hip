@@ -36,7 +36,15 @@ struct AttnArgs {
   // split s writes (num[HD], max, den) per head to ws[((b * n_heads + head) * splits + s) * (HD + 2)] and a second launch
   // merges them (caller-owned scratch)
   float* ws;
+#ifdef GBX_STAMPS
+  unsigned long long* stamps;   // diagnostic build only
+#endif
 };
+#ifdef GBX_STAMPS
+#define ATT_STAMP(i) do { if ((threadIdx.x & 63) == 0 && a.stamps) a.stamps[(static_cast<size_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ATT_STAMP(i) do {} while (0)
+#endif
 
 template <bool BF16, int HD>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
@@ -53,6 +61,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
   const int kvh = h / rep;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  ATT_STAMP(0);
   {                                   // synchronous batched decode: sequence blockIdx.y, every sequence at *pos
     const size_t b = blockIdx.y;
     a.q += b * a.n_heads * HD; a.out += b * a.n_heads * HD;
@@ -74,6 +83,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     v0[u] = *reinterpret_cast<const u32x4*>(vbase + static_cast<size_t>(tc) * HD + d0);
   }
   const int pos = static_cast<int>(*a.pos);
+  ATT_STAMP(1);
 
   // ---- RoPE on this head's q and on its kv head's k (fp32 math, one rounding to the activation dtype like
   //      mx.fast.rope); the first q head of a kv group appends k, v to the cache ----
@@ -108,6 +118,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     if (h % rep == 0) a.vcache[(static_cast<size_t>(kvh) * a.capacity + pos) * HD + j] = vb;
   }
   __syncthreads();
+  ATT_STAMP(2);
 
   // ---- cached positions [0, pos): LP lanes per position, online softmax per (wave, sub) group ----
   float qr[8];
@@ -175,10 +186,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     m = mn;
   }
   const int g = wave * PPW + sub;
+  ATT_STAMP(3);
   if (lane % LP == 0) { gm[g] = m; gl[g] = l; }
 #pragma unroll
   for (int j = 0; j < 8; ++j) gacc[g][d0 + j] = acc[j];
   __syncthreads();
+  ATT_STAMP(4);
   // ---- merge the NG partial states; one output feature per thread ----
   if (tid < HD) {
     float M = NEG;
@@ -193,6 +206,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     }
     a.out[static_cast<size_t>(h) * HD + tid] = f32_to_act<BF16>(num / den);
   }
+  ATT_STAMP(6);
 }
 
 // (Round 2, measured and not kept: the sweep below on the matrix cores -- S^T = mfma(K rows from the cache in operand layout,
@@ -566,6 +580,9 @@ hipError_t launch_attn_decode(const void* q, const void* k, const void* v, void*
              static_cast<const unsigned short*>(q_norm_w), static_cast<const unsigned short*>(k_norm_w), norm_eps,
              static_cast<const unsigned short*>(q_bias), static_cast<const unsigned short*>(k_bias),
              static_cast<const unsigned short*>(v_bias), nullptr};
+#ifdef GBX_STAMPS
+  a.stamps = stamp_region();
+#endif
   const int rep = n_heads / n_kv;
   const int splits = ws ? attn_splits(batch, n_heads, n_kv, capacity) : 1;
   if (splits > 1) a.ws = ws;

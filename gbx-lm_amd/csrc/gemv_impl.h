@@ -284,7 +284,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
     }
   };
 #ifdef GBX_STAMPS
-#define GBX_STAMP(i) do { if (lane == 0) a.stamps[(static_cast<size_t>(blockIdx.x) * NW + wave) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define GBX_STAMP(i) do { if (lane == 0 && a.stamps) a.stamps[(static_cast<size_t>(blockIdx.x) * NW + wave) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define GBX_STAMP(i) do {} while (0)
 #endif
@@ -321,6 +321,11 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
   };
   RowBatch<BITS, P> ring[D];
   GBX_STAMP(0);
+#ifdef GBX_STAMPS
+  if (lane == 0 && a.stamps)   // where the wave runs: XCC id << 32 | HW_ID (wave, simd, cu, sh, se)
+    a.stamps[(static_cast<size_t>(blockIdx.x) * NW + wave) * 16 + 7] =
+        (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((31 << 11) | 20)) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
   // ---------------- 1. activation (and norm weight) loads first: vmcnt retires in order -------------------------
   const int nunits = K / F::UNIT_VALS;
   // fused RMSNorm only where a wave owns whole rows (KS == 1: K = hidden size); the launcher rejects it otherwise
@@ -380,6 +385,10 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
   GBX_STAMP(1);
   // ---------------- 3a. optional fused RMSNorm: block-wide mean of squares ---------------------------------------
   float rstd = 1.f;
+#ifdef GBX_STAMPS
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(R * P + (PK ? P + 1 : 0)) : "memory");   // x (and w) have landed (diagnostic build only)
+  GBX_STAMP(8);
+#endif
   if (norm) {
     float ssq = 0.f;
 #pragma unroll
@@ -399,6 +408,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
     for (int i = 0; i < NW; ++i) tot += red_lds[i];
     rstd = rsqrtf(tot / static_cast<float>(K) + a.eps);
   }
+  GBX_STAMP(9);
 
   // ---------------- 3b. activations -> pre-shifted fp16 pairs, one block exponent per 32-value sub-slot ----------
 #pragma unroll
@@ -447,6 +457,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
       if ((u % UPSUB) == 0) xs_lds[u / UPSUB] = make_float2(ssum, exp2i(24 - E));
     }
   }
+  GBX_STAMP(10);
   __syncthreads();
 
   GBX_STAMP(2);

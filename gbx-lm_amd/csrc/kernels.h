@@ -8,6 +8,12 @@ namespace gbx {
 
 struct GemvArgs;
 
+#ifdef GBX_STAMPS
+// diagnostic build only: the next per-launch region of the s_memrealtime stamp buffer (GBX_STAMP_PTR / GBX_STAMP_SLOTS), capi.hip
+unsigned long long* stamp_region();
+constexpr int STAMP_REGION_WORDS = 4096 * 16;
+#endif
+
 template <int BITS>
 hipError_t launch_gemv(const GemvArgs& a, int M, bool bf16, hipStream_t stream);
 

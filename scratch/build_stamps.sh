@@ -1,0 +1,13 @@
+#!/bin/bash
+# diagnostic build of the whole library with in-kernel s_memrealtime stamps (-DGBX_STAMPS) -> scratch/stamps/libgbx_stamps.so
+set -e
+cd "$(dirname "$0")/../gbx-lm_amd/csrc"
+mkdir -p ../../scratch/stamps/_obj
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -I. -Wno-unused-value -ffp-contract=on -DGBX_STAMPS"
+for f in *.hip; do
+  o=../../scratch/stamps/_obj/${f%.hip}.o
+  if [ ! -f $o ] || [ $f -nt $o ] || [ -n "$(find . -name '*.h' -newer $o)" ]; then
+    echo "/opt/rocm/bin/hipcc $FLAGS -c $f -o $o"
+  fi
+done | xargs -P 8 -I{} bash -c "{}"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../scratch/stamps/libgbx_stamps.so ../../scratch/stamps/_obj/*.o
