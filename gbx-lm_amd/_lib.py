@@ -76,7 +76,8 @@ class FusedDesc(ctypes.Structure):
                 ("y", ctypes.c_void_p * 3), ("N", ctypes.c_int32 * 3),
                 ("norm_weight", ctypes.c_void_p), ("norm_eps", ctypes.c_float),
                 ("residual", ctypes.c_void_p), ("swiglu", ctypes.c_int32),
-                ("sz", ctypes.c_void_p)]
+                ("sz", ctypes.c_void_p),
+                ("x_acc", ctypes.c_void_p), ("x_out", ctypes.c_void_p), ("zero_buf", ctypes.c_void_p), ("zero_n", ctypes.c_int32)]
 
 
 def _declare_optional(L) -> None:
@@ -94,6 +95,8 @@ def _declare_optional(L) -> None:
         "gbx_stream_run": [p, p, i32, i32, i32, p],
         "gbx_attn_decode": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, f32, f32, i32, i32, p],
         "gbx_attn_decode_batched": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, f32, i32, i32, p],
+        "gbx_attn_oproj_supported": [i32, i32, i32, i32, i32, i32],
+        "gbx_attn_oproj_decode": [p, p, p, p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, i32, i32, f32, f32, i32, i32, p],
         "gbx_attn_decode_normed": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, f32, i32, p, p, f32, p, p, p, i32, p],
         "gbx_attn_decode_ws": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, f32, i32, p, p, f32, p, p, p, i32, p, ctypes.c_size_t, p],
         "gbx_attn_workspace_bytes": [i32, i32, i32, i32, i32],

@@ -219,6 +219,16 @@ int gbx_qlinear_fused_forward(const gbx_qlinear_fused* d, void* hip_stream) {
   a.eps = d->norm_eps;
   a.residual = static_cast<const unsigned short*>(d->residual);
   a.swiglu = d->swiglu ? 1 : 0;
+  if (d->x_acc) {
+    if (!d->sz || nslots > 128 || d->group_size < 64) return fail(GBX_ERR_UNSUPPORTED, "x_acc needs the packed companion (sz), one pass per wave over K (K <= %d) and group_size >= 64", 128 * vpl);
+    if (!aligned(d->x_acc, 16) || (d->x_out && !aligned(d->x_out, 16))) return fail(GBX_ERR_INVALID, "x_acc / x_out must be 16-byte aligned");
+    if (d->x_out == d->x) return fail(GBX_ERR_INVALID, "x_out must not alias x (the other workgroups are still reading it)");
+  } else if (d->x_out) return fail(GBX_ERR_INVALID, "x_out without x_acc");
+  if (d->zero_buf && (d->zero_n < 0 || !aligned(d->zero_buf, 8))) return fail(GBX_ERR_INVALID, "bad zero_buf / zero_n");
+  a.x_acc = reinterpret_cast<const long long*>(d->x_acc);
+  a.x_out = static_cast<unsigned short*>(d->x_out);
+  a.zero_buf = reinterpret_cast<long long*>(d->zero_buf);
+  a.zero_n = d->zero_buf ? d->zero_n : 0;
 #ifdef GBX_STAMPS
   a.stamps = gbx::stamp_region();
 #endif
@@ -242,6 +252,7 @@ int gbx_stream_encode(const gbx_qlinear_fused* descs, int32_t n, void* out, size
   for (int k = 0; k < n; ++k) {
     const gbx_qlinear_fused* d = descs + k;
     if (d->nseg < 1 || d->nseg > 3) return fail(GBX_ERR_INVALID, "op %d: nseg must be 1..3 (got %d)", k, d->nseg);
+    if (d->x_acc || d->x_out || d->zero_buf) return fail(GBX_ERR_UNSUPPORTED, "op %d: x_acc / x_out / zero_buf run on gbx_qlinear_fused_forward", k);
     if (d->act_dtype != GBX_F16 && d->act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "op %d: act_dtype must be GBX_F16 or GBX_BF16", k);
     int ntot = 0;
     for (int i = 0; i < d->nseg; ++i) {
@@ -516,6 +527,32 @@ int gbx_attn_decode(const void* q, const void* k, const void* v, void* kcache, v
                     void* hip_stream) {
   return gbx_attn_decode_batched(q, k, v, kcache, vcache, inv_freq, pos, out, 1, n_heads, n_kv_heads, head_dim, capacity,
                                  rope_scale, sm_scale, traditional, act_dtype, hip_stream);
+}
+
+int gbx_attn_oproj_supported(int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int32_t D, int32_t bits, int32_t group_size) {
+  return gbx::attn_oproj_supported(n_heads, n_kv_heads, head_dim, D, bits, group_size, 1) ? 1 : 0;
+}
+
+int gbx_attn_oproj_decode(const void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
+                          const int64_t* pos, const uint32_t* o_qweight, const void* o_scales, const void* o_zeros,
+                          int64_t* acc, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int32_t capacity, int32_t D,
+                          int32_t bits, int32_t group_size, float rope_scale, float sm_scale, int32_t traditional,
+                          int32_t act_dtype, void* hip_stream) {
+  if (!q || !k || !v || !kcache || !vcache || !inv_freq || !pos || !o_qweight || !o_scales || !o_zeros || !acc)
+    return fail(GBX_ERR_INVALID, "null device pointer");
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  if (capacity < 1) return fail(GBX_ERR_INVALID, "capacity must be positive");
+  if (!gbx::attn_oproj_supported(n_heads, n_kv_heads, head_dim, D, bits, group_size, capacity))
+    return fail(GBX_ERR_UNSUPPORTED, "attention + o_proj launch needs head_dim 128, n_heads == 4 n_kv_heads, D %% 128 == 0, bits 2/3/4, group 64/128 "
+                "(got heads %d/%d x %d, D %d, %d bits, group %d)", n_heads, n_kv_heads, head_dim, D, bits, group_size);
+  if (!aligned(o_qweight, 16) || !aligned(kcache, 16) || !aligned(vcache, 16) || !aligned(acc, 8))
+    return fail(GBX_ERR_INVALID, "o_qweight / caches must be 16-byte aligned, acc 8-byte aligned");
+  hipError_t e = gbx::launch_attn_oproj(q, k, v, kcache, vcache, inv_freq, reinterpret_cast<const long long*>(pos), o_qweight, o_scales,
+                                        o_zeros, reinterpret_cast<long long*>(acc), n_heads, n_kv_heads, head_dim, capacity, D, bits,
+                                        log2_group(group_size), rope_scale, sm_scale, traditional, act_dtype == GBX_BF16,
+                                        static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_attn_oproj_decode launch");
+  return GBX_OK;
 }
 
 int gbx_attn_decode_batched(const void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,

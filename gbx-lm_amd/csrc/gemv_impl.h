@@ -57,8 +57,16 @@ struct GemvArgs {
   int x_div;                       // pairs that share one activation row (k for up/gate, 1 for down); >= 1
   int num_experts;
   long long e_stride_w, e_stride_g;   // elements between experts: N*W words, N*G scales
+  // ---- activation vector formed in the prologue (launches behind gbx_attn_oproj_decode): x <- round(x + round(x_acc * 2^-32)),
+  // x_acc = 64-bit fixed-point sums of the o_proj slices; workgroup 0 also writes the new x to x_out (the residual stream
+  // of the block, qllama.py:138: h = x + r) -- never x itself, which the other workgroups are still reading
+  const long long* x_acc;          // [K] or null
+  unsigned short* x_out;           // [K] or null
+  // ---- buffer this launch clears for a later one (the accumulator above, once its consumer has run) ----
+  long long* zero_buf;
+  int zero_n;
 #ifdef GBX_STAMPS
-  unsigned long long* stamps;      // diagnostic build only: [workgroup][wave][8] s_memrealtime stamps
+  unsigned long long* stamps;      // diagnostic build only: [workgroup][wave][16] s_memrealtime stamps
 #endif
 };
 
@@ -98,6 +106,10 @@ __device__ __forceinline__ float dot2h(unsigned wbits, h2 xv, float acc) {
 // ---- per-unit dot products: masks select fields in place (fp16 subnormals) ---------------------
 // 2-bit: one word = 16 fields; pairs (f_j, f_{8+j}).
 __device__ __forceinline__ float dot_unit_b2(unsigned w, const h2* xp, float acc) {
+#ifdef GBX_EXP_SKIPDOT   // timing experiment only (wrong results): a quarter of the vector-ALU work per packed word
+  acc = dot2h(w & 0x00030003u, xp[0], acc);
+  return dot2h(w & 0x000C000Cu, xp[1], acc);
+#endif
   acc = dot2h(w & 0x00030003u, xp[0], acc);
   acc = dot2h(w & 0x000C000Cu, xp[1], acc);
   acc = dot2h(w & 0x00300030u, xp[2], acc);
@@ -213,9 +225,11 @@ template <int P> struct WavesPerBlock { static constexpr int value = (P == 1) ? 
 // MODE 1 (PK): scales/zeros come from the packed companion GemvArgs::sz (N of every segment even).
 // MODE 2 (GATHER): expert-indexed launch (GemvArgs::expert_idx).  Compile-time so that the plain decode launches carry
 // neither the expert-offset arithmetic nor its kernel arguments' loads (measured: 1.5-2 % of a token when done at run time).
+// MODE 3 (PK + XACC): packed companion and the activation vector comes as residual stream + fixed-point accumulator
+// (GemvArgs::x_acc): the launch that follows gbx_attn_oproj_decode.
 template <int BITS, int P, int KS, int D, bool BF16, bool SPLIT, int NW, int MODE>
 __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
-  constexpr bool PK = MODE == 1, GATHER = MODE == 2;
+  constexpr bool PK = MODE == 1 || MODE == 3, GATHER = MODE == 2, XACC = MODE == 3;
   constexpr int NT = NW * 64;
   constexpr int GPB = NW / 4;                                 // KS == 4: row groups (of four K-quarter waves) per workgroup
   using F = Fmt<BITS>;
@@ -224,9 +238,6 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
   constexpr int PAIRS = L::PAIRS, SSTR = L::SSTR, NSUB = F::NSUB;
   constexpr int R = GEMV_R;
   constexpr int UPS = F::VPL / F::UNIT_VALS;                 // units per slot
-  constexpr int UPT = (P * KS * 64 * UPS + NT - 1) / NT;     // units per thread in the prologue
-  constexpr int UW = F::UNIT_VALS / 2;                       // 32-bit words of activations per unit
-  constexpr int UPSUB = (32 / F::UNIT_VALS) ? (32 / F::UNIT_VALS) : 1;   // units per 32-value sub-slot
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int K = a.K, N = a.N;
@@ -327,26 +338,75 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
         (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((31 << 11) | 20)) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
 #endif
   // ---------------- 1. activation (and norm weight) loads first: vmcnt retires in order -------------------------
+  // Prologue geometry (round 3): the conversion of x into the pre-shifted image is redundant per workgroup and bound by
+  // the CU's vector ALUs (~10 instructions per value; stamps: 0.5-0.9 us with one 16-value unit per thread and three
+  // quarters of a fat workgroup's threads idle), so a thread takes PP PAIRS of one unit -- as few as keeps every thread
+  // of the workgroup busy (2 pairs = 4 values in the 16-wave geometry at K = 4096) -- and the per-32-value statistics meet
+  // through DPP inside the 16 / PP neighbouring lanes.  3 bits keeps whole units (its pairs are not contiguous).
+  constexpr int UP = F::UNIT_PAIRS;
+  constexpr int PAIRS_MAX = P * KS * 64 * (F::VPL / 2);
+  constexpr int PPQ = (PAIRS_MAX + NT - 1) / NT;
+  constexpr int PP = (BITS == 3) ? UP : (PPQ <= 2 ? 2 : (PPQ <= 4 ? 4 : UP));     // pairs per thread and unit (<= UP: 4-bit units have 4)
+  static_assert(PP <= UP || BITS == 3, "pairs per thread");
+  constexpr int PPU = PP < UP ? PP : UP;
+  constexpr int TPU = UP / PPU;                               // threads per unit
+  constexpr int UPT = (PAIRS_MAX + NT * PPU - 1) / (NT * PPU);   // (unit, part) items per thread
+  constexpr int GL = (BITS == 3) ? 1 : 16 / PPU;              // lanes that share one 32-value sub-slot
+  constexpr int XW = PPU;                                     // 32-bit words of activations per item (2 * PPU values)
   const int nunits = K / F::UNIT_VALS;
+  const int nitems = nunits * TPU;
   // fused RMSNorm only where a wave owns whole rows (KS == 1: K = hidden size); the launcher rejects it otherwise
   const bool norm = (KS == 1) && a.norm_w != nullptr;
   const unsigned short* __restrict__ wg = norm ? a.norm_w : xg;       // dummy source keeps the loads unconditional
   constexpr int WPT = (KS == 1) ? UPT : 1;
-  unsigned xr[UPT][UW], wr[WPT][UW];
+  unsigned xr[UPT][XW], wr[WPT][XW];
+  auto load_item = [&](const unsigned short* base, int it, unsigned* out) {
+    const int u = it / TPU, t = it % TPU;
+    if constexpr (BITS == 3) {                                // the whole 32-value unit: four 16-byte loads
+      const u32x4* src = reinterpret_cast<const u32x4*>(base + static_cast<size_t>(u) * F::UNIT_VALS);
 #pragma unroll
-  for (int j = 0; j < UPT; ++j) {
-    const int u = min(tid + NT * j, nunits - 1);
-    const unsigned* src = reinterpret_cast<const unsigned*>(xg + static_cast<size_t>(u) * F::UNIT_VALS);
-    const unsigned* wsrc = reinterpret_cast<const unsigned*>(wg + static_cast<size_t>(u) * F::UNIT_VALS);
-#pragma unroll
-    for (int q = 0; q < UW; q += 4) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(src + q);
-      xr[j][q] = v.x; xr[j][q + 1] = v.y; xr[j][q + 2] = v.z; xr[j][q + 3] = v.w;
-      if constexpr (KS == 1) {
-        const u32x4 t = *reinterpret_cast<const u32x4*>(wsrc + q);
-        wr[j][q] = t.x; wr[j][q + 1] = t.y; wr[j][q + 2] = t.z; wr[j][q + 3] = t.w;
+      for (int q = 0; q < 4; ++q) { const u32x4 v = src[q]; out[4 * q] = v.x; out[4 * q + 1] = v.y; out[4 * q + 2] = v.z; out[4 * q + 3] = v.w; }
+    } else {                                                  // values [PPU t, +PPU) and [UP + PPU t, +PPU) of the unit
+      const unsigned short* pa = base + static_cast<size_t>(u) * F::UNIT_VALS + PPU * t;
+      const unsigned short* pb = pa + UP;
+      if constexpr (PPU == 2) {
+        out[0] = *reinterpret_cast<const unsigned*>(pa);
+        out[1] = *reinterpret_cast<const unsigned*>(pb);
+      } else if constexpr (PPU == 4) {
+        const u32x2 va = *reinterpret_cast<const u32x2*>(pa), vb = *reinterpret_cast<const u32x2*>(pb);
+        out[0] = va.x; out[1] = va.y; out[2] = vb.x; out[3] = vb.y;
+      } else {
+        const u32x4 va = *reinterpret_cast<const u32x4*>(pa), vb = *reinterpret_cast<const u32x4*>(pb);
+        out[0] = va.x; out[1] = va.y; out[2] = va.z; out[3] = va.w; out[4] = vb.x; out[5] = vb.y; out[6] = vb.z; out[7] = vb.w;
       }
     }
+  };
+#pragma unroll
+  for (int j = 0; j < UPT; ++j) {
+    const int it = min(tid + NT * j, nitems - 1);
+    load_item(xg, it, xr[j]);
+    if constexpr (KS == 1) load_item(wg, it, wr[j]);
+  }
+  // XACC: the accumulator entries of the same values (two per 16-byte load), in the order of the item's registers
+  long long xacc[XACC ? UPT : 1][XACC ? 2 * XW : 1];
+  if constexpr (XACC) {
+#pragma unroll
+    for (int j = 0; j < UPT; ++j) {
+      const int it = min(tid + NT * j, nitems - 1);
+      const int u = it / TPU, t = it % TPU;
+#pragma unroll
+      for (int q = 0; q < XW; ++q) {          // word q of the item holds values (2q, 2q + 1) of its a-part / b-part (or of the unit at 3 bits)
+        int k0;
+        if constexpr (BITS == 3) k0 = u * F::UNIT_VALS + 2 * q;
+        else k0 = u * F::UNIT_VALS + (q < PPU / 2 ? PPU * t + 2 * q : UP + PPU * t + 2 * (q - PPU / 2));
+        const u32x4 v = *reinterpret_cast<const u32x4*>(a.x_acc + k0);
+        xacc[j][2 * q] = static_cast<long long>((static_cast<unsigned long long>(v.y) << 32) | v.x);
+        xacc[j][2 * q + 1] = static_cast<long long>((static_cast<unsigned long long>(v.w) << 32) | v.z);
+      }
+    }
+  }
+  if (a.zero_buf) {                          // wave-uniform; a handful of 8-byte stores per thread at most
+    for (int i = blockIdx.x * NT + tid; i < a.zero_n; i += static_cast<int>(gridDim.x) * NT) a.zero_buf[i] = 0;
   }
 
   // ---------------- 2. the first batch of packed rows goes in flight before any activation math ---------------
@@ -383,6 +443,34 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
   issue(ring[0], batch_of(0) * rowstep);
 
   GBX_STAMP(1);
+  // ---------------- 3.0 XACC: x <- round(x + round(acc * 2^-32)) (the o_proj epilogue `h + r` of qllama.py:138) ------
+  if constexpr (XACC) {
+#pragma unroll
+    for (int j = 0; j < UPT; ++j) {
+#pragma unroll
+      for (int q = 0; q < XW; ++q) {
+        const float r0 = round_bf16_or_f16(static_cast<float>(xacc[j][2 * q]) * (1.f / 4294967296.f), BF16);
+        const float r1 = round_bf16_or_f16(static_cast<float>(xacc[j][2 * q + 1]) * (1.f / 4294967296.f), BF16);
+        const unsigned lo = f32_to_act<BF16>(act_lo<BF16>(xr[j][q]) + r0), hi = f32_to_act<BF16>(act_hi<BF16>(xr[j][q]) + r1);
+        xr[j][q] = lo | (hi << 16);
+      }
+      const int it = tid + NT * j;
+      if (blockIdx.x == 0 && a.x_out && it < nitems) {        // the new residual stream, once
+        const int u = it / TPU, t = it % TPU;
+        if constexpr (BITS == 3) {
+          u32x4* dst = reinterpret_cast<u32x4*>(a.x_out + static_cast<size_t>(u) * F::UNIT_VALS);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dst[q] = u32x4{xr[j][4 * q], xr[j][4 * q + 1], xr[j][4 * q + 2], xr[j][4 * q + 3]};
+        } else {
+          unsigned* da = reinterpret_cast<unsigned*>(a.x_out + static_cast<size_t>(u) * F::UNIT_VALS + PPU * t);
+          unsigned* db = reinterpret_cast<unsigned*>(a.x_out + static_cast<size_t>(u) * F::UNIT_VALS + UP + PPU * t);
+#pragma unroll
+          for (int q = 0; q < PPU / 2; ++q) { da[q] = xr[j][q]; db[q] = xr[j][PPU / 2 + q]; }
+        }
+      }
+    }
+  }
+
   // ---------------- 3a. optional fused RMSNorm: block-wide mean of squares ---------------------------------------
   float rstd = 1.f;
 #ifdef GBX_STAMPS
@@ -393,9 +481,9 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
     float ssq = 0.f;
 #pragma unroll
     for (int j = 0; j < UPT; ++j) {
-      const bool live = (tid + NT * j) < nunits;
+      const bool live = (tid + NT * j) < nitems;
 #pragma unroll
-      for (int q = 0; q < UW; ++q) {
+      for (int q = 0; q < XW; ++q) {
         const float lo = act_lo<BF16>(xr[j][q]), hi = act_hi<BF16>(xr[j][q]);
         ssq += live ? (lo * lo + hi * hi) : 0.f;
       }
@@ -413,48 +501,65 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
   // ---------------- 3b. activations -> pre-shifted fp16 pairs, one block exponent per 32-value sub-slot ----------
 #pragma unroll
   for (int j = 0; j < UPT; ++j) {
-    const int u = tid + NT * j;
-    float xf[F::UNIT_VALS];
-    unsigned amax = 0;
+    // waves whose items all lie past the end skip the arithmetic (wave-uniform): in a fat workgroup they would only compete
+    // with the live waves for the vector ALUs
+    if ((tid & ~63) + NT * j < nitems) {
+      const int it = tid + NT * j;
+      const int u = it / TPU, t = it % TPU;
+      // value of pair i: low half xa[i] (field ka), high half xb[i] (field kb)
+      float xa[PPU], xb[PPU];
+      unsigned amax = 0;
+      float usum = 0.f;
 #pragma unroll
-    for (int q = 0; q < UW; ++q) {
-      float lo = act_lo<BF16>(xr[j][q]), hi = act_hi<BF16>(xr[j][q]);
-      if constexpr (KS == 1) {
-        if (norm) {   // one rounding to the activation dtype, like the reference's RMSNorm output
-          lo = round_bf16_or_f16(lo * rstd * act_lo<BF16>(wr[j][q]), BF16);
-          hi = round_bf16_or_f16(hi * rstd * act_hi<BF16>(wr[j][q]), BF16);
+      for (int i = 0; i < PPU; ++i) {
+        int wa, ha, wb, hb;                                     // (word, half) of the two values inside the item's registers
+        if constexpr (BITS == 3) { wa = F::ka(i) >> 1; ha = F::ka(i) & 1; wb = F::kb(i) >> 1; hb = F::kb(i) & 1; }
+        else { wa = i >> 1; ha = i & 1; wb = (PPU >> 1) + (i >> 1); hb = i & 1; }
+        float va = ha ? act_hi<BF16>(xr[j][wa]) : act_lo<BF16>(xr[j][wa]);
+        float vb = hb ? act_hi<BF16>(xr[j][wb]) : act_lo<BF16>(xr[j][wb]);
+        if constexpr (KS == 1) {
+          if (norm) {   // one rounding to the activation dtype, like the reference's RMSNorm output
+            va = round_bf16_or_f16(va * rstd * (ha ? act_hi<BF16>(wr[j][wa]) : act_lo<BF16>(wr[j][wa])), BF16);
+            vb = round_bf16_or_f16(vb * rstd * (hb ? act_hi<BF16>(wr[j][wb]) : act_lo<BF16>(wr[j][wb])), BF16);
+          }
         }
+        xa[i] = va;
+        xb[i] = vb;
+        usum += va + vb;
+        amax = max(amax, max(__float_as_uint(va) & 0x7FFFFFFFu, __float_as_uint(vb) & 0x7FFFFFFFu));
       }
-      xf[2 * q] = lo;
-      xf[2 * q + 1] = hi;
-      amax = max(amax, max(__float_as_uint(lo) & 0x7FFFFFFFu, __float_as_uint(hi) & 0x7FFFFFFFu));
-    }
-    float usum = 0.f;
+      // sub-slot statistics over the GL lanes that share it (every lane of a live wave takes part; items past the end hold
+      // copies of the last item and only ever meet each other or are never stored)
+      float ssum = usum;
+      if constexpr (GL >= 2) { ssum += dpp_f32<0xB1>(ssum); amax = max(amax, dpp_u32<0xB1>(amax)); }
+      if constexpr (GL >= 4) { ssum += dpp_f32<0x4E>(ssum); amax = max(amax, dpp_u32<0x4E>(amax)); }
+      if constexpr (GL >= 8) { ssum += dpp_f32<0x141>(ssum); amax = max(amax, dpp_u32<0x141>(amax)); }
+      // largest |x| of the sub-slot lands in [2^14, 2^15) as fp16; products with q*2^(pos-24) stay exact
+      int E = 141 - static_cast<int>(amax >> 23);
+      E = min(max(E, -100), 110);
+      if (it < nitems) {
+        const int slot = u / UPS, uin = u % UPS;
+        unsigned* dst = reinterpret_cast<unsigned*>(xp_lds + static_cast<size_t>(slot) * SSTR + uin * UP + PPU * t);
+        unsigned img[PPU];
 #pragma unroll
-    for (int q = 0; q < F::UNIT_VALS; ++q) usum += xf[q];
-    // every lane takes part in the DPP exchanges; units past the end only ever pair with each other
-    float ssum;
-    if constexpr (BITS == 2) { ssum = pair_sum(usum); amax = max(amax, dpp_u32<0xB1>(amax)); }
-    else if constexpr (BITS == 4) {
-      ssum = quad_sum(usum);
-      amax = max(amax, dpp_u32<0xB1>(amax));
-      amax = max(amax, dpp_u32<0x4E>(amax));
-    } else ssum = usum;
-    // largest |x| of the sub-slot lands in [2^14, 2^15) as fp16; products with q*2^(pos-24) stay exact
-    int E = 141 - static_cast<int>(amax >> 23);
-    E = min(max(E, -100), 110);
-    if (u < nunits) {
-      const int slot = u / UPS, uin = u % UPS;
-      h2* dst = xp_lds + static_cast<size_t>(slot) * SSTR + uin * F::UNIT_PAIRS;
+        for (int i = 0; i < PPU; ++i) {
+          int ps;                                               // bit position of pair (PPU t + i) of the unit
+          if constexpr (BITS == 3) ps = F::pos(i);
+          else if constexpr (BITS == 2) { const int pi = PPU * t + i; ps = 2 * (pi < 5 ? pi : pi - 5); }
+          else { ps = ((PPU * t + i) & 1) ? 4 : 0; }
+          const float sc = exp2i(E - ps);
+          h2 v;
+          v.x = static_cast<_Float16>(xa[i] * sc);
+          v.y = static_cast<_Float16>(xb[i] * sc);
+          img[i] = as_u32(v);
+        }
+        if constexpr (PPU == 2) *reinterpret_cast<u32x2*>(dst) = u32x2{img[0], img[1]};
+        else {
 #pragma unroll
-      for (int i = 0; i < F::UNIT_PAIRS; ++i) {
-        const float sc = exp2i(E - F::pos(i));
-        h2 v;
-        v.x = static_cast<_Float16>(xf[F::ka(i)] * sc);
-        v.y = static_cast<_Float16>(xf[F::kb(i)] * sc);
-        dst[i] = v;
+          for (int i = 0; i < PPU; i += 4) *reinterpret_cast<u32x4*>(dst + i) = u32x4{img[i], img[i + 1], img[i + 2], img[i + 3]};
+        }
+        if ((it % GL) == 0) xs_lds[it / GL] = make_float2(ssum, exp2i(24 - E));
       }
-      if ((u % UPSUB) == 0) xs_lds[u / UPSUB] = make_float2(ssum, exp2i(24 - E));
     }
   }
   GBX_STAMP(10);
@@ -671,21 +776,35 @@ static hipError_t launch_gemv_nw(const GemvArgs& a, int M, bool bf16, int nbatch
   return launch_gemv_d<BITS, P, KS, 2, SPLIT, NW, PK>(a, M, bf16, bpo, nbatches, stream);
 }
 
-// Geometry: small matrices (a few rows per wave) launch as 4-wave workgroups (fast launch ramp, the duplicated
-// activation prologue is cheap in absolute terms); large ones as fat workgroups (prologue amortised 16x).
+// Geometry: large matrices launch as fat workgroups (16 waves at one pass per row, 8 at two: the activation prologue is
+// amortised over a whole CU and, since round 3, spread over all of its threads); small ones (a few rows per wave: q/k/v, o)
+// as 4-wave workgroups (several per CU: every CU gets a prologue-light workgroup early).
+// (measured, round 3, with the per-thread prologue items: 8 / 12 / 16-wave workgroups for q/k/v and o: 753 / 758 / 748 tok/s vs 764)
+template <int BITS, int P, int KS, bool SPLIT, int MODE>
+static hipError_t launch_gemv_small(const GemvArgs& a, int M, bool bf16, int nbatches, hipStream_t stream) {
+  return launch_gemv_nw<BITS, P, KS, SPLIT, 4, MODE>(a, M, bf16, nbatches, stream);
+}
 template <int BITS, int P, int KS, bool SPLIT>
 static hipError_t launch_gemv_p(const GemvArgs& a, int M, bool bf16, hipStream_t stream) {
   const int rowstep = a.swiglu ? 1 : GEMV_R;
   const int nbatches = (a.N + rowstep - 1) / rowstep;
+  if (a.sz && a.x_acc) {   // ... whose activations are residual stream + fixed-point accumulator (behind gbx_attn_oproj_decode)
+    if constexpr (KS == 1 && !SPLIT) {
+      if (nbatches <= 4096) return launch_gemv_small<BITS, P, KS, SPLIT, 3>(a, M, bf16, nbatches, stream);
+      return launch_gemv_nw<BITS, P, KS, SPLIT, WavesPerBlock<P>::value, 3>(a, M, bf16, nbatches, stream);
+    }
+    return hipErrorInvalidValue;
+  }
   if (a.sz) {              // packed scale/zero companion of the launch (decode runner)
-    if (KS == 1 && nbatches <= 4096) return launch_gemv_nw<BITS, P, KS, SPLIT, 4, 1>(a, M, bf16, nbatches, stream);
+    if (KS == 1 && nbatches <= 4096) return launch_gemv_small<BITS, P, KS, SPLIT, 1>(a, M, bf16, nbatches, stream);
+    // (measured, round 3: 14-wave workgroups on all 256 CUs instead of 16 waves on 224: 12.8 vs 11.2 us for gate|up; 12 waves: 14.3)
     return launch_gemv_nw<BITS, P, KS, SPLIT, WavesPerBlock<P>::value, 1>(a, M, bf16, nbatches, stream);
   }
   if (a.expert_idx) {      // expert-indexed pairs (QuantizedSwitchLinear)
-    if (KS == 1 && nbatches <= 4096) return launch_gemv_nw<BITS, P, KS, SPLIT, 4, 2>(a, M, bf16, nbatches, stream);
+    if (KS == 1 && nbatches <= 4096) return launch_gemv_small<BITS, P, KS, SPLIT, 2>(a, M, bf16, nbatches, stream);
     return launch_gemv_nw<BITS, P, KS, SPLIT, WavesPerBlock<P>::value, 2>(a, M, bf16, nbatches, stream);
   }
-  if (KS == 1 && nbatches <= 4096) return launch_gemv_nw<BITS, P, KS, SPLIT, 4, 0>(a, M, bf16, nbatches, stream);
+  if (KS == 1 && nbatches <= 4096) return launch_gemv_small<BITS, P, KS, SPLIT, 0>(a, M, bf16, nbatches, stream);
   return launch_gemv_nw<BITS, P, KS, SPLIT, WavesPerBlock<P>::value, 0>(a, M, bf16, nbatches, stream);
 }
 

@@ -87,6 +87,12 @@ hipError_t launch_attn_decode(const void* q, const void* k, const void* v, void*
                               const void* q_bias = nullptr, const void* k_bias = nullptr, const void* v_bias = nullptr,
                               float* ws = nullptr);
 int attn_splits(int batch, int n_heads, int n_kv, int capacity);
+// attn_oproj.hip: attention + o_proj slices of one decode token in one launch (short caches)
+bool attn_oproj_supported(int n_heads, int n_kv, int head_dim, int D, int bits, int group_size, int capacity);
+hipError_t launch_attn_oproj(const void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
+                             const long long* pos, const uint32_t* qweight, const void* scales, const void* zeros, long long* acc,
+                             int n_heads, int n_kv, int head_dim, int capacity, int D, int bits, int log2g, float rope_scale,
+                             float sm_scale, int traditional, bool bf16, hipStream_t s);
 size_t attn_workspace_bytes(int batch, int n_heads, int n_kv, int head_dim, int capacity);
 hipError_t launch_dense_gemv(const void* x, const void* w, void* y, const void* norm_w, float eps, int N, int K, void* best,
                              bool bf16, hipStream_t s);

@@ -312,7 +312,19 @@ class FusedDecodeRunner(DecodeRunner):
         self.attn_ws = torch.empty((need,), dtype=torch.uint8, device=dev) if need else None   # context split of long caches
         self.chain = False                  # True while capturing / replaying the on-device greedy chain
         self.graph_chain = None
+        # Short caches (no context split): attention + o_proj as ONE launch whose partial sums land in a fixed-point
+        # accumulator; the gate|up launch forms h + o in its prologue and the down launch clears the accumulator -- four
+        # launches per block instead of five (gbx_attn_oproj_decode).  GBX_FUSE_AO=0 keeps the five-launch block.
+        import os
+        self.acc = torch.zeros((D + a0.n_kv_heads * ops.ATTN_OPROJ_HANDOFF_WORDS,), dtype=torch.int64, device=dev)   # o_proj sums | hand-off words
+        self.fuse_ao = (os.environ.get("GBX_FUSE_AO", "1") != "0" and not tp and self.attn_ws is None and
+                        all(getattr(b.self_attn, "q_norm", None) is None and b.self_attn.q_proj.bias is None and
+                            ops.attn_oproj_supported(b.self_attn.n_heads, b.self_attn.n_kv_heads, b.self_attn.head_dim, b.self_attn.o_proj) and
+                            b.mlp.gate_proj.group_size >= 64 and
+                            b.mlp.gate_proj.input_dims // (64 if b.mlp.gate_proj.bits == 2 else 32) <= 128
+                            for b in model.model.layers))
         self.descs = []
+        self.descs_ao = []
         self.packed = []                    # load-time (scale | zero) companions, kept alive for the descriptors
         for blk in model.model.layers:
             at, mlp = blk.self_attn, blk.mlp
@@ -333,6 +345,17 @@ class FusedDecodeRunner(DecodeRunner):
                 ops.make_fused_desc(self.actb, (mlp.down_proj,), (self.hb,), residual=self.pb if r0 else None, packed=p_dn) if tp else
                 ops.make_fused_desc(self.actb, (mlp.down_proj,), (self.hb,), residual=self.hb, packed=p_dn),
             ))
+            if self.fuse_ao and p_gu is not None:
+                self.descs_ao.append((
+                    # x = hb + round(acc) formed in the prologue, the new stream written to pb once
+                    ops.make_fused_desc(self.hb, (mlp.gate_proj, mlp.up_proj), (self.actb,),
+                                        norm_weight=blk.post_attention_layernorm.weight, eps=blk.post_attention_layernorm.eps,
+                                        swiglu=True, packed=p_gu, x_acc=self.acc[:D], x_out=self.pb),
+                    # hb = pb + down(act); clears the accumulator for the next block
+                    ops.make_fused_desc(self.actb, (mlp.down_proj,), (self.hb,), residual=self.pb, packed=p_dn, zero_buf=self.acc),
+                ))
+            else:
+                self.fuse_ao = False
         super().__init__(model, caches, use_graph=use_graph)
 
     def _forward(self):
@@ -342,9 +365,17 @@ class FusedDecodeRunner(DecodeRunner):
         # from them and advances the position: no host involvement between tokens)
         ops.embed_next_token(self.keys, self.tok, self.pos, m.embed_tokens.weight, self.hb, from_keys=self.chain,
                              advance_pos=self.chain)
-        for blk, c, (d_qkv, d_o, d_gu, d_dn) in zip(m.layers, self.caches, self.descs):
+        for li, (blk, c, (d_qkv, d_o, d_gu, d_dn)) in enumerate(zip(m.layers, self.caches, self.descs)):
             at = blk.self_attn
             ops.qlinear_fused(d_qkv, dev)
+            if self.fuse_ao:
+                d_gu2, d_dn2 = self.descs_ao[li]
+                ops.attn_oproj_decode(self.qb, self.kb, self.vb, c.keys, c.values, at.rope.inv_freq, self.pos, at.o_proj, self.acc,
+                                      at.n_heads, at.n_kv_heads, at.head_dim, c.capacity, getattr(at.rope, "scale", 1.0), at.scale,
+                                      at.rope.traditional)
+                ops.qlinear_fused(d_gu2, dev)
+                ops.qlinear_fused(d_dn2, dev)
+                continue
             qn = getattr(at, "q_norm", None)
             if qn is not None or at.q_proj.bias is not None or self.attn_ws is not None:
                 # Qwen3 (per-head q / k norms) and Qwen2 (q / k / v biases): the grouped kernel takes both in its prologue;

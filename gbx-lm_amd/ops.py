@@ -481,10 +481,13 @@ def gemv_tiled(x: torch.Tensor, wt: torch.Tensor, szt: torch.Tensor, n: int, k: 
 
 def make_fused_desc(x: torch.Tensor, mods, ys, norm_weight: Optional[torch.Tensor] = None, eps: float = 0.0,
                     residual: Optional[torch.Tensor] = None, swiglu: bool = False, packed=None,
-                    bias_elsewhere: bool = False) -> "_lib.FusedDesc":
+                    bias_elsewhere: bool = False, x_acc: Optional[torch.Tensor] = None, x_out: Optional[torch.Tensor] = None,
+                    zero_buf: Optional[torch.Tensor] = None) -> "_lib.FusedDesc":
     """Descriptor for one launch over 1-3 QuantizedLinear modules sharing ``x`` (q/k/v, gate/up, or a single one).
     ``packed``: ``pack_scales_zeros`` companion of the launch (per-module packs concatenated in order, or the one
     gate/up-interleaved tensor with ``swiglu``).
+    ``x_acc`` (int64 [K], the fixed-point o_proj sums of ``attn_oproj_decode``): the launch forms x <- x + round(x_acc * 2^-32)
+    in its prologue and writes it to ``x_out`` once; ``zero_buf`` (int64): cleared by this launch for a later one.
     All tensors must stay alive and in place while the descriptor is used (the decode runner owns static buffers)."""
     m0 = mods[0]
     for m in mods:
@@ -514,6 +517,15 @@ def make_fused_desc(x: torch.Tensor, mods, ys, norm_weight: Optional[torch.Tenso
         if packed.dtype != torch.int32 or packed.numel() != rows * (m0.input_dims // m0.group_size):
             raise ValueError("packed scales/zeros do not match the launch (int32, one dword per row and group)")
         d.sz = packed.data_ptr()
+    if x_acc is not None:
+        if x_acc.dtype != torch.int64 or x_acc.numel() != m0.input_dims:
+            raise ValueError("x_acc must be int64 [K]")
+        d.x_acc = x_acc.data_ptr()
+        d.x_out = x_out.data_ptr() if x_out is not None else None
+    if zero_buf is not None:
+        if zero_buf.dtype != torch.int64:
+            raise ValueError("zero_buf must be int64")
+        d.zero_buf, d.zero_n = zero_buf.data_ptr(), zero_buf.numel()
     return d
 
 
@@ -553,6 +565,29 @@ def attn_decode(q, k, v, kcache, vcache, inv_freq, pos, out, n_heads: int, n_kv:
                                           inv_freq.data_ptr(), pos.data_ptr(), out.data_ptr(), n_heads, n_kv, head_dim,
                                           capacity, float(rope_scale), float(sm_scale), int(bool(traditional)),
                                           _DT[q.dtype], _stream_ptr(q.device)))
+
+
+ATTN_OPROJ_HANDOFF_WORDS = 288     # GBX_ATTN_OPROJ_HANDOFF_WORDS (include/gbx_qlinear.h)
+
+
+def attn_oproj_supported(n_heads: int, n_kv: int, head_dim: int, o_proj) -> bool:
+    return bool(_lib.lib().gbx_attn_oproj_supported(n_heads, n_kv, head_dim, o_proj.output_dims, o_proj.bits, o_proj.group_size)) \
+        and o_proj.input_dims == n_heads * head_dim and o_proj.bias is None
+
+
+def attn_oproj_decode(q, k, v, kcache, vcache, inv_freq, pos, o_proj, acc, n_heads: int, n_kv: int, head_dim: int, capacity: int,
+                      rope_scale: float, sm_scale: float, traditional: bool) -> None:
+    """RoPE + cache append + attention + o_proj of one new token (batch 1, short cache) in one launch; the o_proj sums are
+    ADDED into ``acc[:D]`` (int64, fixed point 2^-32); ``acc`` is int64 [D + n_kv * ATTN_OPROJ_HANDOFF_WORDS], all zero on
+    entry (the tail is the in-launch hand-off area) -- gbx_attn_oproj_decode."""
+    if acc.dtype != torch.int64 or acc.numel() != o_proj.output_dims + n_kv * ATTN_OPROJ_HANDOFF_WORDS:
+        raise ValueError("acc must be int64 [D + n_kv * ATTN_OPROJ_HANDOFF_WORDS]")
+    _lib.check(_lib.lib().gbx_attn_oproj_decode(q.data_ptr(), k.data_ptr(), v.data_ptr(), kcache.data_ptr(), vcache.data_ptr(),
+                                                inv_freq.data_ptr(), pos.data_ptr(), o_proj.qweight.data_ptr(),
+                                                o_proj.scales.data_ptr(), o_proj.zeros.data_ptr(), acc.data_ptr(), n_heads, n_kv,
+                                                head_dim, capacity, o_proj.output_dims, o_proj.bits, o_proj.group_size,
+                                                float(rope_scale), float(sm_scale), int(bool(traditional)), _DT[q.dtype],
+                                                _stream_ptr(q.device)))
 
 
 def attn_decode_batched(q, k, v, kcache, vcache, inv_freq, pos, out, n_heads: int, n_kv: int, head_dim: int,

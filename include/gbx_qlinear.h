@@ -122,6 +122,15 @@ typedef struct gbx_qlinear_fused {
    * gbx_pack_scales_zeros (segments concatenated in order, every N even; gate/up interleaved for swiglu) --
    * one 8-byte load per lane and row pair instead of four 2-byte loads. */
   const uint32_t* sz;
+  /* optional (round 3; needs sz, K <= one row pass, group_size >= 64): the activation vector is formed in the launch's
+   * prologue as x <- round(x + round(x_acc * 2^-32)) -- x_acc = the int64 fixed-point o_proj sums gbx_attn_oproj_decode
+   * leaves behind, i.e. the residual add `h = x + r` of qllama.py:138 -- and, with x_out != NULL (never x itself), the new
+   * x is also written there once. */
+  const int64_t* x_acc;
+  void* x_out;
+  /* optional: zero_n int64 words at zero_buf are cleared by this launch (the accumulator, once its consumer has run) */
+  int64_t* zero_buf;
+  int32_t zero_n;
 } gbx_qlinear_fused;
 
 int gbx_qlinear_fused_forward(const gbx_qlinear_fused* desc, void* hip_stream);
@@ -248,6 +257,27 @@ int gbx_attn_decode(const void* q, const void* k, const void* v, void* kcache, v
                     const float* inv_freq, const int64_t* pos, void* out,
                     int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int32_t capacity,
                     float rope_scale, float sm_scale, int32_t traditional, int32_t act_dtype, void* hip_stream);
+
+/* gbx_attn_decode and the o_proj QuantizedLinear call behind it (qllama.py:78-96; quantized_linear_gba.py:195-203 at M = 1)
+ * in ONE launch, for short caches: workgroup (kv group g, row block r) computes the attention of the group's query heads
+ * and multiplies its slice Wo[128 r .. 128 r + 127, columns of group g]; the partial row sums are ADDED into acc[D] as
+ * 64-bit fixed-point integers in units of 2^-32 (integer adds: the result does not depend on the arrival order).  The
+ * workgroups r < 4 of a group each compute ONE query head (all 16 waves) and hand its 128 outputs to the group's other
+ * workgroups inside the launch as 72 eight-byte {tag, value} words written through to memory; consumers poll them
+ * (bounded spin; they only ever wait for workgroups with a lower block index).
+ * acc: int64[D + n_kv_heads * GBX_ATTN_OPROJ_HANDOFF_WORDS]: the first D words receive the sums, the rest is the hand-off
+ * area; ALL of it must be zero on entry (a gbx_qlinear_fused launch with zero_buf = acc, zero_n = its length clears it
+ * again once the consumer -- a gbx_qlinear_fused launch with x_acc = acc -- has run).  Shapes: head_dim 128,
+ * n_heads == 4 * n_kv_heads, D % 128 == 0, D >= 512, o_proj [D, n_heads * head_dim] at 2 / 3 / 4 bits with group_size 64 or
+ * 128 (gbx_attn_oproj_supported says so).  The context is not split over workgroups: callers switch to gbx_attn_decode_ws +
+ * gbx_qlinear_fused_forward once the cache is long (the decode runner: capacity >= 1024). */
+#define GBX_ATTN_OPROJ_HANDOFF_WORDS 288
+int gbx_attn_oproj_supported(int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int32_t D, int32_t bits, int32_t group_size);
+int gbx_attn_oproj_decode(const void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
+                          const int64_t* pos, const uint32_t* o_qweight, const void* o_scales, const void* o_zeros,
+                          int64_t* acc, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int32_t capacity, int32_t D,
+                          int32_t bits, int32_t group_size, float rope_scale, float sm_scale, int32_t traditional,
+                          int32_t act_dtype, void* hip_stream);
 
 /* y[N] = W[N,K] x'[K] for an UNQUANTISED 16-bit weight (lm_head / tied embed_tokens.as_linear,
  * qllama.py:194-198), x' = x or RMSNorm(x)*norm_weight (the final model.norm, qllama.py:174) when

@@ -90,7 +90,7 @@ for n in names:
     gp = np.mean(gaps[n]) if gaps[n] else float("nan")
     tot += span + (gp if gp == gp else 0)
     print(f"{n:7s} waves {rows[n][0][3]:5d}  span {span:6.2f} us  start-spread {np.mean([r[4] for r in rows[n]]):5.2f}  gap-to-next {gp:5.2f}")
-    print("         stamp medians: " + "  ".join(f"s{i}={med[i]:.2f}" for i in (0, 1, 8, 9, 10, 2, 3, 4, 5, 6)))
+    print("         stamp medians: " + "  ".join(f"s{i}={med[i]:.2f}" for i in (0, 1, 8, 9, 10, 11, 12, 2, 3, 4, 5, 6, 7)))
     print("         stamp maxima:  " + "  ".join(f"s{i}={mx[i]:.2f}" for i in range(7)))
 print(f"sum over a 2-bit layer (spans + gaps): {tot:.2f} us")
 print("gemv stamps: 0 start, 1 x + first batch issued, 2 prologue done (barrier), 3 ring issued, 4 loop done, 5 first drain consumed, 6 end")
