@@ -18,6 +18,7 @@
 //     s*sum(q*x) + z*sum(x), then one DPP wave reduction per row.
 #pragma once
 #include "gbx_device.h"
+#include "kernels.h"
 #include <cstdlib>
 
 namespace gbx {
@@ -831,6 +832,7 @@ static hipError_t dispatch_gemv(const GemvArgs& a, int M, bool bf16, hipStream_t
 
 #define GBX_DEFINE_LAUNCH_GEMV(BITS)                                                              \
   template <> hipError_t launch_gemv<BITS>(const GemvArgs& a, int M, bool bf16, hipStream_t s) { \
+    if (BITS == 2 && gemv_mx_eligible(a, M) && gemv_mx_shape_ok(a)) return launch_gemv_mx(a, bf16, s); \
     return dispatch_gemv<BITS>(a, M, bf16, s);                                                    \
   }
 

@@ -16,6 +16,10 @@ constexpr int STAMP_REGION_WORDS = 4096 * 16;
 
 template <int BITS>
 hipError_t launch_gemv(const GemvArgs& a, int M, bool bf16, hipStream_t stream);
+// gemv_mx.hip: the 2-bit decode GEMV on the block-scaled matrix cores (FP4 weights in place x FP8 activation limbs)
+bool gemv_mx_eligible(const GemvArgs& a, int M);
+bool gemv_mx_shape_ok(const GemvArgs& a);
+hipError_t launch_gemv_mx(const GemvArgs& a, bool bf16, hipStream_t s);
 
 hipError_t launch_unpack(const uint32_t* qw, int32_t* q, int N, int K, int bits, hipStream_t s);
 hipError_t launch_dequant(const uint32_t* qw, const void* sc, const void* ze, void* w, int N, int K, int bits,
