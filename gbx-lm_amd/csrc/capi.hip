@@ -874,7 +874,8 @@ int gbx_dense_forward_ws(const void* x, const void* w, const void* bias, void* y
   if (M < 0 || N <= 0 || K <= 0) return fail(GBX_ERR_INVALID, "bad shape M=%lld N=%d K=%d", (long long)M, N, K);
   if (M == 0) return GBX_OK;
   if (!x || !w || !y) return fail(GBX_ERR_INVALID, "null device pointer");
-  if (!aligned(x, 16) || !aligned(w, 16) || !aligned(y, 2)) return fail(GBX_ERR_INVALID, "x and w must be 16-byte aligned");
+  if (!aligned(x, 16) || !aligned(w, 16) || !aligned(y, (N % 8) == 0 ? 16 : 2))
+    return fail(GBX_ERR_INVALID, "x and w must be 16-byte aligned (and y too when N %% 8 == 0: the epilogue stores 16 bytes at a time)");
   if (M > 2147483647LL || !gbx::gemm_dense_supported(static_cast<int>(M), N, K))
     return fail(GBX_ERR_UNSUPPORTED, "dense matrix-core GEMM needs K %% 64 == 0 and M*K, N*K < 2^30 elements (M=%lld N=%d K=%d)", (long long)M, N, K);
   const size_t need = gbx_dense_workspace_bytes(M, N, K);
@@ -891,7 +892,8 @@ int gbx_dense_forward(const void* x, const void* w, const void* bias, void* y, i
   if (M < 0 || N <= 0 || K <= 0) return fail(GBX_ERR_INVALID, "bad shape M=%lld N=%d K=%d", (long long)M, N, K);
   if (M == 0) return GBX_OK;
   if (!x || !w || !y) return fail(GBX_ERR_INVALID, "null device pointer");
-  if (!aligned(x, 16) || !aligned(w, 16) || !aligned(y, 2)) return fail(GBX_ERR_INVALID, "x and w must be 16-byte aligned");
+  if (!aligned(x, 16) || !aligned(w, 16) || !aligned(y, (N % 8) == 0 ? 16 : 2))
+    return fail(GBX_ERR_INVALID, "x and w must be 16-byte aligned (and y too when N %% 8 == 0: the epilogue stores 16 bytes at a time)");
   if (M > 2147483647LL || !gbx::gemm_dense_supported(static_cast<int>(M), N, K))
     return fail(GBX_ERR_UNSUPPORTED, "dense matrix-core GEMM needs K %% 64 == 0 and M*K, N*K < 2^30 elements (M=%lld N=%d K=%d)", (long long)M, N, K);
   hipError_t e = gbx::launch_gemm_dense(x, w, bias, y, static_cast<int>(M), N, K, act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));

@@ -486,7 +486,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
       for (int q = 0; q < XW; ++q) {
         const float lo = act_lo<BF16>(xr[j][q]), hi = act_hi<BF16>(xr[j][q]);
-        ssq += live ? (lo * lo + hi * hi) : 0.f;
+        ssq += live ? fmaf(hi, hi, lo * lo) : 0.f;   // explicit: -ffp-contract=on may pick either product for the fma, per instantiation
       }
     }
     ssq = wave_sum(ssq);

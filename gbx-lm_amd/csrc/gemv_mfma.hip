@@ -323,12 +323,12 @@ static hipError_t launch_gemv_mfma_spw(const GemvMfmaArgs& a0, bool bf16, hipStr
   a.rg_per_block = RG;
   a.ks = KS;
   const size_t shmem = static_cast<size_t>(nsteps) * 1024 + static_cast<size_t>(G) * 8 + static_cast<size_t>(RG) * tprg * KS * 16 * 4 + 64;
-  static bool attr[2] = {false, false};
-  if (!attr[bf16]) {
+  static DeviceOnce attr[2];
+  if (attr[bf16].pending()) {
     hipError_t e = bf16 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_mfma_kernel<true, SPW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
                         : hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_mfma_kernel<false, SPW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr[bf16] = true;
+    attr[bf16].done();
   }
   dim3 grid(blocks), block(KS * RG * 64);
   if (bf16) hipLaunchKernelGGL((gemv_mfma_kernel<true, SPW>), grid, block, shmem, s, a);

@@ -253,7 +253,7 @@ __device__ __forceinline__ void run_gemv_op(int opi, IssueCur& cur, WaveCtx& w) 
 #pragma unroll
       for (int q = 0; q < UW; ++q) {
         const float lo = act_lo<BF16>(xr[j][q]), hi = act_hi<BF16>(xr[j][q]);
-        ssq += live ? (lo * lo + hi * hi) : 0.f;
+        ssq += live ? fmaf(hi, hi, lo * lo) : 0.f;   // explicit: -ffp-contract=on may pick either product for the fma, per instantiation
       }
     }
     ssq = wave_sum(ssq);
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(ST_NT) void stream_kernel(const StOp first_op, cons
 
 hipError_t launch_stream(const void* dev_prog, const void* host_first_op, int op_begin, int op_end, bool bf16, hipStream_t s) {
   static int ncu = 0;
-  static bool attr_done = false;
+  static DeviceOnce attr_done;
   if (ncu == 0) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -525,12 +525,12 @@ hipError_t launch_stream(const void* dev_prog, const void* host_first_op, int op
     if (e != hipSuccess) return e;
     ncu = prop.multiProcessorCount;
   }
-  if (!attr_done) {
+  if (attr_done.pending()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stream_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_BYTES);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(stream_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_done.done();
   }
   const StOp* prog = static_cast<const StOp*>(dev_prog);
   const StOp first = *static_cast<const StOp*>(host_first_op);

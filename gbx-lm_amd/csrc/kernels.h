@@ -3,8 +3,19 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <atomic>
 
 namespace gbx {
+
+// hipFuncSetAttribute (the opt-in to more than 64 KB of dynamic LDS) is a PER-DEVICE setting: a process that drives several GPUs
+// must make it once on each, and two host threads may race to be first.  `pending()` is true until `done()` has been called on the
+// calling thread's current device; setting the attribute twice is harmless, launching before it is set is not.
+struct DeviceOnce {
+  std::atomic<unsigned long long> seen{0};
+  unsigned long long bit() const { int d = 0; (void)hipGetDevice(&d); return 1ull << (d & 63); }
+  bool pending() const { return (seen.load(std::memory_order_acquire) & bit()) == 0; }
+  void done() { seen.fetch_or(bit(), std::memory_order_release); }
+};
 
 struct GemvArgs;
 

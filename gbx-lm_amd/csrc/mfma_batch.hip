@@ -464,12 +464,12 @@ template <int BITS, int TNW, int NG, int KG, int GRP>
 static hipError_t launch_batch_grp(const MfmaArgs& a, bool bf16, hipStream_t s) {
   constexpr int ROWS = NG * TNW;
   constexpr int SHMEM = 2 * 8 * 32 * XROW + 2 * 8 * (128 / GRP) * 32 * 4;
-  static bool done[2] = {false, false};
-  if (!done[bf16]) {
+  static DeviceOnce done[2];
+  if (done[bf16].pending()) {
     hipError_t e = bf16 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&qgemm_batch_kernel<BITS, TNW, NG, KG, GRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM)
                         : hipFuncSetAttribute(reinterpret_cast<const void*>(&qgemm_batch_kernel<BITS, TNW, NG, KG, GRP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SHMEM);
     if (e != hipSuccess) return e;
-    done[bf16] = true;
+    done[bf16].done();
   }
   dim3 grid(a.swiglu ? (a.n_seg[0] + ROWS / 2 - 1) / (ROWS / 2) : (a.N + ROWS - 1) / ROWS, a.ws ? a.ksplit : 1), block(768);
 #ifdef BX_STAMPS

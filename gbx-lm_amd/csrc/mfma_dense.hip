@@ -316,13 +316,13 @@ hipError_t launch_gemm_dense(const void* x, const void* w, const void* bias, voi
                              bool swiglu, float* part) {
   if (swiglu && (N % 256 || bias)) return hipErrorInvalidValue;
   const int ksplit = (part && !swiglu && N % 4 == 0) ? gemm_dense_ksplit(M, N, K) : 1;
-  static bool done = false;
-  if (!done) {
+  static DeviceOnce once;
+  if (once.pending()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dense_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_LDS);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dense_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_LDS);
     if (e != hipSuccess) return e;
-    done = true;
+    once.done();
   }
   DenseArgs2 a{static_cast<const unsigned short*>(x), static_cast<const unsigned short*>(w), static_cast<const unsigned short*>(bias),
                static_cast<unsigned short*>(y), M, N, K, swiglu ? 1 : 0, ksplit > 1 ? part : nullptr, ksplit};

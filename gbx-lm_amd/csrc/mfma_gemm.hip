@@ -267,12 +267,12 @@ static hipError_t launch_prefill_cfg(const MfmaArgs& a, bool bf16, hipStream_t s
   dim3 grid(8 * ((tiles + 7) / 8), a.ws ? a.ksplit : 1), block(WV * 64);   // x: the kernel maps workgroup -> tile XCD-aware
   const size_t shmem = 2 * static_cast<size_t>(BM + BN) * PROW;
   if (shmem > 48 * 1024) {        // opt in to the large LDS carve-out once per instantiation
-    static bool done[2] = {false, false};
-    if (!done[bf16]) {
+    static DeviceOnce done[2];
+    if (done[bf16].pending()) {
       hipError_t e = bf16 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&qgemm_prefill_kernel<BITS, MT, NT, WV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shmem))
                           : hipFuncSetAttribute(reinterpret_cast<const void*>(&qgemm_prefill_kernel<BITS, MT, NT, WV, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shmem));
       if (e != hipSuccess) return e;
-      done[bf16] = true;
+      done[bf16].done();
     }
   }
   if (bf16) hipLaunchKernelGGL((qgemm_prefill_kernel<BITS, MT, NT, WV, true>), grid, block, shmem, s, a);

@@ -208,12 +208,12 @@ static hipError_t launch_skinny_cfg(const MfmaArgs& a, bool bf16, hipStream_t s)
   const size_t slab_bytes = static_cast<size_t>(KW) * ROWS * XROW;
   const size_t shmem = red_bytes > slab_bytes ? red_bytes : slab_bytes;
   if (shmem > 48 * 1024) {        // opt in to the large LDS carve-out once per instantiation
-    static bool done[2] = {false, false};
-    if (!done[bf16]) {
+    static DeviceOnce done[2];
+    if (done[bf16].pending()) {
       hipError_t e = bf16 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&qgemm_skinny_kernel<BITS, TN, MT, KW, NCH, G128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shmem))
                           : hipFuncSetAttribute(reinterpret_cast<const void*>(&qgemm_skinny_kernel<BITS, TN, MT, KW, NCH, G128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shmem));
       if (e != hipSuccess) return e;
-      done[bf16] = true;
+      done[bf16].done();
     }
   }
   if (bf16) hipLaunchKernelGGL((qgemm_skinny_kernel<BITS, TN, MT, KW, NCH, G128, true>), grid, block, shmem, s, a);

@@ -237,9 +237,12 @@ def graph_decode_step(model, y: torch.Tensor, prompt_cache: List[KVCache]) -> to
             or c0.keys.data_ptr() != getattr(runner, "_kptr", None):
         try:
             runner = GraphDecodeRunner(model, prompt_cache)
-        except RuntimeError:
-            # a forward that cannot be captured (e.g. more (token, expert) pairs than the expert-indexed launch covers needs
-            # the host-grouped gather): this model decodes eagerly from here on
+        except ops.NotCapturable as e:
+            # a forward that cannot be captured (more (token, expert) pairs than the expert-indexed launch covers needs the
+            # host-grouped gather): this model decodes eagerly from here on.  Anything else -- out of memory, a HIP error, a bug
+            # in the captured forward -- propagates.
+            import warnings
+            warnings.warn(f"gbx_lm_amd: graph-replayed decode is unavailable for this model ({e}); decoding eagerly")
             for c in prompt_cache:
                 c.static_active, c.static_pos = False, None
             model._graph_decode_unavailable = True

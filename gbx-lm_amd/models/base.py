@@ -101,12 +101,16 @@ def rope_keys_and_update_cache(rope, k: torch.Tensor, v: torch.Tensor, cache, st
             and rope.inv_freq.is_cuda and rope.inv_freq.dtype == torch.float32):
         prev = cache.offset
         cache.reserve(L, k, v)
+        # (the kernel indexes the cache with k's batch and head counts: a reused cache of another geometry takes the generic path,
+        # whose update_and_fetch raises the shape error)
         if (cache.keys.dtype == k.dtype and cache.values.dtype == k.dtype and cache.keys.is_contiguous() and cache.values.is_contiguous()
-                and cache.keys.shape[3] == D and cache.values.shape[3] == D):
+                and cache.keys.shape[3] == D and cache.values.shape[3] == D
+                and tuple(cache.keys.shape[:2]) == tuple(k.shape[:2]) and tuple(cache.values.shape[:2]) == tuple(v.shape[:2])):
             from .. import ops
             ops.rope_kv_write(k, v, cache.keys, cache.values, rope.inv_freq, start, prev, getattr(rope, "scale", 1.0), rope.traditional)
             cache.offset = prev + L
             return cache.keys[..., :cache.offset, :], cache.values[..., :cache.offset, :]
+        cache.offset = prev                              # fast path not taken: hand an untouched offset to the generic path
     k = rope(k, offset=start)
     if cache is not None:
         k, v = cache.update_and_fetch(k, v)

@@ -27,6 +27,11 @@ def _require_cuda(t: torch.Tensor, name: str) -> None:
             "MI355X (no CPU fallback).")
 
 
+class NotCapturable(RuntimeError):
+    """Raised by an op that would need a host round trip while a HIP graph is being captured (the only failure the graph-replay
+    decode path treats as "decode eagerly instead")."""
+
+
 class _DenseCache:
     """Dequantised copies of packed weights that prompt-sized calls on the dense path (M >= 4096 rows, or >= 1024 with enough tiles)
     left in their workspace, kept resident and reused
@@ -34,7 +39,9 @@ class _DenseCache:
     (25 us per 4096 x 4096 matrix, 11 ms of an 8 x 4096-token prompt pass).  288 GB of HBM per GPU make the 16 GB an 8B model's
     bf16 image takes a fair trade; ``GBX_DENSE_CACHE_GB`` bounds it (default 32, 0 disables), least recently used entries go
     first.  An entry is valid only for the very tensor OBJECTS it was built from (weak references + their in-place version
-    counters and storage addresses), so reloaded, re-created or modified weights never see a stale image."""
+    counters and storage addresses), so reloaded, re-created or modified weights never see a stale image; it is dropped the
+    moment one of those tensors dies (finalizers), and a consumer on another stream waits for the event recorded after the build.
+    NOT seen: a write through ``tensor.data`` (it bumps no version counter) -- call ``dense_cache_invalidate(tensor)`` after one."""
 
     def __init__(self):
         import collections
@@ -47,33 +54,52 @@ class _DenseCache:
         return tuple(id(t) for t in tensors) + tuple(extra)
 
     def get(self, tensors, extra):
-        ent = self.entries.get(self._key(tensors, extra))
+        key = self._key(tensors, extra)
+        ent = self.entries.get(key)
         if ent is None:
             return None
-        refs, versions, dense = ent
+        refs, versions, dense, event, stream = ent
         if any(r() is not t for r, t in zip(refs, tensors)) or versions != tuple((t._version, t.data_ptr()) for t in tensors):
-            self.drop(tensors, extra)
+            self._drop_key(key)
             return None
-        self.entries.move_to_end(self._key(tensors, extra))
+        self.entries.move_to_end(key)
+        cur = torch.cuda.current_stream(dense.device)
+        if event is not None and cur != stream:       # built on another stream: order this consumer behind the build
+            cur.wait_event(event)
         return dense
 
-    def drop(self, tensors, extra):
-        ent = self.entries.pop(self._key(tensors, extra), None)
+    def _drop_key(self, key):
+        ent = self.entries.pop(key, None)
         if ent is not None:
             self.nbytes -= ent[2].numel() * ent[2].element_size()
+
+    def drop(self, tensors, extra):
+        self._drop_key(self._key(tensors, extra))
+
+    def invalidate(self, tensor):
+        """Drop every image built from ``tensor`` (by identity)."""
+        tid = id(tensor)
+        for key in [k for k, ent in self.entries.items() if any(r() is tensor for r in ent[0]) or tid in k[:len(ent[0])]]:
+            self._drop_key(key)
 
     def put(self, tensors, extra, dense):
         import weakref
         size = dense.numel() * dense.element_size()
         if size > self.budget or torch.cuda.is_current_stream_capturing():
             return
-        self.drop(tensors, extra)
+        key = self._key(tensors, extra)
+        self._drop_key(key)
         while self.entries and self.nbytes + size > self.budget:
-            _, (_, _, old) = self.entries.popitem(last=False)
-            self.nbytes -= old.numel() * old.element_size()
-        self.entries[self._key(tensors, extra)] = (tuple(weakref.ref(t) for t in tensors),
-                                                   tuple((t._version, t.data_ptr()) for t in tensors), dense)
+            _, old = self.entries.popitem(last=False)
+            self.nbytes -= old[2].numel() * old[2].element_size()
+        stream = torch.cuda.current_stream(dense.device)
+        event = torch.cuda.Event()
+        event.record(stream)
+        self.entries[key] = (tuple(weakref.ref(t) for t in tensors), tuple((t._version, t.data_ptr()) for t in tensors), dense,
+                             event, stream)
         self.nbytes += size
+        for t in tensors:                              # a dead weight must not pin its image until LRU pressure finds it
+            weakref.finalize(t, self._drop_key, key)
 
     def clear(self):
         self.entries.clear()
@@ -86,6 +112,32 @@ _dense_cache = _DenseCache()
 def dense_cache_clear() -> None:
     """Free the resident dequantised weight images (see ``_DenseCache``)."""
     _dense_cache.clear()
+
+
+def dense_cache_invalidate(tensor: torch.Tensor) -> None:
+    """Drop the resident images built from ``tensor`` (a packed weight, its scales or zeros).  Needed only after a write that
+    PyTorch's version counter does not see (``tensor.data.copy_(...)``, a raw pointer write); in-place ops on the tensor or on a
+    view of it, and re-assigned tensors, are detected without it."""
+    _dense_cache.invalidate(tensor)
+
+
+def dense_cache_bytes() -> int:
+    """Bytes of HBM the resident images hold right now."""
+    return _dense_cache.nbytes
+
+
+def _alloc_dense(shape, dtype, device):
+    """Storage for a new image: on out-of-memory the cache is emptied and the allocation retried once; None = give up (the caller
+    falls back to the workspace path, which needs no resident image)."""
+    try:
+        return torch.empty(shape, dtype=dtype, device=device)
+    except torch.cuda.OutOfMemoryError:
+        _dense_cache.clear()
+        torch.cuda.empty_cache()
+        try:
+            return torch.empty(shape, dtype=dtype, device=device)
+        except torch.cuda.OutOfMemoryError:
+            return None
 
 
 def quantized_matmul(x: torch.Tensor, w: torch.Tensor, scales: torch.Tensor, biases: torch.Tensor,
@@ -147,16 +199,18 @@ def quantized_matmul(x: torch.Tensor, w: torch.Tensor, scales: torch.Tensor, bia
         ckey = (n, k, bits, group_size, x.dtype, x.device.index)
         dense = _dense_cache.get(src, ckey)
         if dense is None:
-            dense = torch.empty((n, k), dtype=x.dtype, device=x.device)
-            _lib.check(L.gbx_dequantize(w.data_ptr(), scales.data_ptr(), biases.data_ptr(), dense.data_ptr(), n, k, bits, group_size,
-                                        _DT[x.dtype], _DT[x.dtype], _stream_ptr(x.device)))
-            _dense_cache.put(src, ckey, dense)
-        part = L.gbx_dense_workspace_bytes(m, n, k)
-        scratch = torch.empty((part,), dtype=torch.uint8, device=x.device) if part else None
-        rc = L.gbx_dense_forward_ws(x2.data_ptr(), dense.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(),
-                                    m, n, k, _DT[x.dtype], scratch.data_ptr() if part else None, part, _stream_ptr(x.device))
-        if rc == _lib.GBX_OK:
-            return out.reshape(*x.shape[:-1], n)
+            dense = _alloc_dense((n, k), x.dtype, x.device)
+            if dense is not None:
+                _lib.check(L.gbx_dequantize(w.data_ptr(), scales.data_ptr(), biases.data_ptr(), dense.data_ptr(), n, k, bits, group_size,
+                                            _DT[x.dtype], _DT[x.dtype], _stream_ptr(x.device)))
+                _dense_cache.put(src, ckey, dense)
+        if dense is not None:
+            part = L.gbx_dense_workspace_bytes(m, n, k)
+            scratch = torch.empty((part,), dtype=torch.uint8, device=x.device) if part else None
+            rc = L.gbx_dense_forward_ws(x2.data_ptr(), dense.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(),
+                                        m, n, k, _DT[x.dtype], scratch.data_ptr() if part else None, part, _stream_ptr(x.device))
+            if rc == _lib.GBX_OK:
+                return out.reshape(*x.shape[:-1], n)
     if need:                                            # decode batches / short prompts: k split across workgroups; long prompts: dequantise once
         ws = torch.empty((need,), dtype=torch.uint8, device=x.device)      # caller-owned scratch (caching allocator: no sync)
         rc = L.gbx_qlinear_forward_ws(
@@ -313,7 +367,7 @@ def gather_quantized_matmul(x: torch.Tensor, w: torch.Tensor, scales: torch.Tens
             _stream_ptr(x.device)))
     else:                                               # grouped by expert (one host sync for the expert list)
         if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError(f"gather_quantized_matmul: {pairs} (token, expert) pairs / K={K} need the host-grouped path, which "
+            raise NotCapturable(f"gather_quantized_matmul: {pairs} (token, expert) pairs / K={K} need the host-grouped path, which "
                                "cannot be captured into a HIP graph (the expert-indexed launch covers <= 64 pairs, K % 128 == 0)")
         ar = torch.arange(pairs, device=x.device)
         rows = ar // k if shared else ar

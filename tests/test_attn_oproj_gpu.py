@@ -99,7 +99,11 @@ def test_x_acc_prologue_and_zero_buf(oracle, bits, dt, n):
     ops.qlinear_fused(ops.make_fused_desc(h, (gate, up), (a_new,), norm_weight=nw, eps=1e-5, swiglu=True, packed=pgu,
                                           x_acc=acc, x_out=x_out), h.device)
     assert torch.equal(x_out, hsum)
-    assert torch.equal(a_new, a_ref)
+    # same arithmetic on the same vector; the two instantiations may differ in the last bit of the RMS statistic (one ulp on a
+    # tenth of the outputs for some inputs), never by more
+    d = (a_new.float() - a_ref.float()).abs()
+    ulp = torch.maximum(a_ref.float().abs(), torch.tensor(1e-3, device=DEV)) * (2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10)
+    assert (d <= 1.01 * ulp).all() and (d == 0).float().mean() > 0.8
     # zero_buf on a residual launch
     dn, _ = _mod(oracle, 256, n if n % 128 == 0 else 1024, bits, g, 5, act)
     xa = torch.randn(dn.input_dims).to(dt).to(DEV)
@@ -119,7 +123,7 @@ def test_x_acc_rejections(oracle):
     acc = torch.zeros(4096, dtype=torch.int64, device=DEV)
     with pytest.raises(RuntimeError):        # no packed companion
         ops.qlinear_fused(ops.make_fused_desc(h, (gate,), (y,), x_acc=acc), h.device)
-    with pytest.raises(RuntimeError):        # x_out aliasing x
+    with pytest.raises(ValueError):          # x_out aliasing x
         ops.qlinear_fused(ops.make_fused_desc(h, (gate,), (y,), packed=ops.pack_scales_zeros(gate), x_acc=acc, x_out=h), h.device)
     assert not _lib.lib().gbx_attn_oproj_supported(32, 8, 64, 4096, 2, 128)
     assert not _lib.lib().gbx_attn_oproj_supported(24, 8, 128, 3072, 4, 128)
