@@ -635,6 +635,7 @@ struct DenseArgs {
   float eps;
   int N, K, rows_per_wave;
   unsigned long long* best;      // optional [GBX_ARGMAX_SLOTS] packed (value, index) maxima: fused greedy argmax
+  int null_rows;              // measurement only (GBX_CHAIN_FLOOR=2): every row read is row 0 / 1
 };
 
 // Greedy sampling fused into the head: every workgroup folds its rows' rounded logits into one of 64 sharded 64-bit
@@ -681,7 +682,7 @@ __global__ __launch_bounds__(256) void dense_gemv_kernel(const DenseArgs a) {
     wv[p] = *reinterpret_cast<const u32x4*>(nw + static_cast<size_t>(cc) * 8);
   }
   auto issue = [&](u32x4 (&buf)[P], int row) {
-    const unsigned short* wr = a.w + static_cast<size_t>(min(row, N - 1)) * K;
+    const unsigned short* wr = a.w + static_cast<size_t>(a.null_rows ? (row & 1) : min(row, N - 1)) * K;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int cc = min(p * 64 + lane, nchunks - 1);
@@ -823,6 +824,9 @@ hipError_t launch_dense_gemv(const void* x, const void* w, void* y, const void* 
   if (rpw < 2) rpw = 2;
   a.rows_per_wave = rpw;
   const int blocks = (N + 4 * rpw - 1) / (4 * rpw);
+  static const int chain_floor = [] { const char* e = getenv("GBX_CHAIN_FLOOR"); return e ? atoi(e) : 0; }();      // measurement only: see gemv_impl.h
+  if (chain_floor == 1) a.rows_per_wave = 2;
+  a.null_rows = chain_floor == 2 ? 1 : 0;
   const int P = (K / 8 + 63) / 64;
   dim3 grid(blocks), block(256);
 #define GBX_DENSE(PP)                                                                                  \

@@ -66,6 +66,7 @@ struct GemvArgs {
   // ---- buffer this launch clears for a later one (the accumulator above, once its consumer has run) ----
   long long* zero_buf;
   int zero_n;
+  int null_rows;                   // measurement only (GBX_CHAIN_FLOOR=2): every batch re-reads rows 0 / 1 -- the whole launch sequence with no weight stream
 #ifdef GBX_STAMPS
   unsigned long long* stamps;      // diagnostic build only: [workgroup][wave][16] s_memrealtime stamps
 #endif
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
       row = r - (sg == 0 ? 0 : (sg == 1 ? n0 : n01));
     }
   };
+  const bool null_rows = a.null_rows != 0;
 #ifdef GBX_STAMPS
 #define GBX_STAMP(i) do { if (lane == 0 && a.stamps) a.stamps[(static_cast<size_t>(blockIdx.x) * NW + wave) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
       const __amdgpu_buffer_rsrc_t qd = rsrc(sgi == 0 ? q0 : (sgi == 1 ? q1 : q2));
       const __amdgpu_buffer_rsrc_t sd = rsrc(sgi == 0 ? s0 : (sgi == 1 ? s1 : s2));
       const __amdgpu_buffer_rsrc_t zd = rsrc(sgi == 0 ? z0 : (sgi == 1 ? z1 : z2));
-      const int woff = row * (W * 4), goff = row * (G * 2);
+      const int woff = null_rows ? (row & 1) * (W * 4) : row * (W * 4), goff = row * (G * 2);
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         if constexpr (BITS == 3) b.w[i][p] = __builtin_amdgcn_raw_buffer_load_b96(qd, voff_w[p], woff, 2);   // nt
@@ -748,6 +750,12 @@ static hipError_t launch_gemv_d(const GemvArgs& a, int M, bool bf16, int bpo, in
   const size_t shmem = gemv_shmem<BITS, P, KS, NW>(a.K, bpo);
   const int batches_per_block = (KS == 1 ? NW : NW / 4) * bpo;
   const int blocks = (nbatches + batches_per_block - 1) / batches_per_block;
+  // GBX_CHAIN_FLOOR (measurement only, wrong results): 1 = the same grid, every wave stops after ONE ring round; 2 = every batch
+  // re-reads rows 0 / 1 (same instruction stream, no weight stream from HBM) -- what is left of
+  // a decode step is its dependency chain (launch boundaries, activation prologues, reductions) with next to no weight stream
+  static const int chain_floor = [] { const char* e = getenv("GBX_CHAIN_FLOOR"); return e ? atoi(e) : 0; }();
+  if (chain_floor == 1) args.batches_per_owner = D;
+  if (chain_floor == 2) args.null_rows = 1;
   dim3 grid(blocks, M), block(NW * 64);
   if (bf16) hipLaunchKernelGGL((gemv_kernel<BITS, P, KS, D, true, SPLIT, NW, PK>), grid, block, shmem, stream, args);
   else hipLaunchKernelGGL((gemv_kernel<BITS, P, KS, D, false, SPLIT, NW, PK>), grid, block, shmem, stream, args);

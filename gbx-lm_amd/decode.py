@@ -317,10 +317,11 @@ class FusedDecodeRunner(DecodeRunner):
         self.graph_chain = None
         # Short caches (no context split): attention + o_proj as ONE launch whose partial sums land in a fixed-point
         # accumulator; the gate|up launch forms h + o in its prologue and the down launch clears the accumulator -- four
-        # launches per block instead of five (gbx_attn_oproj_decode).  GBX_FUSE_AO=0 keeps the five-launch block.
+        # launches per block instead of five (gbx_attn_oproj_decode).  Opt-in (GBX_FUSE_AO=1): measured neutral -- the in-launch
+        # hand-off costs what the removed boundary cost (profiles/r03_chain_floor.txt: 750-753 vs 750-762 tok/s).
         import os
         self.acc = torch.zeros((D + a0.n_kv_heads * ops.ATTN_OPROJ_HANDOFF_WORDS,), dtype=torch.int64, device=dev)   # o_proj sums | hand-off words
-        self.fuse_ao = (os.environ.get("GBX_FUSE_AO", "1") != "0" and not tp and self.attn_ws is None and
+        self.fuse_ao = (os.environ.get("GBX_FUSE_AO", "0") == "1" and not tp and self.attn_ws is None and
                         all(getattr(b.self_attn, "q_norm", None) is None and b.self_attn.q_proj.bias is None and
                             ops.attn_oproj_supported(b.self_attn.n_heads, b.self_attn.n_kv_heads, b.self_attn.head_dim, b.self_attn.o_proj) and
                             b.mlp.gate_proj.group_size >= 64 and

@@ -141,7 +141,7 @@ def test_runner_four_launch_block_matches_five_launch_block():
     model = S.build_model(cfg, S.make_strategy("S22", cfg["num_hidden_layers"], 128), device=DEV, seed=3)
 
     def run(fuse):
-        os.environ["GBX_FUSE_AO"] = "1" if fuse else "0"
+        os.environ["GBX_FUSE_AO"] = "1" if fuse else "0"          # opt-in launch structure
         try:
             at = model.model.layers[0].self_attn
             caches = []
