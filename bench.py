@@ -229,28 +229,35 @@ def make_caches(model, batch, cap, dev):
     return caches
 
 
-def decode_leg(model, cfg, dev, batch, context, steps, warmup):
-    """A secondary decode point of the metric on one GPU (same protocol as the headline leg)."""
+def decode_leg(model, cfg, dev, batch, context, steps, warmup, world=1, use_graph=True):
+    """A secondary decode point of the metric (same protocol as the headline leg; with world > 1 every rank runs it on its
+    shard and the time is the maximum over ranks)."""
     from gbx_lm_amd.decode import DecodeRunner, FusedDecodeRunner, fused_eligible
     cap = ((context + warmup + steps + 2 + 255) // 256) * 256
     caches = make_caches(model, batch, cap, dev)
     Runner = FusedDecodeRunner if (fused_eligible(model) and batch == 1) else DecodeRunner
-    runner = Runner(model, caches, use_graph=True)
+    runner = Runner(model, caches, use_graph=use_graph)
     for t in range(context):
         runner.step(torch.full((batch,), t % cfg["vocab_size"], device=dev, dtype=torch.long))
     runner.start_greedy(torch.argmax(runner.logits, -1))
-    ms = time_decode(runner, steps, warmup, batch) / steps
+    ms = time_decode(runner, steps, warmup, batch, world, dev) / steps
     ql_b, head_b, kv_b = token_bytes(model, context + warmup + steps // 2)
     nbytes = ql_b + head_b + kv_b * batch
     return {"tok_s": batch * 1e3 / ms, "ms_per_step": ms, "steps": steps, "context": context, "batch": batch,
             "bytes_per_step": nbytes, "achieved_GBps": nbytes / ms / 1e6, "frac_of_8TBps": nbytes / ms / 1e6 / HBM_PEAK_GBPS,
-            "decode_block": Runner.__name__}
+            "decode_block": Runner.__name__, "parallelism": f"tp{world}"}
 
 
 def prefill_leg(model, cfg, dev, B=8, T=4096):
     """BASELINE.json configs[3]: prefill of B x T tokens through the model's own forward (chunks of 2048 like
-    generate_step), then the QuantizedLinear GEMMs alone at the same M (MFMA-bound: fraction of the 2.5 PFLOP/s dense
-    bf16 peak from the algorithmic flops 2 M N K)."""
+    generate_step), then the QuantizedLinear calls alone at the same M (MFMA-bound: fraction of the 2.5 PFLOP/s dense
+    bf16 peak from the algorithmic flops 2 M N K).
+
+    Every number comes in two states of ``ops._DenseCache`` (the resident bf16 images of the packed weights, 2 bytes per weight,
+    that a long call leaves behind): COLD = cache emptied inside the timed region, every QuantizedLinear call dequantises its
+    weight first (a dequant + matmul, what a first request pays); WARM = images resident, the timed calls are dense bf16 GEMMs on
+    pre-expanded weights (what the second chunk of a prompt and every later request pay)."""
+    from gbx_lm_amd import ops
     from gbx_lm_amd.models.cache import make_prompt_cache
     toks = (torch.arange(B * T, device=dev) % cfg["vocab_size"]).view(B, T)
 
@@ -259,38 +266,51 @@ def prefill_leg(model, cfg, dev, B=8, T=4096):
         with torch.no_grad():
             for s0 in range(0, T, 2048):
                 model.model(toks[:, s0:s0 + 2048], cache=cache)
-    run()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    run()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1)
+
+    def timed(fn, cold):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        if cold:
+            ops.dense_cache_clear()                 # inside the timed region: the images are rebuilt under the clock
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
+
+    run()                                            # lazy initialisation, allocator warm-up
+    ms_cold = timed(run, True)
+    image_bytes = ops.dense_cache_bytes()
+    ms_warm = timed(run, False)
     mods = [m for blk in model.model.layers for m in (blk.self_attn.q_proj, blk.self_attn.k_proj, blk.self_attn.v_proj,
                                                       blk.self_attn.o_proj, blk.mlp.gate_proj, blk.mlp.up_proj, blk.mlp.down_proj)]
     flops = 2.0 * B * T * sum(m.input_dims * m.output_dims for m in mods)
     x = {k: torch.randn(B * 2048, k, device=dev).to(torch.bfloat16) for k in {m.input_dims for m in mods}}
-    with torch.no_grad():
-        for m in mods[:7]:
-            m(x[m.input_dims])
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(T // 2048):
-            for m in mods:
-                m(x[m.input_dims])
-        e1.record()
-    torch.cuda.synchronize()
-    tg = e0.elapsed_time(e1)
-    return {"tok_s": B * T / ms * 1e3, "ms": ms, "batch": B, "seq_len": T, "qlinear_ms": tg, "qlinear_flops": flops,
-            "qlinear_TFLOPs": flops / tg / 1e9, "frac_of_2500_TFLOPs_dense_bf16": flops / tg / 1e9 / 2500.0,
-            "note": "whole forward incl. gbx_attn_prefill (HIP causal attention) and glue (RoPE, norms, cache writes); qlinear_* = the 224 dequant-GEMMs alone at M = B*2048 rows"}
+
+    def qlinear_only():
+        with torch.no_grad():
+            for _ in range(T // 2048):
+                for m in mods:
+                    m(x[m.input_dims])
+    tg_cold = timed(qlinear_only, True)
+    tg_warm = timed(qlinear_only, False)
+    return {"tok_s": B * T / ms_warm * 1e3, "ms": ms_warm, "tok_s_cold": B * T / ms_cold * 1e3, "ms_cold": ms_cold,
+            "batch": B, "seq_len": T, "dense_image_bytes": image_bytes,
+            "qlinear_flops": flops,
+            "qlinear_ms": tg_warm, "qlinear_TFLOPs": flops / tg_warm / 1e9, "frac_of_2500_TFLOPs_dense_bf16": flops / tg_warm / 1e9 / 2500.0,
+            "qlinear_ms_cold": tg_cold, "qlinear_TFLOPs_cold": flops / tg_cold / 1e9,
+            "frac_of_2500_TFLOPs_dense_bf16_cold": flops / tg_cold / 1e9 / 2500.0,
+            "note": "ms / tok_s: whole forward incl. gbx_attn_prefill (HIP causal attention) and glue (RoPE, norms, cache writes). qlinear_*: "
+                    "the 224 QuantizedLinear calls of the model alone at M = B*2048 rows, two chunks. *_cold: ops.dense_cache_clear() inside "
+                    "the timed region, so every call dequantises its packed weight once (dequant + matmul); without the suffix the "
+                    "dequantised bf16 images (dense_image_bytes of HBM, 2 bytes per weight) are resident and the timed calls are dense "
+                    "bf16 GEMMs on pre-expanded weights -- no dequantisation runs in that loop"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=512, help="timed decode steps (default: > 0.5 s of GPU time, so that a coarse GPU-busy sampler sees the run)")
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--context", type=int, default=128, help="synthetic prompt length already in the KV cache")
     ap.add_argument("--strategy", default="S22", choices=["S22", "S40", "S20", "S30"])
@@ -405,6 +425,15 @@ def main():
             except Exception as e:
                 extra[name] = {"failed": f"{type(e).__name__}: {e}"[:200]}
             torch.cuda.empty_cache()
+    if world > 1 and not args.no_extra and args.model == "llama3-8b" and args.batch == 1 and args.strategy == "S22":
+        # BASELINE.json configs[4] on the N ranks of this run: batch-32 greedy decode, row / column-sharded QuantizedLinear, one
+        # all-reduce after o_proj and after down_proj (every rank takes part: the collectives are in the step)
+        try:
+            leg = decode_leg(model, cfg, dev, 32, 128, 16, 2, world=world, use_graph=use_graph)
+        except Exception as e:
+            leg = {"failed": f"{type(e).__name__}: {e}"[:200]}
+        if rank == 0:
+            extra = {"b32_decode_S22": leg}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             cpu = cpu_baseline(model, cfg)

@@ -113,6 +113,8 @@ def _declare_optional(L) -> None:
         "gbx_dense_gemv": [p, p, p, p, f32, i32, i32, i32, p],
         "gbx_rmsnorm": [p, p, p, i64, i32, f32, i32, p],
         "gbx_dense_gemv_argmax": [p, p, p, p, f32, i32, i32, p, i32, p],
+        "gbx_dense_gemv_argmax_shard": [p, p, p, p, f32, i32, i32, p, i32, i32, p],
+        "gbx_embed_next_token_sharded": [p, i32, p, p, p, p, p, i32, i32, i32, i32, p],
         "gbx_embed_next_token": [p, p, p, p, p, i32, i32, i32, i32, i32, p],
         "gbx_qlinear_forward_multi": [p, i32, p, p, p, p, p, p, i64, i32, i32, i32, i32, p],
         "gbx_gather_qlinear_forward": [p, p, p, p, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, p],

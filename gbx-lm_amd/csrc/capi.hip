@@ -621,6 +621,36 @@ int gbx_embed_next_token(void* argmax_keys, int64_t* token_io, int64_t* pos, con
   return GBX_OK;
 }
 
+int gbx_embed_next_token_sharded(void* gathered_keys, int32_t nkeys, void* local_keys, int64_t* token_io, int64_t* pos,
+                                 const void* embed_table, void* h, int32_t D, int32_t vocab, int32_t advance_pos, int32_t act_dtype,
+                                 void* hip_stream) {
+  if (!gathered_keys || !token_io || !pos || !embed_table || !h) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (nkeys < GBX_ARGMAX_SLOTS || (nkeys % GBX_ARGMAX_SLOTS)) return fail(GBX_ERR_INVALID, "nkeys must be a multiple of %d (got %d)", GBX_ARGMAX_SLOTS, nkeys);
+  if (D <= 0 || (D % 8) || vocab <= 0) return fail(GBX_ERR_INVALID, "need D %% 8 == 0 and vocab > 0");
+  if (!aligned(embed_table, 16) || !aligned(h, 16) || !aligned(gathered_keys, 8) || (local_keys && !aligned(local_keys, 8)))
+    return fail(GBX_ERR_INVALID, "misaligned pointer");
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  hipError_t e = gbx::launch_embed_next(gathered_keys, token_io, pos, embed_table, h, D, vocab, 1, advance_pos ? 1 : 0,
+                                        act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream), nkeys, local_keys);
+  if (e != hipSuccess) return hip_fail(e, "gbx_embed_next_token_sharded launch");
+  return GBX_OK;
+}
+
+int gbx_dense_gemv_argmax_shard(const void* x, const void* w, void* y, const void* norm_weight, float norm_eps, int32_t N, int32_t K,
+                                void* argmax_keys, int32_t index_offset, int32_t act_dtype, void* hip_stream) {
+  if (!x || !w || !y) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (N <= 0 || K <= 0 || (K % 8) || index_offset < 0) return fail(GBX_ERR_INVALID, "need N > 0, K %% 8 == 0, index_offset >= 0 (N=%d K=%d)", N, K);
+  if (K > 8192) return fail(GBX_ERR_UNSUPPORTED, "K = %d exceeds the dense GEMV limit of 8192", K);
+  if (!aligned(x, 16) || !aligned(w, 16) || (norm_weight && !aligned(norm_weight, 16)))
+    return fail(GBX_ERR_INVALID, "x, w and norm_weight must be 16-byte aligned");
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  if (argmax_keys && !aligned(argmax_keys, 8)) return fail(GBX_ERR_INVALID, "argmax_keys must be 8-byte aligned");
+  hipError_t e = gbx::launch_dense_gemv(x, w, y, norm_weight, norm_eps, N, K, argmax_keys, act_dtype == GBX_BF16,
+                                        static_cast<hipStream_t>(hip_stream), index_offset);
+  if (e != hipSuccess) return hip_fail(e, "gbx_dense_gemv_argmax_shard launch");
+  return GBX_OK;
+}
+
 int gbx_dense_gemv(const void* x, const void* w, void* y, const void* norm_weight, float norm_eps, int32_t N, int32_t K,
                    int32_t act_dtype, void* hip_stream) {
   return gbx_dense_gemv_argmax(x, w, y, norm_weight, norm_eps, N, K, nullptr, act_dtype, hip_stream);

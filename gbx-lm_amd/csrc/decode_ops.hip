@@ -636,6 +636,7 @@ struct DenseArgs {
   int N, K, rows_per_wave;
   unsigned long long* best;      // optional [GBX_ARGMAX_SLOTS] packed (value, index) maxima: fused greedy argmax
   int null_rows;              // measurement only (GBX_CHAIN_FLOOR=2): every row read is row 0 / 1
+  int index_offset;           // vocabulary shard: global index of row 0 (argmax keys carry global indices)
 };
 
 // Greedy sampling fused into the head: every workgroup folds its rows' rounded logits into one of 64 sharded 64-bit
@@ -740,7 +741,7 @@ __global__ __launch_bounds__(256) void dense_gemv_kernel(const DenseArgs a) {
     if (lane == 0 && row < N) {
       const unsigned short o = f32_to_act<BF16>(tot);
       a.y[row] = o;
-      const unsigned long long key = argmax_key(act_to_f32<BF16>(o), row);
+      const unsigned long long key = argmax_key(act_to_f32<BF16>(o), row + a.index_offset);
       wbest = key > wbest ? key : wbest;
     }
   };
@@ -776,11 +777,14 @@ __global__ __launch_bounds__(256) void dense_gemv_kernel(const DenseArgs a) {
 template <bool BF16>
 __global__ __launch_bounds__(256) void embed_next_kernel(unsigned long long* best, long long* tok_io, long long* pos,
                                                          const unsigned short* __restrict__ table, unsigned short* __restrict__ h,
-                                                         int D, int vocab, int mode, int advance) {
+                                                         int D, int vocab, int mode, int advance, int nkeys, unsigned long long* also_clear) {
   __shared__ long long tok_s;
   const int tid = threadIdx.x;
   if (tid < 64) {
-    unsigned long long k = best[tid];
+    // nkeys = 64 (one GPU) or 64 * world (vocabulary-sharded head: every rank's keys, gathered): lane-wise maximum first
+    unsigned long long k = 0ull;
+    for (int i = tid; i < nkeys; i += 64) { const unsigned long long v = best[i]; k = v > k ? v : k; best[i] = 0ull; }
+    if (also_clear) also_clear[tid] = 0ull;
     // 64-lane max of a 64-bit key via two 32-bit stages (hi word, then lo word among the winners)
     const unsigned hi = static_cast<unsigned>(k >> 32);
     const unsigned mhi = wave_max_u32(hi);
@@ -793,7 +797,6 @@ __global__ __launch_bounds__(256) void embed_next_kernel(unsigned long long* bes
       *tok_io = t;
       if (advance) *pos = *pos + 1;
     }
-    best[tid] = 0ull;
   }
   __syncthreads();
   const long long t = tok_s;
@@ -803,19 +806,20 @@ __global__ __launch_bounds__(256) void embed_next_kernel(unsigned long long* bes
 }
 
 hipError_t launch_embed_next(void* best, void* tok_io, void* pos, const void* table, void* h, int D, int vocab, int mode,
-                             int advance, bool bf16, hipStream_t s) {
+                             int advance, bool bf16, hipStream_t s, int nkeys, void* also_clear) {
   auto B = static_cast<unsigned long long*>(best);
   auto T = static_cast<long long*>(tok_io);
   auto P = static_cast<long long*>(pos);
   auto E = static_cast<const unsigned short*>(table);
   auto H = static_cast<unsigned short*>(h);
-  if (bf16) hipLaunchKernelGGL((embed_next_kernel<true>), dim3(1), dim3(256), 0, s, B, T, P, E, H, D, vocab, mode, advance);
-  else hipLaunchKernelGGL((embed_next_kernel<false>), dim3(1), dim3(256), 0, s, B, T, P, E, H, D, vocab, mode, advance);
+  auto C = static_cast<unsigned long long*>(also_clear);
+  if (bf16) hipLaunchKernelGGL((embed_next_kernel<true>), dim3(1), dim3(256), 0, s, B, T, P, E, H, D, vocab, mode, advance, nkeys, C);
+  else hipLaunchKernelGGL((embed_next_kernel<false>), dim3(1), dim3(256), 0, s, B, T, P, E, H, D, vocab, mode, advance, nkeys, C);
   return hipGetLastError();
 }
 
 hipError_t launch_dense_gemv(const void* x, const void* w, void* y, const void* norm_w, float eps, int N, int K, void* best,
-                             bool bf16, hipStream_t s) {
+                             bool bf16, hipStream_t s, int index_offset) {
   DenseArgs a{static_cast<const unsigned short*>(x), static_cast<const unsigned short*>(w), static_cast<unsigned short*>(y),
               static_cast<const unsigned short*>(norm_w), eps, N, K, 0, static_cast<unsigned long long*>(best)};
   const int owners = 256 * 8 * 4;                       // waves when every workgroup is resident (8 per CU)
@@ -827,6 +831,7 @@ hipError_t launch_dense_gemv(const void* x, const void* w, void* y, const void* 
   static const int chain_floor = [] { const char* e = getenv("GBX_CHAIN_FLOOR"); return e ? atoi(e) : 0; }();      // measurement only: see gemv_impl.h
   if (chain_floor == 1) a.rows_per_wave = 2;
   a.null_rows = chain_floor == 2 ? 1 : 0;
+  a.index_offset = index_offset;
   const int P = (K / 8 + 63) / 64;
   dim3 grid(blocks), block(256);
 #define GBX_DENSE(PP)                                                                                  \

@@ -110,9 +110,9 @@ hipError_t launch_attn_oproj(const void* q, const void* k, const void* v, void* 
                              float sm_scale, int traditional, bool bf16, hipStream_t s);
 size_t attn_workspace_bytes(int batch, int n_heads, int n_kv, int head_dim, int capacity);
 hipError_t launch_dense_gemv(const void* x, const void* w, void* y, const void* norm_w, float eps, int N, int K, void* best,
-                             bool bf16, hipStream_t s);
+                             bool bf16, hipStream_t s, int index_offset = 0);
 hipError_t launch_embed_next(void* best, void* tok_io, void* pos, const void* table, void* h, int D, int vocab, int mode,
-                             int advance, bool bf16, hipStream_t s);
+                             int advance, bool bf16, hipStream_t s, int nkeys = 64, void* also_clear = nullptr);
 hipError_t launch_pack_sz(const void* s0, const void* z0, const void* s1, const void* z1, uint32_t* out, int N, int G,
                           hipStream_t s);
 hipError_t launch_rope(const void* x, void* y, const float* inv_freq, const long long* posp, long long offset, long long B,

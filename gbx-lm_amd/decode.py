@@ -144,10 +144,23 @@ class DecodeRunner:
         self._next = token.reshape(-1).clone()
 
     def step_greedy(self) -> torch.Tensor:
-        """One greedy token: feeds the previous argmax back in.  Generic version (argmax by torch)."""
-        logits = self.step(self._next)
-        self._next = torch.argmax(logits, -1)
-        return logits
+        """One greedy token: feeds the previous argmax back in.  Generic version (argmax by torch).  With a vocabulary-sharded
+        head (tensor parallel) the ranks exchange one (value, index) pair per sequence instead of the logits."""
+        if getattr(self.model, "tp_vocab", None) is None:
+            logits = self.step(self._next)
+            self._next = torch.argmax(logits, -1)
+            return logits
+        local = self._step_local(self._next)                        # [B, V / world]
+        lo = self.model.tp_vocab[0]
+        val, idx = torch.max(local.float(), -1)
+        pair = torch.stack([val, (idx + lo).float()], -1)           # token ids < 2^24: exact in fp32
+        world = self.model.tp_world
+        allp = torch.empty((world,) + tuple(pair.shape), dtype=pair.dtype, device=pair.device)
+        from .tp import all_gather_into
+        all_gather_into(allp, pair, getattr(self.model, "tp_group", None))
+        best = torch.argmax(allp[..., 0], 0)                        # first maximum = lowest rank = lowest index on ties
+        self._next = allp[best, torch.arange(pair.shape[0], device=pair.device), 1].long()
+        return local
 
     def _check_room(self, off: int) -> None:
         # the attention / append kernels index the cache with the device-resident position and do no bounds check
@@ -155,7 +168,16 @@ class DecodeRunner:
             raise RuntimeError(f"KV cache is full ({off} of {self.capacity} positions): grow it (KVCache.reserve) and build a new runner")
 
     def step(self, token: torch.Tensor) -> torch.Tensor:
-        """Consumes one token id per sequence (device tensor, shape [B]); returns logits [B, V] (a static buffer)."""
+        """Consumes one token id per sequence (device tensor, shape [B]); returns logits [B, V] (a static buffer; with a
+        vocabulary-sharded head: the all-gathered logits)."""
+        local = self._step_local(token)
+        tv = getattr(self.model, "tp_vocab", None)
+        if tv is None or local.shape[-1] == tv[2]:          # (the fused runner gathers inside its launch sequence)
+            return local
+        from .tp import gather_vocab
+        return gather_vocab(local, self.model)
+
+    def _step_local(self, token: torch.Tensor) -> torch.Tensor:
         off = self.caches[0].offset
         self._check_room(off)
         self.tok.copy_(token.reshape(-1))
@@ -310,6 +332,11 @@ class FusedDecodeRunner(DecodeRunner):
         r0 = getattr(model, "tp_rank", 0) == 0
         self.logits_buf = torch.zeros((1, model.head_weight().shape[0]), dtype=dt, device=dev)
         self.keys = torch.zeros((64,), dtype=torch.int64, device=dev)      # sharded (value, index) argmax keys (uint64 bits)
+        # vocabulary-sharded head (tensor parallel): every rank's keys, gathered; the full logits for callers of step()
+        self.tp_vocab = getattr(model, "tp_vocab", None)
+        if self.tp_vocab is not None:
+            self.all_keys = torch.zeros((64 * model.tp_world,), dtype=torch.int64, device=dev)
+            self.logits_full = torch.zeros((1, self.tp_vocab[2]), dtype=dt, device=dev)
         from . import _lib as _l
         need = _l.lib().gbx_attn_workspace_bytes(1, a0.n_heads, a0.n_kv_heads, a0.head_dim, caches[0].capacity)
         self.attn_ws = torch.empty((need,), dtype=torch.uint8, device=dev) if need else None   # context split of long caches
@@ -367,8 +394,11 @@ class FusedDecodeRunner(DecodeRunner):
         dev = self.dev
         # token -> residual stream on the device (also clears the argmax keys and, in a greedy chain, takes the token
         # from them and advances the position: no host involvement between tokens)
-        ops.embed_next_token(self.keys, self.tok, self.pos, m.embed_tokens.weight, self.hb, from_keys=self.chain,
-                             advance_pos=self.chain)
+        if self.chain and self.tp_vocab is not None:
+            ops.embed_next_token_sharded(self.all_keys, self.keys, self.tok, self.pos, m.embed_tokens.weight, self.hb, advance_pos=True)
+        else:
+            ops.embed_next_token(self.keys, self.tok, self.pos, m.embed_tokens.weight, self.hb, from_keys=self.chain,
+                                 advance_pos=self.chain)
         for li, (blk, c, (d_qkv, d_o, d_gu, d_dn)) in enumerate(zip(m.layers, self.caches, self.descs)):
             at = blk.self_attn
             ops.qlinear_fused(d_qkv, dev)
@@ -402,8 +432,16 @@ class FusedDecodeRunner(DecodeRunner):
             if self.tp_world > 1:            # ... and the stream returns to hb
                 all_reduce_(self.hb, blk.mlp.tp_group)
         ops.dense_gemv(self.hb, self.model.head_weight(), out=self.logits_buf.view(-1), norm_weight=m.norm.weight,
-                       eps=m.norm.eps, argmax_keys=self.keys)
-        return self.logits_buf
+                       eps=m.norm.eps, argmax_keys=self.keys, index_offset=self.tp_vocab[0] if self.tp_vocab is not None else 0)
+        if self.tp_vocab is None:
+            return self.logits_buf
+        from .tp import all_gather_into
+        grp = getattr(self.model, "tp_group", None)
+        if self.chain:                       # greedy chain: 64 keys per rank are all the next step needs
+            all_gather_into(self.all_keys, self.keys, grp)
+            return self.logits_buf
+        all_gather_into(self.logits_full, self.logits_buf, grp)          # rank order = vocabulary order
+        return self.logits_full
 
     # ---- on-device greedy chain: replay after replay with nothing in between ------------------------------------
     def start_greedy(self, token: torch.Tensor) -> None:
@@ -414,11 +452,15 @@ class FusedDecodeRunner(DecodeRunner):
             key -= 1 << 64                                            # same bits as a signed int64
         self.keys.zero_()
         self.keys[0] = key
+        if self.tp_vocab is not None:
+            self.all_keys.zero_()
+            self.all_keys[0] = key
         self.pos.fill_(off - 1)                                       # the embed kernel advances it to `off`
         if self.use_graph and self.graph_chain is None:
             self.chain = True
             saved = (self.graph, self.logits)
             keys0, pos0 = self.keys.clone(), self.pos.clone()
+            akeys0 = self.all_keys.clone() if self.tp_vocab is not None else None
             self._capture()                                           # captures _forward with from_keys / advance_pos set
             self.graph_chain = self.graph
             self.graph, self.logits = saved
@@ -427,6 +469,8 @@ class FusedDecodeRunner(DecodeRunner):
                 c.offset = off
             self.keys.copy_(keys0)
             self.pos.copy_(pos0)
+            if akeys0 is not None:
+                self.all_keys.copy_(akeys0)
 
     def step_greedy(self) -> torch.Tensor:
         off = self.caches[0].offset

@@ -221,11 +221,20 @@ class Model(nn.Module):
 
     def head_weight(self) -> torch.Tensor:
         """[vocab, hidden] matrix of the output head (tied: the embedding table, ``embed_tokens.as_linear``)."""
+        shard = getattr(self, "_tp_head", None)         # tensor parallel: this rank's rows of the vocabulary (tp.shard_llama)
+        if shard is not None:
+            return shard
         return self.model.embed_tokens.weight if self.args.tie_word_embeddings else self.lm_head.weight
+
+    def _full_logits(self, logits):
+        if getattr(self, "_tp_head", None) is None:
+            return logits
+        from ..tp import gather_vocab
+        return gather_vocab(logits, self)
 
     def forward(self, inputs, mask=None, cache=None, hidden_states: bool = False):
         hidden = self.model(inputs, mask, cache)
-        logits = F.linear(hidden, self.head_weight())
+        logits = self._full_logits(F.linear(hidden, self.head_weight()))
         return (logits, hidden) if hidden_states else logits
 
     def prefill(self, inputs, cache) -> None:
@@ -237,7 +246,7 @@ class Model(nn.Module):
         """``self(inputs, cache=cache)[:, -1, :]`` (gbx_lm/utils.py:291-294) with the output head applied to the last
         position only -- at a 4096-token prompt the full head is 2 x 4096 x vocab x hidden flops of discarded work."""
         hidden = self.model(inputs, None, cache)
-        return F.linear(hidden[:, -1:, :], self.head_weight())[:, -1, :]
+        return self._full_logits(F.linear(hidden[:, -1:, :], self.head_weight())[:, -1, :])
 
     def decode_step(self, y: torch.Tensor, prompt_cache) -> torch.Tensor:
         """Single-token fast path (fused HIP decode block, HIP-graph replay); see gbx_lm_amd/decode.py."""

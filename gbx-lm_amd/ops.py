@@ -797,18 +797,28 @@ def embed_next_token(keys: torch.Tensor, token_io: torch.Tensor, pos: torch.Tens
 
 def dense_gemv(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None,
                norm_weight: Optional[torch.Tensor] = None, eps: float = 0.0,
-               argmax_keys: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """logits[N] = W[N,K] @ (x or RMSNorm(x)) for the unquantised head (qllama.py:194-198)."""
+               argmax_keys: Optional[torch.Tensor] = None, index_offset: int = 0) -> torch.Tensor:
+    """logits[N] = W[N,K] @ (x or RMSNorm(x)) for the unquantised head (qllama.py:194-198).  ``index_offset``: global index of
+    row 0 when ``w`` is one rank's shard of the vocabulary (the argmax keys then carry global token ids)."""
     for t, nm in ((x, "x"), (w, "w")):
         _require_cuda(t, nm)
     n, k = w.shape
     if out is None:
         out = torch.empty((n,), dtype=x.dtype, device=x.device)
-    _lib.check(_lib.lib().gbx_dense_gemv_argmax(x.data_ptr(), w.data_ptr(), out.data_ptr(),
-                                                norm_weight.data_ptr() if norm_weight is not None else None, float(eps),
-                                                n, k, argmax_keys.data_ptr() if argmax_keys is not None else None,
-                                                _DT[x.dtype], _stream_ptr(x.device)))
+    _lib.check(_lib.lib().gbx_dense_gemv_argmax_shard(x.data_ptr(), w.data_ptr(), out.data_ptr(),
+                                                      norm_weight.data_ptr() if norm_weight is not None else None, float(eps),
+                                                      n, k, argmax_keys.data_ptr() if argmax_keys is not None else None,
+                                                      int(index_offset), _DT[x.dtype], _stream_ptr(x.device)))
     return out
+
+
+def embed_next_token_sharded(gathered_keys: torch.Tensor, local_keys: torch.Tensor, token_io: torch.Tensor, pos: torch.Tensor,
+                             table: torch.Tensor, h: torch.Tensor, advance_pos: bool) -> None:
+    """Greedy token of a vocabulary-sharded head from every rank's argmax keys (gbx_embed_next_token_sharded)."""
+    _lib.check(_lib.lib().gbx_embed_next_token_sharded(gathered_keys.data_ptr(), gathered_keys.numel(), local_keys.data_ptr(),
+                                                       token_io.data_ptr(), pos.data_ptr(), table.data_ptr(), h.data_ptr(),
+                                                       table.shape[1], table.shape[0], int(advance_pos), _DT[h.dtype],
+                                                       _stream_ptr(h.device)))
 
 
 def eminf_optimize(logits: torch.Tensor, alpha: float = 0.65, num_steps: Optional[int] = None, threshold: float = 0.05):

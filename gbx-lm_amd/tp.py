@@ -6,6 +6,10 @@ Build-side extension: the reference has no tensor parallelism.  T
   * o_proj/down    -- consume those sharded activations, so split INPUT columns K at multiples of 128 values
                       (a whole number of 32-value periods, groups and 16-byte slots for every bits/group in scope);
                       each rank produces a full-N partial sum -> ONE all-reduce(sum) after each.
+  * lm_head        -- (round 3) split over the VOCABULARY: rank r streams rows [r V/world, (r+1) V/world) of the 16-bit head
+                      (at TP = 8 a replicated head was 1.05 GB per rank per token next to 0.27 GB of sharded QuantizedLinear:
+                      a <= 2.4x ceiling).  Greedy decode exchanges 64 argmax keys per rank (one 512-byte all-gather); callers
+                      that need the logits get them all-gathered.
 
 One process per GPU; ``torch.distributed`` backend "nccl" (= RCCL) on GPUs, "gloo" in the CPU tests.
 """
@@ -65,8 +69,36 @@ def shard_llama(model, rank: int, world: int, group: Optional[dist.ProcessGroup]
         at.n_kv_heads //= world
         at.tp_group, mlp.tp_group = group, group
         at.tp_world, mlp.tp_world = world, world
-    model.tp_world, model.tp_rank = world, rank
+    model.tp_world, model.tp_rank, model.tp_group = world, rank, group
+    hw = model.head_weight()
+    v = hw.shape[0]
+    if v % world == 0 and (v // world) % 2 == 0:      # vocabulary shard of the output head (the embedding lookup keeps the table)
+        lo, hi = rank * v // world, (rank + 1) * v // world
+        model._tp_head = hw[lo:hi].detach().clone().contiguous()
+        model.tp_vocab = (lo, hi, v)
+        if not model.args.tie_word_embeddings:          # an untied head is not needed in full any more
+            model.lm_head.weight = torch.nn.Parameter(model._tp_head, requires_grad=False)
     return model
+
+
+def all_gather_into(out: torch.Tensor, inp: torch.Tensor, group=None) -> torch.Tensor:
+    """out[r * n : (r + 1) * n] = rank r's ``inp`` (flat, n = inp.numel()); one collective."""
+    try:
+        dist.all_gather_into_tensor(out.view(-1), inp.reshape(-1), group=group)
+    except (RuntimeError, NotImplementedError):          # a backend without the flat form
+        parts = [torch.empty_like(inp.reshape(-1)) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(parts, inp.reshape(-1), group=group)
+        out.view(-1).copy_(torch.cat(parts))
+    return out
+
+
+def gather_vocab(logits_local: torch.Tensor, model) -> torch.Tensor:
+    """[..., V / world] shards of the logits -> [..., V] on every rank (rank order = vocabulary order)."""
+    world = model.tp_world
+    flat = logits_local.reshape(-1, logits_local.shape[-1]).contiguous()
+    out = torch.empty((world,) + tuple(flat.shape), dtype=flat.dtype, device=flat.device)
+    all_gather_into(out, flat, getattr(model, "tp_group", None))
+    return out.permute(1, 0, 2).reshape(*logits_local.shape[:-1], -1)
 
 
 def all_reduce_(t: torch.Tensor, group=None) -> torch.Tensor:

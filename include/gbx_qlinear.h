@@ -301,6 +301,18 @@ int gbx_embed_next_token(void* argmax_keys, int64_t* token_io, int64_t* pos, con
                          int32_t D, int32_t vocab, int32_t from_keys, int32_t advance_pos, int32_t act_dtype,
                          void* hip_stream);
 
+/* Vocabulary-sharded output head (tensor parallel, build-side extension: the reference has no TP): rank r holds rows
+ * [index_offset, index_offset + N) of the head.  gbx_dense_gemv_argmax_shard is gbx_dense_gemv_argmax whose keys carry GLOBAL
+ * row indices; after the ranks have exchanged their GBX_ARGMAX_SLOTS keys (one all-gather of 512 bytes per rank),
+ * gbx_embed_next_token_sharded reduces the nkeys = GBX_ARGMAX_SLOTS * world gathered keys to the next token exactly like
+ * gbx_embed_next_token(from_keys = 1) -- same token on every rank, lowest index wins ties -- clears them and (local_keys != NULL)
+ * the rank's own GBX_ARGMAX_SLOTS keys. */
+int gbx_dense_gemv_argmax_shard(const void* x, const void* w, void* y, const void* norm_weight, float norm_eps, int32_t N, int32_t K,
+                                void* argmax_keys, int32_t index_offset, int32_t act_dtype, void* hip_stream);
+int gbx_embed_next_token_sharded(void* gathered_keys, int32_t nkeys, void* local_keys, int64_t* token_io, int64_t* pos,
+                                 const void* embed_table, void* h, int32_t D, int32_t vocab, int32_t advance_pos, int32_t act_dtype,
+                                 void* hip_stream);
+
 /* gbx_attn_decode for `batch` sequences that all stand at position *pos (synchronous batched decode): q / out
  * [batch, n_heads * head_dim], k / v [batch, n_kv * head_dim], caches [batch, n_kv, capacity, head_dim]. */
 int gbx_attn_decode_batched(const void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,

@@ -26,6 +26,7 @@ def _worker(rank, world, port, out, batch=1):
                    num_key_value_heads=2)                      # head_dim 128; per-rank K: o_proj 256, down_proj 512
         strat = S.make_strategy("S22", 3, 64)
         toks = [5, 9, 300, 17, 2, 44, 101, 7]
+        chains = {}
 
         def run(model):
             at = model.model.layers[0].self_attn
@@ -39,7 +40,15 @@ def _worker(rank, world, port, out, batch=1):
                 r = DecodeRunner(model, caches, use_graph=False)
                 return [r.step(torch.tensor([(t + 37 * b) % 512 for b in range(batch)], device=dev)).float().cpu().clone() for t in toks]
             r = FusedDecodeRunner(model, caches, use_graph=False)
-            return [r.step(torch.tensor([t], device=dev)).float().cpu().clone() for t in toks]
+            lg = [r.step(torch.tensor([t], device=dev)).float().cpu().clone() for t in toks]
+            # on-device greedy chain (vocabulary-sharded head: 64 argmax keys per rank are exchanged, never the logits)
+            r.start_greedy(torch.argmax(r.logits, -1))
+            ids = []
+            for _ in range(6):
+                r.step_greedy()
+                ids.append(int(r.tok.item()))
+            chains[id(model)] = ids
+            return lg
 
         full = S.build_model(cfg, strat, device=dev, seed=9)
         assert fused_eligible(full)
@@ -47,8 +56,11 @@ def _worker(rank, world, port, out, batch=1):
         shard = S.build_model(cfg, strat, device=dev, seed=9)
         tp.shard_llama(shard, rank, world)
         assert fused_eligible(shard)
+        assert getattr(shard, "tp_vocab", None) is not None and shard.head_weight().shape[0] * world == full.head_weight().shape[0]
         got = run(shard)
         out[rank] = max((g - w).abs().max().item() / (w.abs().max().item() + 1e-6) for g, w in zip(got, want))
+        if batch == 1:                       # same greedy continuation from the sharded head (first tokens: before bf16 noise can flip a tie)
+            assert chains[id(shard)][:2] == chains[id(full)][:2], (chains[id(shard)], chains[id(full)])
     finally:
         dist.destroy_process_group()
 
