@@ -350,8 +350,14 @@ def main():
     cfg = {"llama3-8b": S.LLAMA3_8B, "llama3.2-3b": S.LLAMA32_3B, "tiny": S.TINY}[args.model]
     strat = S.make_strategy(args.strategy, cfg["num_hidden_layers"], 128)
     model = S.build_model(cfg, strat, device=dev, seed=0)          # same seed on every rank -> identical weights
+    tp_allreduce = "none"
     if world > 1:
         tp.shard_llama(model, rank, world)
+        tp_allreduce = "rccl"
+        if os.environ.get("GBX_TP_P2P") == "1":
+            # opt-in: one-shot push all-reduce through hipIpc inboxes (gbx_p2p_allreduce) instead of RCCL for the [B, D] exchanges
+            tp.enable_p2p(rank, world, cfg["hidden_size"] * 32, dev)
+            tp_allreduce = "p2p one-shot (gbx_p2p_allreduce)"
     torch.cuda.synchronize()
 
     total = args.context + args.warmup + args.steps + 2
@@ -451,7 +457,8 @@ def main():
             "config": {"workload": f"{args.model} layer-mix {args.strategy} greedy decode batch={args.batch} "
                                    f"context={args.context} (BASELINE.json configs[{2 if args.batch == 1 else 4}])",
                        "global_batch": args.batch, "seq_len": args.context, "parallelism": f"tp{world}",
-                       "launch": graph_note, "decode_block": Runner.__name__, "bits_mix": args.strategy, "group_size": 128},
+                       "launch": graph_note, "decode_block": Runner.__name__, "bits_mix": args.strategy, "group_size": 128,
+                       "tp_allreduce": tp_allreduce, "tp_head": "vocabulary-sharded" if getattr(model, "tp_vocab", None) else "full"},
             "roofline": roof,
             "cpu_baseline": cpu,
             "e2e": {"bytes_per_token_per_gpu": per_gpu_bytes, "qlinear_bytes": ql_b, "lm_head_bytes": head_b,

@@ -55,6 +55,9 @@ def lib() -> ctypes.CDLL:
             L.gbx_qlinear_partials_bytes.argtypes = [i64, i32, i32, i32, i32]
             L.gbx_qlinear_partials_bytes.restype = ctypes.c_size_t
         L.gbx_attn_workspace_bytes.restype = ctypes.c_size_t
+        if hasattr(L, 'gbx_p2p_inbox_bytes'):
+            L.gbx_p2p_inbox_bytes.argtypes = [i32, i32]
+            L.gbx_p2p_inbox_bytes.restype = ctypes.c_size_t
         L.gbx_dense_swiglu_forward.argtypes = [p, p, p, i64, i32, i32, i32, p]
         L.gbx_dense_workspace_bytes.argtypes = [i64, i32, i32]
         L.gbx_dense_workspace_bytes.restype = ctypes.c_size_t
@@ -113,6 +116,11 @@ def _declare_optional(L) -> None:
         "gbx_dense_gemv": [p, p, p, p, f32, i32, i32, i32, p],
         "gbx_rmsnorm": [p, p, p, i64, i32, f32, i32, p],
         "gbx_dense_gemv_argmax": [p, p, p, p, f32, i32, i32, p, i32, p],
+        "gbx_p2p_inbox_create": [i32, i32, ctypes.POINTER(p), p],
+        "gbx_p2p_inbox_open": [p, ctypes.POINTER(p)],
+        "gbx_p2p_inbox_close": [p],
+        "gbx_p2p_inbox_destroy": [p],
+        "gbx_p2p_allreduce": [p, i32, i32, i32, ctypes.POINTER(p), i32, i32, p],
         "gbx_dense_gemv_argmax_shard": [p, p, p, p, f32, i32, i32, p, i32, i32, p],
         "gbx_embed_next_token_sharded": [p, i32, p, p, p, p, p, i32, i32, i32, i32, p],
         "gbx_embed_next_token": [p, p, p, p, p, i32, i32, i32, i32, i32, p],

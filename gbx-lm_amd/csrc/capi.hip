@@ -621,6 +621,58 @@ int gbx_embed_next_token(void* argmax_keys, int64_t* token_io, int64_t* pos, con
   return GBX_OK;
 }
 
+/* ---- one-shot P2P all-reduce: inbox management (hipIpc) and the collective ---- */
+size_t gbx_p2p_inbox_bytes(int32_t world, int32_t max_elems) {
+  if (world < 2 || world > 8 || max_elems <= 0) return 0;
+  return static_cast<size_t>(2) * world * ((max_elems + 1) / 2) * 8 + 64;       /* [parity][source][granule] + the state words */
+}
+
+int gbx_p2p_inbox_create(int32_t world, int32_t max_elems, void** inbox_out, void* ipc_handle_out) {
+  const size_t bytes = gbx_p2p_inbox_bytes(world, max_elems);
+  if (!bytes || !inbox_out || !ipc_handle_out) return fail(GBX_ERR_INVALID, "bad world / max_elems / output pointers");
+  void* p = nullptr;
+  hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);   /* peers write it, this GPU polls it */
+  if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&p, bytes); }
+  if (e != hipSuccess) return hip_fail(e, "gbx_p2p_inbox_create allocation");
+  e = hipMemset(p, 0, bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  hipIpcMemHandle_t h;
+  if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
+  if (e != hipSuccess) { (void)hipFree(p); return hip_fail(e, "gbx_p2p_inbox_create (memset / hipIpcGetMemHandle)"); }
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+  memcpy(ipc_handle_out, &h, sizeof(h));
+  *inbox_out = p;
+  return GBX_OK;
+}
+
+int gbx_p2p_inbox_open(const void* ipc_handle, void** mapped_out) {
+  if (!ipc_handle || !mapped_out) return fail(GBX_ERR_INVALID, "null pointer");
+  hipIpcMemHandle_t h;
+  memcpy(&h, ipc_handle, sizeof(h));
+  void* p = nullptr;
+  hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+  if (e != hipSuccess) return hip_fail(e, "hipIpcOpenMemHandle");
+  *mapped_out = p;
+  return GBX_OK;
+}
+
+int gbx_p2p_inbox_close(void* mapped) { return mapped && hipIpcCloseMemHandle(mapped) != hipSuccess ? fail(GBX_ERR_HIP, "hipIpcCloseMemHandle failed") : GBX_OK; }
+int gbx_p2p_inbox_destroy(void* inbox) { return inbox && hipFree(inbox) != hipSuccess ? fail(GBX_ERR_HIP, "hipFree failed") : GBX_OK; }
+
+int gbx_p2p_allreduce(void* x, int32_t n, int32_t rank, int32_t world, void* const* inboxes, int32_t max_elems, int32_t act_dtype,
+                      void* hip_stream) {
+  if (!x || !inboxes) return fail(GBX_ERR_INVALID, "null pointer");
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  if (world < 2 || world > 8 || rank < 0 || rank >= world) return fail(GBX_ERR_INVALID, "bad rank / world (%d / %d)", rank, world);
+  if (n <= 0 || (n & 1) || n > max_elems || !aligned(x, 4)) return fail(GBX_ERR_INVALID, "n must be even, <= max_elems (%d), x 4-byte aligned (n = %d)", max_elems, n);
+  for (int p = 0; p < world; ++p) if (!inboxes[p] || !aligned(inboxes[p], 8)) return fail(GBX_ERR_INVALID, "inbox %d missing or misaligned", p);
+  const int cap = (max_elems + 1) / 2;
+  void* state = static_cast<char*>(inboxes[rank]) + static_cast<size_t>(2) * world * cap * 8;     /* own inbox: the two state words behind the slabs */
+  hipError_t e = gbx::launch_p2p_allreduce(x, n, rank, world, inboxes, cap, state, act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_p2p_allreduce launch");
+  return GBX_OK;
+}
+
 int gbx_embed_next_token_sharded(void* gathered_keys, int32_t nkeys, void* local_keys, int64_t* token_io, int64_t* pos,
                                  const void* embed_table, void* h, int32_t D, int32_t vocab, int32_t advance_pos, int32_t act_dtype,
                                  void* hip_stream) {

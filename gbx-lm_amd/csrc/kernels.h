@@ -102,6 +102,8 @@ hipError_t launch_attn_decode(const void* q, const void* k, const void* v, void*
                               const void* q_bias = nullptr, const void* k_bias = nullptr, const void* v_bias = nullptr,
                               float* ws = nullptr);
 int attn_splits(int batch, int n_heads, int n_kv, int capacity);
+// p2p_allreduce.hip: one-shot push all-reduce of a short 16-bit vector over peer-mapped inboxes
+hipError_t launch_p2p_allreduce(void* x, int n, int rank, int world, void* const* inbox, int cap, void* state, bool bf16, hipStream_t s);
 // attn_oproj.hip: attention + o_proj slices of one decode token in one launch (short caches)
 bool attn_oproj_supported(int n_heads, int n_kv, int head_dim, int D, int bits, int group_size, int capacity);
 hipError_t launch_attn_oproj(const void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,

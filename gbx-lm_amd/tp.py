@@ -101,7 +101,72 @@ def gather_vocab(logits_local: torch.Tensor, model) -> torch.Tensor:
     return out.permute(1, 0, 2).reshape(*logits_local.shape[:-1], -1)
 
 
+class P2PAllReduce:
+    """One-shot push all-reduce of a short 16-bit vector through peer-mapped inboxes (gbx_p2p_allreduce, csrc/p2p_allreduce.hip):
+    every rank writes its vector into every peer's memory over xGMI and sums what arrived in its own, in rank order, fp32, one
+    rounding -- identical bits on every rank, one launch, graph-capturable.  The inbox handles travel through ``group`` once at
+    construction (any backend).  Validated on ranks that share one GPU (tests/test_p2p_gpu.py); opt-in for real multi-GPU runs
+    (``GBX_TP_P2P=1``, see ``enable_p2p``) until a multi-GPU box has confirmed it."""
+
+    def __init__(self, rank: int, world: int, max_elems: int, device, group=None):
+        import ctypes
+        from . import _lib
+        self.L = _lib.lib()
+        self.rank, self.world, self.max_elems = rank, world, int(max_elems)
+        self.device = torch.device(device)
+        with torch.cuda.device(self.device):
+            own = ctypes.c_void_p()
+            handle = ctypes.create_string_buffer(64)
+            _lib.check(self.L.gbx_p2p_inbox_create(world, self.max_elems, ctypes.byref(own), handle))
+            self.own = own
+            handles = [None] * world
+            dist.all_gather_object(handles, bytes(handle.raw), group=group)
+            self.mapped = []
+            arr = (ctypes.c_void_p * world)()
+            for p in range(world):
+                if p == rank:
+                    arr[p] = own.value
+                    continue
+                m = ctypes.c_void_p()
+                _lib.check(self.L.gbx_p2p_inbox_open(ctypes.create_string_buffer(handles[p], 64), ctypes.byref(m)))
+                self.mapped.append(m)
+                arr[p] = m.value
+            self.inboxes = arr
+        dist.barrier(group=group)                       # nobody pushes before everybody has mapped
+
+    def __call__(self, t: torch.Tensor) -> torch.Tensor:
+        from . import _lib
+        from .ops import _DT, _stream_ptr
+        if not (t.is_cuda and t.is_contiguous() and t.dtype in (torch.bfloat16, torch.float16) and t.numel() % 2 == 0
+                and t.numel() <= self.max_elems):
+            raise ValueError("P2PAllReduce: contiguous bf16 / fp16 CUDA tensor with an even element count <= max_elems")
+        _lib.check(self.L.gbx_p2p_allreduce(t.data_ptr(), t.numel(), self.rank, self.world, self.inboxes, self.max_elems,
+                                            _DT[t.dtype], _stream_ptr(t.device)))
+        return t
+
+    def close(self) -> None:
+        for m in getattr(self, "mapped", []):
+            self.L.gbx_p2p_inbox_close(m)
+        self.mapped = []
+        if getattr(self, "own", None) is not None:
+            self.L.gbx_p2p_inbox_destroy(self.own)
+            self.own = None
+
+
+_p2p: Optional[P2PAllReduce] = None
+
+
+def enable_p2p(rank: int, world: int, max_elems: int, device, group=None) -> P2PAllReduce:
+    """Route ``all_reduce_`` of 16-bit tensors with at most ``max_elems`` elements through the one-shot P2P kernel."""
+    global _p2p
+    _p2p = P2PAllReduce(rank, world, max_elems, device, group)
+    return _p2p
+
+
 def all_reduce_(t: torch.Tensor, group=None) -> torch.Tensor:
     """Sum of the per-rank partial outputs of a K-split layer (the path's only exchange step)."""
+    if (_p2p is not None and t.is_cuda and t.dtype in (torch.bfloat16, torch.float16) and t.is_contiguous()
+            and t.numel() % 2 == 0 and t.numel() <= _p2p.max_elems):
+        return _p2p(t)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t

@@ -301,6 +301,21 @@ int gbx_embed_next_token(void* argmax_keys, int64_t* token_io, int64_t* pos, con
                          int32_t D, int32_t vocab, int32_t from_keys, int32_t advance_pos, int32_t act_dtype,
                          void* hip_stream);
 
+/* One-shot peer-to-peer all-reduce(sum) of a short 16-bit vector x[n] (n even, <= max_elems) over the `world` GPUs (2..8) of one
+ * node -- the exchange after o_proj / down_proj of tensor-parallel decode (build-side extension).  Every rank owns an INBOX
+ * (gbx_p2p_inbox_create: device memory + its 64-byte hipIpc handle), maps every peer's inbox (gbx_p2p_inbox_open on the handles the
+ * ranks exchanged out of band) and passes the `world` mapped pointers, own inbox at index `rank`.  gbx_p2p_allreduce pushes x into
+ * the peers' inboxes as 8-byte {epoch, payload} granules and sums what arrived in its own inbox in rank order, fp32, one rounding:
+ * the same bits on every rank.  Stream-ordered, no host synchronisation, graph-capturable (the epoch lives in the inbox).  All
+ * ranks must make the same sequence of calls with the same n. */
+size_t gbx_p2p_inbox_bytes(int32_t world, int32_t max_elems);
+int gbx_p2p_inbox_create(int32_t world, int32_t max_elems, void** inbox_out, void* ipc_handle_out /* 64 bytes */);
+int gbx_p2p_inbox_open(const void* ipc_handle, void** mapped_out);
+int gbx_p2p_inbox_close(void* mapped);
+int gbx_p2p_inbox_destroy(void* inbox);
+int gbx_p2p_allreduce(void* x, int32_t n, int32_t rank, int32_t world, void* const* inboxes, int32_t max_elems, int32_t act_dtype,
+                      void* hip_stream);
+
 /* Vocabulary-sharded output head (tensor parallel, build-side extension: the reference has no TP): rank r holds rows
  * [index_offset, index_offset + N) of the head.  gbx_dense_gemv_argmax_shard is gbx_dense_gemv_argmax whose keys carry GLOBAL
  * row indices; after the ranks have exchanged their GBX_ARGMAX_SLOTS keys (one all-gather of 512 bytes per rank),
