@@ -487,6 +487,88 @@ class FusedDecodeRunner(DecodeRunner):
         return self.logits_buf
 
 
+class PromptRunner:
+    """Short prompts (2..128 tokens into an EMPTY cache) as ONE replayed HIP graph per length bucket.
+
+    The prompt pass of the reference (gbx_lm/utils.py:312-323: ``model(y[None], cache=prompt_cache)`` then the logits of the last
+    position) is ~16 launches per layer: host-bound up to ~100 tokens (Llama-3-8B shapes, measured, scratch/ttft.py: 16 tokens
+    7.8 -> 4.1 ms, 128 tokens 8.4 -> 7.5 ms with the graph).  From 256 tokens on the pass is GPU-bound -- the 224 GEMMs at M = 512
+    ARE the 14 ms, graph or not (round 2 had that wrong) -- and what helps there is the dense GEMM on resident bf16 images
+    (ops.dense_cache_prewarm: 512 tokens 14.2 -> 11.2 ms), so the buckets stop at 128.  A bucket (32, 64, 128 tokens) owns static token ids, static KV staging buffers and the captured forward of the model's OWN body
+    over ``bucket`` positions starting at 0: the prompt is padded to the bucket with token 0 (causal attention: positions >= L never
+    reach positions < L), the hidden state of position L - 1 is picked by a device-resident index, the head runs on that row only.
+    After the replay the first L cache rows of every layer are copied into the caller's cache (its ``offset`` becomes L), so
+    everything downstream -- the decode runner, a longer second prompt -- sees exactly what the eager pass would have left.
+    Bit-identical to the eager pass (tests/test_prompt_graph_gpu.py): same kernels on the same rows; tile dispatch depends on the
+    row count, so the eager comparison runs on the padded bucket as well."""
+
+    BUCKETS = (32, 64, 128)
+
+    def __init__(self, model, bucket: int):
+        self.model, self.bucket = model, bucket
+        dev = next(model.parameters()).device
+        dt = model.model.embed_tokens.weight.dtype
+        at = model.model.layers[0].self_attn
+        self.ids = torch.zeros((1, bucket), dtype=torch.long, device=dev)
+        self.last = torch.zeros((1,), dtype=torch.long, device=dev)
+        self.caches = []
+        for _ in model.model.layers:
+            c = KVCache(step=bucket)
+            like = torch.empty((1, at.n_kv_heads, 1, at.head_dim), dtype=dt, device=dev)
+            c.reserve(bucket, like, like)
+            self.caches.append(c)
+        torch.cuda.synchronize(dev)
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s), torch.no_grad():
+            for _ in range(2):                                    # lazy initialisation outside the capture
+                self._forward()
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.logits = self._forward()
+
+    def _forward(self):
+        for c in self.caches:
+            c.offset = 0
+        hidden = self.model.model(self.ids, None, self.caches)                 # [1, bucket, D]
+        h_last = hidden.index_select(1, self.last)                            # [1, 1, D]: position L - 1
+        return F.linear(h_last, self.model.head_weight())[:, -1, :]
+
+    def run(self, y: torch.Tensor, prompt_cache: List[KVCache]) -> torch.Tensor:
+        L = y.numel()
+        self.ids.zero_()
+        self.ids[0, :L] = y
+        self.last.fill_(L - 1)
+        self.graph.replay()
+        for dst, src in zip(prompt_cache, self.caches):
+            dst.reserve(L, src.keys[:, :, :1], src.values[:, :, :1])
+            dst.keys[:, :, :L].copy_(src.keys[:, :, :L])
+            dst.values[:, :, :L].copy_(src.values[:, :, :L])
+            dst.offset = L
+        return self.logits
+
+
+def prompt_step(model, y: torch.Tensor, prompt_cache) -> Optional[torch.Tensor]:
+    """``model.prompt_step`` hook of generate_step: logits [1, V] of the last prompt position through a graph-replayed bucket, or
+    None when the call is not a short fresh prompt on the GPU (the caller then runs the eager pass).  GBX_PROMPT_GRAPH=0 disables."""
+    import os
+    L = y.numel()
+    if L < 2 or L > PromptRunner.BUCKETS[-1] or os.environ.get("GBX_PROMPT_GRAPH", "1") == "0":
+        return None
+    c0 = prompt_cache[0] if prompt_cache else None
+    if (not isinstance(c0, KVCache) or any(type(c) is not KVCache or c.offset != 0 or c.static_active for c in prompt_cache)
+            or not y.is_cuda or getattr(model, "tp_world", 1) > 1 or torch.cuda.is_current_stream_capturing()):
+        return None
+    bucket = next(b for b in PromptRunner.BUCKETS if b >= L)
+    runners = model.__dict__.setdefault("_prompt_runners", {})
+    r = runners.get(bucket)
+    if r is None:
+        r = runners[bucket] = PromptRunner(model, bucket)
+    return r.run(y, prompt_cache)
+
+
 def _rope_at(x: torch.Tensor, rope, pos: torch.Tensor) -> torch.Tensor:
     """RoPE at a device-resident position (graph-safe twin of rope_utils.apply_rope)."""
     inv = rope.inv_freq

@@ -129,8 +129,8 @@ class MLP(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         act = None
-        if x.is_cuda and x.numel() // x.shape[-1] >= 1024 and type(self.gate_proj) is QuantizedLinear and type(self.up_proj) is QuantizedLinear:
-            from .. import ops                       # long prompt: both projections and the SwiGLU as one dense matrix-core GEMM
+        if x.is_cuda and x.numel() // x.shape[-1] >= 256 and type(self.gate_proj) is QuantizedLinear and type(self.up_proj) is QuantizedLinear:
+            from .. import ops                       # long prompt (or a short one with resident images): both projections and the SwiGLU as one dense matrix-core GEMM
             act = ops.quantized_swiglu(x, self.gate_proj, self.up_proj)
         if act is None:
             act = swiglu(self.gate_proj(x), self.up_proj(x))
@@ -247,6 +247,11 @@ class Model(nn.Module):
         position only -- at a 4096-token prompt the full head is 2 x 4096 x vocab x hidden flops of discarded work."""
         hidden = self.model(inputs, None, cache)
         return self._full_logits(F.linear(hidden[:, -1:, :], self.head_weight())[:, -1, :])
+
+    def prompt_step(self, y: torch.Tensor, prompt_cache):
+        """Short fresh prompts: the prompt pass as one replayed HIP graph per length bucket (decode.PromptRunner); None = not applicable."""
+        from ..decode import prompt_step
+        return prompt_step(self, y, prompt_cache)
 
     def decode_step(self, y: torch.Tensor, prompt_cache) -> torch.Tensor:
         """Single-token fast path (fused HIP decode block, HIP-graph replay); see gbx_lm_amd/decode.py."""

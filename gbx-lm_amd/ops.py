@@ -121,6 +121,39 @@ def dense_cache_invalidate(tensor: torch.Tensor) -> None:
     _dense_cache.invalidate(tensor)
 
 
+def dense_cache_prewarm(model, dtype: Optional[torch.dtype] = None) -> int:
+    """Build the resident bf16 / fp16 image of every QuantizedLinear weight of ``model`` now (serving: the first request then already
+    runs its prompt on dense GEMMs -- from 256 rows on -- instead of paying the dequantisation or the fused tiles).  Costs 2 bytes per
+    weight of HBM under the ``GBX_DENSE_CACHE_GB`` budget; returns the bytes resident afterwards."""
+    from .models.quantized_linear_gba import QuantizedLinear
+    L = _lib.lib()
+    for mod in model.modules():
+        if not isinstance(mod, QuantizedLinear) or mod.scales is None or not mod.qweight.is_cuda:
+            continue
+        dt = dtype or mod.scales.dtype
+        n, k = mod.output_dims, mod.input_dims
+        if dt not in _DT or mod.scales.dtype != dt or k % 128 or n * k * 2 > _dense_cache.budget - _dense_cache.nbytes:
+            continue
+        src = (mod.qweight, mod.scales, mod.zeros)
+        ckey = (n, k, mod.bits, mod.group_size, dt, mod.qweight.device.index)
+        if not all(t.is_contiguous() for t in src) or _dense_cache.get(src, ckey) is not None:
+            continue
+        dense = _alloc_dense((n, k), dt, mod.qweight.device)
+        if dense is None:
+            break
+        _lib.check(L.gbx_dequantize(mod.qweight.data_ptr(), mod.scales.data_ptr(), mod.zeros.data_ptr(), dense.data_ptr(), n, k, mod.bits,
+                                    mod.group_size, _DT[dt], _DT[dt], _stream_ptr(dense.device)))
+        _dense_cache.put(src, ckey, dense)
+    # the interleaved gate | up image of every SwiGLU MLP (built by one long call on a dummy activation)
+    for mod in model.modules():
+        gate, up = getattr(mod, "gate_proj", None), getattr(mod, "up_proj", None)
+        if (type(gate) is QuantizedLinear and type(up) is QuantizedLinear and gate.scales is not None and gate.qweight.is_cuda
+                and 2 * gate.output_dims * gate.input_dims * 2 <= _dense_cache.budget - _dense_cache.nbytes):
+            x = torch.zeros((1024, gate.input_dims), dtype=dtype or gate.scales.dtype, device=gate.qweight.device)
+            quantized_swiglu(x, gate, up)
+    return _dense_cache.nbytes
+
+
 def dense_cache_bytes() -> int:
     """Bytes of HBM the resident images hold right now."""
     return _dense_cache.nbytes
@@ -193,10 +226,21 @@ def quantized_matmul(x: torch.Tensor, w: torch.Tensor, scales: torch.Tensor, bia
     dense_path = m >= 1024 and need >= n * k * 2 and 31 <= L.gbx_qlinear_kernel_id(m, n, k, bits, group_size, 1) <= 33
     cacheable = (dense_path and _dense_cache.budget >= n * k * 2 and m <= 61440 and all(a is b for a, b in zip((w, scales, biases), src))
                  and not torch.cuda.is_current_stream_capturing())
+    ckey = (n, k, bits, group_size, x.dtype, x.device.index)
+    if (not cacheable and 256 <= m < 4096 and k % 64 == 0 and _dense_cache.budget > 0 and all(a is b for a, b in zip((w, scales, biases), src))):
+        # short prompt and the bf16 image of this weight is ALREADY resident (an earlier long call, or dense_cache_prewarm): the dense
+        # GEMM beats the fused dequantising tiles from 256 rows on (Llama-3-8B layer at 512 rows: 398 -> 250 us); never built here
+        dense = _dense_cache.get(src, ckey)
+        if dense is not None:
+            part = L.gbx_dense_workspace_bytes(m, n, k)
+            scratch = torch.empty((part,), dtype=torch.uint8, device=x.device) if part else None
+            rc = L.gbx_dense_forward_ws(x2.data_ptr(), dense.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(),
+                                        m, n, k, _DT[x.dtype], scratch.data_ptr() if part else None, part, _stream_ptr(x.device))
+            if rc == _lib.GBX_OK:
+                return out.reshape(*x.shape[:-1], n)
     if cacheable:
         # prompt-sized call on the dense path: the [N, K] image is built once (gbx_dequantize), kept resident, and every call
         # runs the GEMM alone (gbx_dense_forward_ws: k split over workgroups with fp32 scratch for few-tile shapes)
-        ckey = (n, k, bits, group_size, x.dtype, x.device.index)
         dense = _dense_cache.get(src, ckey)
         if dense is None:
             dense = _alloc_dense((n, k), x.dtype, x.device)
@@ -409,6 +453,17 @@ def quantized_swiglu(x: torch.Tensor, gate, up) -> Optional[torch.Tensor]:
     m = x2.shape[0]
     same = ((gate.bits, gate.group_size, gate.input_dims, gate.output_dims) == (up.bits, up.group_size, up.input_dims, up.output_dims)
             and gate.bias is None and up.bias is None and gate.scales is not None and up.scales is not None)
+    if (x.is_cuda and x.dtype in _DT and 256 <= m < 1024 and same and gate.scales.dtype == x.dtype and up.scales.dtype == x.dtype
+            and _dense_cache.budget > 0 and n % 256 == 0):
+        # short prompt: only when the interleaved gate | up image is ALREADY resident (an earlier long call, dense_cache_prewarm)
+        src = (gate.qweight, gate.scales, gate.zeros, up.qweight, up.scales, up.zeros)
+        dense = _dense_cache.get(src, ("swiglu", n, k, gate.bits, gate.group_size, x.dtype, x.device.index))
+        if dense is not None:
+            x2c = x2.contiguous()
+            y = torch.empty((m, n), dtype=x.dtype, device=x.device)
+            rc = _lib.lib().gbx_dense_swiglu_forward(x2c.data_ptr(), dense.data_ptr(), y.data_ptr(), m, n, k, _DT[x.dtype], _stream_ptr(x.device))
+            if rc == _lib.GBX_OK:
+                return y.reshape(*x.shape[:-1], n)
     if x.is_cuda and x.dtype in _DT and m >= 1024 and same and gate.scales.dtype == x.dtype and up.scales.dtype == x.dtype:
         # long prompt: gate | up dequantised once into one dense matrix, one matrix-core GEMM with the SwiGLU in its epilogue
         need = _lib.lib().gbx_qlinear_swiglu_workspace_bytes(m, n, k)

@@ -295,7 +295,11 @@ def generate_step(prompt: torch.Tensor, model: nn.Module, *, max_tokens: int = 2
             logits, prompt_hidden_states = model(y[None], cache=prompt_cache, hidden_states=True)
             logits = logits[:, -1, :]
         elif hasattr(model, "last_logits"):
-            logits = model.last_logits(y[None], prompt_cache)          # output head on the last position only
+            logits = None
+            if hasattr(model, "prompt_step") and not logits_processors:
+                logits = model.prompt_step(y, prompt_cache)           # short fresh prompt: one replayed graph (None: not applicable)
+            if logits is None:
+                logits = model.last_logits(y[None], prompt_cache)      # output head on the last position only
         else:
             logits = model(y[None], cache=prompt_cache)[:, -1, :]
         if logits_processors:
