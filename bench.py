@@ -108,8 +108,25 @@ def kernel_leg(model, reps=20):
             traffic = rec["traffic_bytes_per_launch"] if rec else None
     except (OSError, ValueError, KeyError):
         traffic = None
+    # what the launch can attain at all: its measured chain head (the same launch with the weight stream removed,
+    # GBX_CHAIN_FLOOR=2, recorded by scratch/profile_r03.sh) + its bytes at the chip's measured copy rate
+    attainable = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_chain_floor.json")) as f:
+            cf = json.load(f)
+        null_us = cf.get("gateup_us_per_launch_null_weights")
+        if null_us:
+            # the launch with its weight stream removed (same instructions) takes as long as the real one: what bounds it is its
+            # head + vector-ALU consumption, so that time -- not bytes / copy rate (%.1f us) -- is what this kernel can attain
+            stream_us = nbytes / (cf.get("copy_rate_GBps", 6290.0) * 1e3)
+            att_us = max(null_us, stream_us)
+            attainable = {"us_per_launch": att_us, "GBps": nbytes / att_us / 1e3, "frac_of_peak": nbytes / att_us / 1e3 / HBM_PEAK_GBPS,
+                          "null_weights_us": null_us, "stream_only_us": stream_us,
+                          "source": "profiles/r03_chain_floor.json: max(launch with null weights [GBX_CHAIN_FLOOR=2], bytes / measured copy rate)"}
+    except (OSError, ValueError, KeyError):
+        attainable = None
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "attainable": attainable,
             "kernel": f"gbx::gemv_kernel<{bits},...> fused RMSNorm+gate_proj+up_proj+SwiGLU, 2 x [N={n}, K={k}] g={grp}",
             "bytes_per_launch": nbytes, "us_per_launch": us, "launches_timed": reps * len(descs),
             "working_set_bytes": nbytes * len(descs)}
