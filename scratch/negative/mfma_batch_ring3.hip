@@ -96,6 +96,7 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
   const int ksplit = a.ws ? a.ksplit : 1;
   const int nchunks = K / KC / ksplit, cbase = blockIdx.y * nchunks;
   const int steps = nchunks / 8, cpk = nchunks / KG;
+  const int steps3 = (steps + 2) / 3 * 3;
 
   // segment of this workgroup's rows (uniform): a workgroup never straddles two matrices (launcher)
   const int nwg = blockIdx.x * (NG * TNW);
@@ -143,19 +144,20 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
 #pragma unroll
   for (int i = 0; i < (TNW == 16 ? MT : 1); ++i) acc16[i] = f32x4v{0};
 
-  unsigned wq[2][NCHW][WL];                        // packed words: current step, next step
+  constexpr int WD = 3;                             // packed words: a ring of WD steps (the current one + WD-1 in flight)
+  unsigned wq[WD][NCHW][WL];
   constexpr int SR = NCHW * NF >= 2 ? NCHW * NF / 2 : 1;   // dwords holding the step's NCHW * NF scales (zeros) of the lane's row
-  unsigned scq[2][SR], zeq[2][SR];
+  unsigned scq[WD][SR], zeq[WD][SR];
   u32x4 xs[8][2];                                   // loader: activations of the step being staged
-#ifdef BX_KNOCK                                     // -DBX_KNOCK=1..4: knock-out builds (scratch/build_exp.sh), timing only
+#ifdef BX_KNOCK
 #pragma unroll
   for (int i = 0; i < 8; ++i) { xs[i][0] = u32x4{0, 0, 0, 0}; xs[i][1] = u32x4{0, 0, 0, 0}; }
 #pragma unroll
   for (int j = 0; j < NCHW; ++j)
 #pragma unroll
-    for (int q = 0; q < WL; ++q) wq[1][j][q] = 0x55555555u;
+    for (int q = 0; q < WL; ++q) wq[0][j][q] = wq[1][j][q] = wq[2][j][q] = 0x55555555u;
 #pragma unroll
-  for (int q = 0; q < SR; ++q) { scq[1][q] = 0x3C003C00u; zeq[1][q] = 0; }
+  for (int q = 0; q < SR; ++q) { scq[0][q] = scq[1][q] = scq[2][q] = 0x3C003C00u; zeq[0][q] = zeq[1][q] = zeq[2][q] = 0; }
 #endif
 
   auto load_x = [&](int step) {
@@ -165,15 +167,9 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
 #endif
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-#if defined(BX_KNOCK) && BX_KNOCK == 5               // timing only: every instruction covers whole 128-byte lines (pieces end up in the wrong lanes)
-      const unsigned short* p = xrow - lpc * 8 + xoff(it) + step * (NCHW * KC);
-      xs[it][0] = *reinterpret_cast<const u32x4*>(p);
-      xs[it][1] = *reinterpret_cast<const u32x4*>(p + 64);
-#else
       const unsigned short* p = xrow + xoff(it) + step * (NCHW * KC);
       xs[it][0] = *reinterpret_cast<const u32x4*>(p);
       xs[it][1] = *reinterpret_cast<const u32x4*>(p + 8);
-#endif
     }
   };
   auto load_w = [&](unsigned (&wn)[NCHW][WL], unsigned (&sc_n)[SR], unsigned (&ze_n)[SR], int step) {
@@ -362,7 +358,7 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
     if (steps > 1) load_x(kstep(1));
     STAMP();
     __syncthreads();
-    for (int step = 0; step < steps; ++step) {
+    for (int step = 0; step < steps3; ++step) {     // (steps3 barriers: the compute loop is unrolled by three)
       if (step + 1 < steps) {
         store_x((step & 1) ^ 1);                    // step+1: registers -> slab (+ xsum)
         if (step + 2 < steps) load_x(kstep(step + 2));
@@ -372,29 +368,29 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
       STAMP();
     }
   } else {
-    load_w(wq[1], scq[1], zeq[1], kstep(0));
+    // the packed words of steps s+1 and s+2 are in flight while step s is multiplied (a ring of three register sets, rotated by
+    // unrolling): with one step of cover the HBM latency under load (2-3 us) outlasted a step's arithmetic (~1.5 us) and
+    // every step waited for its weights (knock-out builds, M = 32, 28672 x 4096: 21.1 us; without weight loads 13.7)
+    load_w(wq[0], scq[0], zeq[0], kstep(0));
+    if (steps > 1) load_w(wq[1], scq[1], zeq[1], kstep(1));
     STAMP();
     __syncthreads();
-    for (int step = 0; step < steps; ++step) {
-#ifdef BX_STAMPS
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+    auto one = [&](const unsigned (&wc)[NCHW][WL], const unsigned (&sc_c)[SR], const unsigned (&ze_c)[SR],
+                   unsigned (&wn)[NCHW][WL], unsigned (&sc_n)[SR], unsigned (&ze_n)[SR], int step) {
       STAMP();
-#pragma unroll
-      for (int j = 0; j < NCHW; ++j)
-#pragma unroll
-        for (int q = 0; q < WL; ++q) wq[0][j][q] = wq[1][j][q];
-#pragma unroll
-      for (int q = 0; q < SR; ++q) { scq[0][q] = scq[1][q]; zeq[0][q] = zeq[1][q]; }
-      if (step + 1 < steps) load_w(wq[1], scq[1], zeq[1], kstep(step + 1));
+      if (step + 2 < steps) load_w(wn, sc_n, ze_n, kstep(step + 2));
+      __builtin_amdgcn_sched_barrier(0);            // (the three inlined copies of a step must not be interleaved: registers)
       STAMP();
-      compute(wq[0], scq[0], zeq[0], step & 1);
-#ifdef BX_STAMPS
+      if (step < steps) compute(wc, sc_c, ze_c, step & 1);
       __builtin_amdgcn_sched_barrier(0);
-#endif
       STAMP();
       __syncthreads();
       STAMP();
+    };
+    for (int step = 0; step < steps3; step += 3) {
+      one(wq[0], scq[0], zeq[0], wq[2], scq[2], zeq[2], step);
+      one(wq[1], scq[1], zeq[1], wq[0], scq[0], zeq[0], step + 1);
+      one(wq[2], scq[2], zeq[2], wq[1], scq[1], zeq[1], step + 2);
     }
   }
   __syncthreads();                                  // the slabs become the reduction buffer
