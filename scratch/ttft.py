@@ -23,4 +23,7 @@ for T in (16, 128, 256, 512, 1024):
             with torch.no_grad():
                 lg = model.last_logits(y[None], cache) if mode.startswith("eager") else prompt_step(model, y, cache)
             torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+        if lg is None:                      # prompt_step declines prompts beyond its largest bucket: the caller runs the eager pass
+            print(f"T={T:5d} {mode}: no bucket (> 128 tokens): eager pass is used")
+            continue
         print(f"T={T:5d} {mode}: prompt pass {min(ts[1:]):6.2f} ms (first call {ts[0]:.1f} ms)")

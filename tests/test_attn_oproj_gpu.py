@@ -99,11 +99,13 @@ def test_x_acc_prologue_and_zero_buf(oracle, bits, dt, n):
     ops.qlinear_fused(ops.make_fused_desc(h, (gate, up), (a_new,), norm_weight=nw, eps=1e-5, swiglu=True, packed=pgu,
                                           x_acc=acc, x_out=x_out), h.device)
     assert torch.equal(x_out, hsum)
-    # same arithmetic on the same vector; the two instantiations may differ in the last bit of the RMS statistic (one ulp on a
-    # tenth of the outputs for some inputs), never by more
+    # same arithmetic on the same vector; the two instantiations may differ in the last bit of the RMS statistic: one ulp on a few
+    # normalised activations, which the SwiGLU epilogue's three roundings (gate, silu(gate), product) can turn into up to three ulps
+    # of an output -- on a handful of entries; most are identical
     d = (a_new.float() - a_ref.float()).abs()
     ulp = torch.maximum(a_ref.float().abs(), torch.tensor(1e-3, device=DEV)) * (2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10)
-    assert (d <= 1.01 * ulp).all() and (d == 0).float().mean() > 0.8
+    assert (d <= 3.01 * ulp).all(), float((d / ulp).max())
+    assert (d <= 1.01 * ulp).float().mean() > 0.99 and (d == 0).float().mean() > 0.8
     # zero_buf on a residual launch
     dn, _ = _mod(oracle, 256, n if n % 128 == 0 else 1024, bits, g, 5, act)
     xa = torch.randn(dn.input_dims).to(dt).to(DEV)
