@@ -102,8 +102,10 @@ def test_x_acc_prologue_and_zero_buf(oracle, bits, dt, n):
     # same arithmetic on the same vector; the two instantiations may differ in the last bit of the RMS statistic: one ulp on a few
     # normalised activations, which the SwiGLU epilogue's three roundings (gate, silu(gate), product) can turn into up to three ulps
     # of an output -- on a handful of entries; most are identical
+    # (an output far below the typical magnitude -- a cancelling up row, a strongly negative gate -- inherits the ABSOLUTE wobble of
+    # its pre-activations: units are ulps of max(|a|, mean |a|))
     d = (a_new.float() - a_ref.float()).abs()
-    ulp = torch.maximum(a_ref.float().abs(), torch.tensor(1e-3, device=DEV)) * (2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10)
+    ulp = torch.maximum(a_ref.float().abs(), a_ref.float().abs().mean()) * (2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10)
     assert (d <= 3.01 * ulp).all(), float((d / ulp).max())
     assert (d <= 1.01 * ulp).float().mean() > 0.99 and (d == 0).float().mean() > 0.8
     # zero_buf on a residual launch
