@@ -115,7 +115,7 @@ def kernel_leg(model, reps=20):
         with open(os.path.join(ROOT, "profiles", "r03_chain_floor.json")) as f:
             cf = json.load(f)
         null_us = cf.get("gateup_us_per_launch_null_weights")
-        if null_us:
+        if null_us and cf.get("kernel_key") == f"gateup_b{bits}_N{n}_K{k}_g{grp}":       # measured for this exact launch only
             # the launch with its weight stream removed (same instructions) takes as long as the real one: what bounds it is its
             # head + vector-ALU consumption, so that time -- not bytes / copy rate (%.1f us) -- is what this kernel can attain
             stream_us = nbytes / (cf.get("copy_rate_GBps", 6290.0) * 1e3)
