@@ -66,6 +66,11 @@ struct GemvArgs {
   // ---- buffer this launch clears for a later one (the accumulator above, once its consumer has run) ----
   long long* zero_buf;
   int zero_n;
+  // Uneven split (KS == 1 fat geometry): waves [0, long_waves) of every workgroup own batches_per_owner batches, the others one
+  // less, so that a row count that is not a multiple of (resident workgroups x waves x 2) still puts one workgroup on EVERY CU
+  // with equal work per SIMD (waves w, w+4, w+8, w+12 share a SIMD: long_waves is a multiple of 4).  0: every wave owns
+  // batches_per_owner batches.
+  int long_waves;
   int null_rows;                   // measurement only (GBX_CHAIN_FLOOR=2): every batch re-reads rows 0 / 1 -- the whole launch sequence with no weight stream
 #ifdef GBX_STAMPS
   unsigned long long* stamps;      // diagnostic build only: [workgroup][wave][16] s_memrealtime stamps
@@ -271,7 +276,15 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
   // and a multi-microsecond straggler tail).
   const int owner = KS == 1 ? (blockIdx.x * NW + wave) : (blockIdx.x * GPB + rg);
   const int owners = static_cast<int>(gridDim.x) * (KS == 1 ? NW : GPB);
-  auto batch_of = [&](int j) { return owner + j * owners; };
+  // (uneven split: the last round belongs to the long waves only, packed densely; a short wave's last ring slot points past the
+  // end -- its loads clamp to the last row, an L2 hit, and it is never consumed)
+  const int long_waves = KS == 1 ? a.long_waves : 0;
+  const int my_n = (long_waves && wave >= long_waves) ? bpo - 1 : bpo;
+  auto batch_of = [&](int j) {
+    if (KS == 1 && long_waves && j == bpo - 1)
+      return wave < long_waves ? (bpo - 1) * owners + static_cast<int>(blockIdx.x) * long_waves + wave : (N + rowstep - 1) / rowstep;
+    return owner + j * owners;
+  };
   const int slot0 = (KS == 1 ? 0 : kq * 64) + lane;        // this lane's slot in pass 0
   constexpr int PSTRIDE = 64 * KS;                          // slot stride between passes
   const int n0 = a.seg[0].N, n01 = n0 + a.seg[1].N;
@@ -680,7 +693,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
   GBX_STAMP(4);
 #pragma unroll
   for (int d = 0; d < D; ++d) {
-    consume(ring[d], base + d);
+    if (base + d < my_n) consume(ring[d], base + d);      // (wave-uniform; no loads behind this branch)
     if (d == 0) GBX_STAMP(5);
   }
   GBX_STAMP(6);
@@ -754,7 +767,7 @@ static hipError_t launch_gemv_d(const GemvArgs& a, int M, bool bf16, int bpo, in
   // re-reads rows 0 / 1 (same instruction stream, no weight stream from HBM) -- what is left of
   // a decode step is its dependency chain (launch boundaries, activation prologues, reductions) with next to no weight stream
   static const int chain_floor = [] { const char* e = getenv("GBX_CHAIN_FLOOR"); return e ? atoi(e) : 0; }();
-  if (chain_floor == 1) args.batches_per_owner = D;
+  if (chain_floor == 1) { args.batches_per_owner = D; args.long_waves = 0; }
   if (chain_floor == 2) args.null_rows = 1;
   dim3 grid(blocks, M), block(NW * 64);
   if (bf16) hipLaunchKernelGGL((gemv_kernel<BITS, P, KS, D, true, SPLIT, NW, PK>), grid, block, shmem, stream, args);
@@ -782,6 +795,21 @@ static hipError_t launch_gemv_nw(const GemvArgs& a, int M, bool bf16, int nbatch
   int bpo = (nbatches + own2 - 1) / own2;
   bpo = ((bpo + 1) / 2) * 2;
   if (KS == 4 && bpo > GEMV_MAX_BATCHES_PER_GROUP_KS4) bpo = GEMV_MAX_BATCHES_PER_GROUP_KS4;
+  if constexpr (KS == 1 && NW % 4 == 0) {
+    // Uneven split: when the even split above leaves resident slots empty (gate|up of an 8B layer: 14336 batches = 3.5 per wave of
+    // 256 x 16 -> 224 workgroups x 4 batches, 32 CUs idle in a launch that is bound by the vector ALUs of each CU), give
+    // every resident workgroup `lw` waves with bpo batches and NW - lw with bpo - 1.
+    const int res = own2 / opb;                             // resident workgroups
+    static const bool uneven = [] { const char* e = getenv("GBX_GEMV_UNEVEN"); return !e || atoi(e) != 0; }();
+    if (uneven && nbatches % res == 0 && (nbatches + NW * bpo - 1) / (NW * bpo) < res) {
+      const int lw = nbatches / res - NW * (bpo - 1);       // res * (lw * bpo + (NW - lw) * (bpo - 1)) == nbatches
+      if (lw > 0 && lw < NW && lw % 4 == 0) {
+        GemvArgs u = a;
+        u.long_waves = lw;
+        return launch_gemv_d<BITS, P, KS, 2, SPLIT, NW, PK>(u, M, bf16, bpo, res * NW * bpo, stream);
+      }
+    }
+  }
   return launch_gemv_d<BITS, P, KS, 2, SPLIT, NW, PK>(a, M, bf16, bpo, nbatches, stream);
 }
 
