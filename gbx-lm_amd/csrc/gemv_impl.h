@@ -665,6 +665,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
     const float t0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tot), 31));
     const float t1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tot), 63));
     if constexpr (KS == 1) {
+      // (measured, round 3: parking the totals in lane j and running ONE vector epilogue for all of the wave's batches at the end
+      // is slower -- 776 -> 764 tok/s: it moves the epilogues from under the stream onto the launch's tail)
       if (lane == 0) {
         if constexpr (PK) finish(b * rowstep, t0, t1, static_cast<unsigned short>(cur.res2 & 0xFFFFu), static_cast<unsigned short>(cur.res2 >> 16));
         else finish(b * rowstep, t0, t1, cur.res[0], cur.res[1]);
@@ -868,6 +870,7 @@ static hipError_t dispatch_gemv(const GemvArgs& a, int M, bool bf16, hipStream_t
 
 #define GBX_DEFINE_LAUNCH_GEMV(BITS)                                                              \
   template <> hipError_t launch_gemv<BITS>(const GemvArgs& a, int M, bool bf16, hipStream_t s) { \
+    if (BITS == 2 && gemv_mxd_eligible(a, M, bf16)) return launch_gemv_mxd(a, s);                 \
     if (BITS == 2 && gemv_mx_eligible(a, M) && gemv_mx_shape_ok(a)) return launch_gemv_mx(a, bf16, s); \
     return dispatch_gemv<BITS>(a, M, bf16, s);                                                    \
   }

@@ -31,6 +31,10 @@ hipError_t launch_gemv(const GemvArgs& a, int M, bool bf16, hipStream_t stream);
 bool gemv_mx_eligible(const GemvArgs& a, int M);
 bool gemv_mx_shape_ok(const GemvArgs& a);
 hipError_t launch_gemv_mx(const GemvArgs& a, bool bf16, hipStream_t s);
+// gemv_mxd.hip: the same launches with ONE packed row per scaled-MFMA operand (16 consecutive groups, diagonal of the result):
+// 2 bits, group 128, bf16, K = 2048 / 4096, packed scale|zero companion
+bool gemv_mxd_eligible(const GemvArgs& a, int M, bool bf16);
+hipError_t launch_gemv_mxd(const GemvArgs& a, hipStream_t s);
 
 hipError_t launch_unpack(const uint32_t* qw, int32_t* q, int N, int K, int bits, hipStream_t s);
 hipError_t launch_dequant(const uint32_t* qw, const void* sc, const void* ze, void* w, int N, int K, int bits,
