@@ -234,9 +234,15 @@ template <int P> struct WavesPerBlock { static constexpr int value = (P == 1) ? 
 // neither the expert-offset arithmetic nor its kernel arguments' loads (measured: 1.5-2 % of a token when done at run time).
 // MODE 3 (PK + XACC): packed companion and the activation vector comes as residual stream + fixed-point accumulator
 // (GemvArgs::x_acc): the launch that follows gbx_attn_oproj_decode.
+// MODE 5: PK with exactly one plain / residual segment, fixed at compile time.
 template <int BITS, int P, int KS, int D, bool BF16, bool SPLIT, int NW, int MODE>
 __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
-  constexpr bool PK = MODE == 1 || MODE == 3, GATHER = MODE == 2, XACC = MODE == 3;
+  constexpr bool PK = MODE == 1 || MODE == 3 || MODE == 5, GATHER = MODE == 2, XACC = MODE == 3;
+  // MODE 5 (PK, ONE plain or residual segment known at compile time: o_proj, down_proj of the decode block): row location,
+  // descriptor selects and the epilogue's runtime branches are ~200 scalar and ~20 vector instructions per 2-row batch otherwise,
+  // and launches whose rows are a few thousand values long are bound by exactly that: 775 -> 794 tok/s (A/B, GBX_GEMV_CEPI).
+  // (The same for the SwiGLU pair -- MODE 4 in the experiment -- measured slightly slower than the runtime form: 772 tok/s; not kept.)
+  constexpr bool CSWI = false, CONE = MODE == 5;
   constexpr int NT = NW * 64;
   constexpr int GPB = NW / 4;                                 // KS == 4: row groups (of four K-quarter waves) per workgroup
   using F = Fmt<BITS>;
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
   }
   const unsigned short* __restrict__ xg = static_cast<const unsigned short*>(a.x) + static_cast<size_t>(xrow) * K;
   const int gshift = a.log2g - 5;                 // 32-value sub-slot index -> group index
-  const bool swiglu = a.swiglu != 0;
+  const bool swiglu = CSWI ? true : (CONE ? false : a.swiglu != 0);
   const int rowstep = swiglu ? 1 : R;             // output rows covered by one batch
   const int bpo = a.batches_per_owner;
   const int kq = wave & 3, rg = wave >> 2;        // KS == 4: K-quarter of this wave, row group inside the workgroup
@@ -303,6 +309,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvArgs a) {
   // row of batch element i -> (segment, local row); wave-uniform
   auto locate = [&](int r0, int i, int& sg, int& row) {
     if (swiglu) { sg = i; row = min(r0, N - 1); }
+    else if (CONE) { sg = 0; row = min(r0 + i, N - 1); }
     else {
       const int r = min(r0 + i, N - 1);
       sg = (r >= n0) + (r >= n01);
@@ -835,6 +842,11 @@ static hipError_t launch_gemv_p(const GemvArgs& a, int M, bool bf16, hipStream_t
     return hipErrorInvalidValue;
   }
   if (a.sz) {              // packed scale/zero companion of the launch (decode runner)
+    static const bool cepi = [] { const char* e = getenv("GBX_GEMV_CEPI"); return !e || atoi(e) != 0; }();   // A/B switch
+    if (cepi && !a.swiglu && a.nseg == 1) {
+      if (KS == 1 && nbatches <= 4096) return launch_gemv_small<BITS, P, KS, SPLIT, 5>(a, M, bf16, nbatches, stream);
+      return launch_gemv_nw<BITS, P, KS, SPLIT, WavesPerBlock<P>::value, 5>(a, M, bf16, nbatches, stream);
+    }
     if (KS == 1 && nbatches <= 4096) return launch_gemv_small<BITS, P, KS, SPLIT, 1>(a, M, bf16, nbatches, stream);
     // (measured, round 3: 14-wave workgroups on all 256 CUs instead of 16 waves on 224: 12.8 vs 11.2 us for gate|up; 12 waves: 14.3)
     return launch_gemv_nw<BITS, P, KS, SPLIT, WavesPerBlock<P>::value, 1>(a, M, bf16, nbatches, stream);

@@ -322,7 +322,9 @@ class FusedDecodeRunner(DecodeRunner):
         D = model.args.hidden_size
         I = model.model.layers[0].mlp.gate_proj.output_dims
         mk = lambda n: torch.zeros((n,), dtype=dt, device=dev)
-        self.hb, self.qb, self.kb, self.vb = mk(D), mk(a0.n_heads * a0.head_dim), mk(a0.n_kv_heads * a0.head_dim), mk(a0.n_kv_heads * a0.head_dim)
+        nq, nkv = a0.n_heads * a0.head_dim, a0.n_kv_heads * a0.head_dim
+        self.qkvb = mk(nq + 2 * nkv)             # q | k | v of the token: one buffer (one-segment q|k|v launch below), three views
+        self.hb, self.qb, self.kb, self.vb = mk(D), self.qkvb[:nq], self.qkvb[nq:nq + nkv], self.qkvb[nq + nkv:]
         self.ab, self.actb = mk(a0.n_heads * a0.head_dim), mk(I)
         # TP: the residual stream ping-pongs between hb and pb.  Rank 0 folds the residual into its partial sum
         # (y = stream + W_0 x), the other ranks write bare partials, and the all-reduce of that buffer IS the new stream --
@@ -363,10 +365,21 @@ class FusedDecodeRunner(DecodeRunner):
             even = all(m.output_dims % 2 == 0 for m in (at.q_proj, at.k_proj, at.v_proj, at.o_proj, mlp.gate_proj, mlp.down_proj))
             pk = lambda *mods: torch.cat([ops.pack_scales_zeros(m) for m in mods]) if even else None
             p_qkv, p_o, p_dn = pk(at.q_proj, at.k_proj, at.v_proj), pk(at.o_proj), pk(mlp.down_proj)
+            # q|k|v as ONE matrix (rows concatenated once at load time, +7 MB per 2-bit 8B layer): a one-segment launch skips the
+            # per-row segment location of the three-segment form (the launch is bound by per-batch instruction overhead)
+            qkv_mods, qkv_ys = (at.q_proj, at.k_proj, at.v_proj), (self.qb, self.kb, self.vb)
+            if (os.environ.get("GBX_QKV_CAT", "1") == "1" and p_qkv is not None and nq % 16 == 0 and nkv % 16 == 0 and
+                    len({(m.bits, m.group_size) for m in qkv_mods}) == 1 and all(m.bias is None for m in qkv_mods)):
+                from .models.quantized_linear_gba import QuantizedLinear
+                cat = QuantizedLinear(at.q_proj.input_dims, nq + 2 * nkv, False, at.q_proj.group_size, at.q_proj.bits)
+                for nm in ("qweight", "scales", "zeros"):
+                    cat._buffers[nm] = torch.cat([getattr(m, nm) for m in qkv_mods]).contiguous()
+                self.packed.append((cat,))
+                qkv_mods, qkv_ys = (cat,), (self.qkvb,)
             p_gu = ops.pack_scales_zeros(mlp.gate_proj, mlp.up_proj) if even else None
             self.packed.append((p_qkv, p_o, p_gu, p_dn))
             self.descs.append((
-                ops.make_fused_desc(self.hb, (at.q_proj, at.k_proj, at.v_proj), (self.qb, self.kb, self.vb),
+                ops.make_fused_desc(self.hb, qkv_mods, qkv_ys,
                                     norm_weight=blk.input_layernorm.weight, eps=eps, packed=p_qkv, bias_elsewhere=True),
                 ops.make_fused_desc(self.ab, (at.o_proj,), (self.pb,), residual=self.hb if r0 else None, packed=p_o) if tp else
                 ops.make_fused_desc(self.ab, (at.o_proj,), (self.hb,), residual=self.hb, packed=p_o),
