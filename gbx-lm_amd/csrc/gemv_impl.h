@@ -226,7 +226,10 @@ __device__ __forceinline__ float round_bf16_or_f16(float v, bool bf16) {
 // NW = wavefronts per workgroup.  The activation vector is converted ONCE per workgroup (through LDS), so fat
 // workgroups (16 waves = one per CU-slot) make that prologue a small fraction of the row work even when every wave
 // owns only one or two rows.
-template <int P> struct WavesPerBlock { static constexpr int value = (P == 1) ? 16 : 8; };   // "fat" geometry
+#ifndef GBX_FAT_NW_P1
+#define GBX_FAT_NW_P1 16        // (experiment builds: -DGBX_FAT_NW_P1=8 -- two 8-wave workgroups per CU for gate|up: 799 -> 765 tok/s)
+#endif
+template <int P> struct WavesPerBlock { static constexpr int value = (P == 1) ? GBX_FAT_NW_P1 : 8; };   // "fat" geometry
 
 // SPLIT (2-bit only): group_size 32, i.e. the two 32-value halves of a lane's slot carry different scales.
 // MODE 1 (PK): scales/zeros come from the packed companion GemvArgs::sz (N of every segment even).
