@@ -122,7 +122,10 @@ def kernel_leg(model, reps=20):
             att_us = max(null_us, stream_us)
             attainable = {"us_per_launch": att_us, "GBps": nbytes / att_us / 1e3, "frac_of_peak": nbytes / att_us / 1e3 / HBM_PEAK_GBPS,
                           "null_weights_us": null_us, "stream_only_us": stream_us,
-                          "source": "profiles/r03_chain_floor.json: max(launch with null weights [GBX_CHAIN_FLOOR=2], bytes / measured copy rate)"}
+                          "source": "profiles/r03_chain_floor.json: max(launch with null weights [GBX_CHAIN_FLOOR=2], bytes / measured copy rate)",
+                          "note": "null_weights_us = the same launch with every row read redirected to two L2-resident rows: its non-memory time "
+                                  "(heads + vector-ALU consumption); it can exceed the real launch by a few per cent (all waves then share two hot "
+                                  "lines), i.e. the launch is at what this kernel design attains -- the gap to the HBM roofline is not memory time"}
     except (OSError, ValueError, KeyError):
         attainable = None
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
