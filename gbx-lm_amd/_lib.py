@@ -66,6 +66,9 @@ def lib() -> ctypes.CDLL:
         L.gbx_qlinear_swiglu_workspace_bytes.restype = ctypes.c_size_t
         L.gbx_qlinear_swiglu_forward_ws.argtypes = [p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, p, ctypes.c_size_t, p]
         _declare_optional(L)
+        if L.gbx_version() < GBX_MIN_VERSION and not os.environ.get("GBX_QLINEAR_LIB"):
+            raise RuntimeError(f"gbx_lm_amd: {_SO} reports ABI version {L.gbx_version()}, this binding needs >= {GBX_MIN_VERSION}: "
+                               "rebuild it (`make -C gbx-lm_amd/csrc`)")
         _lib = L
     return _lib
 
@@ -83,12 +86,30 @@ class FusedDesc(ctypes.Structure):
                 ("x_acc", ctypes.c_void_p), ("x_out", ctypes.c_void_p), ("zero_buf", ctypes.c_void_p), ("zero_n", ctypes.c_int32)]
 
 
+class DgDesc(ctypes.Structure):
+    """Mirror of ``gbx_dgemv`` (include/gbx_qlinear.h)."""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("epilogue", ctypes.c_int32),
+                ("x", ctypes.c_void_p), ("qweight", ctypes.c_void_p), ("qweight_up", ctypes.c_void_p), ("sz", ctypes.c_void_p),
+                ("y", ctypes.c_void_p), ("residual", ctypes.c_void_p), ("norm_weight", ctypes.c_void_p),
+                ("ssq_in", ctypes.c_void_p), ("ssq_out", ctypes.c_void_p),
+                ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("bits", ctypes.c_int32), ("group_size", ctypes.c_int32),
+                ("act_dtype", ctypes.c_int32), ("rows_per_batch", ctypes.c_int32), ("norm_eps", ctypes.c_float)]
+
+
+GBX_DG_PLAIN, GBX_DG_RESIDUAL, GBX_DG_SWIGLU = 0, 1, 2
+GBX_DG_SSQ_SLOTS = 1024
+GBX_MIN_VERSION = 1100          # the header this binding mirrors
+
+
 def _declare_optional(L) -> None:
     """argtypes of the entry points beyond the core forward (declared one by one so that a diagnostic build that lacks
     one of them -- GBX_QLINEAR_LIB -- still loads; calling a missing entry point raises AttributeError)."""
     i64, i32, p, f32 = ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_float
     table = {
         "gbx_qlinear_fused_forward": [ctypes.POINTER(FusedDesc), p],
+        "gbx_dgemv_plan": [i32, i32, i32, i32, i32, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)],
+        "gbx_dgemv_pack": [p, p, p, p, p, i32, i32, i32, p],
+        "gbx_dgemv_forward": [ctypes.POINTER(DgDesc), p],
         "gbx_qlinear_kernel_id": [i64, i32, i32, i32, i32, i32],
         "gbx_qlinear_swiglu_forward": [p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, p],
         "gbx_qlinear_forward_partials": [p, p, p, p, p, ctypes.c_size_t, ctypes.POINTER(i32), i64, i32, i32, i32, i32, i32, p],

@@ -3,6 +3,7 @@
 // thread-local error text.  No allocation, no synchronisation: every call is graph-capturable.
 #include "gbx_qlinear.h"
 #include "gemv_impl.h"
+#include "dgemv_impl.h"
 #include "gemv_stream.h"
 #include "kernels.h"
 
@@ -61,7 +62,9 @@ extern "C" void gbx_debug_stamp_reset(void) { gbx::g_stamp_launch = 0; }
 
 extern "C" {
 
-int gbx_version(void) { return 1000; }
+/* 1100: gbx_dgemv_* entry points; gbx_qlinear_fused (x_acc, x_out, zero_buf, zero_n since 1001) -- a consumer built against
+ * an older header must not pass its shorter struct to this library: check gbx_version() >= the header it compiled with. */
+int gbx_version(void) { return 1100; }
 
 const char* gbx_last_error(void) { return g_err; }
 
@@ -1034,6 +1037,85 @@ int gbx_dequantize(const uint32_t* qweight, const void* scales, const void* zero
     e = gbx::launch_dequant(qweight, scales, zeros, w, N, K, bits, log2_group(group_size), sz_dtype == GBX_BF16,
                             out_dtype, static_cast<hipStream_t>(hip_stream));
   if (e != hipSuccess) return hip_fail(e, "gbx_dequantize launch");
+  return GBX_OK;
+}
+
+
+/* ---- decode-block GEMV (dgemv_impl.h) ---- */
+int gbx_dgemv_plan(int32_t N, int32_t K, int32_t bits, int32_t group_size, int32_t epilogue, int32_t with_norm,
+                   int32_t* rows_per_batch, int32_t* ssq_partials) {
+  int rc = check_shape(1, N, K, bits, group_size);
+  if (rc) return rc;
+  if (epilogue < GBX_DG_PLAIN || epilogue > GBX_DG_SWIGLU) return fail(GBX_ERR_INVALID, "epilogue must be GBX_DG_PLAIN / RESIDUAL / SWIGLU (got %d)", epilogue);
+  gbx::DgPlan pl;
+  if (!gbx::dg_plan(bits, N, K, group_size, epilogue, with_norm != 0, 0, &pl))
+    return fail(GBX_ERR_UNSUPPORTED, "dgemv does not cover N=%d K=%d bits=%d group=%d epilogue=%d (use gbx_qlinear_fused_forward)", N, K, bits, group_size, epilogue);
+  if (rows_per_batch) *rows_per_batch = pl.R;
+  if (ssq_partials) *ssq_partials = epilogue == GBX_DG_SWIGLU ? 0 : pl.ssq_n;
+  return GBX_OK;
+}
+
+int gbx_dgemv_pack(const void* scales0, const void* zeros0, const void* scales1, const void* zeros1, uint32_t* out,
+                   int32_t N, int32_t G, int32_t rows_per_batch, void* hip_stream) {
+  if (N <= 0 || G <= 0) return fail(GBX_ERR_INVALID, "bad shape N=%d G=%d", N, G);
+  if (rows_per_batch != 2 && rows_per_batch != 4) return fail(GBX_ERR_INVALID, "rows_per_batch must be 2 or 4 (got %d)", rows_per_batch);
+  if (!scales0 || !zeros0 || !out) return fail(GBX_ERR_INVALID, "null device pointer");
+  if ((scales1 == nullptr) != (zeros1 == nullptr)) return fail(GBX_ERR_INVALID, "scales1 and zeros1 go together");
+  const int ro = scales1 ? rows_per_batch / 2 : rows_per_batch;
+  if (N % ro) return fail(GBX_ERR_INVALID, "N (%d) must be a multiple of %d", N, ro);
+  if (!aligned(out, 16)) return fail(GBX_ERR_INVALID, "out must be 16-byte aligned");
+  hipError_t e = gbx::launch_dg_pack(scales0, zeros0, scales1, zeros1, out, N, G, rows_per_batch, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_dgemv_pack launch");
+  return GBX_OK;
+}
+
+int gbx_dgemv_forward(const gbx_dgemv* d, void* hip_stream) {
+  if (!d) return fail(GBX_ERR_INVALID, "null descriptor");
+  if (d->struct_size != sizeof(gbx_dgemv)) return fail(GBX_ERR_INVALID, "gbx_dgemv.struct_size is %u, this library expects %zu (header / library mismatch)", d->struct_size, sizeof(gbx_dgemv));
+  if (d->act_dtype != GBX_F16 && d->act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  if (d->epilogue < GBX_DG_PLAIN || d->epilogue > GBX_DG_SWIGLU) return fail(GBX_ERR_INVALID, "epilogue must be GBX_DG_PLAIN / RESIDUAL / SWIGLU (got %d)", d->epilogue);
+  int rc = check_shape(1, d->N, d->K, d->bits, d->group_size);
+  if (rc) return rc;
+  if (!d->x || !d->qweight || !d->sz || !d->y) return fail(GBX_ERR_INVALID, "null device pointer (x / qweight / sz / y)");
+  if (!aligned(d->x, 16) || !aligned(d->qweight, 16) || !aligned(d->sz, 16) || !aligned(d->y, 4))
+    return fail(GBX_ERR_INVALID, "x / qweight / sz must be 16-byte aligned, y 4-byte aligned");
+  if (d->epilogue == GBX_DG_SWIGLU && (!d->qweight_up || !aligned(d->qweight_up, 16))) return fail(GBX_ERR_INVALID, "SWIGLU needs qweight_up (16-byte aligned)");
+  if (d->epilogue == GBX_DG_RESIDUAL && !d->residual) return fail(GBX_ERR_INVALID, "RESIDUAL needs residual");
+  if (d->norm_weight && !aligned(d->norm_weight, 16)) return fail(GBX_ERR_INVALID, "norm_weight must be 16-byte aligned");
+  if (d->ssq_in && (!d->norm_weight || !aligned(d->ssq_in, 16))) return fail(GBX_ERR_INVALID, "ssq_in goes with norm_weight and must be 16-byte aligned");
+  if (d->ssq_out && d->epilogue == GBX_DG_SWIGLU) return fail(GBX_ERR_INVALID, "ssq_out is for PLAIN / RESIDUAL launches");
+  gbx::DgPlan pl;
+  if (!gbx::dg_plan(d->bits, d->N, d->K, d->group_size, d->epilogue, d->norm_weight != nullptr, d->rows_per_batch, &pl))
+    return fail(GBX_ERR_UNSUPPORTED, "dgemv does not cover N=%d K=%d bits=%d group=%d epilogue=%d rows_per_batch=%d", d->N, d->K, d->bits, d->group_size, d->epilogue, d->rows_per_batch);
+  if (d->norm_weight && pl.KS != 1) return fail(GBX_ERR_UNSUPPORTED, "fused RMSNorm needs K <= 128 lane slots (K = %d at %d bits); call gbx_rmsnorm first", d->K, d->bits);
+  if (d->ssq_out && pl.ssq_n == 0) return fail(GBX_ERR_UNSUPPORTED, "ssq_out: this launch geometry cannot leave its partial statistic in %d slots (gbx_dgemv_plan reports 0)", GBX_DG_SSQ_SLOTS);
+  static_assert(GBX_DG_SSQ_SLOTS == gbx::DG_SSQ_SLOTS, "public constant out of sync");
+  gbx::DgArgs a{};
+  a.x = static_cast<const unsigned short*>(d->x);
+  a.qw = d->qweight;
+  a.qw2 = d->epilogue == GBX_DG_SWIGLU ? d->qweight_up : d->qweight;
+  a.sz = d->sz;
+  a.y = static_cast<unsigned short*>(d->y);
+  a.residual = static_cast<const unsigned short*>(d->residual);
+  a.norm_w = static_cast<const unsigned short*>(d->norm_weight);
+  a.ssq_in = d->ssq_in;
+  a.ssq_out = d->ssq_out;
+  a.N = d->N; a.K = d->K; a.log2g = log2_group(d->group_size);
+  a.eps = d->norm_eps;
+  static const int chain_floor = [] { const char* e = getenv("GBX_CHAIN_FLOOR"); return e ? atoi(e) : 0; }();
+  a.null_rows = chain_floor == 2 ? 1 : 0;
+#ifdef GBX_STAMPS
+  a.stamps = gbx::stamp_region();
+#endif
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  const bool bf16 = d->act_dtype == GBX_BF16;
+  hipError_t e;
+  switch (d->bits) {
+    case 2: e = gbx::launch_dgemv<2>(a, pl, d->epilogue, bf16, stream); break;
+    case 3: e = gbx::launch_dgemv<3>(a, pl, d->epilogue, bf16, stream); break;
+    default: e = gbx::launch_dgemv<4>(a, pl, d->epilogue, bf16, stream); break;
+  }
+  if (e != hipSuccess) return hip_fail(e, "gbx_dgemv_forward launch");
   return GBX_OK;
 }
 

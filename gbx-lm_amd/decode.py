@@ -358,6 +358,11 @@ class FusedDecodeRunner(DecodeRunner):
                             for b in model.model.layers))
         self.descs = []
         self.descs_ao = []
+        self.dg = []                        # per layer: [qkv, o, gate|up, down] dgemv descriptors (None: the launch stays on gbx_qlinear_fused_forward)
+        self.dg_keep = []
+        self.use_dg = os.environ.get("GBX_DGEMV", "1") == "1"
+        self.use_ssq = os.environ.get("GBX_DG_SSQ", "1") == "1" and not tp
+        self.ssq_prev = None                # partial sums of h^2 left by the previous layer's down_proj launch
         self.packed = []                    # load-time (scale | zero) companions, kept alive for the descriptors
         for blk in model.model.layers:
             at, mlp = blk.self_attn, blk.mlp
@@ -389,6 +394,10 @@ class FusedDecodeRunner(DecodeRunner):
                 ops.make_fused_desc(self.actb, (mlp.down_proj,), (self.hb,), residual=self.pb if r0 else None, packed=p_dn) if tp else
                 ops.make_fused_desc(self.actb, (mlp.down_proj,), (self.hb,), residual=self.hb, packed=p_dn),
             ))
+            # Round 4: the four launches on the decode-block GEMV (gbx_dgemv_forward: compact kernel arguments, 2 / 4 rows per
+            # batch, vector epilogue) wherever it covers the shape; the RMSNorm statistic of h is carried from the launch that
+            # writes h (o_proj / down_proj epilogue, one partial per workgroup) to the launch that normalises it (GBX_DG_SSQ).
+            self.dg.append(self._dgemv_descs(blk, qkv_mods[0] if len(qkv_mods) == 1 else None, qkv_ys[0], tp, r0, len(self.dg)))
             if self.fuse_ao and p_gu is not None:
                 self.descs_ao.append((
                     # x = hb + round(acc) formed in the prologue, the new stream written to pb once
@@ -402,6 +411,63 @@ class FusedDecodeRunner(DecodeRunner):
                 self.fuse_ao = False
         super().__init__(model, caches, use_graph=use_graph)
 
+    def _dgemv_descs(self, blk, qkv_cat, qkv_y, tp: bool, r0: bool, li: int):
+        """dgemv descriptors of one block's four launches (None where the shape is not covered or dgemv is switched off)."""
+        from . import _lib as _l
+        none = [None, None, None, None]
+        if not self.use_dg or self.fuse_ao:
+            return none
+        at, mlp = blk.self_attn, blk.mlp
+        dev = self.hb.device
+        out = list(none)
+
+        def plan(m, epi, norm=False):
+            return ops.dgemv_plan(m.output_dims, m.input_dims, m.bits, m.group_size, epi, norm)
+
+        def ssq_buf():
+            t = torch.zeros((_l.GBX_DG_SSQ_SLOTS,), dtype=torch.float32, device=dev)
+            self.dg_keep.append(t)
+            return t
+
+        ssq_o = ssq_dn = None
+        # o_proj (+ residual)
+        res_o = (self.hb if r0 else None) if tp else self.hb
+        pl = plan(at.o_proj, _l.GBX_DG_RESIDUAL if res_o is not None else _l.GBX_DG_PLAIN) if at.o_proj.bias is None else None
+        if pl is not None:
+            pk = ops.dgemv_pack(at.o_proj, pl[0])
+            if self.use_ssq and pl[1] > 0:
+                ssq_o = ssq_buf()
+            out[1] = ops.make_dgemv_desc(self.ab, at.o_proj, self.pb if tp else self.hb, pk, pl[0], residual=res_o, ssq_out=ssq_o)
+            self.dg_keep.append(pk)
+        # down_proj (+ residual)
+        res_d = (self.pb if r0 else None) if tp else self.hb
+        pl = plan(mlp.down_proj, _l.GBX_DG_RESIDUAL if res_d is not None else _l.GBX_DG_PLAIN) if mlp.down_proj.bias is None else None
+        if pl is not None:
+            pk = ops.dgemv_pack(mlp.down_proj, pl[0])
+            if self.use_ssq and pl[1] > 0:
+                ssq_dn = ssq_buf()
+            out[3] = ops.make_dgemv_desc(self.actb, mlp.down_proj, self.hb, pk, pl[0], residual=res_d, ssq_out=ssq_dn)
+            self.dg_keep.append(pk)
+        # q|k|v as one matrix: RMSNorm prologue; its statistic comes from the previous block's down_proj launch
+        if qkv_cat is not None:
+            pl = plan(qkv_cat, _l.GBX_DG_PLAIN, True)
+            if pl is not None:
+                pk = ops.dgemv_pack(qkv_cat, pl[0])
+                out[0] = ops.make_dgemv_desc(self.hb, qkv_cat, qkv_y, pk, pl[0], norm_weight=blk.input_layernorm.weight,
+                                             eps=blk.input_layernorm.eps, ssq_in=self.ssq_prev)
+                self.dg_keep.append(pk)
+        # gate | up + SwiGLU: RMSNorm prologue; statistic from this block's o_proj launch
+        if mlp.gate_proj.bias is None and mlp.up_proj.bias is None:
+            pl = plan(mlp.gate_proj, _l.GBX_DG_SWIGLU, True)
+            if pl is not None:
+                pk = ops.dgemv_pack(mlp.gate_proj, pl[0], mlp.up_proj)
+                out[2] = ops.make_dgemv_desc(self.pb if tp else self.hb, mlp.gate_proj, self.actb, pk, pl[0], mod_up=mlp.up_proj,
+                                             norm_weight=blk.post_attention_layernorm.weight, eps=blk.post_attention_layernorm.eps,
+                                             ssq_in=ssq_o if out[1] is not None else None)
+                self.dg_keep.append(pk)
+        self.ssq_prev = ssq_dn if out[3] is not None else None
+        return out
+
     def _forward(self):
         m = self.model.model
         dev = self.dev
@@ -414,7 +480,9 @@ class FusedDecodeRunner(DecodeRunner):
                                  advance_pos=self.chain)
         for li, (blk, c, (d_qkv, d_o, d_gu, d_dn)) in enumerate(zip(m.layers, self.caches, self.descs)):
             at = blk.self_attn
-            ops.qlinear_fused(d_qkv, dev)
+            g_qkv, g_o, g_gu, g_dn = self.dg[li]
+            run = lambda g, d: ops.dgemv(g, dev) if g is not None else ops.qlinear_fused(d, dev)
+            run(g_qkv, d_qkv)
             if self.fuse_ao:
                 d_gu2, d_dn2 = self.descs_ao[li]
                 ops.attn_oproj_decode(self.qb, self.kb, self.vb, c.keys, c.values, at.rope.inv_freq, self.pos, at.o_proj, self.acc,
@@ -437,11 +505,11 @@ class FusedDecodeRunner(DecodeRunner):
                 ops.attn_decode(self.qb, self.kb, self.vb, c.keys, c.values, at.rope.inv_freq, self.pos, self.ab,
                                 at.n_heads, at.n_kv_heads, at.head_dim, c.capacity, getattr(at.rope, "scale", 1.0), at.scale,
                                 at.rope.traditional)
-            ops.qlinear_fused(d_o, dev)
+            run(g_o, d_o)
             if self.tp_world > 1:            # K-split layer: partial sums (+ rank 0's residual) meet over RCCL in pb
                 all_reduce_(self.pb, at.tp_group)
-            ops.qlinear_fused(d_gu, dev)
-            ops.qlinear_fused(d_dn, dev)
+            run(g_gu, d_gu)
+            run(g_dn, d_dn)
             if self.tp_world > 1:            # ... and the stream returns to hb
                 all_reduce_(self.hb, blk.mlp.tp_group)
         ops.dense_gemv(self.hb, self.model.head_weight(), out=self.logits_buf.view(-1), norm_weight=m.norm.weight,

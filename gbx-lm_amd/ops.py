@@ -643,6 +643,77 @@ def qlinear_fused(desc, device) -> None:
     _lib.check(_lib.lib().gbx_qlinear_fused_forward(ctypes.byref(desc), _stream_ptr(device)))
 
 
+def dgemv_plan(n: int, k: int, bits: int, group_size: int, epilogue: int, with_norm: bool = False):
+    """(rows_per_batch, ssq_partials) of the decode-block GEMV launch for this shape -- ssq_partials = how many partial sums
+    of y^2 the launch leaves in an ``ssq_out`` buffer, 0 if it cannot -- or None when dgemv does not cover the shape."""
+    import ctypes
+    r, wg = ctypes.c_int32(0), ctypes.c_int32(0)
+    rc = _lib.lib().gbx_dgemv_plan(n, k, bits, group_size, epilogue, 1 if with_norm else 0, ctypes.byref(r), ctypes.byref(wg))
+    if rc == _lib.GBX_ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc)
+    return r.value, wg.value
+
+
+def dgemv_pack(mod, rows_per_batch: int, mod_up=None) -> torch.Tensor:
+    """Load-time (scale | zero << 16) companion of one dgemv launch in batch order (gbx_dgemv_pack): int32
+    ``[N / R, G, R]``, or ``[N / (R/2), G, R]`` with gate (``mod``) and up (``mod_up``) rows of a SwiGLU launch."""
+    n, g = mod.scales.shape
+    for t in (mod.scales, mod.zeros) + ((mod_up.scales, mod_up.zeros) if mod_up is not None else ()):
+        _require_cuda(t, "scales/zeros")
+        if t.shape != (n, g) or t.dtype != mod.scales.dtype or not t.is_contiguous():
+            raise ValueError("scales/zeros must be contiguous and agree in shape and dtype")
+    ro = rows_per_batch // 2 if mod_up is not None else rows_per_batch
+    out = torch.empty((n // ro, g, rows_per_batch), dtype=torch.int32, device=mod.scales.device)
+    _lib.check(_lib.lib().gbx_dgemv_pack(mod.scales.data_ptr(), mod.zeros.data_ptr(),
+                                         mod_up.scales.data_ptr() if mod_up is not None else None,
+                                         mod_up.zeros.data_ptr() if mod_up is not None else None,
+                                         out.data_ptr(), n, g, rows_per_batch, _stream_ptr(out.device)))
+    return out
+
+
+def make_dgemv_desc(x: torch.Tensor, mod, y: torch.Tensor, packed: torch.Tensor, rows_per_batch: int, mod_up=None,
+                    norm_weight: Optional[torch.Tensor] = None, eps: float = 0.0, residual: Optional[torch.Tensor] = None,
+                    ssq_in: Optional[torch.Tensor] = None, ssq_out: Optional[torch.Tensor] = None) -> "_lib.DgDesc":
+    """Descriptor of one decode-block GEMV launch (gbx_dgemv_forward): ``mod`` alone (optionally ``+ residual``), or
+    ``silu(mod(x)) * mod_up(x)``.  ``ssq_out`` / ``ssq_in``: float32 [GBX_DG_SSQ_SLOTS] buffers that carry the RMSNorm
+    statistic from the launch that writes ``x`` to the launch that normalises it.  Tensors must stay alive and in place."""
+    import ctypes
+    for m in (mod,) + ((mod_up,) if mod_up is not None else ()):
+        if m.bias is not None:
+            raise NotImplementedError("dgemv launches carry no bias")
+        for t in (m.qweight, m.scales, m.zeros):
+            _require_cuda(t, "QuantizedLinear tensor")
+        if m.scales.dtype != x.dtype:
+            raise ValueError("scales/zeros must already be in the activation dtype")
+    if mod_up is not None and (mod_up.bits, mod_up.group_size, mod_up.input_dims, mod_up.output_dims) != (
+            mod.bits, mod.group_size, mod.input_dims, mod.output_dims):
+        raise ValueError("gate and up must be packed alike")
+    for t in (ssq_in, ssq_out):
+        if t is not None and (t.dtype != torch.float32 or t.numel() != _lib.GBX_DG_SSQ_SLOTS or not t.is_contiguous()):
+            raise ValueError("ssq buffers are float32 [GBX_DG_SSQ_SLOTS]")
+    d = _lib.DgDesc()
+    d.struct_size = ctypes.sizeof(_lib.DgDesc)
+    d.epilogue = _lib.GBX_DG_SWIGLU if mod_up is not None else (_lib.GBX_DG_RESIDUAL if residual is not None else _lib.GBX_DG_PLAIN)
+    d.x, d.qweight, d.sz, d.y = x.data_ptr(), mod.qweight.data_ptr(), packed.data_ptr(), y.data_ptr()
+    d.qweight_up = mod_up.qweight.data_ptr() if mod_up is not None else None
+    d.residual = residual.data_ptr() if residual is not None else None
+    d.norm_weight = norm_weight.data_ptr() if norm_weight is not None else None
+    d.ssq_in = ssq_in.data_ptr() if ssq_in is not None else None
+    d.ssq_out = ssq_out.data_ptr() if ssq_out is not None else None
+    d.N, d.K, d.bits, d.group_size, d.act_dtype = mod.output_dims, mod.input_dims, mod.bits, mod.group_size, _DT[x.dtype]
+    d.rows_per_batch = rows_per_batch
+    d.norm_eps = float(eps)
+    if packed.dtype != torch.int32 or packed.numel() != (2 if mod_up is not None else 1) * mod.output_dims * (mod.input_dims // mod.group_size):
+        raise ValueError("packed scales/zeros do not match the launch")
+    return d
+
+
+def dgemv(desc, device) -> None:
+    import ctypes
+    _lib.check(_lib.lib().gbx_dgemv_forward(ctypes.byref(desc), _stream_ptr(device)))
+
+
 class StreamProgram:
     """Device-resident program of the streamed decode GEMV / persistent engine (gbx_stream_encode / gbx_stream_run):
     one entry per ``make_fused_desc`` descriptor.  ``run(begin, end)`` enqueues ONE launch that walks ops [begin, end)

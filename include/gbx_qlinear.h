@@ -135,6 +135,53 @@ typedef struct gbx_qlinear_fused {
 
 int gbx_qlinear_fused_forward(const gbx_qlinear_fused* desc, void* hip_stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Decode-block GEMV (round 4): ONE packed matrix (or the gate / up pair) against ONE activation vector, the launch the
+ * graph-replayed batch-1 decode runs 4x per layer.  Same arithmetic and result contract as gbx_qlinear_fused_forward
+ * (bit-identical for equal workgroup widths); what differs is the launch overhead around it (104 bytes of kernel
+ * arguments, 2 / 4 rows per batch with one (scale | zero) load, vector epilogue, no steady-state loop) and an RMSNorm
+ * statistic that can be CARRIED between launches: a launch with ssq_out leaves one partial sum of y^2 per workgroup, the
+ * next launch with ssq_in adds them instead of reducing x^2 itself.
+ *   mx.quantized_matmul at M == 1: gbx_lm/models/quantized_linear_gba.py:195-203; call sites qllama.py:76,115,137-141.
+ * Covered: bits 2/3/4, group 64/128 (3/4 bits also 32), K % 128 == 0, K <= 512 lane slots, N a multiple of
+ * rows_per_batch (epilogue SWIGLU: of rows_per_batch / 2), whole matrix < 2 GB.  gbx_dgemv_plan answers whether a shape is
+ * covered and how the companion must be packed; everything else stays on gbx_qlinear_fused_forward.
+ * ------------------------------------------------------------------------------------------------ */
+#define GBX_DG_PLAIN 0
+#define GBX_DG_RESIDUAL 1    /* y[n] <- residual[n] + round(result[n])                 (qllama.py:138,140) */
+#define GBX_DG_SWIGLU 2      /* y[n] <- silu(qweight . x)[n] * (qweight_up . x)[n]      (qllama.py:115) */
+#define GBX_DG_SSQ_SLOTS 1024 /* floats of a partial-statistic buffer; zero-filled by the caller once */
+
+typedef struct gbx_dgemv {
+  uint32_t struct_size;        /* sizeof(gbx_dgemv) of the caller's header: a mismatch is GBX_ERR_INVALID */
+  int32_t epilogue;            /* GBX_DG_* */
+  const void* x;               /* [K], act_dtype, 16-byte aligned */
+  const uint32_t* qweight;     /* [N, K*bits/32] (SWIGLU: gate_proj) */
+  const uint32_t* qweight_up;  /* SWIGLU: up_proj, same shape; else NULL */
+  const uint32_t* sz;          /* gbx_dgemv_pack output for this launch's rows_per_batch */
+  void* y;                     /* [N] */
+  const void* residual;        /* RESIDUAL: [N] (may alias y) */
+  const void* norm_weight;     /* optional RMSNorm weight [K]: x <- RMSNorm(x) * w, rounded once (K <= 128 lane slots) */
+  const float* ssq_in;         /* optional with norm_weight: GBX_DG_SSQ_SLOTS partial sums of x^2 (a producer's ssq_out) */
+  float* ssq_out;              /* optional (PLAIN / RESIDUAL): GBX_DG_SSQ_SLOTS floats; this launch writes its first
+                                  `ssq_partials` (gbx_dgemv_plan) entries, the rest must be zero */
+  int32_t N, K, bits, group_size, act_dtype;
+  int32_t rows_per_batch;      /* what sz was packed for (gbx_dgemv_plan) */
+  float norm_eps;
+} gbx_dgemv;
+
+/* rows_per_batch (2 / 4) the library prefers for this launch (with_norm: it will carry norm_weight) and the number of partial
+ * sums of y^2 it writes when given ssq_out (0: this launch cannot carry the statistic); GBX_ERR_UNSUPPORTED when dgemv does not
+ * cover the shape.  gbx_dgemv_forward accepts either packing (rows_per_batch 2 or 4) where the rows divide. */
+int gbx_dgemv_plan(int32_t N, int32_t K, int32_t bits, int32_t group_size, int32_t epilogue, int32_t with_norm,
+                   int32_t* rows_per_batch, int32_t* ssq_partials);
+/* out[b][g][r] = scale | zero << 16 (16-bit patterns verbatim; gbx_lm/utils.py:841-843 is the cast that made them) of row r
+ * of batch b: row b*R + r of (scales0, zeros0), or -- scales1 != NULL, SWIGLU -- r < R/2: row b*R/2 + r of (scales0, zeros0) =
+ * gate, else row b*R/2 + r - R/2 of (scales1, zeros1) = up.  out = uint32[N * G] (SWIGLU: [2 * N * G]), G = K / group_size. */
+int gbx_dgemv_pack(const void* scales0, const void* zeros0, const void* scales1, const void* zeros1, uint32_t* out,
+                   int32_t N, int32_t G, int32_t rows_per_batch, void* hip_stream);
+int gbx_dgemv_forward(const gbx_dgemv* desc, void* hip_stream);
+
 /* Load-time companion of the loader's scale/zero cast (gbx_lm/utils.py:841-843): out[p][g][i] = scale bits | zero bits << 16
  * (16-bit act-dtype patterns, copied verbatim) for the two rows a GEMV batch streams together:
  *   scales1 == NULL : rows (2p, 2p+1) of (scales0, zeros0), out = uint32[N/2][G][2], N even;

@@ -1,0 +1,251 @@
+"""GPU: the decode-block GEMV (gbx_dgemv_forward, csrc/dgemv_impl.h) through the C-ABI against the oracle
+(fp64 x . dequantised weights; gbx_lm/models/quantized_linear_gba.py:195-205 restated in oracle/gba_oracle.py), against the
+previous decode kernel (gbx_qlinear_fused_forward: bit-identical where the arithmetic order is the same), with the carried RMSNorm
+statistic, and at the exact launch geometries the bench times (Llama-3-8B / 3.2-3B shapes, every bit width)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _mk(oracle, n, k, bits, g, seed):
+    from gbx_lm_amd.models.quantized_linear_gba import QuantizedLinear
+    d = oracle.synth_layer(n, k, bits, g, seed=seed)
+    m = QuantizedLinear(k, n, False, g, bits)
+    m._buffers["qweight"] = torch.from_numpy(d["qweight"].view(np.int32)).view(torch.uint32).to(DEV)
+    m._buffers["scales"], m._buffers["zeros"] = d["scales"].to(DEV), d["zeros"].to(DEV)
+    return m, d
+
+
+def _rms(x, w, eps):
+    xf = x.float()
+    return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps) * w.float()).to(x.dtype)
+
+
+def _ref(oracle, x_cpu, d, bits, g):
+    return oracle.qlinear_ref(x_cpu[None], d["qweight"], d["scales"], d["zeros"], bits, g, acc=np.float64)
+
+
+def _plan(ops, m, epi, norm=False):
+    pl = ops.dgemv_plan(m.output_dims, m.input_dims, m.bits, m.group_size, epi, norm)
+    assert pl is not None, "dgemv must cover this shape"
+    return pl
+
+
+def _ulps(a, b):
+    """distance in bf16 / fp16 units of the larger magnitude, elementwise"""
+    a, b = a.float(), b.float()
+    scale = torch.maximum(a.abs(), b.abs()).clamp_min(1e-30)
+    return ((a - b).abs() / scale * 256).max().item()
+
+
+# (n, k): one lane pass (P1 KS1), two passes (P2 KS1, 3/4 bits at K 4096), K split over four waves (KS4), both
+SHAPES = [(256, 512), (520, 4096), (1024, 8192), (136, 14336)]
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("n,k", SHAPES)
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_dgemv_plain_and_residual_vs_oracle(oracle, bits, n, k, dt):
+    from gbx_lm_amd import ops, _lib
+    g = 128 if (n + k) % 3 else 64
+    m, d = _mk(oracle, n, k, bits, g, seed=bits * 7 + n)
+    if dt == torch.float16:
+        for nm in ("scales", "zeros"):
+            m._buffers[nm] = m._buffers[nm].to(dt)
+        d = dict(d, scales=m.scales.cpu(), zeros=m.zeros.cpu())
+    x = (torch.randn(k) * 2).to(dt).to(DEV)
+    y64 = _ref(oracle, x.cpu(), d, bits, g)
+    name = "bf16" if dt == torch.bfloat16 else "fp16"
+    # plain
+    r, wg = _plan(ops, m, _lib.GBX_DG_PLAIN)
+    pk = ops.dgemv_pack(m, r)
+    y = torch.full((n,), 7.0, dtype=dt, device=DEV)
+    ops.dgemv(ops.make_dgemv_desc(x, m, y, pk, r), x.device)
+    oracle.assert_close(y[None], y64, name, f"dgemv plain b{bits} {n}x{k}")
+    # residual, in place, with the partial statistic of the new stream
+    h = torch.randn(n).to(dt).to(DEV)
+    h0 = h.clone()
+    r1, wg = _plan(ops, m, _lib.GBX_DG_RESIDUAL)
+    pk1 = pk if r1 == r else ops.dgemv_pack(m, r1)
+    ssq = torch.zeros(_lib.GBX_DG_SSQ_SLOTS, dtype=torch.float32, device=DEV) if wg > 0 else None
+    ops.dgemv(ops.make_dgemv_desc(x, m, h, pk1, r1, residual=h, ssq_out=ssq), x.device)
+    oracle.assert_close(h[None], h0.cpu().double().numpy()[None] + y64, name, "dgemv residual")
+    if ssq is not None:
+        want = h.double().pow(2).sum().item()
+        got = ssq.double().sum().item()
+        assert abs(got - want) <= 1e-5 * want, (got, want)
+        assert (ssq[wg:] == 0).all(), "the launch writes exactly the partials the plan reports"
+    # the previous kernel on the same inputs: same arithmetic, same order -> same bits
+    y2 = torch.zeros(n, dtype=dt, device=DEV)
+    if n % 2 == 0:
+        ops.qlinear_fused(ops.make_fused_desc(x, (m,), (y2,), packed=ops.pack_scales_zeros(m)), x.device)
+        assert torch.equal(y, y2), f"dgemv vs gemv_kernel: {(y != y2).sum().item()} of {n} differ, {_ulps(y, y2):.2f} ulp"
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("n,k,g", [(512, 4096, 128), (1032, 4096, 64), (384, 1024, 128), (256, 3072, 128)])
+@pytest.mark.parametrize("carried", [False, True])
+def test_dgemv_norm_swiglu_vs_oracle(oracle, bits, n, k, g, carried):
+    from gbx_lm_amd import ops, _lib
+    gate, dg = _mk(oracle, n, k, bits, g, seed=1 + bits)
+    up, du = _mk(oracle, n, k, bits, g, seed=2 + bits)
+    x = (torch.randn(k) * 2).to(torch.bfloat16).to(DEV)
+    nw = (1 + 0.1 * torch.randn(k)).to(torch.bfloat16).to(DEV)
+    act = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+    r, _ = _plan(ops, gate, _lib.GBX_DG_SWIGLU, True)
+    pk = ops.dgemv_pack(gate, r, up)
+    ssq = None
+    if carried:      # partial sums as a producer leaves them: any split of sum(x^2) over the slots
+        sq = x.float().pow(2)
+        ssq = torch.zeros(_lib.GBX_DG_SSQ_SLOTS, dtype=torch.float32, device=DEV)
+        parts = sq.view(256, -1).sum(1)
+        ssq[:256] = parts
+    ops.dgemv(ops.make_dgemv_desc(x, gate, act, pk, r, mod_up=up, norm_weight=nw, eps=1e-5, ssq_in=ssq), x.device)
+    xn = _rms(x, nw, 1e-5).cpu()
+    g64, u64 = _ref(oracle, xn, dg, bits, g), _ref(oracle, xn, du, bits, g)
+    oracle.assert_close(act[None], (g64 / (1 + np.exp(-g64))) * u64, "bf16", f"dgemv swiglu b{bits} carried={carried}")
+    if not carried:
+        act2 = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+        ops.qlinear_fused(ops.make_fused_desc(x, (gate, up), (act2,), norm_weight=nw, eps=1e-5, swiglu=True,
+                                              packed=ops.pack_scales_zeros(gate, up)), x.device)
+        same = (act == act2).float().mean().item()
+        # equal workgroup width -> equal statistic order -> equal bits; a different width may move rstd by an ulp
+        assert same > 0.98 and _ulps(act, act2) <= 4.0, (same, _ulps(act, act2))
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+def test_dgemv_norm_plain_qkv(oracle, bits):
+    from gbx_lm_amd import ops, _lib
+    k, n, g = 4096, 768, 128
+    m, d = _mk(oracle, n, k, bits, g, seed=5)
+    x = (torch.randn(k) * 3).to(torch.bfloat16).to(DEV)
+    nw = (1 + 0.1 * torch.randn(k)).to(torch.bfloat16).to(DEV)
+    y = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+    r, _ = _plan(ops, m, _lib.GBX_DG_PLAIN, True)
+    ops.dgemv(ops.make_dgemv_desc(x, m, y, ops.dgemv_pack(m, r), r, norm_weight=nw, eps=1e-5), x.device)
+    oracle.assert_close(y[None], _ref(oracle, _rms(x, nw, 1e-5).cpu(), d, bits, g), "bf16", "dgemv norm + plain")
+
+
+@pytest.mark.parametrize("r", [2, 4])
+@pytest.mark.parametrize("epi", ["plain", "residual", "swiglu"])
+def test_dgemv_either_packing(oracle, r, epi):
+    """gbx_dgemv_forward takes the companion packed for 2 or for 4 rows per batch wherever the rows divide; same results."""
+    from gbx_lm_amd import ops
+    n, k, g, bits = 512, 4096, 128, 2
+    m, d = _mk(oracle, n, k, bits, g, seed=3)
+    up, du = _mk(oracle, n, k, bits, g, seed=4)
+    x = (torch.randn(k) * 2).to(torch.bfloat16).to(DEV)
+    y64 = _ref(oracle, x.cpu(), d, bits, g)
+    y = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+    if epi == "swiglu":
+        u64 = _ref(oracle, x.cpu(), du, bits, g)
+        ops.dgemv(ops.make_dgemv_desc(x, m, y, ops.dgemv_pack(m, r, up), r, mod_up=up), x.device)
+        oracle.assert_close(y[None], (y64 / (1 + np.exp(-y64))) * u64, "bf16", f"swiglu R={r}")
+    elif epi == "residual":
+        h = torch.randn(n).to(torch.bfloat16).to(DEV)
+        h0 = h.clone()
+        ops.dgemv(ops.make_dgemv_desc(x, m, h, ops.dgemv_pack(m, r), r, residual=h), x.device)
+        oracle.assert_close(h[None], h0.cpu().double().numpy()[None] + y64, "bf16", f"residual R={r}")
+    else:
+        ops.dgemv(ops.make_dgemv_desc(x, m, y, ops.dgemv_pack(m, r), r), x.device)
+        oracle.assert_close(y[None], y64, "bf16", f"plain R={r}")
+
+
+def test_dgemv_pack_layout():
+    """gbx_dgemv_pack against the layout restated with torch ops: [batch][group][row of the batch]."""
+    from gbx_lm_amd import ops
+    from gbx_lm_amd.models.quantized_linear_gba import QuantizedLinear
+    n, k, g = 64, 1024, 128
+    mods = []
+    for s in range(2):
+        m = QuantizedLinear(k, n, False, g, 2)
+        m._buffers["scales"] = torch.randn(n, k // g).to(torch.bfloat16).to(DEV)
+        m._buffers["zeros"] = torch.randn(n, k // g).to(torch.bfloat16).to(DEV)
+        mods.append(m)
+    word = lambda m: (m.scales.view(torch.int16).to(torch.int32) & 0xFFFF) | (m.zeros.view(torch.int16).to(torch.int32) << 16)
+    for r in (2, 4):
+        got = ops.dgemv_pack(mods[0], r)
+        want = word(mods[0]).view(n // r, r, k // g).permute(0, 2, 1).contiguous()
+        assert torch.equal(got, want)
+        got = ops.dgemv_pack(mods[0], r, mods[1])
+        h = r // 2
+        wg, wu = word(mods[0]).view(n // h, h, k // g), word(mods[1]).view(n // h, h, k // g)
+        want = torch.cat([wg, wu], 1).permute(0, 2, 1).contiguous()
+        assert torch.equal(got, want)
+
+
+def test_dgemv_rejections():
+    from gbx_lm_amd import ops, _lib
+    assert ops.dgemv_plan(4096, 4096, 2, 32, 0) is None          # two groups per lane: gemv_kernel's split form
+    assert ops.dgemv_plan(4097, 4096, 2, 128, 0) is None         # rows do not divide
+    assert ops.dgemv_plan(4096, 14336, 2, 128, 2) is None        # SwiGLU needs whole rows per wave
+    assert ops.dgemv_plan(4096, 4096 * 16, 4, 128, 0) is None    # beyond 512 lane slots
+    d = _lib.DgDesc()
+    with pytest.raises(ValueError):
+        ops.dgemv(d, torch.device(DEV))                          # struct_size 0
+
+
+# ---- the launches the bench times, at their own geometry (Llama-3-8B and 3.2-3B shapes) ----------------------
+FULL = [  # (name, N, K, epilogue)
+    ("8B qkv", 6144, 4096, "plain+norm"), ("8B o", 4096, 4096, "residual"), ("8B gate|up", 14336, 4096, "swiglu+norm"),
+    ("8B down", 4096, 14336, "residual"),
+    ("3B qkv", 5120, 3072, "plain+norm"), ("3B o", 3072, 3072, "residual"), ("3B gate|up", 8192, 3072, "swiglu+norm"),
+    ("3B down", 3072, 8192, "residual"),
+]
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("name,n,k,kind", FULL)
+def test_dgemv_bench_geometry_vs_dequantised_fp64(oracle, bits, name, n, k, kind):
+    """The exact instantiation / grid the decode runner launches, against fp64 x . gbx_dequantize(weights) (the GPU dequantise
+    is itself bit-exact against the C oracle, tests/test_fullsize_gpu.py) -- the full-size rows make the numpy oracle too slow."""
+    from gbx_lm_amd import ops, _lib
+    g = 128
+    torch.manual_seed(bits * 100 + n % 97)
+
+    def rand_mod(seed):
+        from gbx_lm_amd.models.quantized_linear_gba import QuantizedLinear
+        m = QuantizedLinear(k, n, False, g, bits)
+        gen = torch.Generator().manual_seed(seed)
+        m._buffers["qweight"] = torch.randint(-2 ** 31, 2 ** 31 - 1, (n, k // 32 * bits), dtype=torch.int32, generator=gen).view(torch.uint32).to(DEV)
+        sc = (0.5 + torch.rand(n, k // g, generator=gen)) * (2.0 / (2 ** bits - 1)) * 0.02
+        m._buffers["scales"] = sc.to(torch.bfloat16).to(DEV)
+        m._buffers["zeros"] = (-m.scales.float().cpu() * (2 ** bits - 1) / 2 + 0.1 * sc * torch.randn(n, k // g, generator=gen)).to(torch.bfloat16).to(DEV)
+        return m
+
+    deq = lambda m: ops.dequantize(m.qweight, m.scales, m.zeros, m.group_size, m.bits, dtype=torch.float32).double()
+    x = (torch.randn(k) * (1.0 if "norm" in kind else 0.5)).to(torch.bfloat16).to(DEV)
+    nw = (1 + 0.1 * torch.randn(k)).to(torch.bfloat16).to(DEV)
+    m = rand_mod(1)
+    if kind == "swiglu+norm":
+        up = rand_mod(2)
+        r, wg = _plan(ops, m, _lib.GBX_DG_SWIGLU, True)
+        act = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+        ops.dgemv(ops.make_dgemv_desc(x, m, act, ops.dgemv_pack(m, r, up), r, mod_up=up, norm_weight=nw, eps=1e-5), x.device)
+        xn = _rms(x, nw, 1e-5).double()
+        g64, u64 = deq(m) @ xn, deq(up) @ xn
+        # the op-by-op roundings of qllama.py:115 are part of the contract: compare with them applied
+        gb, ub = g64.to(torch.bfloat16).double(), u64.to(torch.bfloat16).double()
+        want = (gb / (1 + torch.exp(-gb))).to(torch.bfloat16).double() * ub
+        oracle.assert_close(act[None].cpu(), want[None].cpu().numpy(), "bf16", name)
+    elif kind == "residual":
+        r, wg = _plan(ops, m, _lib.GBX_DG_RESIDUAL)
+        h = torch.randn(n).to(torch.bfloat16).to(DEV)
+        h0 = h.clone()
+        ssq = torch.zeros(_lib.GBX_DG_SSQ_SLOTS, dtype=torch.float32, device=DEV) if wg > 0 else None
+        ops.dgemv(ops.make_dgemv_desc(x, m, h, ops.dgemv_pack(m, r), r, residual=h, ssq_out=ssq), x.device)
+        want = h0.double() + (deq(m) @ x.double())
+        oracle.assert_close(h[None].cpu(), want[None].cpu().numpy(), "bf16", name)
+        if ssq is not None:
+            assert abs(ssq.double().sum().item() - h.double().pow(2).sum().item()) <= 1e-5 * h.double().pow(2).sum().item()
+        if bits == 2 and name.startswith("8B"):
+            assert ssq is not None, "the 2-bit o_proj / down_proj launches of the headline bench carry the statistic"
+    else:
+        r, wg = _plan(ops, m, _lib.GBX_DG_PLAIN, True)
+        y = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+        ops.dgemv(ops.make_dgemv_desc(x, m, y, ops.dgemv_pack(m, r), r, norm_weight=nw, eps=1e-5), x.device)
+        want = deq(m) @ _rms(x, nw, 1e-5).double()
+        oracle.assert_close(y[None].cpu(), want[None].cpu().numpy(), "bf16", name)
