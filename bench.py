@@ -76,14 +76,28 @@ def kernel_leg(model, reps=20):
     dt = g0.scales.dtype
     x = torch.randn(g0.input_dims, device=dev).to(dt)
     act = torch.empty(g0.output_dims, device=dev, dtype=dt)
-    packs = [ops.pack_scales_zeros(blk.mlp.gate_proj, blk.mlp.up_proj) for blk in layers]   # as the decode runner does
-    descs = [ops.make_fused_desc(x, (blk.mlp.gate_proj, blk.mlp.up_proj), (act,),
-                                 norm_weight=blk.post_attention_layernorm.weight.to(dt), eps=blk.post_attention_layernorm.eps,
-                                 swiglu=True, packed=pk) for blk, pk in zip(layers, packs)]
+    # exactly the launch the decode runner replays: the decode-block GEMV (gbx_dgemv_forward) with the RMSNorm statistic
+    # carried in from the o_proj launch, unless dgemv is switched off / does not cover the shape (then gbx_qlinear_fused_forward)
+    from gbx_lm_amd import _lib as _l
+    pl = ops.dgemv_plan(g0.output_dims, g0.input_dims, g0.bits, g0.group_size, _l.GBX_DG_SWIGLU, True) if os.environ.get("GBX_DGEMV", "1") == "1" else None
+    if pl is not None:
+        ssq = torch.zeros(_l.GBX_DG_SSQ_SLOTS, dtype=torch.float32, device=dev)
+        ssq[:256] = x.float().pow(2).view(256, -1).sum(1)
+        packs = [ops.dgemv_pack(blk.mlp.gate_proj, pl[0], blk.mlp.up_proj) for blk in layers]
+        descs = [ops.make_dgemv_desc(x, blk.mlp.gate_proj, act, pk, pl[0], mod_up=blk.mlp.up_proj,
+                                     norm_weight=blk.post_attention_layernorm.weight.to(dt), eps=blk.post_attention_layernorm.eps,
+                                     ssq_in=ssq if os.environ.get("GBX_DG_SSQ", "1") == "1" else None) for blk, pk in zip(layers, packs)]
+        launch, kname = ops.dgemv, f"gbx::dgemv_kernel<{bits},P1,KS1,NW16,R{pl[0]},SWIGLU,...>"
+    else:
+        packs = [ops.pack_scales_zeros(blk.mlp.gate_proj, blk.mlp.up_proj) for blk in layers]
+        descs = [ops.make_fused_desc(x, (blk.mlp.gate_proj, blk.mlp.up_proj), (act,),
+                                     norm_weight=blk.post_attention_layernorm.weight.to(dt), eps=blk.post_attention_layernorm.eps,
+                                     swiglu=True, packed=pk) for blk, pk in zip(layers, packs)]
+        launch, kname = ops.qlinear_fused, f"gbx::gemv_kernel<{bits},...>"
 
     def sweep():
         for d in descs:
-            ops.qlinear_fused(d, dev)
+            launch(d, dev)
 
     sweep()
     g = torch.cuda.CUDAGraph()
@@ -108,29 +122,12 @@ def kernel_leg(model, reps=20):
             traffic = rec["traffic_bytes_per_launch"] if rec else None
     except (OSError, ValueError, KeyError):
         traffic = None
-    # what the launch can attain at all: its measured chain head (the same launch with the weight stream removed,
-    # GBX_CHAIN_FLOOR=2, recorded by scratch/profile_r03.sh) + its bytes at the chip's measured copy rate
-    attainable = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r03_chain_floor.json")) as f:
-            cf = json.load(f)
-        null_us = cf.get("gateup_us_per_launch_null_weights")
-        if null_us and cf.get("kernel_key") == f"gateup_b{bits}_N{n}_K{k}_g{grp}":       # measured for this exact launch only
-            # the launch with its weight stream removed (same instructions) takes as long as the real one: what bounds it is its
-            # head + vector-ALU consumption, so that time -- not bytes / copy rate (%.1f us) -- is what this kernel can attain
-            stream_us = nbytes / (cf.get("copy_rate_GBps", 6290.0) * 1e3)
-            att_us = max(null_us, stream_us)
-            attainable = {"us_per_launch": att_us, "GBps": nbytes / att_us / 1e3, "frac_of_peak": nbytes / att_us / 1e3 / HBM_PEAK_GBPS,
-                          "null_weights_us": null_us, "stream_only_us": stream_us,
-                          "source": "profiles/r03_chain_floor.json: max(launch with null weights [GBX_CHAIN_FLOOR=2], bytes / measured copy rate)",
-                          "note": "null_weights_us = the same launch with every row read redirected to two L2-resident rows: its non-memory time "
-                                  "(heads + vector-ALU consumption); it can exceed the real launch by a few per cent (all waves then share two hot "
-                                  "lines), i.e. the launch is at what this kernel design attains -- the gap to the HBM roofline is not memory time"}
-    except (OSError, ValueError, KeyError):
-        attainable = None
+    # reference points measured on the same chip (profiles/r04_stream_floor.txt, scratch/probe4/probe_stream.hip): a launch that only
+    # STREAMS these bytes (no prologue, no arithmetic), replayed the same way, takes 5.7-6.5 us -- the floor of this launch
+    floor = {"pure_stream_us": 5.7, "source": "profiles/r04_stream_floor.txt (29.4 MB of 1 KB rows, 16-wave workgroups, boundary included)"}
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "attainable": attainable,
-            "kernel": f"gbx::gemv_kernel<{bits},...> fused RMSNorm+gate_proj+up_proj+SwiGLU, 2 x [N={n}, K={k}] g={grp}",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "floor": floor,
+            "kernel": f"{kname} fused RMSNorm+gate_proj+up_proj+SwiGLU, 2 x [N={n}, K={k}] g={grp}",
             "bytes_per_launch": nbytes, "us_per_launch": us, "launches_timed": reps * len(descs),
             "working_set_bytes": nbytes * len(descs)}
 
@@ -257,9 +254,12 @@ def decode_leg(model, cfg, dev, batch, context, steps, warmup, world=1, use_grap
     caches = make_caches(model, batch, cap, dev)
     Runner = FusedDecodeRunner if (fused_eligible(model) and batch == 1) else DecodeRunner
     runner = Runner(model, caches, use_graph=use_graph)
+    full = None
     for t in range(context):
-        runner.step(torch.full((batch,), t % cfg["vocab_size"], device=dev, dtype=torch.long))
-    runner.start_greedy(torch.argmax(runner.logits, -1))
+        full = runner.step(torch.full((batch,), t % cfg["vocab_size"], device=dev, dtype=torch.long))
+    # seed the greedy chain from the GATHERED logits step() returns (under a vocabulary-sharded head runner.logits is this rank's
+    # shard: an argmax over it would start every rank on a different token id)
+    runner.start_greedy(torch.argmax(full, -1))
     ms = time_decode(runner, steps, warmup, batch, world, dev) / steps
     ql_b, head_b, kv_b = token_bytes(model, context + warmup + steps // 2)
     nbytes = ql_b + head_b + kv_b * batch
@@ -376,8 +376,10 @@ def main():
         tp_allreduce = "rccl"
         if os.environ.get("GBX_TP_P2P") == "1":
             # opt-in: one-shot push all-reduce through hipIpc inboxes (gbx_p2p_allreduce) instead of RCCL for the [B, D] exchanges
-            tp.enable_p2p(rank, world, cfg["hidden_size"] * 32, dev)
-            tp_allreduce = "p2p one-shot (gbx_p2p_allreduce)"
+            if tp.enable_p2p(rank, world, cfg["hidden_size"] * 32, dev) is not None:
+                tp_allreduce = "p2p one-shot (gbx_p2p_allreduce)"
+            else:
+                tp_allreduce = f"rccl (p2p unavailable: {tp.p2p_unavailable_reason})"
     torch.cuda.synchronize()
 
     total = args.context + args.warmup + args.steps + 2
@@ -401,9 +403,10 @@ def main():
 
     vocab = cfg["vocab_size"]
     # synthetic fixed-shape prompt: token ids arange(L) mod vocab, fed through the decode path to fill the KV cache
+    full = None
     for t in range(args.context):
-        runner.step(torch.full((args.batch,), t % vocab, device=dev, dtype=torch.long))
-    tok = torch.argmax(runner.logits, -1)
+        full = runner.step(torch.full((args.batch,), t % vocab, device=dev, dtype=torch.long))
+    tok = torch.argmax(full, -1)                                    # step() returns the gathered logits under a sharded head
     runner.start_greedy(tok)                                        # greedy chain: argmax + next-token feed stay on the device
 
     ms = time_decode(runner, args.steps, args.warmup, args.batch, world, dev)

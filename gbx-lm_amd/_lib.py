@@ -140,6 +140,7 @@ def _declare_optional(L) -> None:
         "gbx_p2p_inbox_create": [i32, i32, ctypes.POINTER(p), p],
         "gbx_p2p_inbox_open": [p, ctypes.POINTER(p)],
         "gbx_p2p_inbox_close": [p],
+        "gbx_p2p_status": [p, i32, i32, ctypes.POINTER(i32)],
         "gbx_p2p_inbox_destroy": [p],
         "gbx_p2p_allreduce": [p, i32, i32, i32, ctypes.POINTER(p), i32, i32, p],
         "gbx_dense_gemv_argmax_shard": [p, p, p, p, f32, i32, i32, p, i32, i32, p],

@@ -634,9 +634,16 @@ int gbx_p2p_inbox_create(int32_t world, int32_t max_elems, void** inbox_out, voi
   const size_t bytes = gbx_p2p_inbox_bytes(world, max_elems);
   if (!bytes || !inbox_out || !ipc_handle_out) return fail(GBX_ERR_INVALID, "bad world / max_elems / output pointers");
   void* p = nullptr;
-  hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);   /* peers write it, this GPU polls it */
-  if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&p, bytes); }
-  if (e != hipSuccess) return hip_fail(e, "gbx_p2p_inbox_create allocation");
+  /* Peers write this memory over xGMI while a kernel of THIS GPU polls it: that needs fine-grained (uncached-at-L2) memory.  A
+   * coarse-grained hipMalloc would let the local L2 serve stale lines to the poll -- a hang or a stale payload that no single-GPU
+   * test can show -- so there is no fallback: the caller keeps RCCL (tp.enable_p2p).  GBX_P2P_FORCE_COARSE=1: test hook. */
+  const char* force = getenv("GBX_P2P_FORCE_COARSE");
+  hipError_t e = (force && atoi(force)) ? hipErrorNotSupported : hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(GBX_ERR_UNSUPPORTED, "gbx_p2p_inbox_create: fine-grained device memory is not available (%s); the one-shot P2P all-reduce "
+                "needs it -- use the RCCL all-reduce", hipGetErrorString(e));
+  }
   e = hipMemset(p, 0, bytes);
   if (e == hipSuccess) e = hipDeviceSynchronize();
   hipIpcMemHandle_t h;
@@ -661,6 +668,16 @@ int gbx_p2p_inbox_open(const void* ipc_handle, void** mapped_out) {
 
 int gbx_p2p_inbox_close(void* mapped) { return mapped && hipIpcCloseMemHandle(mapped) != hipSuccess ? fail(GBX_ERR_HIP, "hipIpcCloseMemHandle failed") : GBX_OK; }
 int gbx_p2p_inbox_destroy(void* inbox) { return inbox && hipFree(inbox) != hipSuccess ? fail(GBX_ERR_HIP, "hipFree failed") : GBX_OK; }
+
+int gbx_p2p_status(const void* inbox, int32_t world, int32_t max_elems, int32_t* timed_out) {
+  const size_t bytes = gbx_p2p_inbox_bytes(world, max_elems);
+  if (!inbox || !bytes || !timed_out) return fail(GBX_ERR_INVALID, "bad inbox / world / max_elems / output pointer");
+  unsigned flag = 0;        /* state word 2, behind the slabs: set by a launch whose wait for a peer ran into its bound */
+  hipError_t e = hipMemcpy(&flag, static_cast<const char*>(inbox) + bytes - 64 + 8, sizeof(flag), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return hip_fail(e, "gbx_p2p_status copy");
+  *timed_out = flag ? 1 : 0;
+  return GBX_OK;
+}
 
 int gbx_p2p_allreduce(void* x, int32_t n, int32_t rank, int32_t world, void* const* inboxes, int32_t max_elems, int32_t act_dtype,
                       void* hip_stream) {

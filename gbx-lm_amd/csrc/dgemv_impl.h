@@ -135,12 +135,14 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(const DgArgs a) {
   }
   const unsigned voff_r = (lane & 32) ? R : 0;             // residual: lanes 0-31 take the batch's first R/2 rows, 32-63 the others
 
-  auto issue = [&](DgBatch<BITS, P, R>& b, int bi) {
+  // rows [i0, i1) of batch bi; the batch's small loads ((scale|zero) words, residual) go with its last row
+  auto issue_part = [&](DgBatch<BITS, P, R>& b, int bi, int i0, int i1) {
     const bool live = bi < nbatch;
     const int bc = (live && !a.null_rows) ? bi : 0;
     const unsigned kill = live ? 0u : KILL;
 #pragma unroll
     for (int i = 0; i < R; ++i) {
+      if (i < i0 || i >= i1) continue;
       const int row = SWI ? bc * RO + (i % RO) : bc * R + i;
       const int woff = row * W4;
 #pragma unroll
@@ -150,6 +152,7 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(const DgArgs a) {
         else b.w[i][p] = __builtin_amdgcn_raw_buffer_load_b128(d, voff_w[p] | kill, woff, 2);
       }
     }
+    if (i1 < R) return;
     const int soff = (live ? bi : 0) * (G * R * 4);
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -166,6 +169,7 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(const DgArgs a) {
       else b.res = __builtin_amdgcn_raw_buffer_load_b16(resd, voff_r | kill, (live ? bi : 0) * (R * 2), 0);
     }
   };
+  auto issue = [&](DgBatch<BITS, P, R>& b, int bi) { issue_part(b, bi, 0, R); };
 
   // ---------------- 1. activation loads first (vmcnt retires in order), then the statistic partials, then batch 0 ------------
   // Prologue geometry as in gemv_kernel: a thread converts PPU pairs of one unit; sub-slot statistics meet through DPP.
@@ -223,10 +227,17 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(const DgArgs a) {
   }
 
   DgBatch<BITS, P, R> ring[D];
-  if constexpr (!LATE) issue(ring[0], batch_of(0));
+#ifndef DG_EXP_EARLY_LATE
+#define DG_EXP_EARLY_LATE 0      // experiment: rows of batch 0 the LATE form still requests ahead of the prologue
+#endif
+#ifndef DG_EXP_EARLY_EARLY
+#define DG_EXP_EARLY_EARLY R     // experiment: rows of batch 0 the early form requests ahead of the prologue
+#endif
+  constexpr int E0 = LATE ? DG_EXP_EARLY_LATE : DG_EXP_EARLY_EARLY;
+  if constexpr (E0 > 0) issue_part(ring[0], batch_of(0), 0, E0);
   DG_STAMP(1);
 #ifdef GBX_STAMPS
-  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LATE ? 0 : R * P + P + ((EPI == 1 && KS == 1) ? 1 : 0)) : "memory");   // x, norm weight, partials have landed
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(E0 * P + (E0 == R ? P + ((EPI == 1 && KS == 1) ? 1 : 0) : 0)) : "memory");   // x, norm weight, partials have landed
   DG_STAMP(8);
 #endif
 
@@ -321,7 +332,7 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(const DgArgs a) {
     }
   }
   DG_STAMP(10);
-  if constexpr (LATE) issue(ring[0], batch_of(0));
+  if constexpr (E0 < R) issue_part(ring[0], batch_of(0), E0, R);
   __syncthreads();
   DG_STAMP(2);
   if constexpr (D == 2) issue(ring[1], batch_of(1));

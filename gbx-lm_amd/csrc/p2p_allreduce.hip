@@ -59,8 +59,11 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(const P2PArgs a) {
         for (;;) {
           g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           if (static_cast<unsigned>(g >> 32) == e) break;
-          if (++spins > (1u << 22)) __builtin_trap();            // a peer that never arrived: fail loudly, never hang the queue
-          __builtin_amdgcn_s_sleep(1);
+          // a peer that never arrived (tens of seconds: rank skew of a graph instantiate or a slow first launch is NOT that):
+          // raise the device-visible error word (gbx_p2p_status) and leave with whatever is there -- never hang the queue,
+          // never take the whole context down with a trap
+          if (++spins > (1u << 26)) { __hip_atomic_store(a.state + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+          __builtin_amdgcn_s_sleep(8);
         }
         w = static_cast<unsigned>(g);
       }

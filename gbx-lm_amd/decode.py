@@ -554,6 +554,9 @@ class FusedDecodeRunner(DecodeRunner):
                 self.all_keys.copy_(akeys0)
 
     def step_greedy(self) -> torch.Tensor:
+        """One chained greedy step.  Returns ``logits_buf``: the full logits, or -- under a vocabulary-sharded head (tensor
+        parallel) -- THIS RANK'S SHARD only (columns tp_vocab[0]:tp_vocab[1]); the chain itself exchanges just the argmax keys.
+        Callers that need full logits under TP use ``step()``."""
         off = self.caches[0].offset
         self._check_room(off)
         if self.use_graph:
@@ -642,11 +645,33 @@ def prompt_step(model, y: torch.Tensor, prompt_cache) -> Optional[torch.Tensor]:
     if (not isinstance(c0, KVCache) or any(type(c) is not KVCache or c.offset != 0 or c.static_active for c in prompt_cache)
             or not y.is_cuda or getattr(model, "tp_world", 1) > 1 or torch.cuda.is_current_stream_capturing()):
         return None
+    if getattr(model, "_prompt_graph_unavailable", False):
+        return None
     bucket = next(b for b in PromptRunner.BUCKETS if b >= L)
+    # A captured graph bakes in the weights' addresses: key the runners on the storage of the tensors every forward reads first
+    # and last (embedding, head, first and last block) and on their in-place version counters, and rebuild on any mismatch
+    # (load_weights / .to() / a re-quantise) -- the check ops._DenseCache makes for its images.
+    def _sig():
+        l0, l1 = model.model.layers[0], model.model.layers[-1]
+        ts = (model.model.embed_tokens.weight, model.head_weight(), l0.self_attn.q_proj.qweight, l0.self_attn.q_proj.scales,
+              l1.mlp.down_proj.qweight, l1.mlp.down_proj.scales, model.model.norm.weight)
+        return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in ts)
+    sig = _sig()
     runners = model.__dict__.setdefault("_prompt_runners", {})
+    if runners.get("sig") != sig:
+        runners.clear()
+        runners["sig"] = sig
     r = runners.get(bucket)
     if r is None:
-        r = runners[bucket] = PromptRunner(model, bucket)
+        try:
+            r = runners[bucket] = PromptRunner(model, bucket)
+        except Exception as e:      # OOM of the private pool / staging caches, a forward that cannot be captured: the eager pass still works
+            import warnings
+            warnings.warn(f"graph-replayed prompt pass unavailable ({type(e).__name__}: {e}); using the eager pass")
+            model._prompt_graph_unavailable = True
+            runners.clear()
+            torch.cuda.synchronize()
+            return None
     return r.run(y, prompt_cache)
 
 

@@ -72,7 +72,11 @@ def shard_llama(model, rank: int, world: int, group: Optional[dist.ProcessGroup]
     model.tp_world, model.tp_rank, model.tp_group = world, rank, group
     hw = model.head_weight()
     v = hw.shape[0]
-    if v % world == 0 and (v // world) % 2 == 0:      # vocabulary shard of the output head (the embedding lookup keeps the table)
+    # vocabulary shard of the output head (the embedding lookup keeps the table) -- only for model classes whose head_weight() /
+    # forward consult the shard (qllama.Model); others keep the full head and `tp_vocab` unset, so no runner applies an offset
+    code = getattr(getattr(type(model), "head_weight", None), "__code__", None)
+    honours = code is not None and ("_tp_head" in code.co_consts or "_tp_head" in code.co_names)
+    if honours and v % world == 0 and (v // world) % 2 == 0:
         lo, hi = rank * v // world, (rank + 1) * v // world
         model._tp_head = hw[lo:hi].detach().clone().contiguous()
         model.tp_vocab = (lo, hi, v)
@@ -81,11 +85,23 @@ def shard_llama(model, rank: int, world: int, group: Optional[dist.ProcessGroup]
     return model
 
 
+_flat_gather = {}          # process group -> does its backend implement all_gather_into_tensor (decided ONCE, never by exception)
+
+
+def _has_flat_gather(group) -> bool:
+    key = id(group) if group is not None else None
+    if key not in _flat_gather:
+        # gloo (the CPU tests) has no flat form; nccl (= RCCL) has.  A capability of the backend, so every rank answers alike --
+        # an exception-driven fallback around a collective would let ONE rank enqueue a different collective than its peers.
+        _flat_gather[key] = str(dist.get_backend(group)).lower() != "gloo"
+    return _flat_gather[key]
+
+
 def all_gather_into(out: torch.Tensor, inp: torch.Tensor, group=None) -> torch.Tensor:
-    """out[r * n : (r + 1) * n] = rank r's ``inp`` (flat, n = inp.numel()); one collective."""
-    try:
+    """out[r * n : (r + 1) * n] = rank r's ``inp`` (flat, n = inp.numel()); one collective, the same one on every rank."""
+    if _has_flat_gather(group):
         dist.all_gather_into_tensor(out.view(-1), inp.reshape(-1), group=group)
-    except (RuntimeError, NotImplementedError):          # a backend without the flat form
+    else:
         parts = [torch.empty_like(inp.reshape(-1)) for _ in range(dist.get_world_size(group))]
         dist.all_gather(parts, inp.reshape(-1), group=group)
         out.view(-1).copy_(torch.cat(parts))
@@ -101,6 +117,10 @@ def gather_vocab(logits_local: torch.Tensor, model) -> torch.Tensor:
     return out.permute(1, 0, 2).reshape(*logits_local.shape[:-1], -1)
 
 
+class P2PUnavailable(RuntimeError):
+    """Some rank could not set up its peer-mapped inbox (no fine-grained device memory)."""
+
+
 class P2PAllReduce:
     """One-shot push all-reduce of a short 16-bit vector through peer-mapped inboxes (gbx_p2p_allreduce, csrc/p2p_allreduce.hip):
     every rank writes its vector into every peer's memory over xGMI and sums what arrived in its own, in rank order, fp32, one
@@ -114,25 +134,43 @@ class P2PAllReduce:
         self.L = _lib.lib()
         self.rank, self.world, self.max_elems = rank, world, int(max_elems)
         self.device = torch.device(device)
+        self.mapped, self.own = [], None
         with torch.cuda.device(self.device):
             own = ctypes.c_void_p()
             handle = ctypes.create_string_buffer(64)
-            _lib.check(self.L.gbx_p2p_inbox_create(world, self.max_elems, ctypes.byref(own), handle))
-            self.own = own
-            handles = [None] * world
-            dist.all_gather_object(handles, bytes(handle.raw), group=group)
-            self.mapped = []
+            reason = None
+            try:          # fine-grained memory or nothing (gbx_p2p_inbox_create has no coarse-grained fallback)
+                _lib.check(self.L.gbx_p2p_inbox_create(world, self.max_elems, ctypes.byref(own), handle))
+                self.own = own
+            except (NotImplementedError, RuntimeError) as e:
+                reason = f"rank {rank}: {e}"
+            # every rank learns every rank's outcome BEFORE anyone maps or pushes: one failing rank switches all of them back
+            outcomes = [None] * world
+            dist.all_gather_object(outcomes, (reason, bytes(handle.raw)), group=group)
+            bad = [r for r, _ in outcomes if r is not None]
+            if bad:
+                self.close()
+                raise P2PUnavailable("; ".join(bad))
             arr = (ctypes.c_void_p * world)()
             for p in range(world):
                 if p == rank:
                     arr[p] = own.value
                     continue
                 m = ctypes.c_void_p()
-                _lib.check(self.L.gbx_p2p_inbox_open(ctypes.create_string_buffer(handles[p], 64), ctypes.byref(m)))
+                _lib.check(self.L.gbx_p2p_inbox_open(ctypes.create_string_buffer(outcomes[p][1], 64), ctypes.byref(m)))
                 self.mapped.append(m)
                 arr[p] = m.value
             self.inboxes = arr
         dist.barrier(group=group)                       # nobody pushes before everybody has mapped
+
+    def check(self) -> None:
+        """Raise if a launch on this inbox gave up waiting for a peer (synchronous 4-byte read: call it off the timed path)."""
+        import ctypes
+        from . import _lib
+        flag = ctypes.c_int32(0)
+        _lib.check(self.L.gbx_p2p_status(self.own, self.world, self.max_elems, ctypes.byref(flag)))
+        if flag.value:
+            raise RuntimeError(f"P2PAllReduce (rank {self.rank}): a one-shot all-reduce timed out waiting for a peer; its result is invalid")
 
     def __call__(self, t: torch.Tensor) -> torch.Tensor:
         from . import _lib
@@ -154,12 +192,21 @@ class P2PAllReduce:
 
 
 _p2p: Optional[P2PAllReduce] = None
+p2p_unavailable_reason: Optional[str] = None      # why enable_p2p fell back to RCCL (reported in bench.py's config.tp_allreduce)
 
 
-def enable_p2p(rank: int, world: int, max_elems: int, device, group=None) -> P2PAllReduce:
-    """Route ``all_reduce_`` of 16-bit tensors with at most ``max_elems`` elements through the one-shot P2P kernel."""
-    global _p2p
-    _p2p = P2PAllReduce(rank, world, max_elems, device, group)
+def enable_p2p(rank: int, world: int, max_elems: int, device, group=None) -> Optional[P2PAllReduce]:
+    """Route ``all_reduce_`` of 16-bit tensors with at most ``max_elems`` elements through the one-shot P2P kernel.  Returns None --
+    and leaves the RCCL all-reduce in place on EVERY rank, with the reason in ``p2p_unavailable_reason`` -- when any rank cannot
+    provide a fine-grained inbox."""
+    global _p2p, p2p_unavailable_reason
+    try:
+        _p2p = P2PAllReduce(rank, world, max_elems, device, group)
+        p2p_unavailable_reason = None
+    except P2PUnavailable as e:
+        _p2p, p2p_unavailable_reason = None, str(e)
+        import warnings
+        warnings.warn(f"one-shot P2P all-reduce unavailable, keeping RCCL: {e}")
     return _p2p
 
 

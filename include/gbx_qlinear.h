@@ -354,7 +354,11 @@ int gbx_embed_next_token(void* argmax_keys, int64_t* token_io, int64_t* pos, con
  * ranks exchanged out of band) and passes the `world` mapped pointers, own inbox at index `rank`.  gbx_p2p_allreduce pushes x into
  * the peers' inboxes as 8-byte {epoch, payload} granules and sums what arrived in its own inbox in rank order, fp32, one rounding:
  * the same bits on every rank.  Stream-ordered, no host synchronisation, graph-capturable (the epoch lives in the inbox).  All
- * ranks must make the same sequence of calls with the same n. */
+ * ranks must make the same sequence of calls with the same n.
+ * The inbox MUST be fine-grained device memory (a running kernel polls what peers write over xGMI): gbx_p2p_inbox_create returns
+ * GBX_ERR_UNSUPPORTED when the runtime cannot provide it -- there is no coarse-grained fallback -- and the caller keeps its RCCL
+ * all-reduce.  A launch whose wait for a peer exceeds its bound (tens of seconds) raises an error word (gbx_p2p_status) and
+ * returns garbage instead of hanging or trapping. */
 size_t gbx_p2p_inbox_bytes(int32_t world, int32_t max_elems);
 int gbx_p2p_inbox_create(int32_t world, int32_t max_elems, void** inbox_out, void* ipc_handle_out /* 64 bytes */);
 int gbx_p2p_inbox_open(const void* ipc_handle, void** mapped_out);
@@ -362,6 +366,9 @@ int gbx_p2p_inbox_close(void* mapped);
 int gbx_p2p_inbox_destroy(void* inbox);
 int gbx_p2p_allreduce(void* x, int32_t n, int32_t rank, int32_t world, void* const* inboxes, int32_t max_elems, int32_t act_dtype,
                       void* hip_stream);
+/* Host-side check (synchronous 4-byte copy): *timed_out = 1 when a gbx_p2p_allreduce launch on this inbox gave up waiting for a
+ * peer (its result is then garbage); the flag stays set.  Call it outside the timed path (end of a generation, teardown). */
+int gbx_p2p_status(const void* inbox, int32_t world, int32_t max_elems, int32_t* timed_out);
 
 /* Vocabulary-sharded output head (tensor parallel, build-side extension: the reference has no TP): rank r holds rows
  * [index_offset, index_offset + N) of the head.  gbx_dense_gemv_argmax_shard is gbx_dense_gemv_argmax whose keys carry GLOBAL

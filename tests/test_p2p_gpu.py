@@ -78,3 +78,50 @@ def test_p2p_allreduce_shared_gpu(world):
     assert len(out) == world
     for r, v in out.items():
         assert v < 0.02, f"rank {r}: P2P vs gloo relative difference {v}"      # gloo rounds after every hop: a few bf16 ulps at 4 ranks
+
+
+def _worker_fallback(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    if rank == 1:
+        os.environ["GBX_P2P_FORCE_COARSE"] = "1"          # ONE rank cannot get fine-grained memory
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import warnings
+        from gbx_lm_amd import tp
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = tp.enable_p2p(rank, world, 4096, dev)
+        # every rank falls back, with the failing rank named, and all_reduce_ keeps working through the process group
+        x = torch.full((64,), float(rank + 1), dtype=torch.bfloat16, device=dev)
+        tp.all_reduce_(x)
+        out[rank] = (got is None, tp.p2p_unavailable_reason, float(x[0]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_p2p_unavailable_is_reported_and_every_rank_falls_back():
+    """gbx_p2p_inbox_create has no coarse-grained fallback (GBX_ERR_UNSUPPORTED); tp.enable_p2p then keeps the collective backend
+    on EVERY rank and says why."""
+    world = 2
+    port = 28700 + (os.getpid() % 1000)
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_fallback, args=(world, port, out), nprocs=world, join=True)
+    assert len(out) == world
+    for r, (fell_back, reason, v) in out.items():
+        assert fell_back and reason and "rank 1" in reason and "fine-grained" in reason, (r, reason)
+        assert v == 3.0
+
+
+def test_p2p_inbox_create_refuses_coarse_memory(monkeypatch):
+    import ctypes
+    from gbx_lm_amd import _lib
+    monkeypatch.setenv("GBX_P2P_FORCE_COARSE", "1")
+    own, handle = ctypes.c_void_p(), ctypes.create_string_buffer(64)
+    rc = _lib.lib().gbx_p2p_inbox_create(2, 4096, ctypes.byref(own), handle)
+    assert rc == _lib.GBX_ERR_UNSUPPORTED and b"fine-grained" in _lib.lib().gbx_last_error()
