@@ -10,13 +10,16 @@ import os
 import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-_SO = os.environ.get("GBX_QLINEAR_LIB") or os.path.join(_CSRC, "libgbx_qlinear.so")   # override: experiment builds only
+from . import env as _env  # noqa: E402
+_SO = _env.get("GBX_QLINEAR_LIB") or os.path.join(_CSRC, "libgbx_qlinear.so")   # override: experiment builds only
 
 GBX_OK, GBX_ERR_INVALID, GBX_ERR_HIP, GBX_ERR_UNSUPPORTED = 0, 1, 2, 3
 GBX_F16, GBX_BF16, GBX_F32 = 0, 1, 2
 GBX_STREAM_OP_BYTES = 160
 
+_XSO = os.path.join(_CSRC, "libgbx_experimental.so")        # opt-in kernels behind include/gbx_experimental.h
 _lib = None
+_xlib = None
 
 
 def build(force: bool = False, jobs: int = 8) -> str:
@@ -66,7 +69,7 @@ def lib() -> ctypes.CDLL:
         L.gbx_qlinear_swiglu_workspace_bytes.restype = ctypes.c_size_t
         L.gbx_qlinear_swiglu_forward_ws.argtypes = [p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, p, ctypes.c_size_t, p]
         _declare_optional(L)
-        if L.gbx_version() < GBX_MIN_VERSION and not os.environ.get("GBX_QLINEAR_LIB"):
+        if L.gbx_version() < GBX_MIN_VERSION and not _env.get("GBX_QLINEAR_LIB"):
             raise RuntimeError(f"gbx_lm_amd: {_SO} reports ABI version {L.gbx_version()}, this binding needs >= {GBX_MIN_VERSION}: "
                                "rebuild it (`make -C gbx-lm_amd/csrc`)")
         _lib = L
@@ -82,8 +85,46 @@ class FusedDesc(ctypes.Structure):
                 ("y", ctypes.c_void_p * 3), ("N", ctypes.c_int32 * 3),
                 ("norm_weight", ctypes.c_void_p), ("norm_eps", ctypes.c_float),
                 ("residual", ctypes.c_void_p), ("swiglu", ctypes.c_int32),
-                ("sz", ctypes.c_void_p),
-                ("x_acc", ctypes.c_void_p), ("x_out", ctypes.c_void_p), ("zero_buf", ctypes.c_void_p), ("zero_n", ctypes.c_int32)]
+                ("sz", ctypes.c_void_p)]
+
+
+class ExpFusedDesc(ctypes.Structure):
+    """Mirror of ``gbx_exp_qlinear_fused`` (include/gbx_experimental.h): FusedDesc + the fields of the launch behind
+    gbx_attn_oproj_decode."""
+    _fields_ = FusedDesc._fields_ + [("x_acc", ctypes.c_void_p), ("x_out", ctypes.c_void_p), ("zero_buf", ctypes.c_void_p),
+                                     ("zero_n", ctypes.c_int32)]
+
+
+def exp_lib() -> ctypes.CDLL:
+    """libgbx_experimental.so (opt-in / measured-negative kernels; never needed for normal use)."""
+    global _xlib
+    if _xlib is None:
+        if not os.path.exists(_XSO):
+            raise RuntimeError(f"gbx_lm_amd: {_XSO} is not built (`make -C gbx-lm_amd/csrc`)")
+        L = ctypes.CDLL(_XSO)
+        i32, p, f32 = ctypes.c_int32, ctypes.c_void_p, ctypes.c_float
+        L.gbx_exp_version.restype = ctypes.c_int
+        L.gbx_exp_last_error.restype = ctypes.c_char_p
+        L.gbx_exp_qlinear_fused_forward.argtypes = [ctypes.POINTER(ExpFusedDesc), p]
+        L.gbx_stream_encode.argtypes = [ctypes.POINTER(ExpFusedDesc), i32, p, ctypes.c_size_t]
+        L.gbx_stream_run.argtypes = [p, p, i32, i32, i32, p]
+        L.gbx_attn_oproj_supported.argtypes = [i32, i32, i32, i32, i32, i32]
+        L.gbx_attn_oproj_decode.argtypes = [p, p, p, p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, i32, i32, f32, f32, i32, i32, p]
+        L.gbx_qlinear_prepack_tiles.argtypes = [p, p, p, p, p, p, p, p, i32, i32, i32, i32, p]
+        L.gbx_gemv_tiled.argtypes = [p, p, p, p, i32, i32, i32, i32, p, f32, p, i32, i32, p]
+        _xlib = L
+    return _xlib
+
+
+def check_exp(rc: int) -> None:
+    if rc == GBX_OK:
+        return
+    msg = exp_lib().gbx_exp_last_error().decode("utf-8", "replace")
+    if rc == GBX_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == GBX_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise RuntimeError(msg)
 
 
 class DgDesc(ctypes.Structure):
@@ -115,12 +156,8 @@ def _declare_optional(L) -> None:
         "gbx_qlinear_forward_partials": [p, p, p, p, p, ctypes.c_size_t, ctypes.POINTER(i32), i64, i32, i32, i32, i32, i32, p],
         "gbx_add_rmsnorm_slices": [p, p, i32, p, p, i64, i32, f32, i32, p],
         "gbx_dense_forward": [p, p, p, p, i64, i32, i32, i32, p],
-        "gbx_stream_encode": [ctypes.POINTER(FusedDesc), i32, p, ctypes.c_size_t],
-        "gbx_stream_run": [p, p, i32, i32, i32, p],
         "gbx_attn_decode": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, f32, f32, i32, i32, p],
         "gbx_attn_decode_batched": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, f32, i32, i32, p],
-        "gbx_attn_oproj_supported": [i32, i32, i32, i32, i32, i32],
-        "gbx_attn_oproj_decode": [p, p, p, p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, i32, i32, f32, f32, i32, i32, p],
         "gbx_attn_decode_normed": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, f32, i32, p, p, f32, p, p, p, i32, p],
         "gbx_attn_decode_ws": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, f32, i32, p, p, f32, p, p, p, i32, p, ctypes.c_size_t, p],
         "gbx_attn_workspace_bytes": [i32, i32, i32, i32, i32],
@@ -153,8 +190,6 @@ def _declare_optional(L) -> None:
         "gbx_rope": [p, p, p, p, i64, i64, i32, i32, i32, i32, i64, i64, i64, f32, f32, i32, i32, p],
         "gbx_rope_append": [p, p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, i32, i32, p],
         "gbx_pack_scales_zeros": [p, p, p, p, p, i32, i32, p],
-        "gbx_qlinear_prepack_tiles": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, p],
-        "gbx_gemv_tiled": [p, p, p, p, i32, i32, i32, i32, p, f32, p, i32, i32, p],
     }
     for name, argtypes in table.items():
         fn = getattr(L, name, None)

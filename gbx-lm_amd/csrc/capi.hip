@@ -2,9 +2,9 @@
 // asserts, gbx_lm/models/quantized_linear_gba.py:61-62,272 and gbx_lm/utils.py:819-821), kernel dispatch,
 // thread-local error text.  No allocation, no synchronisation: every call is graph-capturable.
 #include "gbx_qlinear.h"
+#include "gbx_env.h"
 #include "gemv_impl.h"
 #include "dgemv_impl.h"
-#include "gemv_stream.h"
 #include "kernels.h"
 
 #include <cstdarg>
@@ -12,38 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 
-namespace {
-
-thread_local char g_err[512] = "";
-
-int fail(int code, const char* fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof(g_err), fmt, ap);
-  va_end(ap);
-  return code;
-}
-
-int hip_fail(hipError_t e, const char* what) {
-  return fail(GBX_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
-}
-
-int log2_group(int g) { return g == 32 ? 5 : g == 64 ? 6 : g == 128 ? 7 : -1; }
-
-bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
-
-int check_shape(int64_t M, int32_t N, int32_t K, int32_t bits, int32_t group) {
-  if (bits != 2 && bits != 3 && bits != 4) return fail(GBX_ERR_INVALID, "bits must be 2, 3 or 4 (got %d)", bits);
-  if (log2_group(group) < 0)
-    return fail(GBX_ERR_INVALID, "The group size value (%d) must be 32, 64 or 128.", group);
-  if (N <= 0 || K <= 0 || M < 0) return fail(GBX_ERR_INVALID, "non-positive dimension M=%lld N=%d K=%d", (long long)M, N, K);
-  if (K % 32) return fail(GBX_ERR_INVALID, "input_dims (%d) must be a multiple of 32", K);
-  if (K % group) return fail(GBX_ERR_INVALID, "input_dims (%d) must be a multiple of group_size (%d)", K, group);
-  if (M > (1LL << 40)) return fail(GBX_ERR_INVALID, "M=%lld is not a plausible row count", (long long)M);
-  return GBX_OK;
-}
-
-}  // namespace
+#include "capi_util.h"
 
 #ifdef GBX_STAMPS
 namespace gbx {
@@ -86,7 +55,7 @@ size_t gbx_qlinear_workspace_bytes(int64_t M, int32_t N, int32_t K, int32_t bits
 
 int gbx_qlinear_kernel_id(int64_t M, int32_t N, int32_t K, int32_t bits, int32_t group_size, int32_t has_workspace) {
   if (check_shape(M, N, K, bits, group_size) != GBX_OK) return -1;
-  static const bool force_generic = getenv("GBX_FORCE_GENERIC") != nullptr;
+  static const bool force_generic = (gbx::env_switch("GBX_FORCE_GENERIC") != 0);
   const int max_k = bits == 2 ? gbx::gemv_max_k<2>() : bits == 3 ? gbx::gemv_max_k<3>() : gbx::gemv_max_k<4>();
   if (M == 0) return 0;
   if (!force_generic && M > 1 && M <= 64 && (K % 128) == 0 && K >= 512) return 20;               /* batched-decode kernels */
@@ -132,7 +101,7 @@ int gbx_qlinear_forward_ws(const void* x, const uint32_t* qweight, const void* s
   const bool bf16 = act_dtype == GBX_BF16;
   const int log2g = log2_group(group_size);
 
-  static const bool force_generic = getenv("GBX_FORCE_GENERIC") != nullptr;
+  static const bool force_generic = (gbx::env_switch("GBX_FORCE_GENERIC") != 0);
   const int max_k = bits == 2 ? gbx::gemv_max_k<2>() : bits == 3 ? gbx::gemv_max_k<3>() : gbx::gemv_max_k<4>();
   hipError_t e;
   // dense path: the image always fits when the caller sized the workspace with gbx_qlinear_workspace_bytes; a few-tile shape takes
@@ -222,16 +191,6 @@ int gbx_qlinear_fused_forward(const gbx_qlinear_fused* d, void* hip_stream) {
   a.eps = d->norm_eps;
   a.residual = static_cast<const unsigned short*>(d->residual);
   a.swiglu = d->swiglu ? 1 : 0;
-  if (d->x_acc) {
-    if (!d->sz || nslots > 128 || d->group_size < 64) return fail(GBX_ERR_UNSUPPORTED, "x_acc needs the packed companion (sz), one pass per wave over K (K <= %d) and group_size >= 64", 128 * vpl);
-    if (!aligned(d->x_acc, 16) || (d->x_out && !aligned(d->x_out, 16))) return fail(GBX_ERR_INVALID, "x_acc / x_out must be 16-byte aligned");
-    if (d->x_out == d->x) return fail(GBX_ERR_INVALID, "x_out must not alias x (the other workgroups are still reading it)");
-  } else if (d->x_out) return fail(GBX_ERR_INVALID, "x_out without x_acc");
-  if (d->zero_buf && (d->zero_n < 0 || !aligned(d->zero_buf, 8))) return fail(GBX_ERR_INVALID, "bad zero_buf / zero_n");
-  a.x_acc = reinterpret_cast<const long long*>(d->x_acc);
-  a.x_out = static_cast<unsigned short*>(d->x_out);
-  a.zero_buf = reinterpret_cast<long long*>(d->zero_buf);
-  a.zero_n = d->zero_buf ? d->zero_n : 0;
 #ifdef GBX_STAMPS
   a.stamps = gbx::stamp_region();
 #endif
@@ -247,78 +206,7 @@ int gbx_qlinear_fused_forward(const gbx_qlinear_fused* d, void* hip_stream) {
   return GBX_OK;
 }
 
-int gbx_stream_encode(const gbx_qlinear_fused* descs, int32_t n, void* out, size_t out_bytes) {
-  static_assert(sizeof(gbx::StOp) == GBX_STREAM_OP_BYTES, "public op size out of sync with the device format");
-  if (!descs || !out || n < 1) return fail(GBX_ERR_INVALID, "null descriptor table / output or n < 1");
-  if (out_bytes < static_cast<size_t>(n) * sizeof(gbx::StOp)) return fail(GBX_ERR_INVALID, "output buffer too small: %zu < %zu", out_bytes, static_cast<size_t>(n) * sizeof(gbx::StOp));
-  gbx::StOp* ops = static_cast<gbx::StOp*>(out);
-  for (int k = 0; k < n; ++k) {
-    const gbx_qlinear_fused* d = descs + k;
-    if (d->nseg < 1 || d->nseg > 3) return fail(GBX_ERR_INVALID, "op %d: nseg must be 1..3 (got %d)", k, d->nseg);
-    if (d->x_acc || d->x_out || d->zero_buf) return fail(GBX_ERR_UNSUPPORTED, "op %d: x_acc / x_out / zero_buf run on gbx_qlinear_fused_forward", k);
-    if (d->act_dtype != GBX_F16 && d->act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "op %d: act_dtype must be GBX_F16 or GBX_BF16", k);
-    int ntot = 0;
-    for (int i = 0; i < d->nseg; ++i) {
-      int rc = check_shape(1, d->N[i], d->K, d->bits, d->group_size);
-      if (rc) return rc;
-      if (!d->qweight[i] || !aligned(d->qweight[i], 16)) return fail(GBX_ERR_INVALID, "op %d: qweight of segment %d missing or not 16-byte aligned", k, i);
-      if (d->N[i] & 1) return fail(GBX_ERR_UNSUPPORTED, "op %d: the streamed path needs even row counts (segment %d has %d)", k, i, d->N[i]);
-      ntot += d->N[i];
-    }
-    if (!d->sz || !aligned(d->sz, 16)) return fail(GBX_ERR_UNSUPPORTED, "op %d: the streamed path needs the packed scale|zero companion (gbx_pack_scales_zeros), 16-byte aligned", k);
-    if ((d->K / d->group_size) & 1) return fail(GBX_ERR_UNSUPPORTED, "op %d: the streamed path needs an even number of groups per row (K / group_size = %d)", k, d->K / d->group_size);
-    if (!d->x || !aligned(d->x, 16) || !d->y[0]) return fail(GBX_ERR_INVALID, "op %d: x / y missing or x not 16-byte aligned", k);
-    if (d->swiglu && (d->nseg != 2 || d->N[0] != d->N[1])) return fail(GBX_ERR_INVALID, "op %d: swiglu needs two equal-sized segments", k);
-    if (!d->swiglu) for (int i = 0; i < d->nseg; ++i) if (!d->y[i]) return fail(GBX_ERR_INVALID, "op %d: null y in segment %d", k, i);
-    if (d->residual && (d->nseg != 1 || d->swiglu)) return fail(GBX_ERR_INVALID, "op %d: residual needs a single plain segment", k);
-    if (d->norm_weight && !aligned(d->norm_weight, 16)) return fail(GBX_ERR_INVALID, "op %d: norm_weight must be 16-byte aligned", k);
-    const int K = d->K, bits = d->bits, vpl = bits == 2 ? 64 : 32;
-    const int nslots = K / vpl;
-    if ((K % 128) != 0 || nslots > 512) return fail(GBX_ERR_UNSUPPORTED, "op %d: needs K %% 128 == 0 and K <= %d (K = %d)", k, 512 * vpl, K);
-    if (bits == 2 && d->group_size == 32) return fail(GBX_ERR_UNSUPPORTED, "op %d: 2-bit group_size 32 runs on gbx_qlinear_fused_forward", k);
-    if ((d->norm_weight || d->swiglu) && nslots > 128) return fail(GBX_ERR_UNSUPPORTED, "op %d: fused RMSNorm / SwiGLU need K <= %d at %d bits", k, 128 * vpl, bits);
-    gbx::StOp o{};
-    o.type = gbx::ST_GEMV;
-    o.bits = bits;
-    o.ks = nslots <= 128 ? 1 : 4;
-    o.P = (nslots <= 64 || (nslots > 128 && nslots <= 256)) ? 1 : 2;
-    o.K = K;
-    o.gshift = log2_group(d->group_size) - 5;
-    o.nseg = d->nseg;
-    o.flags = (d->swiglu ? gbx::ST_F_SWIGLU : 0) | (d->norm_weight ? gbx::ST_F_NORM : 0) | (d->residual ? gbx::ST_F_RESID : 0);
-    o.n0 = d->N[0];
-    o.n01 = d->N[0] + (d->nseg > 1 ? d->N[1] : 0);
-    o.N = d->swiglu ? d->N[0] : ntot;
-    o.nbatch = d->swiglu ? d->N[0] : ntot / 2;
-    o.W4 = K / 32 * bits * 4;
-    o.G8 = (K / d->group_size) * 8;
-    o.nslots = nslots;
-    const int owners = 1 * (o.ks == 1 ? gbx::ST_NW : gbx::ST_NW / 4);   /* per CU; the launch has >= 1 CU ... */
-    (void)owners;
-    for (int i = 0; i < 3; ++i) {
-      const int s = i < d->nseg ? i : 0;
-      o.qw[i] = d->qweight[s];
-      o.y[i] = static_cast<unsigned short*>(d->y[s]);
-    }
-    o.sz = d->sz;
-    o.x = static_cast<const unsigned short*>(d->x);
-    o.norm_w = static_cast<const unsigned short*>(d->norm_weight);
-    o.resid = static_cast<const unsigned short*>(d->residual);
-    o.eps = d->norm_eps;
-    ops[k] = o;
-  }
-  return GBX_OK;
-}
 
-int gbx_stream_run(const void* device_program, const void* host_program, int32_t begin, int32_t end, int32_t act_dtype, void* hip_stream) {
-  if (!device_program || !aligned(device_program, 16)) return fail(GBX_ERR_INVALID, "device program missing or not 16-byte aligned");
-  if (!host_program) return fail(GBX_ERR_INVALID, "host copy of the program missing (its first op of the range rides in the kernel arguments)");
-  if (begin < 0 || end <= begin) return fail(GBX_ERR_INVALID, "empty op range [%d, %d)", begin, end);
-  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
-  hipError_t e = gbx::launch_stream(device_program, static_cast<const gbx::StOp*>(host_program) + begin, begin, end, act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));
-  if (e != hipSuccess) return hip_fail(e, "gbx_stream_run launch");
-  return GBX_OK;
-}
 
 int gbx_pack_scales_zeros(const void* scales0, const void* zeros0, const void* scales1, const void* zeros1,
                           uint32_t* out, int32_t N, int32_t G, void* hip_stream) {
@@ -482,47 +370,8 @@ int gbx_gather_swiglu_forward(const void* x, const uint32_t* gate_qweight, const
   return GBX_OK;
 }
 
-static int check_tiled(int32_t N, int32_t K, int32_t bits, int32_t group_size) {
-  int rc = check_shape(1, N, K, bits, group_size);
-  if (rc) return rc;
-  if (bits != 2 || group_size != 128 || (K % 1024) != 0 || K > 16384)
-    return fail(GBX_ERR_UNSUPPORTED, "tiled decode GEMV covers 2-bit, group_size 128, K %% 1024 == 0, K <= 16384 (got bits=%d g=%d K=%d)", bits, group_size, K);
-  return GBX_OK;
-}
 
-int gbx_qlinear_prepack_tiles(const uint32_t* qweight, const void* scales, const void* zeros,
-                              const uint32_t* qweight_up, const void* scales_up, const void* zeros_up,
-                              uint32_t* wt, uint32_t* szt, int32_t N, int32_t K, int32_t bits, int32_t group_size,
-                              void* hip_stream) {
-  int rc = check_tiled(N, K, bits, group_size);
-  if (rc) return rc;
-  if (N == 0) return GBX_OK;
-  if (!qweight || !scales || !zeros || !wt || !szt) return fail(GBX_ERR_INVALID, "null device pointer");
-  if ((qweight_up != nullptr) != (scales_up != nullptr) || (qweight_up != nullptr) != (zeros_up != nullptr))
-    return fail(GBX_ERR_INVALID, "qweight_up, scales_up and zeros_up go together");
-  if (!aligned(wt, 16) || !aligned(szt, 16)) return fail(GBX_ERR_INVALID, "tiled buffers must be 16-byte aligned");
-  hipError_t e = gbx::launch_prepack_tiles(qweight, scales, zeros, qweight_up, scales_up, zeros_up, wt, szt, N, K,
-                                           static_cast<hipStream_t>(hip_stream));
-  if (e != hipSuccess) return hip_fail(e, "gbx_qlinear_prepack_tiles launch");
-  return GBX_OK;
-}
 
-int gbx_gemv_tiled(const void* x, const uint32_t* wt, const uint32_t* szt, void* y, int32_t N, int32_t K, int32_t bits,
-                   int32_t group_size, const void* norm_weight, float norm_eps, const void* residual, int32_t swiglu,
-                   int32_t act_dtype, void* hip_stream) {
-  int rc = check_tiled(N, K, bits, group_size);
-  if (rc) return rc;
-  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
-  if (N == 0) return GBX_OK;
-  if (!x || !wt || !szt || !y) return fail(GBX_ERR_INVALID, "null device pointer");
-  if (!aligned(x, 16) || !aligned(wt, 16) || !aligned(szt, 16)) return fail(GBX_ERR_INVALID, "x and the tiled buffers must be 16-byte aligned");
-  if (norm_weight && !aligned(norm_weight, 4)) return fail(GBX_ERR_INVALID, "norm_weight must be 4-byte aligned");
-  if (swiglu && residual) return fail(GBX_ERR_INVALID, "swiglu and residual exclude each other");
-  hipError_t e = gbx::launch_gemv_mfma(x, wt, szt, y, N, K, norm_weight, norm_eps, residual, swiglu ? 1 : 0,
-                                       act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));
-  if (e != hipSuccess) return hip_fail(e, "gbx_gemv_tiled launch");
-  return GBX_OK;
-}
 
 int gbx_attn_decode(const void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
                     const int64_t* pos, void* out, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim,
@@ -532,31 +381,7 @@ int gbx_attn_decode(const void* q, const void* k, const void* v, void* kcache, v
                                  rope_scale, sm_scale, traditional, act_dtype, hip_stream);
 }
 
-int gbx_attn_oproj_supported(int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int32_t D, int32_t bits, int32_t group_size) {
-  return gbx::attn_oproj_supported(n_heads, n_kv_heads, head_dim, D, bits, group_size, 1) ? 1 : 0;
-}
 
-int gbx_attn_oproj_decode(const void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
-                          const int64_t* pos, const uint32_t* o_qweight, const void* o_scales, const void* o_zeros,
-                          int64_t* acc, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int32_t capacity, int32_t D,
-                          int32_t bits, int32_t group_size, float rope_scale, float sm_scale, int32_t traditional,
-                          int32_t act_dtype, void* hip_stream) {
-  if (!q || !k || !v || !kcache || !vcache || !inv_freq || !pos || !o_qweight || !o_scales || !o_zeros || !acc)
-    return fail(GBX_ERR_INVALID, "null device pointer");
-  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
-  if (capacity < 1) return fail(GBX_ERR_INVALID, "capacity must be positive");
-  if (!gbx::attn_oproj_supported(n_heads, n_kv_heads, head_dim, D, bits, group_size, capacity))
-    return fail(GBX_ERR_UNSUPPORTED, "attention + o_proj launch needs head_dim 128, n_heads == 4 n_kv_heads, D %% 128 == 0, bits 2/3/4, group 64/128 "
-                "(got heads %d/%d x %d, D %d, %d bits, group %d)", n_heads, n_kv_heads, head_dim, D, bits, group_size);
-  if (!aligned(o_qweight, 16) || !aligned(kcache, 16) || !aligned(vcache, 16) || !aligned(acc, 8))
-    return fail(GBX_ERR_INVALID, "o_qweight / caches must be 16-byte aligned, acc 8-byte aligned");
-  hipError_t e = gbx::launch_attn_oproj(q, k, v, kcache, vcache, inv_freq, reinterpret_cast<const long long*>(pos), o_qweight, o_scales,
-                                        o_zeros, reinterpret_cast<long long*>(acc), n_heads, n_kv_heads, head_dim, capacity, D, bits,
-                                        log2_group(group_size), rope_scale, sm_scale, traditional, act_dtype == GBX_BF16,
-                                        static_cast<hipStream_t>(hip_stream));
-  if (e != hipSuccess) return hip_fail(e, "gbx_attn_oproj_decode launch");
-  return GBX_OK;
-}
 
 int gbx_attn_decode_batched(const void* q, const void* k, const void* v, void* kcache, void* vcache, const float* inv_freq,
                             const int64_t* pos, void* out, int32_t batch, int32_t n_heads, int32_t n_kv_heads,
@@ -637,8 +462,7 @@ int gbx_p2p_inbox_create(int32_t world, int32_t max_elems, void** inbox_out, voi
   /* Peers write this memory over xGMI while a kernel of THIS GPU polls it: that needs fine-grained (uncached-at-L2) memory.  A
    * coarse-grained hipMalloc would let the local L2 serve stale lines to the poll -- a hang or a stale payload that no single-GPU
    * test can show -- so there is no fallback: the caller keeps RCCL (tp.enable_p2p).  GBX_P2P_FORCE_COARSE=1: test hook. */
-  const char* force = getenv("GBX_P2P_FORCE_COARSE");
-  hipError_t e = (force && atoi(force)) ? hipErrorNotSupported : hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+  hipError_t e = gbx::env_switch("GBX_P2P_FORCE_COARSE") ? hipErrorNotSupported : hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     return fail(GBX_ERR_UNSUPPORTED, "gbx_p2p_inbox_create: fine-grained device memory is not available (%s); the one-shot P2P all-reduce "
@@ -1119,7 +943,7 @@ int gbx_dgemv_forward(const gbx_dgemv* d, void* hip_stream) {
   a.ssq_out = d->ssq_out;
   a.N = d->N; a.K = d->K; a.log2g = log2_group(d->group_size);
   a.eps = d->norm_eps;
-  static const int chain_floor = [] { const char* e = getenv("GBX_CHAIN_FLOOR"); return e ? atoi(e) : 0; }();
+  static const int chain_floor = gbx::env_switch("GBX_CHAIN_FLOOR");
   a.null_rows = chain_floor == 2 ? 1 : 0;
 #ifdef GBX_STAMPS
   a.stamps = gbx::stamp_region();

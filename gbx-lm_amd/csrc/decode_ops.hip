@@ -5,6 +5,7 @@
 //   * rmsnorm     : standalone RMSNorm for shapes the GEMV prologue does not fuse
 // All read the decode position from DEVICE memory so one captured HIP graph serves every token.
 #include "gbx_device.h"
+#include "gbx_env.h"
 #include "kernels.h"
 #include <cstdlib>
 
@@ -554,12 +555,12 @@ static int split_heads(int batch, int n_heads, int rep, int capacity) {
 
 int attn_splits(int batch, int n_heads, int n_kv, int capacity) {
   const int rep = n_heads / n_kv;
-  static const int force_r = [] { const char* e = getenv("GBX_ATTN_SPLIT_R"); return e ? atoi(e) : 0; }();   // tuning aid
+  static const int force_r = gbx::env_switch("GBX_ATTN_SPLIT_R");   // tuning aid
   const int R = force_r ? force_r : split_heads(batch, n_heads, rep, capacity);
   const int wgs = n_kv * (rep / R) * batch;
-  static const int min_cap = [] { const char* e = getenv("GBX_ATTN_SPLIT_MIN"); return e ? atoi(e) : 1024; }();   // tuning aid
+  static const int min_cap = gbx::env_switch("GBX_ATTN_SPLIT_MIN");   // tuning aid
   if (capacity < min_cap) return 1;                    // short caches: the un-split kernels win (649 vs 774 tok/s at context 128)
-  static const int div = [] { const char* e = getenv("GBX_ATTN_SPLIT_DIV"); return e ? atoi(e) : 128; }();     // tuning aid
+  static const int div = gbx::env_switch("GBX_ATTN_SPLIT_DIV");     // tuning aid
   int s = std::min(std::min(512 / std::max(wgs, 1), capacity / div), 32);
   return s < 2 ? 1 : s;
 }
@@ -586,11 +587,11 @@ hipError_t launch_attn_decode(const void* q, const void* k, const void* v, void*
   const int rep = n_heads / n_kv;
   const int splits = ws ? attn_splits(batch, n_heads, n_kv, capacity) : 1;
   if (splits > 1) a.ws = ws;
-  static const bool force_grouped = getenv("GBX_ATTN_GROUPED") != nullptr;    // tuning aid: grouped kernel at batch 1 too
+  static const bool force_grouped = (gbx::env_switch("GBX_ATTN_GROUPED") != 0);    // tuning aid: grouped kernel at batch 1 too
   if (q_norm_w || q_bias || (batch > 1 && rep > 1) || (force_grouped && rep > 1) || splits > 1) {         // grouped kernel: batched decode, or q/k norms (any batch)
     // 2 heads per workgroup when the context is split: 120 VGPRs -> two workgroups per CU, whose waves cover each other's
     // dependent dot / DPP / exp chains (with 4 heads, 166 VGPRs, one wave per SIMD ran the cache at 1.2 TB/s)
-    static const int force_r = [] { const char* e = getenv("GBX_ATTN_SPLIT_R"); return e ? atoi(e) : 0; }();
+    static const int force_r = gbx::env_switch("GBX_ATTN_SPLIT_R");
     const int R = splits > 1 ? (force_r ? force_r : split_heads(batch, n_heads, rep, capacity)) : rep % 4 == 0 ? 4 : rep % 3 == 0 ? 3 : rep % 2 == 0 ? 2 : 1;
     if (head_dim == 128) {
       switch (R) {
@@ -828,7 +829,7 @@ hipError_t launch_dense_gemv(const void* x, const void* w, void* y, const void* 
   if (rpw < 2) rpw = 2;
   a.rows_per_wave = rpw;
   const int blocks = (N + 4 * rpw - 1) / (4 * rpw);
-  static const int chain_floor = [] { const char* e = getenv("GBX_CHAIN_FLOOR"); return e ? atoi(e) : 0; }();      // measurement only: see gemv_impl.h
+  static const int chain_floor = gbx::env_switch("GBX_CHAIN_FLOOR");      // measurement only: see gemv_impl.h
   if (chain_floor == 1) a.rows_per_wave = 2;
   a.null_rows = chain_floor == 2 ? 1 : 0;
   a.index_offset = index_offset;

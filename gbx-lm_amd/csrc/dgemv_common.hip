@@ -1,18 +1,13 @@
 // Host-side geometry of the decode-block GEMV (dgemv_impl.h) and the load-time packing of its (scale | zero) companion.
 #include "dgemv_impl.h"
+#include "gbx_env.h"
 #include <cstdlib>
 
 namespace gbx {
 
-namespace {
-int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
-}  // namespace
 
 bool dg_late_default() {
-  static const bool v = env_int("GBX_DG_LATE", 1) != 0;
+  static const bool v = env_switch("GBX_DG_LATE") != 0;
   return v;
 }
 
@@ -33,7 +28,7 @@ bool dg_plan(int bits, int N, int K, int group, int epi, bool norm, int rows_per
   // rows per batch (measured, scratch/dg_sweep.sh): 4 for the plain / residual launches without a norm whose rows are one lane
   // pass long (o_proj: 3.6 vs 4.2 us), 2 everywhere else (q|k|v 4.7 vs 5.0, gate|up 9.9 vs 10.6, down 6.6 vs 7.5); two passes
   // per row keep two-row batches anyway (register budget of 16-wave workgroups)
-  static const int force_r = env_int("GBX_DG_R", 0);
+  static const int force_r = env_switch("GBX_DG_R");
   int R = rows_per_batch ? rows_per_batch : (force_r ? force_r : ((P == 1 && KS == 1 && epi != 2 && !norm) ? 4 : 2));
   if (R != 2 && R != 4) return false;
   if (P == 2 && R == 4) { if (rows_per_batch) return false; R = 2; }
@@ -42,7 +37,7 @@ bool dg_plan(int bits, int N, int K, int group, int epi, bool norm, int rows_per
   const int RO = epi == 2 ? R / 2 : R;
   const int nbatch = N / RO;
   constexpr int CUS = 256;
-  static const int min_nw = env_int("GBX_DG_MIN_NW", 4);
+  static const int min_nw = env_switch("GBX_DG_MIN_NW");
   int NW, grid, bpo, apw;
   if (KS == 1) {
     if (nbatch <= CUS * 16) {

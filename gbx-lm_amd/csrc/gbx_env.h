@@ -1,0 +1,53 @@
+// The ONE reader of the library's environment switches: every switch is an entry of the table below (name, default, what it does);
+// gbx::env_switch refuses names that are not in it, so a switch cannot exist without its line of documentation (DESIGN.md section 8
+// is this table).  None is needed for normal use: they are A/B and diagnostic aids.  Values are read once per call site.
+#pragma once
+#include <cstdlib>
+#include <cstring>
+
+namespace gbx {
+
+struct EnvSwitch {
+  const char* name;
+  int dflt;
+  const char* doc;
+};
+
+inline const EnvSwitch* env_table(int* n) {
+  static const EnvSwitch t[] = {
+      {"GBX_FORCE_GENERIC", 0, "1: every gbx_qlinear_forward call on the shape-generic kernel (diagnostic)"},
+      {"GBX_CHAIN_FLOOR", 0, "measurement only, WRONG results: 2 = every decode-GEMV row read redirected to the first rows (no weight stream), 1 = one ring round per wave"},
+      {"GBX_GEMV_UNEVEN", 1, "gemv_kernel: uneven wave split of the fat geometry (A/B)"},
+      {"GBX_GEMV_CEPI", 1, "gemv_kernel: compile-time one-segment epilogue, MODE 5 (A/B)"},
+      {"GBX_DG_R", 0, "dgemv: force rows per batch (2 / 4); 0 = per-launch default"},
+      {"GBX_DG_MIN_NW", 4, "dgemv: minimum waves per workgroup of the one-round launches (4 / 8 / 16)"},
+      {"GBX_DG_LATE", 1, "dgemv: request batch 0 behind the activation image in the launches with an RMSNorm prologue (A/B)"},
+      {"GBX_ATTN_SPLIT_R", 0, "decode attention: force the context split (tuning aid)"},
+      {"GBX_ATTN_SPLIT_MIN", 1024, "decode attention: smallest cache capacity that is split over workgroups (tuning aid)"},
+      {"GBX_ATTN_SPLIT_DIV", 128, "decode attention: cached positions per split (tuning aid)"},
+      {"GBX_ATTN_GROUPED", 0, "1: the grouped-query decode attention kernel at batch 1 too (tuning aid)"},
+      {"GBX_BATCH_KSPLIT_MINK", 8192, "batch GEMM: smallest K that is split across workgroups (tuning aid)"},
+      {"GBX_BATCH_ROWS", 0, "batch GEMM: force the activation rows staged per pass (tuning aid)"},
+      {"GBX_NO_BATCH_KERNEL", 0, "1: 2 <= M <= 32 on the split-K dequantising kernel instead of the no-dequant batch GEMM (diagnostic)"},
+      {"GBX_PREFILL_TILE", 0, "prefill GEMM: force the tile (11 / 12 / 13) (tuning aid)"},
+      {"GBX_DENSE_NO_8PHASE", 0, "1: the register-staged round-1 tile on dequantised weights instead of the 8-phase dense GEMM (A/B)"},
+      {"GBX_P2P_FORCE_COARSE", 0, "test hook: gbx_p2p_inbox_create behaves as if fine-grained memory were unavailable"},
+  };
+  *n = static_cast<int>(sizeof(t) / sizeof(t[0]));
+  return t;
+}
+
+// value of switch `name` (atoi of the variable; the table's default when unset or empty); aborts on a name the table does not know
+inline int env_switch(const char* name) {
+  int n;
+  const EnvSwitch* t = env_table(&n);
+  for (int i = 0; i < n; ++i) {
+    if (strcmp(t[i].name, name) == 0) {
+      const char* e = getenv(name);
+      return (e && *e) ? atoi(e) : t[i].dflt;
+    }
+  }
+  abort();      // an undocumented switch is a bug
+}
+
+}  // namespace gbx

@@ -18,6 +18,7 @@
 //     s*sum(q*x) + z*sum(x), then one DPP wave reduction per row.
 #pragma once
 #include "gbx_device.h"
+#include "gbx_env.h"
 #include "gemv_fmt.h"
 #include "kernels.h"
 #include <cstdlib>
@@ -651,7 +652,7 @@ static hipError_t launch_gemv_d(const GemvArgs& a, int M, bool bf16, int bpo, in
   // GBX_CHAIN_FLOOR (measurement only, wrong results): 1 = the same grid, every wave stops after ONE ring round; 2 = every batch
   // re-reads rows 0 / 1 (same instruction stream, no weight stream from HBM) -- what is left of
   // a decode step is its dependency chain (launch boundaries, activation prologues, reductions) with next to no weight stream
-  static const int chain_floor = [] { const char* e = getenv("GBX_CHAIN_FLOOR"); return e ? atoi(e) : 0; }();
+  static const int chain_floor = gbx::env_switch("GBX_CHAIN_FLOOR");
   if (chain_floor == 1) { args.batches_per_owner = D; args.long_waves = 0; }
   if (chain_floor == 2) args.null_rows = 1;
   dim3 grid(blocks, M), block(NW * 64);
@@ -685,7 +686,7 @@ static hipError_t launch_gemv_nw(const GemvArgs& a, int M, bool bf16, int nbatch
     // 256 x 16 -> 224 workgroups x 4 batches, 32 CUs idle in a launch that is bound by the vector ALUs of each CU), give
     // every resident workgroup `lw` waves with bpo batches and NW - lw with bpo - 1.
     const int res = own2 / opb;                             // resident workgroups
-    static const bool uneven = [] { const char* e = getenv("GBX_GEMV_UNEVEN"); return !e || atoi(e) != 0; }();
+    static const bool uneven = (gbx::env_switch("GBX_GEMV_UNEVEN") != 0);
     if (uneven && nbatches % res == 0 && (nbatches + NW * bpo - 1) / (NW * bpo) < res) {
       const int lw = nbatches / res - NW * (bpo - 1);       // res * (lw * bpo + (NW - lw) * (bpo - 1)) == nbatches
       if (lw > 0 && lw < NW && lw % 4 == 0) {
@@ -710,6 +711,7 @@ template <int BITS, int P, int KS, bool SPLIT>
 static hipError_t launch_gemv_p(const GemvArgs& a, int M, bool bf16, hipStream_t stream) {
   const int rowstep = a.swiglu ? 1 : GEMV_R;
   const int nbatches = (a.N + rowstep - 1) / rowstep;
+#ifdef GBX_EXPERIMENTAL      // libgbx_experimental.so only (gbx_exp_qlinear_fused_forward)
   if (a.sz && a.x_acc) {   // ... whose activations are residual stream + fixed-point accumulator (behind gbx_attn_oproj_decode)
     if constexpr (KS == 1 && !SPLIT) {
       if (nbatches <= 4096) return launch_gemv_small<BITS, P, KS, SPLIT, 3>(a, M, bf16, nbatches, stream);
@@ -717,8 +719,11 @@ static hipError_t launch_gemv_p(const GemvArgs& a, int M, bool bf16, hipStream_t
     }
     return hipErrorInvalidValue;
   }
+#else
+  if (a.x_acc) return hipErrorInvalidValue;
+#endif
   if (a.sz) {              // packed scale/zero companion of the launch (decode runner)
-    static const bool cepi = [] { const char* e = getenv("GBX_GEMV_CEPI"); return !e || atoi(e) != 0; }();   // A/B switch
+    static const bool cepi = (gbx::env_switch("GBX_GEMV_CEPI") != 0);   // A/B switch
     if (cepi && !a.swiglu && a.nseg == 1) {
       if (KS == 1 && nbatches <= 4096) return launch_gemv_small<BITS, P, KS, SPLIT, 5>(a, M, bf16, nbatches, stream);
       return launch_gemv_nw<BITS, P, KS, SPLIT, WavesPerBlock<P>::value, 5>(a, M, bf16, nbatches, stream);
@@ -756,11 +761,18 @@ static hipError_t dispatch_gemv(const GemvArgs& a, int M, bool bf16, hipStream_t
   return dispatch_gemv_s<BITS, false>(a, M, bf16, s);
 }
 
+#ifdef GBX_EXPERIMENTAL      // the scaled-MFMA GEMVs are opt-in kernels of libgbx_experimental.so (GBX_GEMV_MXD / GBX_GEMV_MX)
 #define GBX_DEFINE_LAUNCH_GEMV(BITS)                                                              \
   template <> hipError_t launch_gemv<BITS>(const GemvArgs& a, int M, bool bf16, hipStream_t s) { \
     if (BITS == 2 && gemv_mxd_eligible(a, M, bf16)) return launch_gemv_mxd(a, s);                 \
     if (BITS == 2 && gemv_mx_eligible(a, M) && gemv_mx_shape_ok(a)) return launch_gemv_mx(a, bf16, s); \
     return dispatch_gemv<BITS>(a, M, bf16, s);                                                    \
   }
+#else
+#define GBX_DEFINE_LAUNCH_GEMV(BITS)                                                              \
+  template <> hipError_t launch_gemv<BITS>(const GemvArgs& a, int M, bool bf16, hipStream_t s) { \
+    return dispatch_gemv<BITS>(a, M, bf16, s);                                                    \
+  }
+#endif
 
 }  // namespace gbx

@@ -43,6 +43,7 @@
 // ~2.5k; ISSUING the next step's 6 weight loads takes 3-5k (they queue behind the loaders' 64 requests in the in-order path).
 // -DBX_STAMPS: diagnostic build with s_memtime phase stamps (scratch/stamps_batch.py).
 #include "mfma_common.h"
+#include "gbx_env.h"
 #include "kernels.h"
 
 namespace gbx {
@@ -520,7 +521,7 @@ static hipError_t launch_batch_grp(const MfmaArgs& a, bool bf16, hipStream_t s) 
 // projection, N = 4096 x K = 14336 -- because every workgroup stages the activations of its whole k range: 16-row
 // workgroups pull 256 x 917 KB of x through the CUs, 128-row workgroups x 7 slices pull 224 x 131 KB.
 static int batch_ksplit(int N, int K, int nseg, bool partials = false) {
-  static const int min_k = [] { const char* e = getenv("GBX_BATCH_KSPLIT_MINK"); return e ? atoi(e) : 8192; }();   // tuning aid
+  static const int min_k = gbx::env_switch("GBX_BATCH_KSPLIT_MINK");   // tuning aid
   // with the summing launch folded into the consumer (partials) the split also pays on the short rows of o_proj: every
   // workgroup then stages 1/s of the activation tile -- the traffic that bounds this kernel
   if (nseg > 1 || N % 4 || N > 8192 || K < (partials ? 2048 : min_k)) return 1;
@@ -556,7 +557,7 @@ static hipError_t launch_batch_bits(const MfmaArgs& a0, bool bf16, hipStream_t s
     return launch_splitk_finish(a.ws, a.bias, a.y, a.ksplit, a.M, a.N, bf16, s);
   }
   int rows = a.N >= 128 * 192 ? 128 : a.N >= 64 * 192 ? 64 : a.N >= 32 * 160 ? 32 : 16;
-  static const int forced = [] { const char* e = getenv("GBX_BATCH_ROWS"); return e ? atoi(e) : 0; }();
+  static const int forced = gbx::env_switch("GBX_BATCH_ROWS");
   if (forced) rows = forced;
   if (a.log2g < 7 && rows == 128) rows = 64;        // small groups: twice the packed words per lane -- the 128-row shape spills
   if (a.swiglu) {                                   // half of a workgroup's rows come from each matrix: rows / 2 must tile n_seg[0]

@@ -19,6 +19,7 @@
 //     two buffers, one barrier per chunk.
 // MFMA-bound (2*M*N*K flop); the weights are re-read from L2/HBM once per (64*MT)-row tile.
 #include "mfma_common.h"
+#include "gbx_env.h"
 #include "kernels.h"
 #include <cstdlib>
 
@@ -302,7 +303,7 @@ size_t qgemm_prefill_workspace_bytes(int M, int N, int K) {
 // CU a workgroup: LDS bytes per flop fall with the tile.  GBX_PREFILL_TILE=1..4 forces one (tuning aid).
 int prefill_tile_id(int M, int N, int K, bool has_ws) {
   if (has_ws && prefill_ksplit(M, N, K) > 1) return 5;
-  static const int force = getenv("GBX_PREFILL_TILE") ? atoi(getenv("GBX_PREFILL_TILE")) : 0;
+  static const int force = gbx::env_switch("GBX_PREFILL_TILE");
   const long t256 = static_cast<long>((M + 255) / 256) * ((N + 255) / 256);
   const long t128 = static_cast<long>((M + 255) / 256) * ((N + 127) / 128);
   if (force == 4) return 4;
@@ -336,7 +337,7 @@ hipError_t launch_qgemm_dense(const void* x, const uint32_t* qw, const void* sc,
                               int N, int K, int bits, int log2g, bool bf16, hipStream_t s, void* wdense, float* part) {
   hipError_t e = launch_dequant_units(qw, sc, ze, wdense, N, K, bits, log2g, bf16, s);
   if (e != hipSuccess) return e;
-  static const bool no8p = getenv("GBX_DENSE_NO_8PHASE") != nullptr;      // tuning aid: the register-staged tiles on dense weights
+  static const bool no8p = (gbx::env_switch("GBX_DENSE_NO_8PHASE") != 0);      // tuning aid: the register-staged tiles on dense weights
   if (!no8p && gemm_dense_supported(M, N, K)) return launch_gemm_dense(x, wdense, bias, y, M, N, K, bf16, s, false, part);   // mfma_dense.hip
   MfmaArgs a{};
   a.x = static_cast<const unsigned short*>(x); a.wdense = static_cast<const unsigned short*>(wdense);

@@ -10,6 +10,7 @@
 //     at most 64 rows: L2-resident), one chunk ahead in registers.
 // Replaces mx.quantized_matmul for x of shape [B, 1, K] with 2 <= B <= 64 (gbx_lm/models/quantized_linear_gba.py:195-203).
 #include "mfma_common.h"
+#include "gbx_env.h"
 #include "kernels.h"
 
 namespace gbx {
@@ -242,7 +243,7 @@ static hipError_t launch_skinny_bits(const MfmaArgs& a, bool bf16, hipStream_t s
 }
 
 static bool use_batch_kernel(const MfmaArgs& a, int bits) {
-  static const bool off = getenv("GBX_NO_BATCH_KERNEL") != nullptr;   // diagnostic: time the split-K kernel instead
+  static const bool off = (gbx::env_switch("GBX_NO_BATCH_KERNEL") != 0);   // diagnostic: time the split-K kernel instead
   // 33..64 rows: two passes pay off only where the wide (128-row) workgroups apply (gate|up: 61 -> 40 us at M = 64;
   // the narrow projections are faster in one pass of the dequantising kernel)
   if (a.M > 32 && a.N < 128 * 192) return false;

@@ -13,7 +13,7 @@ from typing import List, Optional
 import torch
 import torch.nn.functional as F
 
-from . import ops
+from . import env, ops
 from .models.cache import KVCache
 from .tp import all_reduce_
 
@@ -350,7 +350,7 @@ class FusedDecodeRunner(DecodeRunner):
         # hand-off costs what the removed boundary cost (profiles/r03_chain_floor.txt: 750-753 vs 750-762 tok/s).
         import os
         self.acc = torch.zeros((D + a0.n_kv_heads * ops.ATTN_OPROJ_HANDOFF_WORDS,), dtype=torch.int64, device=dev)   # o_proj sums | hand-off words
-        self.fuse_ao = (os.environ.get("GBX_FUSE_AO", "0") == "1" and not tp and self.attn_ws is None and
+        self.fuse_ao = (env.flag("GBX_FUSE_AO") and not tp and self.attn_ws is None and
                         all(getattr(b.self_attn, "q_norm", None) is None and b.self_attn.q_proj.bias is None and
                             ops.attn_oproj_supported(b.self_attn.n_heads, b.self_attn.n_kv_heads, b.self_attn.head_dim, b.self_attn.o_proj) and
                             b.mlp.gate_proj.group_size >= 64 and
@@ -360,8 +360,8 @@ class FusedDecodeRunner(DecodeRunner):
         self.descs_ao = []
         self.dg = []                        # per layer: [qkv, o, gate|up, down] dgemv descriptors (None: the launch stays on gbx_qlinear_fused_forward)
         self.dg_keep = []
-        self.use_dg = os.environ.get("GBX_DGEMV", "1") == "1"
-        self.use_ssq = os.environ.get("GBX_DG_SSQ", "1") == "1" and not tp
+        self.use_dg = env.flag("GBX_DGEMV")
+        self.use_ssq = env.flag("GBX_DG_SSQ") and not tp
         self.ssq_prev = None                # partial sums of h^2 left by the previous layer's down_proj launch
         self.packed = []                    # load-time (scale | zero) companions, kept alive for the descriptors
         for blk in model.model.layers:
@@ -373,7 +373,7 @@ class FusedDecodeRunner(DecodeRunner):
             # q|k|v as ONE matrix (rows concatenated once at load time, +7 MB per 2-bit 8B layer): a one-segment launch skips the
             # per-row segment location of the three-segment form (the launch is bound by per-batch instruction overhead)
             qkv_mods, qkv_ys = (at.q_proj, at.k_proj, at.v_proj), (self.qb, self.kb, self.vb)
-            if (os.environ.get("GBX_QKV_CAT", "1") == "1" and p_qkv is not None and nq % 16 == 0 and nkv % 16 == 0 and
+            if (env.flag("GBX_QKV_CAT") and p_qkv is not None and nq % 16 == 0 and nkv % 16 == 0 and
                     len({(m.bits, m.group_size) for m in qkv_mods}) == 1 and all(m.bias is None for m in qkv_mods)):
                 from .models.quantized_linear_gba import QuantizedLinear
                 cat = QuantizedLinear(at.q_proj.input_dims, nq + 2 * nkv, False, at.q_proj.group_size, at.q_proj.bits)
@@ -639,7 +639,7 @@ def prompt_step(model, y: torch.Tensor, prompt_cache) -> Optional[torch.Tensor]:
     None when the call is not a short fresh prompt on the GPU (the caller then runs the eager pass).  GBX_PROMPT_GRAPH=0 disables."""
     import os
     L = y.numel()
-    if L < 2 or L > PromptRunner.BUCKETS[-1] or os.environ.get("GBX_PROMPT_GRAPH", "1") == "0":
+    if L < 2 or L > PromptRunner.BUCKETS[-1] or not env.flag("GBX_PROMPT_GRAPH"):
         return None
     c0 = prompt_cache[0] if prompt_cache else None
     if (not isinstance(c0, KVCache) or any(type(c) is not KVCache or c.offset != 0 or c.static_active for c in prompt_cache)

@@ -1,0 +1,33 @@
+"""The ONE reader of the package's environment switches (host side; the kernels' switches are csrc/gbx_env.h).
+
+Every switch is a row of ``TABLE`` -- name, default, what it does -- and ``get`` refuses names that are not in it, so a switch
+cannot exist without its line of documentation (DESIGN.md section 8 is this table plus the C++ one).  None is needed for normal use.
+"""
+from __future__ import annotations
+
+import os
+
+TABLE = {
+    # name: (default, doc)
+    "GBX_QLINEAR_LIB": ("", "path of the product shared library (default gbx-lm_amd/csrc/libgbx_qlinear.so): experiment / stamps builds"),
+    "GBX_DGEMV": ("1", "FusedDecodeRunner: the four GEMV launches of a block on gbx_dgemv_forward (0: gbx_qlinear_fused_forward) (A/B)"),
+    "GBX_DG_SSQ": ("1", "FusedDecodeRunner: carry the RMSNorm statistic from the o_proj / down_proj launch to the next norm'd launch (A/B)"),
+    "GBX_QKV_CAT": ("1", "FusedDecodeRunner: q|k|v as one matrix concatenated at load time (A/B)"),
+    "GBX_FUSE_AO": ("0", "FusedDecodeRunner: attention + o_proj as one launch (libgbx_experimental.so; measured neutral)"),
+    "GBX_GEMV_MXD": ("0", "route the fused GEMV launches through libgbx_experimental.so's one-row-per-operand scaled-MFMA GEMV (1: all eligible, 2: gate|up only)"),
+    "GBX_GEMV_MX": ("0", "route the fused GEMV launches through libgbx_experimental.so's loader/consumer scaled-MFMA GEMV"),
+    "GBX_PROMPT_GRAPH": ("1", "graph-replayed prompt buckets for 2..128-token prompts (0: eager pass)"),
+    "GBX_DENSE_CACHE_GB": ("32", "budget of the resident dense weight images of long prompts, GiB (0 disables)"),
+    "GBX_TP_GRAPH": ("1", "bench.py: RCCL collectives inside the HIP graph (0: eager launches)"),
+    "GBX_TP_P2P": ("0", "bench.py: one-shot P2P all-reduce instead of RCCL (falls back to RCCL, with the reason reported, where it cannot work)"),
+}
+
+
+def get(name: str) -> str:
+    """Value of switch ``name`` (its table default when unset); KeyError for an undocumented name."""
+    default, _ = TABLE[name]
+    return os.environ.get(name, default)
+
+
+def flag(name: str) -> bool:
+    return get(name) not in ("", "0")

@@ -11,7 +11,7 @@ from typing import Optional
 
 import torch
 
-from . import _lib
+from . import _lib, env
 
 _DT = {torch.float16: _lib.GBX_F16, torch.bfloat16: _lib.GBX_BF16, torch.float32: _lib.GBX_F32}
 
@@ -45,7 +45,7 @@ class _DenseCache:
 
     def __init__(self):
         import collections
-        self.budget = int(float(os.environ.get("GBX_DENSE_CACHE_GB", "32")) * (1 << 30))
+        self.budget = int(float(env.get("GBX_DENSE_CACHE_GB")) * (1 << 30))
         self.entries = collections.OrderedDict()
         self.nbytes = 0
 
@@ -565,7 +565,7 @@ def prepack_tiles(mod, mod_up=None):
     wt = torch.empty((rows * (k // 16),), dtype=torch.int32, device=mod.qweight.device)
     szt = torch.empty((rows * (k // 128),), dtype=torch.int32, device=mod.qweight.device)
     up = mod_up
-    _lib.check(_lib.lib().gbx_qlinear_prepack_tiles(
+    _lib.check_exp(_lib.exp_lib().gbx_qlinear_prepack_tiles(
         mod.qweight.data_ptr(), mod.scales.data_ptr(), mod.zeros.data_ptr(),
         up.qweight.data_ptr() if up is not None else None, up.scales.data_ptr() if up is not None else None,
         up.zeros.data_ptr() if up is not None else None,
@@ -581,7 +581,7 @@ def gemv_tiled(x: torch.Tensor, wt: torch.Tensor, szt: torch.Tensor, n: int, k: 
     _require_cuda(x, "x")
     if out is None:
         out = torch.empty((n,), dtype=x.dtype, device=x.device)
-    _lib.check(_lib.lib().gbx_gemv_tiled(x.data_ptr(), wt.data_ptr(), szt.data_ptr(), out.data_ptr(), n, k, bits, group_size,
+    _lib.check_exp(_lib.exp_lib().gbx_gemv_tiled(x.data_ptr(), wt.data_ptr(), szt.data_ptr(), out.data_ptr(), n, k, bits, group_size,
                                          norm_weight.data_ptr() if norm_weight is not None else None, float(eps),
                                          residual.data_ptr() if residual is not None else None, int(bool(swiglu)),
                                          _DT[x.dtype], _stream_ptr(x.device)))
@@ -608,7 +608,8 @@ def make_fused_desc(x: torch.Tensor, mods, ys, norm_weight: Optional[torch.Tenso
             _require_cuda(t, "QuantizedLinear tensor")
         if m.scales.dtype != x.dtype or m.zeros.dtype != x.dtype:
             raise ValueError("scales/zeros must already be in the activation dtype")
-    d = _lib.FusedDesc()
+    exp = x_acc is not None or x_out is not None or zero_buf is not None      # fields of the experimental library's descriptor
+    d = _lib.ExpFusedDesc() if exp else _lib.FusedDesc()
     d.x = x.data_ptr()
     d.K, d.bits, d.group_size, d.act_dtype = m0.input_dims, m0.bits, m0.group_size, _DT[x.dtype]
     d.nseg = len(mods)
@@ -638,8 +639,26 @@ def make_fused_desc(x: torch.Tensor, mods, ys, norm_weight: Optional[torch.Tenso
     return d
 
 
+def _exp_kernels_requested() -> bool:
+    """GBX_GEMV_MXD / GBX_GEMV_MX: route the fused launches through libgbx_experimental.so (its scaled-MFMA GEMVs)."""
+    return env.flag("GBX_GEMV_MXD") or env.flag("GBX_GEMV_MX")
+
+
+def _as_exp_desc(desc) -> "_lib.ExpFusedDesc":
+    if isinstance(desc, _lib.ExpFusedDesc):
+        return desc
+    import ctypes
+    e = _lib.ExpFusedDesc()
+    ctypes.memmove(ctypes.addressof(e), ctypes.addressof(desc), ctypes.sizeof(_lib.FusedDesc))
+    return e
+
+
 def qlinear_fused(desc, device) -> None:
     import ctypes
+    if isinstance(desc, _lib.ExpFusedDesc) or _exp_kernels_requested():
+        e = _as_exp_desc(desc)
+        _lib.check_exp(_lib.exp_lib().gbx_exp_qlinear_fused_forward(ctypes.byref(e), _stream_ptr(device)))
+        return
     _lib.check(_lib.lib().gbx_qlinear_fused_forward(ctypes.byref(desc), _stream_ptr(device)))
 
 
@@ -722,9 +741,9 @@ class StreamProgram:
     def __init__(self, descs, device, dtype):
         import ctypes
         n = len(descs)
-        arr = (_lib.FusedDesc * n)(*descs)
+        arr = (_lib.ExpFusedDesc * n)(*[_as_exp_desc(d) for d in descs])
         host = (ctypes.c_uint8 * (n * _lib.GBX_STREAM_OP_BYTES))()
-        _lib.check(_lib.lib().gbx_stream_encode(arr, n, ctypes.addressof(host), len(host)))
+        _lib.check_exp(_lib.exp_lib().gbx_stream_encode(arr, n, ctypes.addressof(host), len(host)))
         self.n = n
         self.dtype = dtype
         self.device = torch.device(device)
@@ -735,7 +754,7 @@ class StreamProgram:
     def run(self, begin: int = 0, end: Optional[int] = None) -> None:
         end = self.n if end is None else end
         import ctypes
-        _lib.check(_lib.lib().gbx_stream_run(self.blob.data_ptr(), ctypes.addressof(self._host), begin, end, _DT[self.dtype],
+        _lib.check_exp(_lib.exp_lib().gbx_stream_run(self.blob.data_ptr(), ctypes.addressof(self._host), begin, end, _DT[self.dtype],
                                              _stream_ptr(self.device)))
 
 
@@ -747,11 +766,11 @@ def attn_decode(q, k, v, kcache, vcache, inv_freq, pos, out, n_heads: int, n_kv:
                                           _DT[q.dtype], _stream_ptr(q.device)))
 
 
-ATTN_OPROJ_HANDOFF_WORDS = 288     # GBX_ATTN_OPROJ_HANDOFF_WORDS (include/gbx_qlinear.h)
+ATTN_OPROJ_HANDOFF_WORDS = 288     # GBX_ATTN_OPROJ_HANDOFF_WORDS (include/gbx_experimental.h)
 
 
 def attn_oproj_supported(n_heads: int, n_kv: int, head_dim: int, o_proj) -> bool:
-    return bool(_lib.lib().gbx_attn_oproj_supported(n_heads, n_kv, head_dim, o_proj.output_dims, o_proj.bits, o_proj.group_size)) \
+    return bool(_lib.exp_lib().gbx_attn_oproj_supported(n_heads, n_kv, head_dim, o_proj.output_dims, o_proj.bits, o_proj.group_size)) \
         and o_proj.input_dims == n_heads * head_dim and o_proj.bias is None
 
 
@@ -762,7 +781,7 @@ def attn_oproj_decode(q, k, v, kcache, vcache, inv_freq, pos, o_proj, acc, n_hea
     entry (the tail is the in-launch hand-off area) -- gbx_attn_oproj_decode."""
     if acc.dtype != torch.int64 or acc.numel() != o_proj.output_dims + n_kv * ATTN_OPROJ_HANDOFF_WORDS:
         raise ValueError("acc must be int64 [D + n_kv * ATTN_OPROJ_HANDOFF_WORDS]")
-    _lib.check(_lib.lib().gbx_attn_oproj_decode(q.data_ptr(), k.data_ptr(), v.data_ptr(), kcache.data_ptr(), vcache.data_ptr(),
+    _lib.check_exp(_lib.exp_lib().gbx_attn_oproj_decode(q.data_ptr(), k.data_ptr(), v.data_ptr(), kcache.data_ptr(), vcache.data_ptr(),
                                                 inv_freq.data_ptr(), pos.data_ptr(), o_proj.qweight.data_ptr(),
                                                 o_proj.scales.data_ptr(), o_proj.zeros.data_ptr(), acc.data_ptr(), n_heads, n_kv,
                                                 head_dim, capacity, o_proj.output_dims, o_proj.bits, o_proj.group_size,

@@ -12,6 +12,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "experimental: exercises libgbx_experimental.so (opt-in kernels outside the product ABI; "
+                                       "always combined with gpu, so -m gpu still selects them)")
 
 
 def pytest_collection_modifyitems(config, items):

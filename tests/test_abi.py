@@ -18,13 +18,10 @@ def lib():
     return _lib.lib()
 
 
-def declared_symbols():
-    names = []
-    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
-        src = open(h).read()
-        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-        names += re.findall(r"\b(gbx_[a-z0-9_]+)\s*\(", src)
-    return sorted(set(names))
+def declared_symbols(header="gbx_qlinear.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gbx_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_header_declares_entry_points():
@@ -36,7 +33,25 @@ def test_header_declares_entry_points():
 
 def test_library_exports_every_declared_symbol(lib):
     for name in declared_symbols():
-        assert hasattr(lib, name), f"{name} declared in include/*.h but not exported"
+        assert hasattr(lib, name), f"{name} declared in include/gbx_qlinear.h but not exported"
+
+
+def test_experimental_library_is_separate():
+    """The opt-in kernels live behind their own header and library: every symbol of include/gbx_experimental.h is exported by
+    libgbx_experimental.so and by nothing else; the product header does not declare them."""
+    from gbx_lm_amd import _lib
+    if not os.path.exists(_lib._XSO):
+        _lib.build()
+    xl = _lib.exp_lib()
+    prod = set(declared_symbols())
+    exp = declared_symbols("gbx_experimental.h")
+    assert exp and "gbx_exp_qlinear_fused_forward" in exp and "gbx_stream_run" in exp
+    for name in exp:
+        assert hasattr(xl, name), f"{name} declared in include/gbx_experimental.h but not exported by libgbx_experimental.so"
+        assert name not in prod, f"{name} is declared by both headers"
+        assert not hasattr(_lib.lib(), name), f"{name} leaked into the product library"
+    assert xl.gbx_exp_version() >= 1100
+    assert len(prod) <= 60, "the product ABI is what a gbx-lm maintainer binds, not the lab notebook"
 
 
 def test_version_and_host_side_validation(lib):

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.experimental]
 DEV = "cuda:0"
 
 
@@ -129,9 +129,9 @@ def test_x_acc_rejections(oracle):
         ops.qlinear_fused(ops.make_fused_desc(h, (gate,), (y,), x_acc=acc), h.device)
     with pytest.raises(ValueError):          # x_out aliasing x
         ops.qlinear_fused(ops.make_fused_desc(h, (gate,), (y,), packed=ops.pack_scales_zeros(gate), x_acc=acc, x_out=h), h.device)
-    assert not _lib.lib().gbx_attn_oproj_supported(32, 8, 64, 4096, 2, 128)
-    assert not _lib.lib().gbx_attn_oproj_supported(24, 8, 128, 3072, 4, 128)
-    assert _lib.lib().gbx_attn_oproj_supported(32, 8, 128, 4096, 2, 128)
+    assert not _lib.exp_lib().gbx_attn_oproj_supported(32, 8, 64, 4096, 2, 128)
+    assert not _lib.exp_lib().gbx_attn_oproj_supported(24, 8, 128, 3072, 4, 128)
+    assert _lib.exp_lib().gbx_attn_oproj_supported(32, 8, 128, 4096, 2, 128)
 
 
 def test_runner_four_launch_block_matches_five_launch_block():

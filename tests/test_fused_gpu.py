@@ -535,6 +535,7 @@ def test_packed_scales_zeros_companion(oracle, bits, g, dt):
         ops.qlinear_fused(ops.make_fused_desc(x, (odd,), (y,), packed=torch.zeros((129 * (k // g),), dtype=torch.int32, device=DEV)), x.device)
 
 
+@pytest.mark.experimental
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 def test_tiled_gemv_fused_variants(oracle, dt):
     """Matrix-core GEMV with the decode-block fusions against the oracle and against the VALU fused launch:

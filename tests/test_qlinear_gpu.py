@@ -239,6 +239,7 @@ def test_batch_kernel_small_groups(ops, oracle, c_oracle, g, m, n, k):
         oracle.assert_close(y, y64, dt, f"batch g{g} M={m} N={n} K={k} {dt}")
 
 
+@pytest.mark.experimental
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("n,k", [(4096, 4096), (130, 1024), (1000, 2048), (4096, 14336), (28672, 4096)])
 def test_tiled_matrix_core_gemv(ops, oracle, c_oracle, dt, n, k):
