@@ -42,16 +42,23 @@ struct AttnArgs {
 #endif
 };
 #ifdef GBX_STAMPS
-#define ATT_STAMP(i) do { if ((threadIdx.x & 63) == 0 && a.stamps) a.stamps[(static_cast<size_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define ATT_STAMP(i) do { if ((threadIdx.x & 63) == 0 && a.stamps) a.stamps[(static_cast<size_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define ATT_STAMP(i) do {} while (0)
 #endif
 
-template <bool BF16, int HD>
-__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
+// NW waves per head.  NW = 4: every (wave, lane group) keeps its own softmax state and the 4 * PPW states meet in LDS.
+// NW = 16 (round 4, head_dim 128): the sweep over the cached positions is the kernel's longest phase (1.2 of 4.1 us at context
+// 128-190: one wave per SIMD walking 8 dependent rounds of load -> dot -> exp -> accumulate), so sixteen waves take two rounds each;
+// the four lane groups of a wave merge their states in registers (v_permlane32_swap / v_permlane16_swap) and 16 states meet in LDS,
+// as many as before.
+template <bool BF16, int HD, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnArgs a) {
   constexpr int LP = HD / 8;          // lanes that share one cached position (8 features = one 16-byte load each)
   constexpr int PPW = 64 / LP;        // positions per wave per iteration
-  constexpr int NG = 4 * PPW;         // (wave, sub) groups that carry partial softmax state
+  constexpr bool WMERGE = NW > 4;     // lane groups of a wave merged in registers
+  static_assert(!WMERGE || HD == 128, "in-wave merge: four lane groups of 16");
+  constexpr int NG = WMERGE ? NW : NW * PPW;         // partial softmax states that meet in LDS
   constexpr float NEG = -1e30f;
   __shared__ float q_s[HD], kn_s[HD], vn_s[HD];
   __shared__ float gm[NG], gl[NG];
@@ -72,14 +79,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
   // ---- the first UB0 * 4 * PPW cached positions are requested before anything else: their addresses depend neither on
   //      the position counter (clamped to the buffer; masked when consumed) nor on q, so the cache latency overlaps the
   //      q/k/v loads, RoPE and the barrier instead of following them (one dependent memory round trip less) ----
-  constexpr int LP0 = HD / 8, PPW0 = 64 / LP0, UB0 = 8;
+  constexpr int LP0 = HD / 8, PPW0 = 64 / LP0, UB0 = NW == 4 ? 8 : 128 / (NW * PPW0);
   const int d0 = (lane % LP0) * 8, sub = lane / LP0;
   const unsigned short* kbase = a.kcache + static_cast<size_t>(kvh) * a.capacity * HD;
   const unsigned short* vbase = a.vcache + static_cast<size_t>(kvh) * a.capacity * HD;
   u32x4 k0[UB0], v0[UB0];
 #pragma unroll
   for (int u = 0; u < UB0; ++u) {
-    const int tc = min(wave * PPW0 + u * 4 * PPW0 + sub, a.capacity - 1);
+    const int tc = min(wave * PPW0 + u * NW * PPW0 + sub, a.capacity - 1);
     k0[u] = *reinterpret_cast<const u32x4*>(kbase + static_cast<size_t>(tc) * HD + d0);
     v0[u] = *reinterpret_cast<const u32x4*>(vbase + static_cast<size_t>(tc) * HD + d0);
   }
@@ -154,14 +161,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     m = mn;
   };
 #pragma unroll
-  for (int u = 0; u < UB0; ++u) consume(k0[u], v0[u], wave * PPW + u * 4 * PPW + sub < pos);
-  constexpr int UB = 4;                 // iterations whose K/V loads are in flight together
-  for (int t0 = UB0 * 4 * PPW + wave * PPW; t0 < pos; t0 += 4 * PPW * UB) {
+  for (int u = 0; u < UB0; ++u) consume(k0[u], v0[u], wave * PPW + u * NW * PPW + sub < pos);
+  constexpr int UB = NW == 4 ? 4 : 2;   // iterations whose K/V loads are in flight together
+  for (int t0 = UB0 * NW * PPW + wave * PPW; t0 < pos; t0 += NW * PPW * UB) {
     u32x4 kv4[UB], vv4[UB];
     bool valid[UB];
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
-      const int t = t0 + u * 4 * PPW + sub;
+      const int t = t0 + u * NW * PPW + sub;
       valid[u] = t < pos;
       const int tc = valid[u] ? t : pos - 1;
       kv4[u] = *reinterpret_cast<const u32x4*>(kbase + static_cast<size_t>(tc) * HD + d0);
@@ -186,11 +193,50 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     for (int j = 0; j < 8; ++j) acc[j] = acc[j] * corr + p * vn_s[d0 + j];
     m = mn;
   }
-  const int g = wave * PPW + sub;
-  ATT_STAMP(3);
-  if (lane % LP == 0) { gm[g] = m; gl[g] = l; }
+  if constexpr (WMERGE) {
+    // the wave's four lane groups (rows of 16 lanes, each holding the same 8 features per lane) -> one state, in registers
+    auto merge = [&](float pm, float pl, const float (&pa)[8]) {
+      const float mn = fmaxf(m, pm);
+      const float c1 = __expf(m - mn), c2 = __expf(pm - mn);
+      l = l * c1 + pl * c2;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) gacc[g][d0 + j] = acc[j];
+      for (int j = 0; j < 8; ++j) acc[j] = acc[j] * c1 + pa[j] * c2;
+      m = mn;
+    };
+    {   // partner lane ^ 32
+      const bool hi = lane >= 32;
+      auto part = [&](float v) {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        const unsigned r0 = r[0], r1 = r[1];
+        return __uint_as_float(hi ? r0 : r1);
+      };
+      float pa[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pa[j] = part(acc[j]);
+      const float pm = part(m), pl = part(l);
+      merge(pm, pl, pa);
+    }
+    {   // partner lane ^ 16
+      const bool odd = (lane >> 4) & 1;
+      auto part = [&](float v) {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        const unsigned r0 = r[0], r1 = r[1];
+        return __uint_as_float(odd ? r0 : r1);
+      };
+      float pa[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pa[j] = part(acc[j]);
+      const float pm = part(m), pl = part(l);
+      merge(pm, pl, pa);
+    }
+  }
+  const int g = WMERGE ? wave : wave * PPW + sub;
+  ATT_STAMP(3);
+  if (WMERGE ? lane == 0 : lane % LP == 0) { gm[g] = m; gl[g] = l; }
+  if (!WMERGE || sub == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gacc[g][d0 + j] = acc[j];
+  }
   __syncthreads();
   ATT_STAMP(4);
   // ---- merge the NG partial states; one output feature per thread ----
@@ -612,7 +658,11 @@ hipError_t launch_attn_decode(const void* q, const void* k, const void* v, void*
     return hipErrorInvalidValue;
   }
   dim3 grid(n_heads, batch), block(256);
-  if (head_dim == 128) {
+  static const bool wide = env_switch("GBX_ATTN_WIDE") != 0;
+  if (head_dim == 128 && wide) {
+    if (bf16) hipLaunchKernelGGL((attn_decode_kernel<true, 128, 16>), grid, dim3(1024), 0, s, a);
+    else hipLaunchKernelGGL((attn_decode_kernel<false, 128, 16>), grid, dim3(1024), 0, s, a);
+  } else if (head_dim == 128) {
     if (bf16) hipLaunchKernelGGL((attn_decode_kernel<true, 128>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((attn_decode_kernel<false, 128>), grid, block, 0, s, a);
   } else if (head_dim == 64) {

@@ -77,7 +77,11 @@ bool dg_plan(int bits, int N, int K, int group, int epi, bool norm, int rows_per
   // partial sums of y^2 the launch can leave behind: one per wave (KS 1), one per workgroup when its row threads fit one wave (KS 4)
   int ssq_n = KS == 1 ? grid * NW : ((NW / 4) * bpo * R <= 64 ? grid : 0);
   if (ssq_n > DG_SSQ_SLOTS) ssq_n = 0;
-  *pl = DgPlan{P, KS, NW, R, grid, bpo, apw, nbatch, ssq_n, lds};
+  // register buffers: one batch per owner -> 1; else 2, or 4 where that puts ALL of an owner's batches in flight (GBX_DG_DEPTH)
+  static const int depth = env_switch("GBX_DG_DEPTH");
+  int D = bpo == 1 ? 1 : 2;
+  if (depth == 4 && bpo > 2 && bpo <= 4 && P == 1 && KS == 1 && NW == 16 && R == 2) D = 4;
+  *pl = DgPlan{P, KS, NW, R, D, grid, bpo, apw, nbatch, ssq_n, lds};
   return true;
 }
 

@@ -75,7 +75,7 @@ struct DgBatch {
 // 4.5, o in 3.4 and down in 6.7 us: these launches are bound by prologue and consumption latency, not by the stream.)
 template <int BITS, int P, int KS, int NW, int R, int EPI, int D, bool LATE, bool BF16>
 __global__ __launch_bounds__(NW * 64) void dgemv_kernel(const DgArgs a) {
-  static_assert(D == 1 || D == 2, "register buffers");
+  static_assert(D == 1 || D == 2 || D == 4, "register buffers");
   static_assert(!LATE || KS == 1, "the late-request form goes with the RMSNorm prologue");
   static_assert(R == 2 || R == 4, "rows per batch");
   static_assert(KS == 1 || KS == 4, "K split");
@@ -335,7 +335,8 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(const DgArgs a) {
   if constexpr (E0 < R) issue_part(ring[0], batch_of(0), E0, R);
   __syncthreads();
   DG_STAMP(2);
-  if constexpr (D == 2) issue(ring[1], batch_of(1));
+#pragma unroll
+  for (int d = 1; d < D; ++d) issue(ring[d], batch_of(d));
 
   // a wave that owns no batch at all is done (it was only here for the prologue); KS == 4 and ssq_out launches meet again at a
   // barrier / store below, so their idle waves stay
@@ -444,22 +445,29 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(const DgArgs a) {
     }
   };
 
-  // ---------------- 6. one batch (D == 1), or the 2-deep ring: the decode shapes have at most two batches per owner and skip the loop -----
+  // ---------------- 6. one batch (D == 1), or the D-deep ring: the decode shapes have at most D batches per owner and skip the loop -----
+#ifdef GBX_STAMPS     // when has batch 0 landed?  (diagnostic build only: the explicit wait is not in the product kernel)
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 1) * (R * P + P + ((EPI == 1 && KS == 1) ? 1 : 0))) : "memory");
+  DG_STAMP(11);
+#endif
   if constexpr (D == 1) {
     consume(ring[0], 0);
     DG_STAMP(4);
   } else {
     int base = 0;
-    for (; base + 2 < bpo; base += 2) {
-      consume(ring[0], base);
-      issue(ring[0], batch_of(base + 2));
-      consume(ring[1], base + 1);
-      issue(ring[1], batch_of(base + 3));
+    for (; base + D < bpo; base += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        consume(ring[d], base + d);
+        issue(ring[d], batch_of(base + D + d));
+      }
     }
-    consume(ring[0], base);
-    DG_STAMP(4);
-    consume(ring[1], base + 1);
-    DG_STAMP(5);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      consume(ring[d], base + d);
+      if (d == 0) DG_STAMP(4);
+      if (d == 1) DG_STAMP(5);
+    }
   }
   DG_STAMP(6);
 
@@ -498,7 +506,7 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(const DgArgs a) {
 // ---- host side -------------------------------------------------------------------------------------------------------------
 // A plan fixes the geometry of one launch: which instantiation, how many workgroups, how its batches are dealt to the row owners.
 struct DgPlan {
-  int P, KS, NW, R, grid, bpo, apw, nbatch;
+  int P, KS, NW, R, D, grid, bpo, apw, nbatch;
   int ssq_n;        // partial sums of y^2 an ssq_out launch writes (0: this geometry cannot)
   size_t shmem;
 };
@@ -513,7 +521,7 @@ bool dg_late_default();     // GBX_DG_LATE (A/B switch, default 1)
 hipError_t launch_dg_pack(const void* s0, const void* z0, const void* s1, const void* z1, uint32_t* out, int N, int G, int R, hipStream_t s);
 
 #define GBX_DG_CASE_D(BITS, P_, KS_, NW_, R_, EPI_, D_)                                                                                  \
-  if (pl.P == P_ && pl.KS == KS_ && pl.NW == NW_ && pl.R == R_ && epi == EPI_ && (pl.bpo == 1 ? 1 : 2) == D_) {                                  \
+  if (pl.P == P_ && pl.KS == KS_ && pl.NW == NW_ && pl.R == R_ && epi == EPI_ && pl.D == D_) {                                  \
     constexpr bool L_ = (KS_ == 1) && (EPI_ != 1);     /* the norm'd launches are the plain / SwiGLU ones of a block */                          \
     if (late && L_) {                                                                                                                         \
       if (bf16) hipLaunchKernelGGL((dgemv_kernel<BITS, P_, KS_, NW_, R_, EPI_, D_, L_, true>), grid, dim3(NW_ * 64), pl.shmem, stream, args); \
@@ -525,6 +533,8 @@ hipError_t launch_dg_pack(const void* s0, const void* z0, const void* s1, const 
     return hipGetLastError();                                                                                                                 \
   }
 #define GBX_DG_CASE(BITS, P_, KS_, NW_, R_, EPI_) GBX_DG_CASE_D(BITS, P_, KS_, NW_, R_, EPI_, 1) GBX_DG_CASE_D(BITS, P_, KS_, NW_, R_, EPI_, 2)
+// 4-deep ring: the one-pass, 16-wave, two-row launches only (gate|up of the 2-bit layers: 3.5 batches per wave, all in flight)
+#define GBX_DG_CASE_D4(BITS) GBX_DG_CASE_D(BITS, 1, 1, 16, 2, 0, 4) GBX_DG_CASE_D(BITS, 1, 1, 16, 2, 1, 4) GBX_DG_CASE_D(BITS, 1, 1, 16, 2, 2, 4)
 #define GBX_DG_EPIS_KS1(BITS, P_, NW_, R_) GBX_DG_CASE(BITS, P_, 1, NW_, R_, 0) GBX_DG_CASE(BITS, P_, 1, NW_, R_, 1) GBX_DG_CASE(BITS, P_, 1, NW_, R_, 2)
 #define GBX_DG_EPIS_KS4(BITS, P_, NW_, R_) GBX_DG_CASE(BITS, P_, 4, NW_, R_, 0) GBX_DG_CASE(BITS, P_, 4, NW_, R_, 1)
 
@@ -535,6 +545,7 @@ hipError_t launch_dg_pack(const void* s0, const void* z0, const void* s1, const 
     args.nbatch = pl.nbatch; args.bpo = pl.bpo; args.apw = pl.apw;                                             \
     const bool late = a.norm_w != nullptr && dg_late_default();                                                \
     const dim3 grid(pl.grid);                                                                                  \
+    GBX_DG_CASE_D4(BITS)                                                                                       \
     GBX_DG_EPIS_KS1(BITS, 1, 4, 2) GBX_DG_EPIS_KS1(BITS, 1, 8, 2) GBX_DG_EPIS_KS1(BITS, 1, 16, 2)              \
     GBX_DG_EPIS_KS1(BITS, 1, 4, 4) GBX_DG_EPIS_KS1(BITS, 1, 8, 4) GBX_DG_EPIS_KS1(BITS, 1, 16, 4)              \
     GBX_DG_EPIS_KS1(BITS, 2, 4, 2) GBX_DG_EPIS_KS1(BITS, 2, 8, 2) GBX_DG_EPIS_KS1(BITS, 2, 16, 2)              \
