@@ -945,12 +945,19 @@ int gbx_dgemv_forward(const gbx_dgemv* d, void* hip_stream) {
   a.eps = d->norm_eps;
   static const int chain_floor = gbx::env_switch("GBX_CHAIN_FLOOR");
   a.null_rows = chain_floor == 2 ? 1 : 0;
+  static const int long_prio = gbx::env_switch("GBX_DG_LONG_PRIO");
+  a.long_prio = (long_prio && pl.bpo > 1 && pl.apw < (pl.KS == 1 ? pl.NW : pl.NW / 4)) ? 1 : 0;
 #ifdef GBX_STAMPS
   a.stamps = gbx::stamp_region();
 #endif
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   const bool bf16 = d->act_dtype == GBX_BF16;
   hipError_t e;
+  if (d->bits == 2 && gbx::dg_mx_wanted(a, pl, d->epilogue, bf16)) {
+    e = gbx::launch_dgemv_mx(a, pl, d->epilogue, stream);
+    if (e != hipSuccess) return hip_fail(e, "gbx_dgemv_forward (matrix-core form) launch");
+    return GBX_OK;
+  }
   switch (d->bits) {
     case 2: e = gbx::launch_dgemv<2>(a, pl, d->epilogue, bf16, stream); break;
     case 3: e = gbx::launch_dgemv<3>(a, pl, d->epilogue, bf16, stream); break;

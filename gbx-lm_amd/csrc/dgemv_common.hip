@@ -80,7 +80,7 @@ bool dg_plan(int bits, int N, int K, int group, int epi, bool norm, int rows_per
   // register buffers: one batch per owner -> 1; else 2, or 4 where that puts ALL of an owner's batches in flight (GBX_DG_DEPTH)
   static const int depth = env_switch("GBX_DG_DEPTH");
   int D = bpo == 1 ? 1 : 2;
-  if (depth == 4 && bpo > 2 && bpo <= 4 && P == 1 && KS == 1 && NW == 16 && R == 2) D = 4;
+  if ((depth == 4 || depth == 3) && bpo > 2 && bpo <= 4 && P == 1 && KS == 1 && NW == 16 && R == 2) D = depth;
   *pl = DgPlan{P, KS, NW, R, D, grid, bpo, apw, nbatch, ssq_n, lds};
   return true;
 }

@@ -44,6 +44,7 @@ struct DgArgs {
   int apw;                          // ... and, in the last round, owners [0, apw) of a workgroup take batch (bpo-1)*owners + block*apw + owner
   float eps;
   int null_rows;                    // measurement only (GBX_CHAIN_FLOOR=2): every batch re-reads batch 0's rows
+  int long_prio;                    // 1: owners with a batch in the last round run at s_setprio 1 (uneven launches: gate|up)
 #ifdef GBX_STAMPS
   unsigned long long* stamps;       // diagnostic build only: [workgroup][wave][16] s_memrealtime stamps
 #endif
@@ -75,7 +76,7 @@ struct DgBatch {
 // 4.5, o in 3.4 and down in 6.7 us: these launches are bound by prologue and consumption latency, not by the stream.)
 template <int BITS, int P, int KS, int NW, int R, int EPI, int D, bool LATE, bool BF16>
 __global__ __launch_bounds__(NW * 64) void dgemv_kernel(const DgArgs a) {
-  static_assert(D == 1 || D == 2 || D == 4, "register buffers");
+  static_assert(D >= 1 && D <= 4, "register buffers");
   static_assert(!LATE || KS == 1, "the late-request form goes with the RMSNorm prologue");
   static_assert(R == 2 || R == 4, "rows per batch");
   static_assert(KS == 1 || KS == 4, "K split");
@@ -368,6 +369,7 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(const DgArgs a) {
     }
   }
 
+  if (a.long_prio && ow < a.apw) __builtin_amdgcn_s_setprio(1);     // wave-uniform
   DG_STAMP(3);
   // ---------------- 5. consume one batch: R row totals, then the epilogue on the lanes that hold them -------------------------
   float sq = 0.f;                                           // this lane's share of sum(y^2) (lanes 31 / 63 only)
@@ -518,6 +520,9 @@ template <int BITS>
 hipError_t launch_dgemv(const DgArgs& a, const DgPlan& pl, int epi, bool bf16, hipStream_t stream);
 
 bool dg_late_default();     // GBX_DG_LATE (A/B switch, default 1)
+// dgemv_mx.hip: the same launches with the dot products on the FP4 x FP8 matrix cores (2 bits, group 128, bf16, K = 2048 SP)
+bool dg_mx_wanted(const DgArgs& a, const DgPlan& pl, int epi, bool bf16);
+hipError_t launch_dgemv_mx(const DgArgs& a, const DgPlan& pl, int epi, hipStream_t stream);
 hipError_t launch_dg_pack(const void* s0, const void* z0, const void* s1, const void* z1, uint32_t* out, int N, int G, int R, hipStream_t s);
 
 #define GBX_DG_CASE_D(BITS, P_, KS_, NW_, R_, EPI_, D_)                                                                                  \
@@ -534,7 +539,8 @@ hipError_t launch_dg_pack(const void* s0, const void* z0, const void* s1, const 
   }
 #define GBX_DG_CASE(BITS, P_, KS_, NW_, R_, EPI_) GBX_DG_CASE_D(BITS, P_, KS_, NW_, R_, EPI_, 1) GBX_DG_CASE_D(BITS, P_, KS_, NW_, R_, EPI_, 2)
 // 4-deep ring: the one-pass, 16-wave, two-row launches only (gate|up of the 2-bit layers: 3.5 batches per wave, all in flight)
-#define GBX_DG_CASE_D4(BITS) GBX_DG_CASE_D(BITS, 1, 1, 16, 2, 0, 4) GBX_DG_CASE_D(BITS, 1, 1, 16, 2, 1, 4) GBX_DG_CASE_D(BITS, 1, 1, 16, 2, 2, 4)
+#define GBX_DG_CASE_D4(BITS) GBX_DG_CASE_D(BITS, 1, 1, 16, 2, 0, 4) GBX_DG_CASE_D(BITS, 1, 1, 16, 2, 1, 4) GBX_DG_CASE_D(BITS, 1, 1, 16, 2, 2, 4) \
+  GBX_DG_CASE_D(BITS, 1, 1, 16, 2, 0, 3) GBX_DG_CASE_D(BITS, 1, 1, 16, 2, 1, 3) GBX_DG_CASE_D(BITS, 1, 1, 16, 2, 2, 3)
 #define GBX_DG_EPIS_KS1(BITS, P_, NW_, R_) GBX_DG_CASE(BITS, P_, 1, NW_, R_, 0) GBX_DG_CASE(BITS, P_, 1, NW_, R_, 1) GBX_DG_CASE(BITS, P_, 1, NW_, R_, 2)
 #define GBX_DG_EPIS_KS4(BITS, P_, NW_, R_) GBX_DG_CASE(BITS, P_, 4, NW_, R_, 0) GBX_DG_CASE(BITS, P_, 4, NW_, R_, 1)
 

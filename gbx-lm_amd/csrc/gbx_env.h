@@ -21,7 +21,9 @@ inline const EnvSwitch* env_table(int* n) {
       {"GBX_GEMV_CEPI", 1, "gemv_kernel: compile-time one-segment epilogue, MODE 5 (A/B)"},
       {"GBX_DG_R", 0, "dgemv: force rows per batch (2 / 4); 0 = per-launch default"},
       {"GBX_DG_MIN_NW", 4, "dgemv: minimum waves per workgroup of the one-round launches (4 / 8 / 16)"},
-      {"GBX_DG_DEPTH", 2, "dgemv: register buffers of the multi-batch launches: 2, or 4 = all of a wave's (up to four) batches in flight (gate|up)"},
+      {"GBX_DG_DEPTH", 2, "dgemv: register buffers of the multi-batch launches: 2 (default), 3, or 4 = all of a wave's (up to four) batches in flight (gate|up)"},
+      {"GBX_DG_MX", 1, "dgemv: dot products on the FP4 x FP8 matrix cores (dgemv_mx.hip; 2 bits, group 128, bf16): 0 off, 1 the SwiGLU (gate|up) launches, 2 every eligible launch"},
+      {"GBX_DG_LONG_PRIO", 0, "dgemv: waves that own a batch in the last (partial) round run at s_setprio 1 (A/B)"},
       {"GBX_DG_LATE", 1, "dgemv: request batch 0 behind the activation image in the launches with an RMSNorm prologue (A/B)"},
       {"GBX_ATTN_WIDE", 1, "decode attention at head_dim 128: 16 waves per head with the in-wave state merge (0: 4 waves) (A/B)"},
       {"GBX_ATTN_SPLIT_R", 0, "decode attention: force the context split (tuning aid)"},

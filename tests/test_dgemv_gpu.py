@@ -249,3 +249,59 @@ def test_dgemv_bench_geometry_vs_dequantised_fp64(oracle, bits, name, n, k, kind
         ops.dgemv(ops.make_dgemv_desc(x, m, y, ops.dgemv_pack(m, r), r, norm_weight=nw, eps=1e-5), x.device)
         want = deq(m) @ _rms(x, nw, 1e-5).double()
         oracle.assert_close(y[None].cpu(), want[None].cpu().numpy(), "bf16", name)
+
+
+# ---- the matrix-core form of the same launches (csrc/dgemv_mx.hip; GBX_DG_MX): opt-in per process, so it runs in a child ------
+_MX_CHILD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from gbx_lm_amd import ops, _lib
+from gbx_lm_amd.models.quantized_linear_gba import QuantizedLinear
+from oracle import gba_oracle as O            # checker only
+DEV = "cuda:0"
+def mk(n, k, seed):
+    d = O.synth_layer(n, k, 2, 128, seed=seed)
+    m = QuantizedLinear(k, n, False, 128, 2)
+    m._buffers["qweight"] = torch.from_numpy(d["qweight"].view(np.int32)).view(torch.uint32).to(DEV)
+    m._buffers["scales"], m._buffers["zeros"] = d["scales"].to(DEV), d["zeros"].to(DEV)
+    return m, d
+def rms(x, w, eps):
+    xf = x.float()
+    return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps) * w.float()).to(x.dtype)
+ref = lambda x, d: O.qlinear_ref(x[None], d["qweight"], d["scales"], d["zeros"], 2, 128, acc=np.float64)
+torch.manual_seed(7)
+for (n, k) in ((512, 4096), (14336, 4096), (1030, 2048), (640, 8192)):
+    gate, dg = mk(n, k, 1); up, du = mk(n, k, 2)
+    x = (torch.randn(k) * 2).to(torch.bfloat16).to(DEV)
+    x[5] = 90.0                                                  # an outlier 2^6 above its block: the limbs must stay exact
+    nw = (1 + 0.1 * torch.randn(k)).to(torch.bfloat16).to(DEV)
+    xn = rms(x, nw, 1e-5).cpu()
+    # SwiGLU + norm, statistic in-kernel and carried
+    for carried in (False, True):
+        ssq = None
+        if carried:
+            ssq = torch.zeros(_lib.GBX_DG_SSQ_SLOTS, dtype=torch.float32, device=DEV); ssq[:256] = x.float().pow(2).view(256, -1).sum(1)
+        act = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+        ops.dgemv(ops.make_dgemv_desc(x, gate, act, ops.dgemv_pack(gate, 2, up), 2, mod_up=up, norm_weight=nw, eps=1e-5, ssq_in=ssq), x.device)
+        g64, u64 = ref(xn, dg), ref(xn, du)
+        O.assert_close(act[None], (g64 / (1 + np.exp(-g64))) * u64, "bf16", f"mx swiglu {n}x{k} carried={carried}")
+    # plain + norm, residual with the partial statistic
+    y = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+    ops.dgemv(ops.make_dgemv_desc(x, gate, y, ops.dgemv_pack(gate, 2), 2, norm_weight=nw, eps=1e-5), x.device)
+    O.assert_close(y[None], ref(xn, dg), "bf16", f"mx plain {n}x{k}")
+    h = torch.randn(n).to(torch.bfloat16).to(DEV); h0 = h.clone()
+    r, parts = ops.dgemv_plan(n, k, 2, 128, 1)
+    ssq_o = torch.zeros(_lib.GBX_DG_SSQ_SLOTS, dtype=torch.float32, device=DEV)
+    ok = ops.dgemv_plan(n, k, 2, 128, 1)[1] > 0
+    ops.dgemv(ops.make_dgemv_desc(x, gate, h, ops.dgemv_pack(gate, 2), 2, residual=h), x.device)
+    O.assert_close(h[None], h0.cpu().double().numpy()[None] + ref(x.cpu(), dg), "bf16", f"mx residual {n}x{k}")
+print("MX_OK")
+"""
+
+
+def test_dgemv_matrix_core_form_vs_oracle():
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GBX_DG_MX="2")
+    out = subprocess.run([sys.executable, "-c", _MX_CHILD % root], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0 and "MX_OK" in out.stdout, out.stderr[-3000:] + out.stdout[-500:]
