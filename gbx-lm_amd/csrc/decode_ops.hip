@@ -52,8 +52,12 @@ struct AttnArgs {
 // 128-190: one wave per SIMD walking 8 dependent rounds of load -> dot -> exp -> accumulate), so sixteen waves take two rounds each;
 // the four lane groups of a wave merge their states in registers (v_permlane32_swap / v_permlane16_swap) and 16 states meet in LDS,
 // as many as before.
+#ifndef GBX_ATTN_XCD_ORDER
+#define GBX_ATTN_XCD_ORDER 1
+#endif
 template <bool BF16, int HD, int NW = 4>
 __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnArgs a) {
+  constexpr bool XCD_ORDER = GBX_ATTN_XCD_ORDER != 0;
   constexpr int LP = HD / 8;          // lanes that share one cached position (8 features = one 16-byte load each)
   constexpr int PPW = 64 / LP;        // positions per wave per iteration
   constexpr bool WMERGE = NW > 4;     // lane groups of a wave merged in registers
@@ -64,7 +68,11 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnArgs a) {
   __shared__ float gm[NG], gl[NG];
   __shared__ float gacc[NG][HD + 8];
 
-  const int h = blockIdx.x;
+  // XCD-aware head order (speed only, never correctness): workgroups b and b + 8 share an XCD under the round-robin placement, so
+  // slot b % 8 takes the CONSECUTIVE heads [slot * H/8, (slot + 1) * H/8) -- at 32 heads / 8 kv heads the four query heads of one kv
+  // group -- and three of the four workgroups find their K / V head in the XCD's L2 instead of pulling it from the Infinity Cache.
+  int h = blockIdx.x;
+  if (XCD_ORDER && (a.n_heads & 7) == 0) h = (static_cast<int>(blockIdx.x) & 7) * (a.n_heads >> 3) + (static_cast<int>(blockIdx.x) >> 3);
   const int rep = a.n_heads / a.n_kv;
   const int kvh = h / rep;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1005,20 +1013,21 @@ typedef float f32x4s __attribute__((ext_vector_type(4)));
 // Rows up to 8192 values stay in registers between the two passes: 16-byte loads, one barrier.
 // ADD == 2: the addend is the sum of `slices` fp32 partial tiles ws[s][M][K] of a k-split GEMM, rounded once to the
 // activation dtype exactly like the summing launch it replaces (batch_finish_kernel: v = ws[0]; v += ws[s], s = 1..).
-template <bool BF16, int ADD>
-__global__ __launch_bounds__(256) void rmsnorm_vec_kernel(unsigned short* __restrict__ h, const unsigned short* __restrict__ d,
+template <bool BF16, int ADD, int NT = 256>
+__global__ __launch_bounds__(NT) void rmsnorm_vec_kernel(unsigned short* __restrict__ h, const unsigned short* __restrict__ d,
                                                           const unsigned short* __restrict__ w, unsigned short* __restrict__ y,
                                                           int K, float eps, const float* __restrict__ ws = nullptr, int slices = 0,
                                                           long long mn = 0) {
-  __shared__ float red[4];
+  __shared__ float red[NT / 64];
+  constexpr int ITERS = 1024 / NT;                  // 16-byte pieces per thread (K <= 8192)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t row = static_cast<size_t>(blockIdx.x) * K;
   const int n8 = K >> 3;                            // 16-byte pieces per row (K % 8 == 0, K <= 8192: at most 4 per thread)
-  u32x4 v[4];
+  u32x4 v[ITERS];
   float ssq = 0.f;
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int p = it * 256 + tid;
+  for (int it = 0; it < ITERS; ++it) {
+    const int p = it * NT + tid;
     if (p < n8) {
       u32x4 hv = reinterpret_cast<const u32x4*>(h + row)[p];
       if constexpr (ADD != 0) {
@@ -1062,16 +1071,18 @@ __global__ __launch_bounds__(256) void rmsnorm_vec_kernel(unsigned short* __rest
       for (int j = 0; j < 4; ++j) { const float a0 = act_lo<BF16>(hw[j]), a1 = act_hi<BF16>(hw[j]); ssq = fmaf(a0, a0, fmaf(a1, a1, ssq)); }
     }
   }
-  u32x4 wq[4];                                      // the norm weights are requested before the reduction, not after it
+  u32x4 wq[ITERS];                                      // the norm weights are requested before the reduction, not after it
 #pragma unroll
-  for (int it = 0; it < 4; ++it) wq[it] = reinterpret_cast<const u32x4*>(w)[min(it * 256 + tid, n8 - 1)];
+  for (int it = 0; it < ITERS; ++it) wq[it] = reinterpret_cast<const u32x4*>(w)[min(it * NT + tid, n8 - 1)];
   ssq = wave_sum(ssq);
   if (lane == 63) red[wave] = ssq;
   __syncthreads();
-  const float rstd = rsqrtf(((red[0] + red[1]) + (red[2] + red[3])) / static_cast<float>(K) + eps);
+  float tot = (red[0] + red[1]) + (red[2] + red[3]);
+  if constexpr (NT == 512) tot += (red[4] + red[5]) + (red[6] + red[7]);
+  const float rstd = rsqrtf(tot / static_cast<float>(K) + eps);
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int p = it * 256 + tid;
+  for (int it = 0; it < ITERS; ++it) {
+    const int p = it * NT + tid;
     if (p < n8) {
       const u32x4 wv = wq[it];
       const unsigned hw[4] = {v[it].x, v[it].y, v[it].z, v[it].w}, ww[4] = {wv.x, wv.y, wv.z, wv.w};
@@ -1136,6 +1147,14 @@ hipError_t launch_add_rmsnorm_slices(void* h, const float* ws, int slices, const
   auto W = static_cast<const unsigned short*>(w);
   auto Y = static_cast<unsigned short*>(y);
   const long long mn = static_cast<long long>(M) * K;
+  // 512 threads (one 16-byte piece of a <= 4096-value row each): the launch is a chain of dependent loads per thread, so the
+  // fewer pieces a thread walks the shorter it is (B = 32 decode: 4.9 -> see DESIGN 3.4)
+  static const bool wide = env_switch("GBX_NORM_WIDE") != 0;      // default 0: measured 2.60 -> 2.57 ms per B = 32 step (noise level), and the
+  if (wide && K > 2048) {                                         // 256-thread form is bit-identical to gbx_add_rmsnorm on summed slices
+    if (bf16) hipLaunchKernelGGL((rmsnorm_vec_kernel<true, 2, 512>), dim3(M), dim3(512), 0, s, H, nullptr, W, Y, K, eps, ws, slices, mn);
+    else hipLaunchKernelGGL((rmsnorm_vec_kernel<false, 2, 512>), dim3(M), dim3(512), 0, s, H, nullptr, W, Y, K, eps, ws, slices, mn);
+    return hipGetLastError();
+  }
   if (bf16) hipLaunchKernelGGL((rmsnorm_vec_kernel<true, 2>), dim3(M), dim3(256), 0, s, H, nullptr, W, Y, K, eps, ws, slices, mn);
   else hipLaunchKernelGGL((rmsnorm_vec_kernel<false, 2>), dim3(M), dim3(256), 0, s, H, nullptr, W, Y, K, eps, ws, slices, mn);
   return hipGetLastError();

@@ -25,6 +25,7 @@ inline const EnvSwitch* env_table(int* n) {
       {"GBX_DG_MX", 1, "dgemv: dot products on the FP4 x FP8 matrix cores (dgemv_mx.hip; 2 bits, group 128, bf16): 0 off, 1 the SwiGLU (gate|up) launches, 2 every eligible launch"},
       {"GBX_DG_LONG_PRIO", 0, "dgemv: waves that own a batch in the last (partial) round run at s_setprio 1 (A/B)"},
       {"GBX_DG_LATE", 1, "dgemv: request batch 0 behind the activation image in the launches with an RMSNorm prologue (A/B)"},
+      {"GBX_NORM_WIDE", 0, "slice-sum + residual + RMSNorm launch of batched decode: 512 threads per row (measured within noise; the 256-thread default is bit-identical to gbx_add_rmsnorm)"},
       {"GBX_ATTN_WIDE", 1, "decode attention at head_dim 128: 16 waves per head with the in-wave state merge (0: 4 waves) (A/B)"},
       {"GBX_ATTN_SPLIT_R", 0, "decode attention: force the context split (tuning aid)"},
       {"GBX_ATTN_SPLIT_MIN", 1024, "decode attention: smallest cache capacity that is split over workgroups (tuning aid)"},
