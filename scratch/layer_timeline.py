@@ -150,3 +150,23 @@ if PER_LAYER == 5 and os.environ.get("ROLES"):
     roles(li * 5 + 2, nws[1], "o")
     roles(li * 5 + 3, nws[2], "gateup")
     roles(li * 5 + 4, nws[3], "down")
+
+# ---- round 4: who ends last in the gate|up launch?  per wave-index (0..15) medians of the end stamp and of "batch 0 landed"
+def by_wave(slot, nw, label):
+    r = s[slot]
+    r = r[r[:, 0] > 0]
+    if len(r) % nw:
+        return
+    t0 = r[:, 0].min()
+    rel = ((r - t0) / 100.0).reshape(-1, nw, 16)
+    print(f"{label}: per wave index, median / max over workgroups of [start, batch 0 landed, end]")
+    for w in range(nw):
+        x = rel[:, w, :]
+        print(f"   wave {w:2d}: start {np.median(x[:, 0]):5.2f}/{x[:, 0].max():5.2f}  landed {np.median(x[:, 11]):5.2f}/{x[:, 11].max():5.2f}  end {np.median(x[:, 6]):5.2f}/{x[:, 6].max():5.2f}")
+    wg_end = rel[:, :, 6].max(1)
+    print(f"   workgroup end: min {wg_end.min():.2f} p10 {np.percentile(wg_end, 10):.2f} median {np.median(wg_end):.2f} p90 {np.percentile(wg_end, 90):.2f} max {wg_end.max():.2f}")
+
+if PER_LAYER == 5 and os.environ.get("BYWAVE"):
+    by_wave(10 * 5 + 3, 16, "gateup")
+    by_wave(10 * 5 + 4, 16, "down")
+    by_wave(10 * 5 + 0, 16, "qkv")
