@@ -39,20 +39,25 @@ bool dg_plan(int bits, int N, int K, int group, int epi, bool norm, int rows_per
   constexpr int CUS = 256;
   static const int min_nw = env_switch("GBX_DG_MIN_NW");
   int NW, grid, bpo, apw;
+  // two-pass rows (3 / 4 bits at K = 4096: twice the bytes per row): GBX_DG_P2_NW workgroup width of the KS == 1 launches
+  static const int p2_nw = env_switch("GBX_DG_P2_NW");
   if (KS == 1) {
     if (nbatch <= CUS * 16) {
       bpo = 1;
       apw = (nbatch + CUS - 1) / CUS;
       NW = apw <= 4 ? 4 : (apw <= 8 ? 8 : 16);
       if (NW < min_nw) NW = min_nw <= 8 ? (min_nw <= 4 ? 4 : 8) : 16;
+      if (P == 2 && p2_nw && p2_nw < NW) { NW = p2_nw; apw = NW; }          // several narrower workgroups per CU
       grid = (nbatch + apw - 1) / apw;
     } else {
-      NW = 16;
+      static const int mr_nw = env_switch("GBX_DG_MR_NW");
+      NW = (P == 2 && p2_nw) ? p2_nw : ((P == 1 && (mr_nw == 8 || mr_nw == 4)) ? mr_nw : 16);
+      const int wgs = CUS * (16 / NW);                                       // 16 resident waves per CU either way
       const int slots = CUS * 16;
       bpo = (nbatch + slots - 1) / slots;
       const int rem = nbatch - (bpo - 1) * slots;
-      apw = (rem + CUS - 1) / CUS;
-      grid = CUS;
+      apw = (rem + wgs - 1) / wgs;
+      grid = wgs;
     }
   } else {
     // row groups of four waves; 16-wave workgroups (4 owners) unless the launch is small

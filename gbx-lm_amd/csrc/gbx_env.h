@@ -21,6 +21,8 @@ inline const EnvSwitch* env_table(int* n) {
       {"GBX_GEMV_CEPI", 1, "gemv_kernel: compile-time one-segment epilogue, MODE 5 (A/B)"},
       {"GBX_DG_R", 0, "dgemv: force rows per batch (2 / 4); 0 = per-launch default"},
       {"GBX_DG_MIN_NW", 4, "dgemv: minimum waves per workgroup of the one-round launches (4 / 8 / 16)"},
+      {"GBX_DG_MR_NW", 16, "dgemv: workgroup width (4 / 8 / 16) of the one-pass launches with more than one batch per wave (gate|up at 2 bits)"},
+      {"GBX_DG_P2_NW", 8, "dgemv: workgroup width (4 / 8) of the launches whose rows take two lane passes (3 / 4 bits at K = 4096); 0 = as the one-pass launches; two 8-wave workgroups per CU measured +3.9 % on the all-4-bit strategy"},
       {"GBX_DG_DEPTH", 2, "dgemv: register buffers of the multi-batch launches: 2 (default), 3, or 4 = all of a wave's (up to four) batches in flight (gate|up)"},
       {"GBX_DG_MX", 1, "dgemv: dot products on the FP4 x FP8 matrix cores (dgemv_mx.hip; 2 bits, group 128, bf16): 0 off, 1 the SwiGLU (gate|up) launches, 2 every eligible launch"},
       {"GBX_DG_LONG_PRIO", 0, "dgemv: waves that own a batch in the last (partial) round run at s_setprio 1 (A/B)"},
