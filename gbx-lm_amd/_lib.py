@@ -42,6 +42,11 @@ def lib() -> ctypes.CDLL:
             raise RuntimeError(
                 f"gbx_lm_amd: HIP extension {_SO} is not built. Run `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (or `make -C gbx-lm_amd/csrc`). There is no CPU fallback for QuantizedLinear.")
+        # PyTorch's HIP runtime must be initialised BEFORE this library is mapped: loaded first, the library's fat binaries register
+        # with a runtime that torch then never initialises for them, and every launch fails with "no ROCm-capable device is detected"
+        # (seen with `build(); smoke()` in one process; any process that imports torch.cuda first was fine).  No GPU: a cheap False.
+        import torch
+        torch.cuda.is_available()
         L = ctypes.CDLL(_SO)
         i64, i32, p = ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p
         L.gbx_version.restype = ctypes.c_int
@@ -101,6 +106,7 @@ def exp_lib() -> ctypes.CDLL:
     if _xlib is None:
         if not os.path.exists(_XSO):
             raise RuntimeError(f"gbx_lm_amd: {_XSO} is not built (`make -C gbx-lm_amd/csrc`)")
+        lib()                                       # (initialisation order: see lib())
         L = ctypes.CDLL(_XSO)
         i32, p, f32 = ctypes.c_int32, ctypes.c_void_p, ctypes.c_float
         L.gbx_exp_version.restype = ctypes.c_int

@@ -145,7 +145,8 @@ class DecodeRunner:
 
     def step_greedy(self) -> torch.Tensor:
         """One greedy token: feeds the previous argmax back in.  Generic version (argmax by torch).  With a vocabulary-sharded
-        head (tensor parallel) the ranks exchange one (value, index) pair per sequence instead of the logits."""
+        head (tensor parallel) the ranks exchange one (value, index) pair per sequence instead of the logits -- and the return
+        value is then THIS RANK'S SHARD of the logits ([B, V / world]); callers that need full logits under TP use ``step()``."""
         if getattr(self.model, "tp_vocab", None) is None:
             logits = self.step(self._next)
             self._next = torch.argmax(logits, -1)
