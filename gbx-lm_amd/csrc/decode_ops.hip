@@ -272,9 +272,11 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnArgs a) {
 // Batched decode variant: one workgroup per (kv head, sequence) serves all REP query heads of the group, so every cached
 // K / V row is read ONCE per group instead of once per query head (at B = 32 the per-head kernel moved 4x the cache
 // bytes: 67 MB per layer at context 128).  Same arithmetic and layout as attn_decode_kernel.
-template <bool BF16, int HD, int REP, bool STATIC>
-__global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
-  constexpr int LP = HD / 8, PPW = 64 / LP, NG = 4 * PPW;
+// NW waves per workgroup (4, or 8: round 4 -- at B = 32 / context 128-190 the four-wave form is a chain of 8 dependent sweep rounds with
+// four heads' arithmetic in each and one wave per SIMD: 9.4 us per layer; eight waves take half the rounds each, two per SIMD).
+template <bool BF16, int HD, int REP, bool STATIC, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(AttnArgs a) {
+  constexpr int LP = HD / 8, PPW = 64 / LP, NG = NW * PPW, NT = NW * 64;
   constexpr float NEG = -1e30f;
   __shared__ float q_s[REP][HD], kn_s[HD], vn_s[HD];
   __shared__ float gm[NG][REP], gl[NG][REP];
@@ -293,14 +295,14 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
     a.k += b * a.n_kv * HD; a.v += b * a.n_kv * HD;
     a.kcache += b * a.n_kv * a.capacity * HD; a.vcache += b * a.n_kv * a.capacity * HD;
   }
-  constexpr int UB0 = 4;
+  constexpr int UB0 = NW == 4 ? 4 : 2;                 // the same 64 speculative positions (head_dim 128) either way
   const int d0 = (lane % LP) * 8, sub = lane / LP;
   const unsigned short* kbase = a.kcache + static_cast<size_t>(kvh) * a.capacity * HD;
   const unsigned short* vbase = a.vcache + static_cast<size_t>(kvh) * a.capacity * HD;
   u32x4 k0[UB0], v0[UB0];
 #pragma unroll
   for (int u = 0; u < UB0; ++u) {                   // first 4 * 4 * PPW positions requested before *pos is known
-    const int tc = min(wave * PPW + u * 4 * PPW + sub, a.capacity - 1);
+    const int tc = min(wave * PPW + u * NW * PPW + sub, a.capacity - 1);
     k0[u] = *reinterpret_cast<const u32x4*>(kbase + static_cast<size_t>(tc) * HD + d0);
     v0[u] = *reinterpret_cast<const u32x4*>(vbase + static_cast<size_t>(tc) * HD + d0);
   }
@@ -308,12 +310,12 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
   const int nctx = STATIC ? pos + 1 : pos;          // cached positions to visit
   // this workgroup's slice of them (all of them unless the launch splits the context)
   const int nsplit = a.ws ? static_cast<int>(gridDim.z) : 1, sp = a.ws ? static_cast<int>(blockIdx.z) : 0;
-  const int per = nsplit > 1 ? (((nctx + nsplit - 1) / nsplit + 4 * PPW - 1) / (4 * PPW)) * (4 * PPW) : nctx;
+  const int per = nsplit > 1 ? (((nctx + nsplit - 1) / nsplit + NW * PPW - 1) / (NW * PPW)) * (NW * PPW) : nctx;
   const int tb = sp * per, te = min(nctx, tb + per);
   const bool last_split = sp == nsplit - 1;
 
   if constexpr (STATIC) {
-    for (int p = tid; p < REP * HD; p += 256) q_s[p / HD][p % HD] = act_to_f32<BF16>(a.q[static_cast<size_t>(hq0) * HD + p]) * a.sm_scale;
+    for (int p = tid; p < REP * HD; p += NT) q_s[p / HD][p % HD] = act_to_f32<BF16>(a.q[static_cast<size_t>(hq0) * HD + p]) * a.sm_scale;
   } else {
   __shared__ float ssq_s[REP + 1];
   // projection output (+ bias, rounded to the activation dtype like the projection's own `+ bias`)
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
   if (normed) {                                     // sum of squares per head (q heads of this part, then the k head)
     if (tid <= REP) ssq_s[tid] = 0.f;
     __syncthreads();
-    for (int p = tid; p < (REP + 1) * (HD / 2); p += 256) {
+    for (int p = tid; p < (REP + 1) * (HD / 2); p += NT) {
       const int hh = p / (HD / 2), i = p % (HD / 2);
       const unsigned short* src = hh == REP ? a.k + static_cast<size_t>(kvh) * HD : a.q + (static_cast<size_t>(hq0) + hh) * HD;
       const unsigned short* bsrc = !a.q_bias ? nullptr : hh == REP ? a.k_bias + static_cast<size_t>(kvh) * HD : a.q_bias + (static_cast<size_t>(hq0) + hh) * HD;
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
     __syncthreads();
   }
   // RoPE on the REP query heads and the kv head's k; append k, v to the cache
-  for (int p = tid; p < (REP + 1) * (HD / 2); p += 256) {
+  for (int p = tid; p < (REP + 1) * (HD / 2); p += NT) {
     const int hh = p / (HD / 2), i = p % (HD / 2);   // hh == REP: the k head
     const bool isk = hh == REP;
     const unsigned short* src = isk ? a.k + static_cast<size_t>(kvh) * HD : a.q + (static_cast<size_t>(hq0) + hh) * HD;
@@ -411,17 +413,17 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
   };
 #pragma unroll
   // (the speculative first positions belong to split 0; the other splits start their own slice below)
-  for (int u = 0; u < UB0; ++u) consume(k0[u], v0[u], sp == 0 && wave * PPW + u * 4 * PPW + sub < te);
+  for (int u = 0; u < UB0; ++u) consume(k0[u], v0[u], sp == 0 && wave * PPW + u * NW * PPW + sub < te);
   // Main loop: UB positions per lane group as ONE block of the online softmax -- UB independent dot / DPP chains, one
   // rescale of the accumulators per block instead of per position (per position the chain dot -> DPP -> max -> exp ->
   // acc * corr ran serially UB times with a single wave or two per SIMD to hide it: 1.2 TB/s of cache at long contexts).
   constexpr int UB = 4;
-  for (int t0 = (sp == 0 ? UB0 * 4 * PPW : tb) + wave * PPW; t0 < te; t0 += 4 * PPW * UB) {
+  for (int t0 = (sp == 0 ? UB0 * NW * PPW : tb) + wave * PPW; t0 < te; t0 += NW * PPW * UB) {
     u32x4 kv4[UB], vv4[UB];
     bool valid[UB];
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
-      const int t = t0 + u * 4 * PPW + sub;
+      const int t = t0 + u * NW * PPW + sub;
       valid[u] = t < te;
       const int tc = valid[u] ? t : max(te - 1, 0);
       kv4[u] = *reinterpret_cast<const u32x4*>(kbase + static_cast<size_t>(tc) * HD + d0);
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnArgs a) {
     for (int j = 0; j < 8; ++j) gacc[g][r][d0 + j] = acc[r][j];
   }
   __syncthreads();
-  for (int o = tid; o < REP * HD; o += 256) {
+  for (int o = tid; o < REP * HD; o += NT) {
     const int r = o / HD, f = o % HD;
     float M = NEG;
 #pragma unroll
@@ -551,6 +553,14 @@ __global__ __launch_bounds__(HD) void attn_merge_kernel(const float* __restrict_
 template <int HD, int REP>
 static hipError_t launch_attn_gqa(const AttnArgs& a, int batch, bool bf16, hipStream_t s, int splits = 1) {
   dim3 grid(a.n_kv * (a.n_heads / a.n_kv / REP), batch, a.ws ? splits : 1), block(256);
+  static const bool wide = env_switch("GBX_ATTN_GQA_WIDE") != 0;
+  if constexpr (HD == 128 && REP == 4) {
+    if (wide && splits <= 1 && !a.ws) {               // eight waves per (kv head, sequence): unsplit contexts of batched decode
+      if (bf16) hipLaunchKernelGGL((attn_decode_gqa_kernel<true, HD, REP, false, 8>), grid, dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((attn_decode_gqa_kernel<false, HD, REP, false, 8>), grid, dim3(512), 0, s, a);
+      return hipGetLastError();
+    }
+  }
   if (bf16) hipLaunchKernelGGL((attn_decode_gqa_kernel<true, HD, REP, false>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((attn_decode_gqa_kernel<false, HD, REP, false>), grid, block, 0, s, a);
   if (a.ws && splits > 1) {

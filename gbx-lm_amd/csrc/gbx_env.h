@@ -29,6 +29,7 @@ inline const EnvSwitch* env_table(int* n) {
       {"GBX_DG_LATE", 1, "dgemv: request batch 0 behind the activation image in the launches with an RMSNorm prologue (A/B)"},
       {"GBX_NORM_WIDE", 0, "slice-sum + residual + RMSNorm launch of batched decode: 512 threads per row (measured within noise; the 256-thread default is bit-identical to gbx_add_rmsnorm)"},
       {"GBX_ATTN_WIDE", 1, "decode attention at head_dim 128: 16 waves per head with the in-wave state merge (0: 4 waves) (A/B)"},
+      {"GBX_ATTN_GQA_WIDE", 1, "batched decode attention (head_dim 128, 4 query heads per kv head, unsplit context): 8 waves per workgroup (0: 4) (A/B)"},
       {"GBX_ATTN_SPLIT_R", 0, "decode attention: force the context split (tuning aid)"},
       {"GBX_ATTN_SPLIT_MIN", 1024, "decode attention: smallest cache capacity that is split over workgroups (tuning aid)"},
       {"GBX_ATTN_SPLIT_DIV", 128, "decode attention: cached positions per split (tuning aid)"},

@@ -83,6 +83,21 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
   constexpr unsigned MAGIC = BF16 ? 0x43004300u : 0x64006400u;   // 128.0 | 1024.0 twice
   constexpr float CF = BF16 ? 128.f : 1024.f;
   constexpr unsigned FMASK = BITS == 2 ? 0x00030003u : BITS == 3 ? 0x00070007u : 0x000F000Fu;
+  // (f & FMASK) | MAGIC as ONE instruction: v_and_or_b32 is a VOP3 encoding, which on gfx9 takes no literal and one scalar operand, so left to
+  // itself the compiler emits v_and_b32 + v_or_b32 with a 32-bit literal each (round 4: 11.6 -> 7.6 vector instructions per MFMA in the
+  // compute waves).  The mask lives in an SGPR, the exponent image in a VGPR.
+  unsigned fmask_s = FMASK, magic_v = MAGIC;
+  asm volatile("" : "+s"(fmask_s));
+  asm volatile("" : "+v"(magic_v));
+  auto fld = [&](unsigned f) {
+#ifdef BX_PLAIN_FIELDS                              // A/B build (scratch/build_exp.sh): what the compiler makes of the C expression
+    return (f & FMASK) | MAGIC;
+#else
+    unsigned d;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(f), "s"(fmask_s), "v"(magic_v));
+    return d;
+#endif
+  };
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][8 chunks][32 rows][XROW] | xsum [2][8][NF][32]
   float* xsum = reinterpret_cast<float*>(smem + 2 * BUF);
   float* red = reinterpret_cast<float*>(smem);                            // after the main loop: [8 waves][MT*AE][64]
@@ -148,7 +163,8 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
   constexpr int SR = NCHW * NF >= 2 ? NCHW * NF / 2 : 1;   // dwords holding the step's NCHW * NF scales (zeros) of the lane's row
   unsigned scq[2][SR], zeq[2][SR];
   u32x4 xs[8][2];                                   // loader: activations of the step being staged
-#ifdef BX_KNOCK                                     // -DBX_KNOCK=1..4: knock-out builds (scratch/build_exp.sh), timing only
+#ifdef BX_KM                                        // -DBX_KM=<bits>: knock-out builds (scratch/build_exp.sh), timing only: 1 no x loads, 2 no staging,
+                                                    // 4 no operand build / MFMA / flush, 8 no weight loads, 16 x loads from one hot 2 KB, 32 loaders fetch the weights
 #pragma unroll
   for (int i = 0; i < 8; ++i) { xs[i][0] = u32x4{0, 0, 0, 0}; xs[i][1] = u32x4{0, 0, 0, 0}; }
 #pragma unroll
@@ -161,15 +177,15 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
 
   auto load_x = [&](int step) {
     if (!lact) return;
-#if defined(BX_KNOCK) && (BX_KNOCK == 1 || BX_KNOCK == 2)
+#if defined(BX_KM) && (BX_KM & 3)
     return;                                         // knock-out experiment: no activation loads
 #endif
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-#if defined(BX_KNOCK) && BX_KNOCK == 5               // timing only: every instruction covers whole 128-byte lines (pieces end up in the wrong lanes)
-      const unsigned short* p = xrow - lpc * 8 + xoff(it) + step * (NCHW * KC);
+#if defined(BX_KM) && (BX_KM & 16)                   // timing only: every load from the same 2 KB (row 0, first 8 chunks)
+      const unsigned short* p = a.x + lpc * 16 + (it & 7) * KC;
       xs[it][0] = *reinterpret_cast<const u32x4*>(p);
-      xs[it][1] = *reinterpret_cast<const u32x4*>(p + 64);
+      xs[it][1] = *reinterpret_cast<const u32x4*>(p + 8);
 #else
       const unsigned short* p = xrow + xoff(it) + step * (NCHW * KC);
       xs[it][0] = *reinterpret_cast<const u32x4*>(p);
@@ -177,8 +193,30 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
 #endif
     }
   };
+#if defined(BX_KM) && (BX_KM & 32)
+  // experiment: the LOADER waves fetch the step's packed words (8 lanes per 128-byte line, 8 rows per instruction) and drop them;
+  // the compute waves issue no loads at all -- what a kernel whose compute waves never touch the vector-memory path would cost
+  u32x4 wl[8];
+  auto load_wl = [&](int step) {
+    const int lt = tid & 255;
+    constexpr int LPR = NCHW * KG * WPC * 4 / 128;          // 128-byte lines per row and step
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int idx = it * 256 + lt;                          // piece of 16 B: [row][line][8 pieces]
+      const int row = idx / (8 * LPR), pc = idx % (8 * LPR);
+      if (row < NG * TNW) {
+        const uint32_t* src = a.qweight + static_cast<size_t>(min(nwg + row, a.N - 1)) * W + static_cast<size_t>(cbase) * WPC + step * (8 * WPC) + pc * 4;
+        wl[it] = *reinterpret_cast<const u32x4*>(src);
+      }
+    }
+  };
+  auto sink_wl = [&]() {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) asm volatile("" :: "v"(wl[it]));
+  };
+#endif
   auto load_w = [&](unsigned (&wn)[NCHW][WL], unsigned (&sc_n)[SR], unsigned (&ze_n)[SR], int step) {
-#if defined(BX_KNOCK) && BX_KNOCK == 4
+#if defined(BX_KM) && (BX_KM & 8)
     return;                                         // knock-out experiment: no weight loads
 #endif
 #pragma unroll
@@ -225,7 +263,7 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
   // registers -> pair order of the packed fields -> slab; xsum of the piece, reduced over the 8 lanes of a row chunk
   auto store_x = [&](int buf) {
     if (!lact) return;
-#if defined(BX_KNOCK) && BX_KNOCK == 2
+#if defined(BX_KM) && (BX_KM & 2)
     return;                                         // knock-out experiment: no staging at all
 #endif
 #pragma unroll
@@ -258,7 +296,7 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
     }
   };
   auto compute = [&](const unsigned (&wc)[NCHW][WL], const unsigned (&sc_c)[SR], const unsigned (&ze_c)[SR], int buf) {
-#if defined(BX_KNOCK) && BX_KNOCK == 3
+#if defined(BX_KM) && (BX_KM & 4)
     {                                               // knock-out experiment: loads stay, no MFMA / flush work
 #pragma unroll
       for (int j = 0; j < NCHW; ++j)
@@ -281,25 +319,22 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
           unsigned w;
           if constexpr (H == 2) w = wc[j][t] >> (8 * h);
           else w = ((h >> 1) ? wc[j][2 * t + 1] : wc[j][2 * t]) >> (8 * (h & 1));
-          bf.x = (w & FMASK) | MAGIC;        bf.y = ((w >> 2) & FMASK) | MAGIC;
-          bf.z = ((w >> 4) & FMASK) | MAGIC; bf.w = ((w >> 6) & FMASK) | MAGIC;
+          bf.x = fld(w); bf.y = fld(w >> 2); bf.z = fld(w >> 4); bf.w = fld(w >> 6);
         } else if constexpr (BITS == 2) {
           const unsigned w = wc[j][t >> 1];
           const int sh = 8 * (t & 1);
-          bf.x = ((w >> sh) & FMASK) | MAGIC;       bf.y = ((w >> (sh + 2)) & FMASK) | MAGIC;
-          bf.z = ((w >> (sh + 4)) & FMASK) | MAGIC; bf.w = ((w >> (sh + 6)) & FMASK) | MAGIC;
+          bf.x = fld(w >> sh); bf.y = fld(w >> (sh + 2)); bf.z = fld(w >> (sh + 4)); bf.w = fld(w >> (sh + 6));
         } else if constexpr (BITS == 3) {
           // unit t = the 24-bit window at bit 24 t of the lane's words; fields (2j, 2j+1) of it sit 3 bits apart: the low
           // field stays, the window shifted 13 bits up puts its neighbour on bit 16 of the same dword
           const int b0 = 24 * t, wi = b0 >> 5, sh = b0 & 31;       // constants after unrolling
           const unsigned win = sh == 0 ? wc[j][wi] : __builtin_amdgcn_alignbit(wc[j][wi + 1 < WL ? wi + 1 : WL - 1], wc[j][wi], sh);
           const unsigned p0 = win, p1 = win >> 6, p2 = win >> 12, p3 = win >> 18;
-          bf.x = (((p0 & 7u) | (p0 << 13)) & FMASK) | MAGIC; bf.y = (((p1 & 7u) | (p1 << 13)) & FMASK) | MAGIC;
-          bf.z = (((p2 & 7u) | (p2 << 13)) & FMASK) | MAGIC; bf.w = (((p3 & 7u) | (p3 << 13)) & FMASK) | MAGIC;
+          bf.x = fld((p0 & 7u) | (p0 << 13)); bf.y = fld((p1 & 7u) | (p1 << 13));
+          bf.z = fld((p2 & 7u) | (p2 << 13)); bf.w = fld((p3 & 7u) | (p3 << 13));
         } else {
           const unsigned w = wc[j][t];
-          bf.x = (w & FMASK) | MAGIC;        bf.y = ((w >> 4) & FMASK) | MAGIC;
-          bf.z = ((w >> 8) & FMASK) | MAGIC; bf.w = ((w >> 12) & FMASK) | MAGIC;
+          bf.x = fld(w); bf.y = fld(w >> 4); bf.z = fld(w >> 8); bf.w = fld(w >> 12);
         }
         const int aoff = (IL ? t * H + h : h * UPL + t) * 16;
         const bool first = t % SPG == 0;            // first step of a group: the accumulator tile restarts from zero
@@ -359,16 +394,36 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
   STAMP();
   if (loader) {
     load_x(kstep(0));
+#if defined(BX_KM) && (BX_KM & 32)
+    load_wl(kstep(0));
+#endif
     store_x(0);
+#if defined(BX_KM) && (BX_KM & 32)
+    sink_wl();
+    if (steps > 1) load_wl(kstep(1));
+#endif
     if (steps > 1) load_x(kstep(1));
     STAMP();
     __syncthreads();
     for (int step = 0; step < steps; ++step) {
+#ifdef BX_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      STAMP();                                      // (stamps build) landed
       if (step + 1 < steps) {
         store_x((step & 1) ^ 1);                    // step+1: registers -> slab (+ xsum)
+#ifdef BX_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        STAMP();                                    // stored
+#if defined(BX_KM) && (BX_KM & 32)
+        sink_wl();
+        if (step + 2 < steps) load_wl(kstep(step + 2));
+#endif
         if (step + 2 < steps) load_x(kstep(step + 2));
-      }
-      STAMP(); STAMP(); STAMP();
+      } else { STAMP(); }
+      STAMP();                                      // issued
       __syncthreads();                              // slab[buf ^ 1] complete, slab[buf] readers done
       STAMP();
     }

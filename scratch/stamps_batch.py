@@ -14,16 +14,22 @@ for it in range(3):
     big.zero_()                    # flush caches
     stamps.zero_(); torch.cuda.synchronize()
     ops.quantized_matmul(x, qw, sc, ze, group_size=g, bits=b); torch.cuda.synchronize()
-s = stamps.cpu().numpy().reshape(-1, 12, 24)[:, :8]     # compute waves
-s = s[s[:, 0, 0] > 0]
-nst = int((s[0, 0] > 0).sum())
-rel = (s - s[:, :, 0].min(axis=1)[:, None, None]).astype(np.float64)      # per workgroup: relative to its first wave's start
-names = ["start", "issued"] + sum([[f"s{i}.arrive", f"s{i}.issued", f"s{i}.computed", f"s{i}.barrier"] for i in range((nst - 3) // 4)], []) + ["end"]
-span = rel[:, :, nst - 1].max(axis=1)
-print("workgroups", s.shape[0], f"; s_memtime ticks; per-workgroup span mean {span.mean():.0f} min {span.min():.0f} max {span.max():.0f}")
-prev = None
-for i in range(nst):
-    col = rel[:, :, i]
-    d = "" if prev is None else f"  (+{col.mean() - prev:7.0f})"
-    print(f"{names[i]:12s} mean {col.mean():8.0f}  min {col.min():6.0f}  max {col.max():6.0f}{d}")
-    prev = col.mean()
+allw = stamps.cpu().numpy().reshape(-1, 12, 24)
+allw = allw[allw[:, 0, 0] > 0]
+t0 = allw[:, :, 0].min(axis=1)[:, None, None]
+for role, sl in (("compute waves", slice(0, 8)), ("loader waves", slice(8, 12))):
+    s = allw[:, sl]
+    nst = int((s[0, 0] > 0).sum())
+    rel = (s - t0).astype(np.float64)      # per workgroup: relative to its first wave's start
+    if role[0] == "c":
+        names = ["start", "issued"] + sum([[f"s{i}.arrive", f"s{i}.issued", f"s{i}.computed", f"s{i}.barrier"] for i in range((nst - 3) // 4)], []) + ["end"]
+    else:
+        names = ["start", "prologue"] + sum([[f"s{i}.landed", f"s{i}.stored", f"s{i}.issued", f"s{i}.barrier"] for i in range((nst - 3) // 4)], []) + ["end"]
+    span = rel[:, :, nst - 1].max(axis=1)
+    print(role, "workgroups", s.shape[0], f"; s_memtime ticks (10 ns); per-workgroup span mean {span.mean():.0f} min {span.min():.0f} max {span.max():.0f}")
+    prev = None
+    for i in range(nst):
+        col = rel[:, :, i]
+        d = "" if prev is None else f"  (+{col.mean() - prev:7.0f})"
+        print(f"{names[i]:12s} mean {col.mean():8.0f}  min {col.min():6.0f}  max {col.max():6.0f}{d}")
+        prev = col.mean()
