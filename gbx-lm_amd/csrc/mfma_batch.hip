@@ -442,6 +442,16 @@ __global__ __launch_bounds__(768) void qgemm_batch_kernel(const MfmaArgs a) {
         for (int q = 0; q < WL; ++q) wq[0][j][q] = wq[1][j][q];
 #pragma unroll
       for (int q = 0; q < SR; ++q) { scq[0][q] = scq[1][q]; zeq[0][q] = zeq[1][q]; }
+#ifndef BX_PLAIN_FIELDS
+      // fld() is inline assembly, and the compiler's s_waitcnt insertion does not cover a register whose FIRST consumer is an asm
+      // operand (found on scratch/negative/mfma_batch2.hip: an unshifted word was read before its load had landed).  The only loads
+      // outstanding here are this step's words, wanted now: wait for them by hand and tie the registers to the wait.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < NCHW; ++j)
+#pragma unroll
+        for (int q = 0; q < WL; ++q) asm volatile("" : "+v"(wq[0][j][q]));
+#endif
       if (step + 1 < steps) load_w(wq[1], scq[1], zeq[1], kstep(step + 1));
       STAMP();
       compute(wq[0], scq[0], zeq[0], step & 1);

@@ -24,12 +24,13 @@ for role, sl in (("compute waves", slice(0, 8)), ("loader waves", slice(8, 12)))
     if role[0] == "c":
         names = ["start", "issued"] + sum([[f"s{i}.arrive", f"s{i}.issued", f"s{i}.computed", f"s{i}.barrier"] for i in range((nst - 3) // 4)], []) + ["end"]
     else:
-        names = ["start", "prologue"] + sum([[f"s{i}.landed", f"s{i}.stored", f"s{i}.issued", f"s{i}.barrier"] for i in range((nst - 3) // 4)], []) + ["end"]
+        names = ["start", "prologue"] + sum([[f"s{i}.a", f"s{i}.b", f"s{i}.c", f"s{i}.barrier"] for i in range((nst - 3) // 4 + 1)], [])   # v1: a landed, b stored, c issued; v2: a issued(s+2), b = c parked(s+1)
     span = rel[:, :, nst - 1].max(axis=1)
     print(role, "workgroups", s.shape[0], f"; s_memtime ticks (10 ns); per-workgroup span mean {span.mean():.0f} min {span.min():.0f} max {span.max():.0f}")
     prev = None
     for i in range(nst):
         col = rel[:, :, i]
         d = "" if prev is None else f"  (+{col.mean() - prev:7.0f})"
-        print(f"{names[i]:12s} mean {col.mean():8.0f}  min {col.min():6.0f}  max {col.max():6.0f}{d}")
+        nm = names[i] if i < len(names) else f"#{i}"
+        print(f"{nm:12s} mean {col.mean():8.0f}  min {col.min():6.0f}  max {col.max():6.0f}{d}")
         prev = col.mean()
