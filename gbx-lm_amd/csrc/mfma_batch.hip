@@ -49,6 +49,10 @@
 namespace gbx {
 
 bool qgemm_batch_supported(int M, int K, int bits, int log2g);
+#ifdef BX_WITH_V2                                   // experiment builds only: scratch/negative/mfma_batch2.hip linked in (scratch/build_v2.sh)
+bool qgemm_batch2_ok(const MfmaArgs& a, int rows);
+hipError_t launch_qgemm_batch2(const MfmaArgs& a, int bits, int rows, bool bf16, hipStream_t s);
+#endif
 
 template <bool BF16> __device__ __forceinline__ float xdot2(unsigned v, float acc) {
   typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
@@ -617,7 +621,12 @@ static hipError_t launch_batch_bits(const MfmaArgs& a0, bool bf16, hipStream_t s
   if (a.ws) {                                       // 128-row workgroups x ksplit slices, then the summing launch
     // (few tiles even after the split -- o_proj: 32 x 4 -- : 64-row workgroups put one on every CU)
     const bool narrow = a.partials_only && ((a.N + 127) / 128) * a.ksplit <= 128 && a.N % 64 == 0;
+#ifdef BX_WITH_V2
+    hipError_t e = qgemm_batch2_ok(a, narrow ? 64 : 128) ? launch_qgemm_batch2(a, BITS, narrow ? 64 : 128, bf16, s)
+                   : narrow ? launch_batch_cfg<BITS, 32, 2, 4>(a, bf16, s) : launch_batch_cfg<BITS, 32, 4, 2>(a, bf16, s);
+#else
     hipError_t e = narrow ? launch_batch_cfg<BITS, 32, 2, 4>(a, bf16, s) : launch_batch_cfg<BITS, 32, 4, 2>(a, bf16, s);
+#endif
     if (e != hipSuccess || a.partials_only) return e;
     return launch_splitk_finish(a.ws, a.bias, a.y, a.ksplit, a.M, a.N, bf16, s);
   }
@@ -634,6 +643,9 @@ static hipError_t launch_batch_bits(const MfmaArgs& a0, bool bf16, hipStream_t s
   for (int i = 0; i < (a.nseg > 1 ? a.nseg : 0); ++i)
     while (a.n_seg[i] % rows) rows >>= 1;
   if (rows < 16) return hipErrorInvalidValue;
+#ifdef BX_WITH_V2
+  if (qgemm_batch2_ok(a, rows)) return launch_qgemm_batch2(a, BITS, rows, bf16, s);
+#endif
   switch (rows) {
     case 128: return launch_batch_cfg<BITS, 32, 4, 2>(a, bf16, s);
     case 64: return launch_batch_cfg<BITS, 32, 2, 4>(a, bf16, s);

@@ -138,6 +138,144 @@ __global__ __launch_bounds__(768) void qgemm_batch2_kernel(const MfmaArgs a) {
 #pragma unroll
   for (int i = 0; i < (TNW == 16 ? MT : 1); ++i) acc16[i] = f32x4v{0};
 
+#ifdef BX2_SPLIT
+  // Experiment: the two streams on DIFFERENT waves (a wave's loads retire in order: words from HBM ahead of activations from L2 in one
+  // wave's queue make the activations wait for HBM).  Waves 8, 9: activations only (two row pieces per thread); waves 10, 11: packed
+  // words + (scale, zero) only.  ROWS = 128, 2 bits (WPT = 4) as built by -DBX2_ONE.
+  if (loader && lt < 128) {
+    const int lrow = lt >> 3, lpc = lt & 7;                       // rows lrow and lrow + 16
+    const unsigned short* xrow0 = a.x + static_cast<size_t>(min(lrow, M - 1)) * K + lpc * 16 + static_cast<size_t>(cbase) * KC;
+    const unsigned short* xrow1 = a.x + static_cast<size_t>(min(lrow + 16, M - 1)) * K + lpc * 16 + static_cast<size_t>(cbase) * KC;
+    const bool act1 = !half_rows;
+    u32x4 xs[2][SCH][2][2];
+    auto issue_x = [&](int set, int ks) {
+#pragma unroll
+      for (int it = 0; it < SCH; ++it) {
+        const unsigned short* p0 = xrow0 + (ks * SCH + it) * KC;
+        const unsigned short* p1 = xrow1 + (ks * SCH + it) * KC;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xs[set][it][0][0]) : "v"(p0) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(xs[set][it][0][1]) : "v"(p0) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xs[set][it][1][0]) : "v"(p1) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(xs[set][it][1][1]) : "v"(p1) : "memory");
+      }
+    };
+    auto landed_x = [&](int set) {
+      asm volatile("s_waitcnt vmcnt(16)"
+                   : "+v"(xs[set][0][0][0]), "+v"(xs[set][0][0][1]), "+v"(xs[set][0][1][0]), "+v"(xs[set][0][1][1]),
+                     "+v"(xs[set][1][0][0]), "+v"(xs[set][1][0][1]), "+v"(xs[set][1][1][0]), "+v"(xs[set][1][1][1]),
+                     "+v"(xs[set][2][0][0]), "+v"(xs[set][2][0][1]), "+v"(xs[set][2][1][0]), "+v"(xs[set][2][1][1]),
+                     "+v"(xs[set][3][0][0]), "+v"(xs[set][3][0][1]), "+v"(xs[set][3][1][0]), "+v"(xs[set][3][1][1])
+                   :: "memory");
+    };
+    auto park_x = [&](int set, int buf) {
+#pragma unroll
+      for (int it = 0; it < SCH; ++it)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          if (rr == 1 && !act1) continue;
+          const u32x4 lo = xs[set][it][rr][0], hi = xs[set][it][rr][1];
+          u32x4 u0, u1;
+          u0.x = __builtin_amdgcn_perm(hi.x, lo.x, 0x05040100u); u0.y = __builtin_amdgcn_perm(hi.x, lo.x, 0x07060302u);
+          u0.z = __builtin_amdgcn_perm(hi.y, lo.y, 0x05040100u); u0.w = __builtin_amdgcn_perm(hi.y, lo.y, 0x07060302u);
+          u1.x = __builtin_amdgcn_perm(hi.z, lo.z, 0x05040100u); u1.y = __builtin_amdgcn_perm(hi.z, lo.z, 0x07060302u);
+          u1.z = __builtin_amdgcn_perm(hi.w, lo.w, 0x05040100u); u1.w = __builtin_amdgcn_perm(hi.w, lo.w, 0x07060302u);
+          unsigned char* dst = xb + buf * XBUF + it * CHUNK + (lrow + 16 * rr) * XROW + lpc * 32;
+          *reinterpret_cast<u32x4*>(dst) = u0;
+          *reinterpret_cast<u32x4*>(dst + 16) = u1;
+          float sm = xdot2b<BF16>(lo.x, 0.f);
+          sm = xdot2b<BF16>(lo.y, sm); sm = xdot2b<BF16>(lo.z, sm); sm = xdot2b<BF16>(lo.w, sm);
+          sm = xdot2b<BF16>(hi.x, sm); sm = xdot2b<BF16>(hi.y, sm); sm = xdot2b<BF16>(hi.z, sm); sm = xdot2b<BF16>(hi.w, sm);
+          sm += dpp_f32<0xB1>(sm); sm += dpp_f32<0x4E>(sm); sm += dpp_f32<0x141>(sm);
+          if (lpc == 0) xsum[(buf * SCH + it) * 32 + lrow + 16 * rr] = sm;
+        }
+    };
+    issue_x(0, kstep(0));
+    issue_x(1, kstep(min(1, steps - 1)));
+    landed_x(0);
+    park_x(0, 0);
+    __syncthreads();
+    for (int step = 0; step < steps; step += 2) {
+      issue_x(0, kstep(min(step + 2, steps - 1)));
+      landed_x(1);
+      park_x(1, 1);
+      __syncthreads();
+      if (step + 1 >= steps) break;
+      issue_x(1, kstep(min(step + 3, steps - 1)));
+      landed_x(0);
+      park_x(0, 0);
+      __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else if (loader) {
+    const int wt = lt - 128;
+    constexpr int WP2 = (ROWS * PPR + 127) / 128;                  // pieces per thread and step (8)
+    static_assert(WP2 == 8 && ROWS * 2 == 256, "built for 2 bits, 128 rows");
+    const uint32_t* wsrc[WP2];
+    int wdst[WP2];
+#pragma unroll
+    for (int p = 0; p < WP2; ++p) {
+      const int idx = p * 128 + wt;
+      const int row = min(idx / PPR, ROWS - 1), pc = idx % PPR;
+      const uint32_t* q; const unsigned short* s_; const unsigned short* z_;
+      const int nrow = row_src(row, q, s_, z_);
+      wsrc[p] = q + static_cast<size_t>(nrow) * W + static_cast<size_t>(cbase) * WPC + pc * 4;
+      wdst[p] = row * WROW + pc * 16;
+    }
+    const unsigned short* zsrc[2];
+    int zdst[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int ent = e * 128 + wt, row = ent >> 1, kind = ent & 1;
+      const uint32_t* q; const unsigned short* s_; const unsigned short* z_;
+      const int nrow = row_src(row, q, s_, z_);
+      zsrc[e] = (kind ? z_ : s_) + static_cast<size_t>(nrow) * G + cbase;
+      zdst[e] = row * 16 + kind * 8;
+    }
+    u32x4 wl[2][WP2];
+    u32x2 zl[2][2];
+    auto issue_w = [&](int set, int ks) {
+#pragma unroll
+      for (int p = 0; p < WP2; ++p) {
+        const uint32_t* src = wsrc[p] + static_cast<size_t>(ks) * (SCH * WPC);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wl[set][p]) : "v"(src) : "memory");
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const unsigned short* zp = zsrc[e] + ks * SCH;
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(zl[set][e]) : "v"(zp) : "memory");
+      }
+    };
+    auto landed_w = [&](int set) {
+      asm volatile("s_waitcnt vmcnt(10)"
+                   : "+v"(wl[set][0]), "+v"(wl[set][1]), "+v"(wl[set][2]), "+v"(wl[set][3]), "+v"(wl[set][4]), "+v"(wl[set][5]),
+                     "+v"(wl[set][6]), "+v"(wl[set][7]), "+v"(zl[set][0]), "+v"(zl[set][1])
+                   :: "memory");
+    };
+    auto park_w = [&](int set, int buf) {
+#pragma unroll
+      for (int p = 0; p < WP2; ++p) *reinterpret_cast<u32x4*>(wb + buf * WBUF + wdst[p]) = wl[set][p];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) *reinterpret_cast<u32x2*>(zb + buf * SZBUF + zdst[e]) = zl[set][e];
+    };
+    issue_w(0, kstep(0));
+    issue_w(1, kstep(min(1, steps - 1)));
+    landed_w(0);
+    park_w(0, 0);
+    __syncthreads();
+    for (int step = 0; step < steps; step += 2) {
+      issue_w(0, kstep(min(step + 2, steps - 1)));
+      landed_w(1);
+      park_w(1, 1);
+      __syncthreads();
+      if (step + 1 >= steps) break;
+      issue_w(1, kstep(min(step + 3, steps - 1)));
+      landed_w(0);
+      park_w(0, 0);
+      __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else
+#endif
   if (loader) {
     // ---------------- loader waves: global -> registers (two sets) -> LDS ----------------
     const int lrow = lt >> 3, lpc = lt & 7;
@@ -531,7 +669,7 @@ static hipError_t launch_batch2_cfg(const MfmaArgs& a, bool bf16, hipStream_t s)
 // rows per workgroup 128 / 64 / 32 -> (TNW, NG, KG) as in mfma_batch.hip; false: the shape is not built here (16-row workgroups,
 // groups under 128, a k range per workgroup that is not a multiple of 512)
 bool qgemm_batch2_ok(const MfmaArgs& a, int rows) {
-  static const bool on = env_switch("GBX_BATCH_V2") != 0;
+  static const bool on = !(getenv("GBX_BATCH_V2") && getenv("GBX_BATCH_V2")[0] == '0');
   const int ksplit = a.ws ? a.ksplit : 1;
 #ifdef BX2_ONE
   if (rows != 128) return false;
