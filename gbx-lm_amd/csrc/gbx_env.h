@@ -35,6 +35,7 @@ inline const EnvSwitch* env_table(int* n) {
       {"GBX_ATTN_SPLIT_DIV", 128, "decode attention: cached positions per split (tuning aid)"},
       {"GBX_ATTN_GROUPED", 0, "1: the grouped-query decode attention kernel at batch 1 too (tuning aid)"},
       {"GBX_BATCH_KSPLIT_MINK", 8192, "batch GEMM: smallest K that is split across workgroups (tuning aid)"},
+      {"GBX_DENSE_SKINNY", 1, "dense GEMM at M <= 32 (the head of a decode batch): the row-streaming kernel (0: the 256 x 256 tile) (A/B)"},
       {"GBX_BATCH_ROWS", 0, "batch GEMM: force the activation rows staged per pass (tuning aid)"},
       {"GBX_NO_BATCH_KERNEL", 0, "1: 2 <= M <= 32 on the split-K dequantising kernel instead of the no-dequant batch GEMM (diagnostic)"},
       {"GBX_PREFILL_TILE", 0, "prefill GEMM: force the tile (11 / 12 / 13) (tuning aid)"},

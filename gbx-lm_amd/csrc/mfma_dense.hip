@@ -18,6 +18,7 @@
 // phase after the counted wait + barrier that retire it (RAW); a buffer is restaged only after a barrier that follows the
 // lgkmcnt(0) retiring its last ds_read in every wave (WAR); raw s_barrier, never __syncthreads() (which would drain vmcnt).
 #include "mfma_common.h"
+#include "gbx_env.h"
 #include "kernels.h"
 
 namespace gbx {
@@ -289,6 +290,136 @@ __global__ __launch_bounds__(512) void gemm_dense_kernel(const DenseArgs2 a) {
   }
 }
 
+
+// ---- M <= 32 (the output head of a decode batch: 32 x 128256 x 4096 = 1.05 GB of weights per launch) -------------------------
+// The 256 x 256 tile above spends 8x the matrix-core work on padding rows at M = 32 (239 us, 4.4 TB/s: MFMA bound).  Here the
+// launch is a stream: a workgroup (NWV waves) owns 32 NWV weight rows over the whole k range, a step is 128 k-values -- the
+// weight tile and the 8 KB activation tile are requested as whole 256-byte row segments (16 lanes per row, 8 fully used lines
+// per wave instruction), parked in ONE LDS image (row stride 272 B: conflict-free ds_read_b128 of 32x32x16 fragments) and
+// consumed by 8 MFMAs per wave; the next step's requests are issued before the MFMAs.  Every workgroup pulls the whole 256 KB
+// of x through its CU beside its weight rows, and the CU's fill path carries the SUM: 128-row workgroups (3 per CU)
+// add 1 MB of x to 4.1 MB of weights per CU and stream at 4.5 TB/s; 256-row workgroups (8 waves, 78 KB of LDS, two per CU, 501
+// workgroups = one round) halve that.  Nothing else is close to a limit (8 MFMAs = 256 cycles against ~4000 cycles of fill per step).
+constexpr int SK = 128;                 // k-values per step
+constexpr int SROW = SK * 2 + 16;       // LDS row stride
+constexpr int skinny_lds(int nwv) { return (32 * nwv + 32) * SROW; }
+
+template <bool BF16, int NWV>
+__global__ __launch_bounds__(NWV * 64) void dense_batch_kernel(const DenseArgs2 a) {
+  constexpr int ROWS = 32 * NWV, NT = 64 * NWV, WIT = ROWS * 16 / NT, XIT = 32 * 16 / NT, RPI = NT / 16;   // pieces per thread, rows per iteration
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* const wl_s = lds;                    // [ROWS][SROW]
+  unsigned char* const xl_s = lds + ROWS * SROW;      // [32 rows][SROW]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int M = a.M, N = a.N, K = a.K;
+  const int n0 = blockIdx.x * ROWS;
+  const int steps = K / SK;
+  // loader mapping: piece idx = it * NT + tid -> (row = idx >> 4, 16-byte piece pc = idx & 15)
+  const int prow = tid >> 4, pc = tid & 15;
+  const unsigned short* wsrc = a.w + static_cast<size_t>(min(n0 + prow, N - 1)) * K + pc * 8;
+  const size_t wrowi = static_cast<size_t>(RPI) * K;  // it -> RPI rows further
+  const int pdst = prow * SROW + pc * 16;
+  // two register sets: the requests of step s+2 go out BEFORE the registers of step s+1 are parked.  The loads are inline assembly
+  // with hand-counted waits (NL per set, retired in order): the compiler's own s_waitcnt insertion loses count across the back edge
+  // and waits for the newer set too.  Requests are unconditional -- past the end the last step again.
+  static_assert(WIT == 8 && XIT == 1, "operand lists below are written for 8 waves");
+  const int rot = static_cast<int>(blockIdx.x % static_cast<unsigned>(steps));
+  constexpr int NL = WIT + XIT;
+  u32x4 wv[2][WIT], xv[2][XIT];
+  auto request = [&](int set, int step) {
+    // every workgroup walks k from a different starting step: rows are K * 2 bytes apart, so the same k offset of every row is the
+    // same few HBM channels (the camping mfma_batch.hip avoids the same way)
+    int ks = min(step, steps - 1) + rot;
+    ks = ks >= steps ? ks - steps : ks;
+    const int k0 = ks * SK;
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+      const int rr = n0 + prow + RPI * it;
+      const unsigned short* src = (rr < N ? wsrc + it * wrowi : wsrc) + k0;
+      asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(wv[set][it]) : "v"(src) : "memory");     // streamed once
+    }
+    const unsigned short* xsrc = a.x + static_cast<size_t>(min(prow, M - 1)) * K + pc * 8 + k0;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xv[set][0]) : "v"(xsrc) : "memory");
+  };
+  auto landed = [&](int set) {                       // only the NL requests of the other set may still be outstanding
+    asm volatile("s_waitcnt vmcnt(%9)"
+                 : "+v"(wv[set][0]), "+v"(wv[set][1]), "+v"(wv[set][2]), "+v"(wv[set][3]), "+v"(wv[set][4]), "+v"(wv[set][5]),
+                   "+v"(wv[set][6]), "+v"(wv[set][7]), "+v"(xv[set][0])
+                 : "n"(NL) : "memory");
+  };
+  auto park = [&](int set) {
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) *reinterpret_cast<u32x4*>(wl_s + pdst + it * RPI * SROW) = wv[set][it];
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) *reinterpret_cast<u32x4*>(xl_s + pdst + it * RPI * SROW) = xv[set][it];
+  };
+  const int r = lane & 31, h = lane >> 5;
+  const unsigned char* wfrag = wl_s + (wave * 32 + r) * SROW + h * 16;
+  const unsigned char* xfrag = xl_s + r * SROW + h * 16;
+  f32x16 acc = f32x16{0};
+  auto compute = [&]() {
+#pragma unroll
+    for (int t = 0; t < SK / 16; ++t) {
+      const u32x4 bf = *reinterpret_cast<const u32x4*>(wfrag + t * 32);
+      const u32x4 af = *reinterpret_cast<const u32x4*>(xfrag + t * 32);
+      acc = mfma<BF16>(af, bf, acc);
+    }
+  };
+  request(0, 0);
+  request(1, 1);
+  for (int step = 0; step < steps; step += 2) {
+    __syncthreads();                                  // the previous step's fragment reads are done
+    landed(0);
+    park(0);
+    request(0, step + 2);
+    __syncthreads();
+    compute();
+    if (step + 1 >= steps) break;
+    __syncthreads();
+    landed(1);
+    park(1);
+    request(1, step + 3);
+    __syncthreads();
+    compute();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the requests past the end land in registers the epilogue reuses
+  // one rounding to the activation dtype (+ bias as a second rounding, like the reference's x + bias)
+  const int n = n0 + wave * 32 + r;
+  if (n < N) {
+    const float b = a.bias ? act_to_f32<BF16>(a.bias[n]) : 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (m < M) {
+        float v = acc[e];
+        if (a.bias) v = act_to_f32<BF16>(f32_to_act<BF16>(v)) + b;
+        a.y[static_cast<size_t>(m) * N + n] = f32_to_act<BF16>(v);
+      }
+    }
+  }
+}
+
+template <int NWV>
+hipError_t launch_dense_batch_w(const DenseArgs2& a, bool bf16, hipStream_t s) {
+  constexpr int LDSB = skinny_lds(NWV);
+  static DeviceOnce once;
+  if (once.pending()) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_batch_kernel<true, NWV>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_batch_kernel<false, NWV>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+    if (e != hipSuccess) return e;
+    once.done();
+  }
+  dim3 grid((a.N + 32 * NWV - 1) / (32 * NWV)), block(64 * NWV);
+  if (bf16) hipLaunchKernelGGL((dense_batch_kernel<true, NWV>), grid, block, LDSB, s, a);
+  else hipLaunchKernelGGL((dense_batch_kernel<false, NWV>), grid, block, LDSB, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_dense_batch(const DenseArgs2& a, bool bf16, hipStream_t s) {
+  return launch_dense_batch_w<8>(a, bf16, s);
+}
+
 }  // namespace
 
 // K % 64 == 0; x and w 16-byte aligned rows (K % 8 == 0).  Byte offsets inside the kernel are 32-bit: M * K and N * K * 2 < 2^31.
@@ -315,6 +446,12 @@ size_t gemm_dense_workspace_bytes(int M, int N, int K) {
 hipError_t launch_gemm_dense(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, bool bf16, hipStream_t s,
                              bool swiglu, float* part) {
   if (swiglu && (N % 256 || bias)) return hipErrorInvalidValue;
+  static const bool skinny = env_switch("GBX_DENSE_SKINNY") != 0;
+  if (skinny && !swiglu && M <= 32 && K % SK == 0 && N >= 128 * 256) {        // a stream of weight rows: one pass, no padding rows
+    DenseArgs2 a{static_cast<const unsigned short*>(x), static_cast<const unsigned short*>(w), static_cast<const unsigned short*>(bias),
+                 static_cast<unsigned short*>(y), M, N, K, 0, nullptr, 1};
+    return launch_dense_batch(a, bf16, s);
+  }
   const int ksplit = (part && !swiglu && N % 4 == 0) ? gemm_dense_ksplit(M, N, K) : 1;
   static DeviceOnce once;
   if (once.pending()) {

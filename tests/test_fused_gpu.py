@@ -759,7 +759,8 @@ def test_partials_gemm_and_slice_folding_norm(oracle, bits, m):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("m,n,k", [(32, 128256, 4096), (2, 1000, 512), (300, 4096 + 40, 3072), (1, 256, 64)])
+@pytest.mark.parametrize("m,n,k", [(32, 128256, 4096), (2, 1000, 512), (300, 4096 + 40, 3072), (1, 256, 64),
+                                   (7, 32768 + 100, 1024), (17, 151936, 2048), (32, 32000 + 1024, 128)])   # M <= 32, N >= 32768: the row-streaming kernel
 def test_dense_forward_matches_fp64(dtype, m, n, k):
     """gbx_dense_forward (the B > 1 output head / the GEMM stage of the long-prompt path) against an fp64 matmul of the same
     16-bit operands, incl. ragged M / N and a bias."""
