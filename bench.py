@@ -100,7 +100,14 @@ def kernel_leg(model, reps=20):
             g_descs.append(ops.make_dgemv_desc(x, blk.mlp.gate_proj, act, pg, pl[0], mod_up=blk.mlp.up_proj,
                                                norm_weight=blk.post_attention_layernorm.weight.to(dt),
                                                eps=blk.post_attention_layernorm.eps, ssq_in=ssq))
-        launch, kname = ops.dgemv, f"gbx::dgemv_kernel<{bits},P1,KS1,NW16,R{pl[0]},SWIGLU,...>"
+        # which kernel gbx_dgemv_forward runs for this launch (csrc/dgemv_mx.hip:dg_mx_wanted): 2-bit group-128 bf16 SwiGLU launches take the
+        # FP4 x FP8 matrix-core form unless GBX_DG_MX=0
+        kk = g0.input_dims
+        mx = (os.environ.get("GBX_DG_MX", "1") != "0" and bits == 2 and g0.group_size == 128 and dt == torch.bfloat16 and kk % 2048 == 0
+              and kk <= 8192 and pl[0] == 2)
+        kname = (f"gbx::dgemv_mx_kernel<SP{kk // 2048},NW16,SWIGLU,LATE> (v_mfma_scale_f32_16x16x128_f8f6f4 dot products)" if mx
+                 else f"gbx::dgemv_kernel<{bits},P1,KS1,NW16,R{pl[0]},SWIGLU,...>")
+        launch = ops.dgemv
     else:
         o_descs, g_descs = [], []
         for blk in layers:
