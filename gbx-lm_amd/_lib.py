@@ -166,6 +166,7 @@ def _declare_optional(L) -> None:
         "gbx_attn_decode_batched": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, f32, i32, i32, p],
         "gbx_attn_decode_normed": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, f32, i32, p, p, f32, p, p, p, i32, p],
         "gbx_attn_decode_ws": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, f32, i32, p, p, f32, p, p, p, i32, p, ctypes.c_size_t, p],
+        "gbx_attn_decode_slices": [p, i32, p, p, p, p, p, i32, i32, i32, i32, i32, f32, f32, i32, p, p, f32, i32, p, ctypes.c_size_t, p],
         "gbx_attn_workspace_bytes": [i32, i32, i32, i32, i32],
         "gbx_attn_cached": [p, p, p, p, p, i32, i32, i32, i32, i32, f32, i32, p],
         "gbx_rope_kv_write": [p, p, p, p, p, i64, i64, i32, i32, i32, i64, i64, i64, i64, i64, i64, i32, i32, f32, i32, i32, p],

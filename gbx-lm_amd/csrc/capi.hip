@@ -437,6 +437,34 @@ int gbx_attn_decode_ws(const void* q, const void* k, const void* v, void* kcache
   return GBX_OK;
 }
 
+int gbx_attn_decode_slices(const float* qkv_slices_ws, int32_t slices, void* kcache, void* vcache, const float* inv_freq,
+                           const int64_t* pos, void* out, int32_t batch, int32_t n_heads, int32_t n_kv_heads,
+                           int32_t head_dim, int32_t capacity, float rope_scale, float sm_scale, int32_t traditional,
+                           const void* q_norm_weight, const void* k_norm_weight, float norm_eps, int32_t act_dtype, void* workspace,
+                           size_t workspace_bytes, void* hip_stream) {
+  if ((q_norm_weight == nullptr) != (k_norm_weight == nullptr)) return fail(GBX_ERR_INVALID, "q and k norm weights come together");
+  if (batch == 0) return GBX_OK;
+  if (batch < 0 || batch > 65535) return fail(GBX_ERR_INVALID, "batch must be in [0, 65535] (got %d)", batch);
+  if (!qkv_slices_ws || !kcache || !vcache || !inv_freq || !pos || !out) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (slices < 1 || slices > 8) return fail(GBX_ERR_UNSUPPORTED, "1 <= slices <= 8 (got %d)", slices);
+  if (head_dim != 64 && head_dim != 128) return fail(GBX_ERR_UNSUPPORTED, "head_dim must be 64 or 128 (got %d)", head_dim);
+  if (n_heads <= 0 || n_kv_heads <= 0 || n_heads % n_kv_heads) return fail(GBX_ERR_INVALID, "n_heads must be a multiple of n_kv_heads");
+  if (capacity <= 0) return fail(GBX_ERR_INVALID, "capacity must be positive");
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  if (!aligned(kcache, 16) || !aligned(vcache, 16) || !aligned(qkv_slices_ws, 4)) return fail(GBX_ERR_INVALID, "misaligned pointer");
+  float* ws = nullptr;
+  {
+    const size_t need = gbx::attn_workspace_bytes(batch, n_heads, n_kv_heads, head_dim, capacity);
+    if (workspace && need && workspace_bytes >= need && aligned(workspace, 16)) ws = static_cast<float*>(workspace);
+  }
+  hipError_t e = gbx::launch_attn_decode(nullptr, nullptr, nullptr, kcache, vcache, inv_freq, reinterpret_cast<const long long*>(pos), out,
+                                         batch, n_heads, n_kv_heads, head_dim, capacity, rope_scale, sm_scale, traditional,
+                                         act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream), q_norm_weight, k_norm_weight,
+                                         norm_eps, nullptr, nullptr, nullptr, ws, qkv_slices_ws, slices);
+  if (e != hipSuccess) return hip_fail(e, "gbx_attn_decode_slices launch");
+  return GBX_OK;
+}
+
 int gbx_embed_next_token(void* argmax_keys, int64_t* token_io, int64_t* pos, const void* embed_table, void* h,
                          int32_t D, int32_t vocab, int32_t from_keys, int32_t advance_pos, int32_t act_dtype, void* hip_stream) {
   if (!argmax_keys || !token_io || !pos || !embed_table || !h) return fail(GBX_ERR_INVALID, "null device pointer");

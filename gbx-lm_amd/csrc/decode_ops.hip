@@ -37,6 +37,12 @@ struct AttnArgs {
   // split s writes (num[HD], max, den) per head to ws[((b * n_heads + head) * splits + s) * (HD + 2)] and a second launch
   // merges them (caller-owned scratch)
   float* ws;
+  // grouped kernel only (batched decode): q | k | v arrive as the fp32 slices of ONE k-split GEMM over the concatenated projection,
+  // qkv_ws[slice][batch][qkv_n] with qkv_n = (n_heads + 2 n_kv) * HD (columns q | k | v); a value is round(ws[0] + ws[1] + ...) exactly
+  // as the GEMM's summing launch would have written it (batch_finish_kernel).  q / k / v above are then unused (null).
+  const float* qkv_ws;
+  int qkv_slices;
+  long long qkv_mn;             // floats per slice = batch * qkv_n
 #ifdef GBX_STAMPS
   unsigned long long* stamps;   // diagnostic build only
 #endif
@@ -291,8 +297,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(AttnArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   {
     const size_t b = blockIdx.y;
-    a.q += b * a.n_heads * HD; a.out += b * a.n_heads * HD;
-    a.k += b * a.n_kv * HD; a.v += b * a.n_kv * HD;
+    a.out += b * a.n_heads * HD;
+    if (a.q) { a.q += b * a.n_heads * HD; a.k += b * a.n_kv * HD; a.v += b * a.n_kv * HD; }
     a.kcache += b * a.n_kv * a.capacity * HD; a.vcache += b * a.n_kv * a.capacity * HD;
   }
   constexpr int UB0 = NW == 4 ? 4 : 2;                 // the same 64 speculative positions (head_dim 128) either way
@@ -319,10 +325,27 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(AttnArgs a) {
   } else {
   __shared__ float ssq_s[REP + 1];
   // projection output (+ bias, rounded to the activation dtype like the projection's own `+ bias`)
-  auto ldb = [](const unsigned short* src, const unsigned short* bias, int i) {
-    const float x = act_to_f32<BF16>(src[i]);
+  // (`col`: first column of this head inside the concatenated q | k | v row, for the slice form)
+  const int qkv_n = (a.n_heads + 2 * a.n_kv) * HD;
+  const float* wsrow = a.qkv_ws ? a.qkv_ws + static_cast<size_t>(blockIdx.y) * qkv_n : nullptr;
+  auto ldb = [&](int col, const unsigned short* src, const unsigned short* bias, int i) {
+    float x;
+    if (wsrow) {                                    // every slice requested before the first add; v = ws[0]; v += ws[s], s = 1..
+      const float* p = wsrow + col + i;
+      float t[8];
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl) t[sl] = p[static_cast<size_t>(min(sl, a.qkv_slices - 1)) * a.qkv_mn];
+      float v = t[0];
+#pragma unroll
+      for (int sl = 1; sl < 8; ++sl)
+        if (sl < a.qkv_slices) v += t[sl];
+      x = act_to_f32<BF16>(f32_to_act<BF16>(v));
+    } else {
+      x = act_to_f32<BF16>(src[i]);
+    }
     return bias ? act_to_f32<BF16>(f32_to_act<BF16>(x + act_to_f32<BF16>(bias[i]))) : x;
   };
+  const int col_k = a.n_heads * HD + kvh * HD, col_v = (a.n_heads + a.n_kv) * HD + kvh * HD;
   const bool normed = a.qn_w != nullptr;
   const bool writer = blockIdx.x % parts == 0 && blockIdx.z == 0;   // one workgroup of the kv group appends k, v
   if (normed) {                                     // sum of squares per head (q heads of this part, then the k head)
@@ -332,7 +355,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(AttnArgs a) {
       const int hh = p / (HD / 2), i = p % (HD / 2);
       const unsigned short* src = hh == REP ? a.k + static_cast<size_t>(kvh) * HD : a.q + (static_cast<size_t>(hq0) + hh) * HD;
       const unsigned short* bsrc = !a.q_bias ? nullptr : hh == REP ? a.k_bias + static_cast<size_t>(kvh) * HD : a.q_bias + (static_cast<size_t>(hq0) + hh) * HD;
-      const float x1 = ldb(src, bsrc, 2 * i), x2 = ldb(src, bsrc, 2 * i + 1);
+      const int col = hh == REP ? col_k : (hq0 + hh) * HD;
+      const float x1 = ldb(col, src, bsrc, 2 * i), x2 = ldb(col, src, bsrc, 2 * i + 1);
       atomicAdd(&ssq_s[hh], x1 * x1 + x2 * x2);
     }
     __syncthreads();
@@ -345,7 +369,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(AttnArgs a) {
     const int i1 = a.traditional ? 2 * i : i;
     const int i2 = a.traditional ? 2 * i + 1 : i + HD / 2;
     const unsigned short* bsrc = !a.q_bias ? nullptr : isk ? a.k_bias + static_cast<size_t>(kvh) * HD : a.q_bias + (static_cast<size_t>(hq0) + hh) * HD;
-    float x1 = ldb(src, bsrc, i1), x2 = ldb(src, bsrc, i2);
+    const int col = isk ? col_k : (hq0 + hh) * HD;
+    float x1 = ldb(col, src, bsrc, i1), x2 = ldb(col, src, bsrc, i2);
     if (normed) {                                   // RMSNorm output rounded to the activation dtype, like the separate op
       const float rstd = rsqrtf(ssq_s[hh] / static_cast<float>(HD) + a.norm_eps);
       const unsigned short* w = isk ? a.kn_w : a.qn_w;
@@ -370,7 +395,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(AttnArgs a) {
     }
   }
   if (tid < HD) {
-    const unsigned short vb = f32_to_act<BF16>(ldb(a.v + static_cast<size_t>(kvh) * HD, a.v_bias ? a.v_bias + static_cast<size_t>(kvh) * HD : nullptr, tid));
+    const unsigned short vb = f32_to_act<BF16>(ldb(col_v, a.v + static_cast<size_t>(kvh) * HD, a.v_bias ? a.v_bias + static_cast<size_t>(kvh) * HD : nullptr, tid));
     vn_s[tid] = act_to_f32<BF16>(vb);
     if (writer) a.vcache[(static_cast<size_t>(kvh) * a.capacity + pos) * HD + tid] = vb;
   }
@@ -638,7 +663,7 @@ hipError_t launch_attn_decode(const void* q, const void* k, const void* v, void*
                               const long long* pos, void* out, int batch, int n_heads, int n_kv, int head_dim, int capacity,
                               float rope_scale, float sm_scale, int traditional, bool bf16, hipStream_t s,
                               const void* q_norm_w, const void* k_norm_w, float norm_eps, const void* q_bias, const void* k_bias,
-                              const void* v_bias, float* ws) {
+                              const void* v_bias, float* ws, const float* qkv_ws, int qkv_slices) {
   AttnArgs a{static_cast<const unsigned short*>(q), static_cast<const unsigned short*>(k), static_cast<const unsigned short*>(v),
              static_cast<unsigned short*>(kcache), static_cast<unsigned short*>(vcache), inv_freq, pos,
              static_cast<unsigned short*>(out), n_heads, n_kv, capacity, rope_scale, sm_scale, traditional,
@@ -651,8 +676,12 @@ hipError_t launch_attn_decode(const void* q, const void* k, const void* v, void*
   const int rep = n_heads / n_kv;
   const int splits = ws ? attn_splits(batch, n_heads, n_kv, capacity) : 1;
   if (splits > 1) a.ws = ws;
+  if (qkv_ws) {
+    a.qkv_ws = qkv_ws; a.qkv_slices = qkv_slices;
+    a.qkv_mn = static_cast<long long>(batch) * (n_heads + 2 * n_kv) * head_dim;
+  }
   static const bool force_grouped = (gbx::env_switch("GBX_ATTN_GROUPED") != 0);    // tuning aid: grouped kernel at batch 1 too
-  if (q_norm_w || q_bias || (batch > 1 && rep > 1) || (force_grouped && rep > 1) || splits > 1) {         // grouped kernel: batched decode, or q/k norms (any batch)
+  if (q_norm_w || q_bias || qkv_ws || (batch > 1 && rep > 1) || (force_grouped && rep > 1) || splits > 1) {   // grouped kernel: batched decode, or q/k norms (any batch)
     // 2 heads per workgroup when the context is split: 120 VGPRs -> two workgroups per CU, whose waves cover each other's
     // dependent dot / DPP / exp chains (with 4 heads, 166 VGPRs, one wave per SIMD ran the cache at 1.2 TB/s)
     static const int force_r = gbx::env_switch("GBX_ATTN_SPLIT_R");

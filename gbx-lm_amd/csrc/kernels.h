@@ -104,7 +104,7 @@ hipError_t launch_attn_decode(const void* q, const void* k, const void* v, void*
                               float rope_scale, float sm_scale, int traditional, bool bf16, hipStream_t s,
                               const void* q_norm_w = nullptr, const void* k_norm_w = nullptr, float norm_eps = 0.f,
                               const void* q_bias = nullptr, const void* k_bias = nullptr, const void* v_bias = nullptr,
-                              float* ws = nullptr);
+                              float* ws = nullptr, const float* qkv_ws = nullptr, int qkv_slices = 0);
 int attn_splits(int batch, int n_heads, int n_kv, int capacity);
 // p2p_allreduce.hip: one-shot push all-reduce of a short 16-bit vector over peer-mapped inboxes
 hipError_t launch_p2p_allreduce(void* x, int n, int rank, int world, void* const* inbox, int cap, void* state, bool bf16, hipStream_t s);

@@ -39,6 +39,23 @@ class DecodeRunner:
         self.n_heads, self.n_kv, self.hd = a0.n_heads, a0.n_kv_heads, a0.head_dim
         self.ar = torch.arange(self.capacity, device=self.dev)
         self.tp_world = getattr(model, "tp_world", 1)
+        # B > 1: q|k|v as ONE row-concatenated matrix (+7 MB per 2-bit 8B layer) so that the batch GEMM can split k across workgroups --
+        # every workgroup then stages a quarter of the activations, the term that bounds it -- and leave fp32 slices that the
+        # attention launch sums (gbx_attn_decode_slices); 11.5 -> 9.4 us per layer at B = 32
+        self.qkv_cat = {}
+        if self.batch > 1 and self.tp_world == 1 and env.flag("GBX_QKV_SLICES"):
+            from .models.quantized_linear_gba import QuantizedLinear
+            for li, layer in enumerate(model.model.layers):
+                at = layer.self_attn
+                mods = (at.q_proj, at.k_proj, at.v_proj)
+                if (len({(m.bits, m.group_size, m.input_dims) for m in mods}) == 1 and all(m.bias is None for m in mods)
+                        and all(getattr(m, "scales", None) is not None and m.scales.dtype == self.dtype for m in mods)
+                        and self.hd in (64, 128) and at.rope.inv_freq.numel() * 2 == self.hd
+                        and type(at.rope).__name__ in ("RoPE", "Llama3RoPE")):
+                    cat = QuantizedLinear(at.q_proj.input_dims, sum(m.output_dims for m in mods), False, at.q_proj.group_size, at.q_proj.bits)
+                    for nm in ("qweight", "scales", "zeros"):
+                        cat._buffers[nm] = torch.cat([getattr(m, nm) for m in mods]).contiguous()
+                    self.qkv_cat[li] = cat
         self.use_graph = use_graph
         if use_graph:
             self._capture()
@@ -51,7 +68,7 @@ class DecodeRunner:
         h = m.embed_tokens(self.tok)[:, None].contiguous()       # [B, 1, D]
         mask = None
         delta = None                                             # residual branch not yet added to h
-        for layer, c in zip(m.layers, self.caches):
+        for li, (layer, c) in enumerate(zip(m.layers, self.caches)):
             at = layer.self_attn
             norm = layer.input_layernorm
             # residual add of the previous block fused with this norm (gbx_add_rmsnorm); plain norm for the first layer
@@ -61,10 +78,23 @@ class DecodeRunner:
                 x = ops.add_rmsnorm_slices(h, delta[0], delta[1], norm.weight, norm.eps)
             else:
                 x = ops.add_rmsnorm(h, delta, norm.weight, norm.eps)
-            q, k, v = (t.reshape(B, -1) for t in ops.quantized_matmul_multi(x, (at.q_proj, at.k_proj, at.v_proj)))
-            full_rope = at.rope.inv_freq.numel() * 2 == self.hd and c.keys.is_contiguous() and c.values.is_contiguous()
             qn, kn = getattr(at, "q_norm", None), getattr(at, "k_norm", None)       # Qwen3: per-head norms before RoPE
-            if full_rope and self.hd in (64, 128) and type(at.rope).__name__ in ("RoPE", "Llama3RoPE"):
+            cat = self.qkv_cat.get(li)
+            parts = ops.quantized_matmul_partials(x.reshape(B, -1), cat) if (cat is not None and c.keys.is_contiguous() and c.values.is_contiguous()) else None
+            if parts is not None and parts[1] <= 8:
+                # one k-split GEMM over q|k|v, its slices summed inside the attention launch
+                o = torch.empty((B, self.n_heads * self.hd), dtype=self.dtype, device=self.dev)
+                ops.attn_decode_slices(parts[0], parts[1], c.keys, c.values, at.rope.inv_freq, pos, o, self.n_heads, self.n_kv, self.hd,
+                                       getattr(at.rope, "scale", 1.0), at.scale, at.rope.traditional,
+                                       qn.weight if qn is not None else None, kn.weight if kn is not None else None,
+                                       qn.eps if qn is not None else 0.0)
+                q = k = v = None
+            else:
+                q, k, v = (t.reshape(B, -1) for t in ops.quantized_matmul_multi(x, (at.q_proj, at.k_proj, at.v_proj)))
+            full_rope = at.rope.inv_freq.numel() * 2 == self.hd and c.keys.is_contiguous() and c.values.is_contiguous()
+            if q is None:
+                pass
+            elif full_rope and self.hd in (64, 128) and type(at.rope).__name__ in ("RoPE", "Llama3RoPE"):
                 # one launch per layer: (q / k norm +) RoPE(q, k) + cache append + softmax(q k^T) v for every sequence
                 o = torch.empty_like(q)
                 ops.attn_decode_batched(q, k, v, c.keys, c.values, at.rope.inv_freq, pos, o, self.n_heads, self.n_kv, self.hd,

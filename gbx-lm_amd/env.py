@@ -13,6 +13,7 @@ TABLE = {
     "GBX_DGEMV": ("1", "FusedDecodeRunner: the four GEMV launches of a block on gbx_dgemv_forward (0: gbx_qlinear_fused_forward) (A/B)"),
     "GBX_DG_SSQ": ("1", "FusedDecodeRunner: carry the RMSNorm statistic from the o_proj / down_proj launch to the next norm'd launch (A/B)"),
     "GBX_QKV_CAT": ("1", "FusedDecodeRunner: q|k|v as one matrix concatenated at load time (A/B)"),
+    "GBX_QKV_SLICES": ("1", "DecodeRunner (B > 1): q|k|v as ONE k-split GEMM whose fp32 slices the attention launch sums (0: three segments, one launch, no split) (A/B)"),
     "GBX_FUSE_AO": ("0", "FusedDecodeRunner: attention + o_proj as one launch (libgbx_experimental.so; measured neutral)"),
     "GBX_GEMV_MXD": ("0", "route the fused GEMV launches through libgbx_experimental.so's one-row-per-operand scaled-MFMA GEMV (1: all eligible, 2: gate|up only)"),
     "GBX_GEMV_MX": ("0", "route the fused GEMV launches through libgbx_experimental.so's loader/consumer scaled-MFMA GEMV"),

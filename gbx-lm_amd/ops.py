@@ -811,6 +811,26 @@ def attn_decode_batched(q, k, v, kcache, vcache, inv_freq, pos, out, n_heads: in
                                                  workspace.numel() if workspace is not None else 0, _stream_ptr(q.device)))
 
 
+def attn_decode_slices(qkv_ws: torch.Tensor, slices: int, kcache, vcache, inv_freq, pos, out, n_heads: int, n_kv: int, head_dim: int,
+                       rope_scale: float, sm_scale: float, traditional: bool, q_norm_w=None, k_norm_w=None, norm_eps: float = 0.0,
+                       workspace=None) -> None:
+    """``attn_decode_batched`` whose q | k | v are the fp32 slices ``qkv_ws [slices, B, (n_heads + 2 n_kv) * hd]`` that
+    ``quantized_matmul_partials`` left for the row-concatenated projection (gbx_attn_decode_slices): the sum of the slices is formed,
+    rounded like the GEMM's own summing launch, inside the attention launch."""
+    b, cap = kcache.shape[0], kcache.shape[2]
+    assert qkv_ws.dtype == torch.float32 and qkv_ws.numel() >= slices * b * (n_heads + 2 * n_kv) * head_dim
+    if workspace is None:
+        need = _lib.lib().gbx_attn_workspace_bytes(b, n_heads, n_kv, head_dim, cap)
+        workspace = torch.empty((need,), dtype=torch.uint8, device=out.device) if need else None
+    _lib.check(_lib.lib().gbx_attn_decode_slices(qkv_ws.data_ptr(), int(slices), kcache.data_ptr(), vcache.data_ptr(), inv_freq.data_ptr(),
+                                                 pos.data_ptr(), out.data_ptr(), b, n_heads, n_kv, head_dim, cap, float(rope_scale),
+                                                 float(sm_scale), int(bool(traditional)),
+                                                 q_norm_w.data_ptr() if q_norm_w is not None else None,
+                                                 k_norm_w.data_ptr() if k_norm_w is not None else None, float(norm_eps), _DT[out.dtype],
+                                                 workspace.data_ptr() if workspace is not None else None,
+                                                 workspace.numel() if workspace is not None else 0, _stream_ptr(out.device)))
+
+
 def attn_cached(q: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, pos: torch.Tensor, scale: float) -> torch.Tensor:
     """softmax(q K^T * scale) V for ONE query token per sequence over cache positions 0..pos (device int64), the new
     token's k / v already stored: q [B, Hq, 1, D] (rotated), caches [B, Hkv, cap, D] -> [B, Hq, 1, D] (gbx_attn_cached)."""

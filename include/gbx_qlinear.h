@@ -363,6 +363,18 @@ int gbx_attn_decode_ws(const void* q, const void* k, const void* v, void* kcache
                        const void* k_bias, const void* v_bias, int32_t act_dtype, void* workspace, size_t workspace_bytes,
                        void* hip_stream);
 
+/* gbx_attn_decode_ws whose q | k | v arrive as the fp32 slices of ONE k-split batch GEMM over the row-concatenated projection
+ * (gbx_qlinear_forward_partials on [q_proj; k_proj; v_proj], N = (n_heads + 2 n_kv_heads) * head_dim): qkv_slices_ws[slices][batch][N],
+ * 1 <= slices <= 8.  Every value is round(ws[0] + ws[1] + ...) to the activation dtype, the rounding and order of the GEMM's own summing
+ * launch -- the results are bit-identical to gbx_attn_decode_ws on the summed q, k, v -- so the batched decode step of
+ * gbx_lm/models/qllama.py:76-95 ([B, 1, K] through q_proj / k_proj / v_proj, RoPE, cache update, SDPA) costs one GEMM launch that
+ * stages a quarter of the activations per workgroup and no summing launch.  Bias-free projections only. */
+int gbx_attn_decode_slices(const float* qkv_slices_ws, int32_t slices, void* kcache, void* vcache, const float* inv_freq,
+                           const int64_t* pos, void* out, int32_t batch, int32_t n_heads, int32_t n_kv_heads,
+                           int32_t head_dim, int32_t capacity, float rope_scale, float sm_scale, int32_t traditional,
+                           const void* q_norm_weight, const void* k_norm_weight, float norm_eps, int32_t act_dtype, void* workspace,
+                           size_t workspace_bytes, void* hip_stream);
+
 /* Single-token attention over a cache that already holds the new token: out[b, h, :] = softmax(q[b, h, :] . K[b, kv(h), 0..*pos, :]^T
  * * sm_scale) V[b, kv(h), 0..*pos, :] with q [batch, n_heads, head_dim] already rotated, caches [batch, n_kv, capacity, head_dim],
  * `pos` a DEVICE int64.  mx.fast.scaled_dot_product_attention as every model graph calls it for L = 1 (models/base.py:65-92),

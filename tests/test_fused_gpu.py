@@ -104,6 +104,62 @@ def test_attn_decode_matches_torch(hd, nh, nkv, pos):
     assert torch.allclose(out.float(), want, atol=2e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("hd,nh,nkv,slices,B,normed", [(128, 32, 8, 4, 32, False), (128, 8, 2, 7, 3, True), (64, 4, 4, 1, 2, False), (128, 6, 2, 8, 5, False)])
+def test_attn_decode_slices_is_the_summed_projection_bit_for_bit(hd, nh, nkv, slices, B, normed):
+    """gbx_attn_decode_slices (q | k | v as the fp32 slices of one k-split GEMM) against gbx_attn_decode_ws on the slices summed and
+    rounded the way the GEMM's own summing launch does (v = ws[0]; v += ws[s]; one rounding): outputs and both caches identical."""
+    from gbx_lm_amd import ops
+    from gbx_lm_amd.models.rope_utils import RoPE
+    torch.manual_seed(hd + slices)
+    cap, pos = 192, 137
+    n = (nh + 2 * nkv) * hd
+    ws = (torch.randn(slices, B, n, device=DEV) * 0.6).float()
+    acc = ws[0].clone()
+    for sl in range(1, slices):
+        acc += ws[sl]
+    qkv = acc.to(torch.bfloat16)
+    q, k, v = qkv[:, :nh * hd].contiguous(), qkv[:, nh * hd:(nh + nkv) * hd].contiguous(), qkv[:, (nh + nkv) * hd:].contiguous()
+    kc = torch.randn(B, nkv, cap, hd, device=DEV).to(torch.bfloat16)
+    vc = torch.randn(B, nkv, cap, hd, device=DEV).to(torch.bfloat16)
+    rope = RoPE(hd, traditional=False, base=500000.0)
+    inv = rope.inv_freq.to(DEV)
+    qn = (torch.rand(hd, device=DEV) + 0.5).to(torch.bfloat16) if normed else None
+    kn = (torch.rand(hd, device=DEV) + 0.5).to(torch.bfloat16) if normed else None
+    p = torch.tensor([pos], device=DEV)
+    k1, v1, k2, v2 = kc.clone(), vc.clone(), kc.clone(), vc.clone()
+    o1 = torch.zeros(B, nh * hd, dtype=torch.bfloat16, device=DEV)
+    o2 = torch.zeros_like(o1)
+    ops.attn_decode_batched(q, k, v, k1, v1, inv, p, o1, nh, nkv, hd, 1.0, hd ** -0.5, False, qn, kn, 1e-6)
+    ops.attn_decode_slices(ws, slices, k2, v2, inv, p, o2, nh, nkv, hd, 1.0, hd ** -0.5, False, qn, kn, 1e-6)
+    assert torch.equal(k1, k2) and torch.equal(v1, v2), "cache rows appended from the slices"
+    assert torch.equal(o1, o2)
+
+
+def test_batched_runner_qkv_slices_switch_agrees():
+    """DecodeRunner at B = 4 with q|k|v as one k-split GEMM + gbx_attn_decode_slices (the default) against the three-segment launch
+    (GBX_QKV_SLICES=0).  The attention launch is bit-identical to the summing launch it replaces (test above); the GEMM itself adds
+    its k ranges in a different association when k is split across workgroups, so the logits agree to rounding, not bit for bit."""
+    import os
+    import bench
+    from gbx_lm_amd import synthetic as S
+    from gbx_lm_amd.decode import DecodeRunner
+    cfg = dict(S.LLAMA3_8B, num_hidden_layers=2, vocab_size=2048)
+    model = S.build_model(cfg, S.make_strategy("S22", 2, 128), device=DEV, seed=11)
+    outs = []
+    for flag in ("1", "0"):
+        os.environ["GBX_QKV_SLICES"] = flag
+        try:
+            r = DecodeRunner(model, bench.make_caches(model, 4, 64, DEV), use_graph=False)
+            assert bool(r.qkv_cat) == (flag == "1")
+            lg = [r.step(torch.tensor([3 + t, 9, 100 + t, 7], device=DEV)).float().clone() for t in range(5)]
+        finally:
+            os.environ.pop("GBX_QKV_SLICES", None)
+        outs.append(torch.stack(lg))
+    assert torch.isfinite(outs[0]).all()
+    scale = outs[1].abs().mean().item()
+    assert (outs[0] - outs[1]).abs().max().item() <= 0.05 * scale + 0.02 * outs[1].abs().max().item()
+
+
 @pytest.mark.parametrize("hd,nh,nkv,traditional", [(128, 8, 2, False), (64, 4, 4, True), (128, 6, 2, True), (128, 4, 2, False)])
 def test_attn_decode_batched_matches_torch(hd, nh, nkv, traditional):
     """gbx_attn_decode_batched: B sequences at the same position, each against its own cache rows."""
