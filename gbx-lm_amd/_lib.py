@@ -145,7 +145,7 @@ class DgDesc(ctypes.Structure):
 
 GBX_DG_PLAIN, GBX_DG_RESIDUAL, GBX_DG_SWIGLU = 0, 1, 2
 GBX_DG_SSQ_SLOTS = 1024
-GBX_MIN_VERSION = 1100          # the header this binding mirrors
+GBX_MIN_VERSION = 1101          # the header this binding mirrors
 
 
 def _declare_optional(L) -> None:
