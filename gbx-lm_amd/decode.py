@@ -88,12 +88,12 @@ class DecodeRunner:
                                        getattr(at.rope, "scale", 1.0), at.scale, at.rope.traditional,
                                        qn.weight if qn is not None else None, kn.weight if kn is not None else None,
                                        qn.eps if qn is not None else 0.0)
-                q = k = v = None
+                q = None
             else:
                 q, k, v = (t.reshape(B, -1) for t in ops.quantized_matmul_multi(x, (at.q_proj, at.k_proj, at.v_proj)))
             full_rope = at.rope.inv_freq.numel() * 2 == self.hd and c.keys.is_contiguous() and c.values.is_contiguous()
             if q is None:
-                pass
+                pass                                 # (attention already done from the slices)
             elif full_rope and self.hd in (64, 128) and type(at.rope).__name__ in ("RoPE", "Llama3RoPE"):
                 # one launch per layer: (q / k norm +) RoPE(q, k) + cache append + softmax(q k^T) v for every sequence
                 o = torch.empty_like(q)
