@@ -89,6 +89,17 @@ def test_glue_entry_points_validate_arguments_on_the_host(lib):
     assert lib.gbx_attn_decode_batched(*args, 2, 8, 3, 128, 64, 1.0, 0.1, 0, _lib.GBX_BF16, None) == _lib.GBX_ERR_INVALID
     with pytest.raises(NotImplementedError, match="head_dim"):
         _lib.check(lib.gbx_attn_decode_batched(*args, 2, 8, 2, 96, 64, 1.0, 0.1, 0, _lib.GBX_BF16, None))
+    # the slice form of the batched attention (round 4): q | k | v as fp32 slices of one k-split GEMM
+    sl = (one, one, one, one, one)                                 # kcache, vcache, inv_freq, pos, out
+    tail = (1.0, 0.1, 0, None, None, 0.0, _lib.GBX_BF16, None, 0, None)
+    assert lib.gbx_attn_decode_slices(one, 4, *sl, 0, 8, 2, 128, 64, *tail) == _lib.GBX_OK             # empty batch
+    assert lib.gbx_attn_decode_slices(one, 0, *sl, 2, 8, 2, 128, 64, *tail) == _lib.GBX_ERR_UNSUPPORTED   # slices
+    assert lib.gbx_attn_decode_slices(one, 9, *sl, 2, 8, 2, 128, 64, *tail) == _lib.GBX_ERR_UNSUPPORTED
+    assert lib.gbx_attn_decode_slices(one, 4, *sl, 2, 8, 2, 96, 64, *tail) == _lib.GBX_ERR_UNSUPPORTED    # head_dim
+    assert lib.gbx_attn_decode_slices(one, 4, *sl, 2, 8, 3, 128, 64, *tail) == _lib.GBX_ERR_INVALID       # n_heads % n_kv
+    assert lib.gbx_attn_decode_slices(None, 4, *sl, 2, 8, 2, 128, 64, *tail) == _lib.GBX_ERR_INVALID      # null slices
+    assert lib.gbx_attn_decode_slices(one, 4, *sl, 2, 8, 2, 128, 64, 1.0, 0.1, 0, one, None, 0.0, _lib.GBX_BF16, None, 0, None) \
+        == _lib.GBX_ERR_INVALID                                                                    # q norm without k norm
 
 
 def test_round2_entry_points_validate_arguments_on_the_host(lib):
