@@ -63,6 +63,9 @@ def lib() -> ctypes.CDLL:
             L.gbx_qlinear_partials_bytes.argtypes = [i64, i32, i32, i32, i32]
             L.gbx_qlinear_partials_bytes.restype = ctypes.c_size_t
         L.gbx_attn_workspace_bytes.restype = ctypes.c_size_t
+        if hasattr(L, 'gbx_dattn_state_bytes'):
+            L.gbx_dattn_state_bytes.argtypes = []
+            L.gbx_dattn_state_bytes.restype = ctypes.c_size_t
         if hasattr(L, 'gbx_p2p_inbox_bytes'):
             L.gbx_p2p_inbox_bytes.argtypes = [i32, i32]
             L.gbx_p2p_inbox_bytes.restype = ctypes.c_size_t
@@ -140,12 +143,25 @@ class DgDesc(ctypes.Structure):
                 ("y", ctypes.c_void_p), ("residual", ctypes.c_void_p), ("norm_weight", ctypes.c_void_p),
                 ("ssq_in", ctypes.c_void_p), ("ssq_out", ctypes.c_void_p),
                 ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("bits", ctypes.c_int32), ("group_size", ctypes.c_int32),
-                ("act_dtype", ctypes.c_int32), ("rows_per_batch", ctypes.c_int32), ("norm_eps", ctypes.c_float)]
+                ("act_dtype", ctypes.c_int32), ("rows_per_batch", ctypes.c_int32), ("norm_eps", ctypes.c_float),
+                ("x_acc", ctypes.c_void_p), ("x_out", ctypes.c_void_p), ("zero_buf", ctypes.c_void_p), ("zero_n", ctypes.c_int32)]
+
+
+class DattnDesc(ctypes.Structure):
+    """Mirror of ``gbx_dattn`` (include/gbx_qlinear.h): the fused attention launch of a decoder block at M == 1."""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("act_dtype", ctypes.c_int32),
+                ("x", ctypes.c_void_p), ("norm_weight", ctypes.c_void_p), ("ssq_in", ctypes.c_void_p),
+                ("qkv_qweight", ctypes.c_void_p), ("qkv_sz", ctypes.c_void_p), ("kcache", ctypes.c_void_p), ("vcache", ctypes.c_void_p),
+                ("inv_freq", ctypes.c_void_p), ("pos", ctypes.c_void_p), ("o_qweight", ctypes.c_void_p), ("o_scales", ctypes.c_void_p),
+                ("o_zeros", ctypes.c_void_p), ("acc", ctypes.c_void_p), ("state", ctypes.c_void_p), ("attn_out", ctypes.c_void_p),
+                ("D", ctypes.c_int32), ("n_heads", ctypes.c_int32), ("capacity", ctypes.c_int32),
+                ("qkv_bits", ctypes.c_int32), ("qkv_group_size", ctypes.c_int32), ("o_bits", ctypes.c_int32), ("o_group_size", ctypes.c_int32),
+                ("traditional", ctypes.c_int32), ("norm_eps", ctypes.c_float), ("rope_scale", ctypes.c_float), ("sm_scale", ctypes.c_float)]
 
 
 GBX_DG_PLAIN, GBX_DG_RESIDUAL, GBX_DG_SWIGLU = 0, 1, 2
 GBX_DG_SSQ_SLOTS = 1024
-GBX_MIN_VERSION = 1101          # the header this binding mirrors
+GBX_MIN_VERSION = 1200          # the header this binding mirrors
 
 
 def _declare_optional(L) -> None:
@@ -157,6 +173,10 @@ def _declare_optional(L) -> None:
         "gbx_dgemv_plan": [i32, i32, i32, i32, i32, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)],
         "gbx_dgemv_pack": [p, p, p, p, p, i32, i32, i32, p],
         "gbx_dgemv_forward": [ctypes.POINTER(DgDesc), p],
+        "gbx_dgemv_kernel_id": [ctypes.POINTER(DgDesc), ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)],
+        "gbx_dattn_plan": [i32, i32, i32, i32, i32, i32, i32, i32],
+        "gbx_dattn_forward": [ctypes.POINTER(DattnDesc), p],
+        "gbx_dattn_status": [p, ctypes.POINTER(i32)],
         "gbx_qlinear_kernel_id": [i64, i32, i32, i32, i32, i32],
         "gbx_qlinear_swiglu_forward": [p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, p],
         "gbx_qlinear_forward_partials": [p, p, p, p, p, ctypes.c_size_t, ctypes.POINTER(i32), i64, i32, i32, i32, i32, i32, p],

@@ -5,6 +5,7 @@
 #include "gbx_env.h"
 #include "gemv_impl.h"
 #include "dgemv_impl.h"
+#include "dattn_impl.h"
 #include "kernels.h"
 
 #include <cstdarg>
@@ -31,9 +32,9 @@ extern "C" void gbx_debug_stamp_reset(void) { gbx::g_stamp_launch = 0; }
 
 extern "C" {
 
-/* 1101: + gbx_attn_decode_slices (an addition: nothing else changed).  1100: gbx_dgemv_* entry points; gbx_qlinear_fused (x_acc, x_out, zero_buf, zero_n since 1001) -- a consumer built against
+/* 1200: gbx_dgemv grows (x_acc, x_out, zero_buf, zero_n) + gbx_dattn_* + gbx_dgemv_kernel_id.  1101: + gbx_attn_decode_slices (an addition: nothing else changed).  1100: gbx_dgemv_* entry points; gbx_qlinear_fused (x_acc, x_out, zero_buf, zero_n since 1001) -- a consumer built against
  * an older header must not pass its shorter struct to this library: check gbx_version() >= the header it compiled with. */
-int gbx_version(void) { return 1101; }
+int gbx_version(void) { return 1200; }
 
 const char* gbx_last_error(void) { return g_err; }
 
@@ -938,7 +939,7 @@ int gbx_dgemv_pack(const void* scales0, const void* zeros0, const void* scales1,
   return GBX_OK;
 }
 
-int gbx_dgemv_forward(const gbx_dgemv* d, void* hip_stream) {
+static int dgemv_prepare(const gbx_dgemv* d, gbx::DgArgs* out, gbx::DgPlan* plo) {
   if (!d) return fail(GBX_ERR_INVALID, "null descriptor");
   if (d->struct_size != sizeof(gbx_dgemv)) return fail(GBX_ERR_INVALID, "gbx_dgemv.struct_size is %u, this library expects %zu (header / library mismatch)", d->struct_size, sizeof(gbx_dgemv));
   if (d->act_dtype != GBX_F16 && d->act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
@@ -953,6 +954,13 @@ int gbx_dgemv_forward(const gbx_dgemv* d, void* hip_stream) {
   if (d->norm_weight && !aligned(d->norm_weight, 16)) return fail(GBX_ERR_INVALID, "norm_weight must be 16-byte aligned");
   if (d->ssq_in && (!d->norm_weight || !aligned(d->ssq_in, 16))) return fail(GBX_ERR_INVALID, "ssq_in goes with norm_weight and must be 16-byte aligned");
   if (d->ssq_out && d->epilogue == GBX_DG_SWIGLU) return fail(GBX_ERR_INVALID, "ssq_out is for PLAIN / RESIDUAL launches");
+  if (d->x_acc && (!d->norm_weight || d->ssq_in || !aligned(d->x_acc, 16)))
+    return fail(GBX_ERR_INVALID, "x_acc goes with norm_weight, without ssq_in (the statistic of the NEW x is reduced in the launch), 16-byte aligned");
+  if (d->x_out && (!d->x_acc || !aligned(d->x_out, 8))) return fail(GBX_ERR_INVALID, "x_out goes with x_acc and must be 8-byte aligned");
+  if (d->x_out && (d->x_out == d->x || d->x_out == d->y)) return fail(GBX_ERR_INVALID, "x_out must not alias x or y (every workgroup reads x)");
+  if (d->zero_buf && (d->zero_n <= 0 || !aligned(d->zero_buf, 8))) return fail(GBX_ERR_INVALID, "zero_buf needs zero_n > 0 and 8-byte alignment");
+  if (d->zero_buf && d->x_acc && reinterpret_cast<const void*>(d->zero_buf) == reinterpret_cast<const void*>(d->x_acc))
+    return fail(GBX_ERR_INVALID, "a launch cannot clear the accumulator it reads");
   gbx::DgPlan pl;
   if (!gbx::dg_plan(d->bits, d->N, d->K, d->group_size, d->epilogue, d->norm_weight != nullptr, d->rows_per_batch, &pl))
     return fail(GBX_ERR_UNSUPPORTED, "dgemv does not cover N=%d K=%d bits=%d group=%d epilogue=%d rows_per_batch=%d", d->N, d->K, d->bits, d->group_size, d->epilogue, d->rows_per_batch);
@@ -969,12 +977,38 @@ int gbx_dgemv_forward(const gbx_dgemv* d, void* hip_stream) {
   a.norm_w = static_cast<const unsigned short*>(d->norm_weight);
   a.ssq_in = d->ssq_in;
   a.ssq_out = d->ssq_out;
+  a.x_acc = reinterpret_cast<const long long*>(d->x_acc);
+  a.x_out = static_cast<unsigned short*>(d->x_out);
+  a.zero_buf = reinterpret_cast<unsigned long long*>(d->zero_buf);
+  a.zero_n = d->zero_buf ? d->zero_n : 0;
   a.N = d->N; a.K = d->K; a.log2g = log2_group(d->group_size);
   a.eps = d->norm_eps;
   static const int chain_floor = gbx::env_switch("GBX_CHAIN_FLOOR");
   a.null_rows = chain_floor == 2 ? 1 : 0;
   static const int long_prio = gbx::env_switch("GBX_DG_LONG_PRIO");
   a.long_prio = (long_prio && pl.bpo > 1 && pl.apw < (pl.KS == 1 ? pl.NW : pl.NW / 4)) ? 1 : 0;
+  *out = a;
+  *plo = pl;
+  return GBX_OK;
+}
+
+int gbx_dgemv_kernel_id(const gbx_dgemv* d, int32_t* kernel, int32_t* waves_per_workgroup, int32_t* rows_per_batch) {
+  gbx::DgArgs a;
+  gbx::DgPlan pl;
+  int rc = dgemv_prepare(d, &a, &pl);
+  if (rc) return rc;
+  const bool mx = d->bits == 2 && gbx::dg_mx_wanted(a, pl, d->epilogue, d->act_dtype == GBX_BF16);
+  if (kernel) *kernel = mx ? 1 : 0;
+  if (waves_per_workgroup) *waves_per_workgroup = pl.NW;
+  if (rows_per_batch) *rows_per_batch = pl.R;
+  return GBX_OK;
+}
+
+int gbx_dgemv_forward(const gbx_dgemv* d, void* hip_stream) {
+  gbx::DgArgs a;
+  gbx::DgPlan pl;
+  int rc = dgemv_prepare(d, &a, &pl);
+  if (rc) return rc;
 #ifdef GBX_STAMPS
   a.stamps = gbx::stamp_region();
 #endif
@@ -992,6 +1026,75 @@ int gbx_dgemv_forward(const gbx_dgemv* d, void* hip_stream) {
     default: e = gbx::launch_dgemv<4>(a, pl, d->epilogue, bf16, stream); break;
   }
   if (e != hipSuccess) return hip_fail(e, "gbx_dgemv_forward launch");
+  return GBX_OK;
+}
+
+/* ---- fused attention launch (dattn_impl.h) ---- */
+int gbx_dattn_plan(int32_t D, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int32_t qkv_bits, int32_t qkv_group_size,
+                   int32_t o_bits, int32_t o_group_size) {
+  gbx::DattnPlan pl;
+  if (!gbx::dattn_plan(D, n_heads, n_kv_heads, head_dim, qkv_bits, qkv_group_size, o_bits, o_group_size, &pl))
+    return fail(GBX_ERR_UNSUPPORTED, "the fused attention launch does not cover D=%d heads=%d/%d head_dim=%d q|k|v %d bits g%d, o %d bits g%d",
+                D, n_heads, n_kv_heads, head_dim, qkv_bits, qkv_group_size, o_bits, o_group_size);
+  return GBX_OK;
+}
+
+size_t gbx_dattn_state_bytes(void) {
+  return static_cast<size_t>(gbx::DA_GROUPS) * gbx::DA_HAND_STRIDE * 8 + static_cast<size_t>(gbx::DA_STATE_WORDS) * 4;
+}
+
+int gbx_dattn_forward(const gbx_dattn* d, void* hip_stream) {
+  if (!d) return fail(GBX_ERR_INVALID, "null descriptor");
+  if (d->struct_size != sizeof(gbx_dattn)) return fail(GBX_ERR_INVALID, "gbx_dattn.struct_size is %u, this library expects %zu (header / library mismatch)", d->struct_size, sizeof(gbx_dattn));
+  if (d->act_dtype != GBX_F16 && d->act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  if (log2_group(d->qkv_group_size) < 0 || log2_group(d->o_group_size) < 0) return fail(GBX_ERR_INVALID, "The group size value must be 32, 64 or 128.");
+  gbx::DattnPlan pl;
+  if (!gbx::dattn_plan(d->D, d->n_heads, 8, 128, d->qkv_bits, d->qkv_group_size, d->o_bits, d->o_group_size, &pl))
+    return fail(GBX_ERR_UNSUPPORTED, "the fused attention launch does not cover D=%d heads=%d q|k|v %d bits g%d, o %d bits g%d (gbx_dattn_plan)",
+                d->D, d->n_heads, d->qkv_bits, d->qkv_group_size, d->o_bits, d->o_group_size);
+  if (!d->x || !d->norm_weight || !d->qkv_qweight || !d->qkv_sz || !d->kcache || !d->vcache || !d->inv_freq || !d->pos || !d->o_qweight ||
+      !d->o_scales || !d->o_zeros || !d->acc || !d->state)
+    return fail(GBX_ERR_INVALID, "null device pointer");
+  if (!aligned(d->x, 16) || !aligned(d->norm_weight, 16) || !aligned(d->qkv_qweight, 16) || !aligned(d->qkv_sz, 16) || !aligned(d->kcache, 16) ||
+      !aligned(d->vcache, 16) || !aligned(d->o_qweight, 16) || !aligned(d->acc, 16) || !aligned(d->state, 64) || (d->ssq_in && !aligned(d->ssq_in, 16)))
+    return fail(GBX_ERR_INVALID, "x / norm_weight / qweights / sz / caches / acc / ssq_in must be 16-byte aligned, state 64-byte aligned");
+  if (d->capacity <= 0) return fail(GBX_ERR_INVALID, "capacity must be positive");
+  gbx::DattnArgs a{};
+  a.x = static_cast<const unsigned short*>(d->x);
+  a.norm_w = static_cast<const unsigned short*>(d->norm_weight);
+  a.ssq_in = d->ssq_in;
+  a.qkv_qw = d->qkv_qweight;
+  a.qkv_sz = d->qkv_sz;
+  a.kcache = static_cast<unsigned short*>(d->kcache);
+  a.vcache = static_cast<unsigned short*>(d->vcache);
+  a.inv_freq = d->inv_freq;
+  a.pos = reinterpret_cast<const long long*>(d->pos);
+  a.o_qw = d->o_qweight;
+  a.o_s = static_cast<const unsigned short*>(d->o_scales);
+  a.o_z = static_cast<const unsigned short*>(d->o_zeros);
+  a.acc = reinterpret_cast<unsigned long long*>(d->acc);
+  a.hand = static_cast<unsigned long long*>(d->state);
+  a.state = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(d->state) + static_cast<size_t>(gbx::DA_GROUPS) * gbx::DA_HAND_STRIDE * 8);
+  a.attn_out = static_cast<unsigned short*>(d->attn_out);
+  a.D = d->D; a.rep = d->n_heads / 8; a.capacity = d->capacity; a.bpw = pl.bpw;
+  a.qkv_log2g = log2_group(d->qkv_group_size); a.o_bits = d->o_bits; a.o_log2g = log2_group(d->o_group_size);
+  a.traditional = d->traditional;
+  a.eps = d->norm_eps; a.rope_scale = d->rope_scale; a.sm_scale = d->sm_scale;
+#ifdef GBX_STAMPS
+  a.stamps = gbx::stamp_region();
+#endif
+  hipError_t e = gbx::launch_dattn(a, pl, d->qkv_bits, d->act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_dattn_forward launch");
+  return GBX_OK;
+}
+
+int gbx_dattn_status(const void* state, int32_t* code) {
+  if (!state || !code) return fail(GBX_ERR_INVALID, "null pointer");
+  unsigned v = 0;
+  const unsigned char* p = static_cast<const unsigned char*>(state) + static_cast<size_t>(gbx::DA_GROUPS) * gbx::DA_HAND_STRIDE * 8 + 8 * 16 * 4;
+  hipError_t e = hipMemcpy(&v, p, 4, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return hip_fail(e, "gbx_dattn_status");
+  *code = static_cast<int32_t>(v);
   return GBX_OK;
 }
 

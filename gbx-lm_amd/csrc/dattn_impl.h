@@ -1,0 +1,80 @@
+// The attention half of a decoder block at M == 1 as ONE launch whose hand-offs never leave an XCD ("dattn", round 5):
+//
+//   RMSNorm(h) -> q | k | v rows of ONE kv group -> RoPE + KV-cache append -> attention of the group's query heads
+//              -> o_proj over that group's rep * 128 input columns -> fixed-point partial sums into acc[D]
+//
+// replaces, per block, three launches of the round-4 decode path (q|k|v GEMV, attention, o_proj GEMV + residual):
+//   mx.quantized_matmul at M == 1 (gbx_lm/models/quantized_linear_gba.py:195-203) at the call sites gbx_lm/models/qllama.py:76
+//   (q, k, v projections) and :96 (o_proj), with the attention between them (qllama.py:78-95) and the input RMSNorm (:137).
+//
+// Mapping: Llama-3's 8 kv heads = the chip's 8 XCDs.  A workgroup reads its XCD from HW_REG_XCC_ID -- that IS its kv group g -- and
+// its member index r = blockIdx.x / 8 (256 workgroups, one per CU; 32 members per group under the round-robin placement measured in
+// profiles/r05_xcd_barrier.txt; a placement that breaks the bijection leaves a group short of a member and the launch reports a
+// time-out in its status word instead of a wrong result).  Roles inside a group (rep = query heads per kv head):
+//   members [0, rep)   : attention of head g * rep + r.  They skip phase 1, prefetch 128 cached K / V rows meanwhile, poll the group's
+//                        q / k / v granules, rotate, append (member 0), sweep, merge, publish 64 granules of output.
+//   members [rep, 32)  : phase 1 -- dgemv's prologue (carried statistic, fp16 image, weights requested behind the image) and ONE
+//                        two-row batch per wave over the group's (rep + 2) * 128 rows of the concatenated q|k|v matrix; the two
+//                        rounded row totals leave as one 8-byte {tag, value} granule.
+//   everyone           : phase 3 -- o_proj rows [r * D/32, (r + 1) * D/32), the group's column range only; the packed words were
+//                        requested at the start of the launch and sit in registers; rep waves poll the attention granules, the
+//                        workgroup builds the operand image once, every lane owns one slot of one row; partial row sums go to
+//                        acc[row] as 2^-32 fixed-point integer adds (order-independent: the eight groups may finish in any order).
+// Hand-off form (measured first, profiles/r05_xcd_barrier.txt P3): granule stores are workgroup-scope (sc0: write-through to the
+// XCD's L2, where the line stays), polls are agent-scope loads (sc1: past the L1, served by that same L2) -- 0.45 us per hand-off
+// against 1.05 us for the device-scope form, and correct by construction because producer and consumer share the L2 they
+// meet in (the group is DEFINED by XCC_ID).  Tags come from a per-group generation word in device memory that member 0 advances at
+// the end of the launch, so no memset node and no host-side epoch is needed and a graph replay is self-contained.
+// The consumer of acc is the gate|up launch (dgemv x_acc / x_out: x = round(h + round(acc * 2^-32)), one rounding each like the
+// reference's o_proj output and residual add), the down_proj launch clears it (dgemv zero_buf).
+#pragma once
+#include "dgemv_impl.h"
+
+namespace gbx {
+
+constexpr int DA_GROUPS = 8;                 // kv groups = XCDs
+constexpr int DA_MEMBERS = 32;               // workgroups per group
+constexpr int DA_NW = 16, DA_NT = DA_NW * 64;
+constexpr int DA_HD = 128;
+constexpr int DA_OP = 2;                     // o_proj lane passes held in registers
+constexpr int DA_HAND_STRIDE = 2048;         // granules (8 bytes) per group: [0, 1024) phase 1, [1024, 2048) attention output
+constexpr int DA_STATE_WORDS = 64 * 16;      // u32: gen[g] at g * 16 (one 64-byte line each), status at 8 * 16, placement at 9 * 16
+constexpr unsigned DA_SPIN_LIMIT = 1u << 22;
+
+struct DattnArgs {
+  const unsigned short* x;          // [D] residual stream
+  const unsigned short* norm_w;     // [D] input RMSNorm weight
+  const float* ssq_in;              // [DG_SSQ_SLOTS] partial sums of x^2 from the producer of x, or null
+  const uint32_t* qkv_qw;           // [(n_heads + 16) * 128, D * bq / 32]: q | k | v rows concatenated
+  const uint32_t* qkv_sz;           // (scale | zero << 16) companion of that matrix in batch order, two rows per batch
+  unsigned short* kcache;           // [8, capacity, 128]
+  unsigned short* vcache;
+  const float* inv_freq;            // [64]
+  const long long* pos;             // device scalar: index of the new token
+  const uint32_t* o_qw;             // [D, n_heads * 128 * bo / 32]
+  const unsigned short* o_s;        // [D, n_heads * 128 / go]
+  const unsigned short* o_z;
+  unsigned long long* acc;          // [D + 1] 2^-32 fixed point (word D: non-finite marker)
+  unsigned long long* hand;         // [8][DA_HAND_STRIDE] granules
+  unsigned* state;                  // [DA_STATE_WORDS]
+  unsigned short* attn_out;         // optional [n_heads * 128]: the attention output (tests)
+  int D, rep, capacity, bpw;        // bpw: phase-1 batches per producer workgroup
+  int qkv_log2g, o_bits, o_log2g, traditional;
+  float eps, rope_scale, sm_scale;
+#ifdef GBX_STAMPS
+  unsigned long long* stamps;
+#endif
+};
+
+struct DattnPlan {
+  int P;            // lane passes of a q|k|v row
+  int bpw;
+  size_t shmem;
+};
+// false: this launch does not cover the shape (the caller keeps the five-launch block)
+bool dattn_plan(int D, int n_heads, int n_kv, int head_dim, int qkv_bits, int qkv_group, int o_bits, int o_group, DattnPlan* pl);
+hipError_t launch_dattn(const DattnArgs& a, const DattnPlan& pl, int qkv_bits, bool bf16, hipStream_t stream);
+template <int BQ>
+hipError_t launch_dattn_bits(const DattnArgs& a, const DattnPlan& pl, bool bf16, hipStream_t stream);
+
+}  // namespace gbx

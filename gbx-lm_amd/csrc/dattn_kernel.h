@@ -1,0 +1,609 @@
+// dattn_kernel: see dattn_impl.h for the role, the mapping and the hand-off form.  One TU per q|k|v bit width (dattn_b{2,3,4}.hip).
+#pragma once
+#include "dattn_impl.h"
+#include "kernels.h"
+#include <type_traits>
+
+namespace gbx {
+
+typedef __attribute__((address_space(1))) unsigned long long da_gu64;
+typedef __attribute__((address_space(1))) unsigned da_gu32;
+
+// LDS map (bytes).  84 KB are requested so that a CU holds exactly one workgroup (the 256 workgroups then cover the 256 CUs).
+constexpr int DA_LDS_IMG1 = 0;                     // phase-1 activation image: Lds<BQ>::bytes(K <= 4096) <= 11.3 KB
+constexpr int DA_LDS_RED = 12 * 1024;              // 16 floats: RMSNorm partials
+constexpr int DA_LDS_ATT = 12 * 1024 + 256;        // attention scratch, 11.2 KB
+constexpr int DA_LDS_P3 = 24 * 1024;               // phase 3: 2 KB of raw attention output, then its operand image (<= 5.2 KB)
+constexpr int DA_LDS_BYTES = 84 * 1024;
+
+#ifdef GBX_STAMPS
+#define DA_STAMP(i) do { if (lane == 0 && a.stamps) a.stamps[(static_cast<size_t>(blockIdx.x) * DA_NW + wave) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define DA_STAMP(i) do {} while (0)
+#endif
+
+// ---- one item of the activation image (dgemv_impl.h, step 3): PPU pairs of one unit -> pre-shifted fp16 pairs + the sub-slot's
+//      {sum, 2^(24 - E)}.  xw / ww: the item's raw 16-bit activations (and norm weights) as packed words, first the ka halves, then kb.
+template <int BITS, bool BF16, int PPU>
+__device__ __forceinline__ void da_image_item(const unsigned (&xw)[PPU], const unsigned (&ww)[PPU], bool norm, float rstd, int it, int nitems,
+                                              h2* xp_lds, float2* xs_lds) {
+  using F = Fmt<BITS>;
+  using L = Lds<BITS>;
+  constexpr int UP = F::UNIT_PAIRS, TPU = UP / PPU, UPS = F::VPL / F::UNIT_VALS, SSTR = L::SSTR;
+  constexpr int GL = (BITS == 3) ? 1 : 16 / PPU;
+  const int u = it / TPU, t = it % TPU;
+  float xa[PPU], xb[PPU];
+  unsigned amax = 0;
+  float usum = 0.f;
+#pragma unroll
+  for (int i = 0; i < PPU; ++i) {
+    int wa, ha, wb, hb;
+    if constexpr (BITS == 3) { wa = F::ka(i) >> 1; ha = F::ka(i) & 1; wb = F::kb(i) >> 1; hb = F::kb(i) & 1; }
+    else { wa = i >> 1; ha = i & 1; wb = (PPU >> 1) + (i >> 1); hb = i & 1; }
+    float va = ha ? act_hi<BF16>(xw[wa]) : act_lo<BF16>(xw[wa]);
+    float vb = hb ? act_hi<BF16>(xw[wb]) : act_lo<BF16>(xw[wb]);
+    if (norm) {
+      va = round_bf16_or_f16(va * rstd * (ha ? act_hi<BF16>(ww[wa]) : act_lo<BF16>(ww[wa])), BF16);
+      vb = round_bf16_or_f16(vb * rstd * (hb ? act_hi<BF16>(ww[wb]) : act_lo<BF16>(ww[wb])), BF16);
+    }
+    xa[i] = va;
+    xb[i] = vb;
+    usum += va + vb;
+    amax = max(amax, max(__float_as_uint(va) & 0x7FFFFFFFu, __float_as_uint(vb) & 0x7FFFFFFFu));
+  }
+  float ssum = usum;
+  if constexpr (GL >= 2) { ssum += dpp_f32<0xB1>(ssum); amax = max(amax, dpp_u32<0xB1>(amax)); }
+  if constexpr (GL >= 4) { ssum += dpp_f32<0x4E>(ssum); amax = max(amax, dpp_u32<0x4E>(amax)); }
+  if constexpr (GL >= 8) { ssum += dpp_f32<0x141>(ssum); amax = max(amax, dpp_u32<0x141>(amax)); }
+  int E = 141 - static_cast<int>(amax >> 23);
+  E = min(max(E, -100), 110);
+  if (it < nitems) {
+    const int slot = u / UPS, uin = u % UPS;
+    unsigned* dst = reinterpret_cast<unsigned*>(xp_lds + static_cast<size_t>(slot) * SSTR + uin * UP + PPU * t);
+    unsigned img[PPU];
+#pragma unroll
+    for (int i = 0; i < PPU; ++i) {
+      int ps;
+      if constexpr (BITS == 3) ps = F::pos(i);
+      else if constexpr (BITS == 2) { const int pi = PPU * t + i; ps = 2 * (pi < 5 ? pi : pi - 5); }
+      else { ps = ((PPU * t + i) & 1) ? 4 : 0; }
+      const float sc = exp2i(E - ps);
+      h2 v;
+      v.x = static_cast<_Float16>(xa[i] * sc);
+      v.y = static_cast<_Float16>(xb[i] * sc);
+      img[i] = as_u32(v);
+    }
+    if constexpr (PPU == 2) *reinterpret_cast<u32x2*>(dst) = u32x2{img[0], img[1]};
+    else {
+#pragma unroll
+      for (int i = 0; i < PPU; i += 4) *reinterpret_cast<u32x4*>(dst + i) = u32x4{img[i], img[i + 1], img[i + 2], img[i + 3]};
+    }
+    if ((it % GL) == 0) xs_lds[it / GL] = make_float2(ssum, exp2i(24 - E));
+  }
+}
+
+// the item's raw words from a 16-bit vector (global or LDS)
+template <int BITS, int PPU>
+__device__ __forceinline__ void da_load_item(const unsigned short* base, int it, unsigned (&out)[PPU]) {
+  using F = Fmt<BITS>;
+  constexpr int UP = F::UNIT_PAIRS, TPU = UP / PPU;
+  const int u = it / TPU, t = it % TPU;
+  if constexpr (BITS == 3) {
+    const u32x4* src = reinterpret_cast<const u32x4*>(base + static_cast<size_t>(u) * F::UNIT_VALS);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const u32x4 v = src[q]; out[4 * q] = v.x; out[4 * q + 1] = v.y; out[4 * q + 2] = v.z; out[4 * q + 3] = v.w; }
+  } else {
+    static_assert(BITS == 3 || PPU == 2, "two pairs per thread");
+    const unsigned short* pa = base + static_cast<size_t>(u) * F::UNIT_VALS + PPU * t;
+    out[0] = *reinterpret_cast<const unsigned*>(pa);
+    out[1] = *reinterpret_cast<const unsigned*>(pa + UP);
+  }
+}
+
+// phase 3, one lane = one slot of one o_proj row: s * sum(q x) + z * sum(x) over the slot (dgemv's consume, one row)
+template <int BO, bool BF16>
+__device__ __forceinline__ float da_o_slot(const u32x4& w, unsigned sc_bits, unsigned ze_bits, const h2* xp_lds, const float2* xs_lds, int slot) {
+  using F = Fmt<BO>;
+  using L = Lds<BO>;
+  constexpr int PAIRS = L::PAIRS, NSUB = F::NSUB;
+  h2 xv[PAIRS];
+  const u32x4* src = reinterpret_cast<const u32x4*>(xp_lds + static_cast<size_t>(slot) * L::SSTR);
+#pragma unroll
+  for (int q = 0; q < PAIRS / 4; ++q) {
+    const u32x4 v = src[q];
+    xv[4 * q + 0] = as_h2(v.x); xv[4 * q + 1] = as_h2(v.y); xv[4 * q + 2] = as_h2(v.z); xv[4 * q + 3] = as_h2(v.w);
+  }
+  typename SlotWords<BO>::type ws;
+  if constexpr (BO == 3) ws = u32x3{w.x, w.y, w.z}; else ws = w;
+  float d[NSUB];
+  dot_slot<BO>(ws, xv, d);
+  const float sc = act_to_f32<BF16>(static_cast<unsigned short>(sc_bits)), ze = act_to_f32<BF16>(static_cast<unsigned short>(ze_bits));
+  if constexpr (NSUB == 2) {
+    const float2 t0 = xs_lds[slot * 2], t1 = xs_lds[slot * 2 + 1];
+    const float t = fmaf(t1.y, d[1], t0.y * d[0]);
+    return fmaf(ze, t0.x + t1.x, sc * t);
+  } else {
+    const float2 t0 = xs_lds[slot];
+    return fmaf(ze, t0.x, (sc * t0.y) * d[0]);
+  }
+}
+
+template <int BQ, int P, bool BF16>
+__global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
+  using F = Fmt<BQ>;
+  using L = Lds<BQ>;
+  using WT = typename SlotWords<BQ>::type;
+  constexpr int NT = DA_NT, NW = DA_NW, R = 2, HD = DA_HD;
+  constexpr int PAIRS = L::PAIRS, SSTR = L::SSTR, NSUB = F::NSUB;
+  constexpr unsigned KILL = 0x80000000u;
+  constexpr int RS_FLAGS = 0x00020000, RS_ALL = 0x7FFFFFFF;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  DA_STAMP(0);
+  const int g = static_cast<int>(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);     // HW_REG_XCC_ID: this XCD = this kv group
+  const int r = static_cast<int>(blockIdx.x) >> 3;                                       // member of the group
+  const int rep = a.rep, D = a.D;
+  da_gu32* gen_p = reinterpret_cast<da_gu32*>(reinterpret_cast<uintptr_t>(a.state)) + g * 16;
+  const unsigned gen = __hip_atomic_load(gen_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  da_gu64* hand1 = reinterpret_cast<da_gu64*>(reinterpret_cast<uintptr_t>(a.hand)) + static_cast<size_t>(g) * DA_HAND_STRIDE;
+  da_gu64* hand2 = hand1 + 1024;
+  auto rsrc = [](const void* ptr, int bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, bytes, RS_FLAGS); };
+  auto timeout = [&](unsigned code) { if (lane == 0) a.state[8 * 16] = code; };
+  // one wave polls 64 granules until every tag matches; returns the lane's value
+  auto sweep = [&](da_gu64* p, unsigned tag, unsigned code) -> unsigned {
+    unsigned long long x;
+    for (unsigned spins = 0;;) {
+      x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           // sc1: past this CU's L1, served by the XCD's L2
+      if (__all(static_cast<unsigned>(x >> 32) == tag)) break;
+      if (++spins > DA_SPIN_LIMIT) { timeout(code); break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    return static_cast<unsigned>(x);
+  };
+
+  // ---------------- o_proj: this workgroup's rows, this group's columns -- requested early, consumed in phase 3 ----------------
+  const int obits = a.o_bits;
+  const int ovpl_l2 = obits == 2 ? 6 : 5;
+  const int KC = rep * HD;                                  // input columns of this group
+  const int KO = KC * DA_GROUPS;                            // o_proj input dims
+  const int spr = KC >> ovpl_l2;                            // slots per row slice
+  const int lpr_l2 = spr <= 8 ? 3 : (spr <= 16 ? 4 : 5);    // lanes per row (power of two >= spr)
+  const int rpp = 64 >> lpr_l2;                             // rows per wave and pass
+  const int RPW = D / DA_MEMBERS;                           // rows of this workgroup
+  const int W4o = (KO >> 3) * obits;                        // bytes per packed o_proj row
+  const int slotb = obits == 3 ? 12 : 16;
+  const int Go = KO >> a.o_log2g;
+  const int oslot = lane & ((1 << lpr_l2) - 1);
+  u32x4 ow[DA_OP];
+  unsigned osc[DA_OP], oze[DA_OP];
+  auto issue_o = [&]() {
+    const __amdgpu_buffer_rsrc_t od = rsrc(a.o_qw, D * W4o);
+    const __amdgpu_buffer_rsrc_t sd = rsrc(a.o_s, RS_ALL), zd = rsrc(a.o_z, RS_ALL);
+#pragma unroll
+    for (int p = 0; p < DA_OP; ++p) {
+      const int rl = (p * NW + wave) * rpp + (lane >> lpr_l2);
+      const bool live = rl < RPW && oslot < spr;
+      const int row = r * RPW + (live ? rl : 0);
+      const unsigned kill = live ? 0u : KILL;
+      ow[p] = __builtin_amdgcn_raw_buffer_load_b128(od, static_cast<unsigned>(row * W4o + (g * spr + oslot) * slotb) | kill, 0, 0);
+      const unsigned so = static_cast<unsigned>((row * Go + ((g * KC + (oslot << ovpl_l2)) >> a.o_log2g)) * 2) | kill;
+      osc[p] = __builtin_amdgcn_raw_buffer_load_b16(sd, so, 0, 0);
+      oze[p] = __builtin_amdgcn_raw_buffer_load_b16(zd, so, 0, 0);
+    }
+  };
+
+  unsigned tag;
+  if (r >= rep) {
+    // =========================================== phase 1: the group's q | k | v rows ===========================================
+    h2* xp_lds = reinterpret_cast<h2*>(smem + DA_LDS_IMG1);
+    const int K = D;
+    const int nslots = K / F::VPL;
+    float2* xs_lds = reinterpret_cast<float2*>(smem + DA_LDS_IMG1 + static_cast<size_t>(nslots) * SSTR * 4);
+    float* red_lds = reinterpret_cast<float*>(smem + DA_LDS_RED);
+    const int W4 = K / 32 * BQ * 4;
+    const int G = K >> a.qkv_log2g;
+    const int gshift = a.qkv_log2g - 5;
+    // this wave's batch: local rows (2 lb, 2 lb + 1) of the group -> rows of the concatenated matrix
+    const int nb = (rep + 2) * (HD / 2);
+    const int lb = (r - rep) * a.bpw + wave;
+    const bool has = wave < a.bpw && lb < nb;
+    const int qrows = rep * HD;
+    const int lr = 2 * (has ? lb : 0);
+    const int grow = lr < qrows ? g * qrows + lr
+                                : (lr < qrows + HD ? DA_GROUPS * qrows + g * HD + (lr - qrows)
+                                                   : DA_GROUPS * qrows + DA_GROUPS * HD + g * HD + (lr - qrows - HD));
+    const int gb = grow >> 1;
+    const __amdgpu_buffer_rsrc_t qd = rsrc(a.qkv_qw, RS_ALL), szd = rsrc(a.qkv_sz, RS_ALL);
+    unsigned voff_w[P], voff_s[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int slot = p * 64 + lane;
+      const unsigned dead = (slot < nslots && has) ? 0u : KILL;
+      voff_w[p] = static_cast<unsigned>(slot * (F::SLOT_WORDS * 4)) | dead;
+      voff_s[p] = static_cast<unsigned>(((slot * NSUB) >> gshift) * (R * 4)) | dead;
+    }
+    // ---- 1. activations and norm weights first, then the carried statistic
+    constexpr int UP = F::UNIT_PAIRS;
+    constexpr int PPU = (BQ == 3) ? UP : 2;
+    constexpr int TPU = UP / PPU;
+    static_assert(P * 64 * (F::VPL / 2) <= NT * PPU, "one item per thread");
+    const int nitems = (K / F::UNIT_VALS) * TPU;
+    unsigned xr[PPU], wr[PPU];
+    {
+      const int it = min(tid, nitems - 1);
+      da_load_item<BQ, PPU>(a.x, it, xr);
+      da_load_item<BQ, PPU>(a.norm_w, it, wr);
+    }
+    u32x4 pq[4] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
+    const bool carried = a.ssq_in != nullptr;
+    {
+      const __amdgpu_buffer_rsrc_t pd = rsrc(carried ? static_cast<const void*>(a.ssq_in) : static_cast<const void*>(a.x), RS_ALL);
+      const unsigned pk = carried ? 0u : KILL;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pq[i] = __builtin_amdgcn_raw_buffer_load_b128(pd, static_cast<unsigned>(lane * 16 + 1024 * i) | pk, 0, 0);
+    }
+    DA_STAMP(1);
+    // ---- 2. RMSNorm statistic
+    float tot;
+    if (carried) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        s += (__uint_as_float(pq[i].x) + __uint_as_float(pq[i].y)) + (__uint_as_float(pq[i].z) + __uint_as_float(pq[i].w));
+      tot = wave_sum(s);
+    } else {
+      float ssq = 0.f;
+      const bool live = tid < nitems;
+#pragma unroll
+      for (int q = 0; q < PPU; ++q) {
+        const float lo = act_lo<BF16>(xr[q]), hi = act_hi<BF16>(xr[q]);
+        ssq += live ? fmaf(hi, hi, lo * lo) : 0.f;
+      }
+      ssq = wave_sum(ssq);
+      if (lane == 0) red_lds[wave] = ssq;
+      __syncthreads();
+      tot = 0.f;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) tot += red_lds[i];
+    }
+    const float rstd = rsqrtf(tot / static_cast<float>(K) + a.eps);
+    DA_STAMP(2);
+    // ---- 3. image
+    if ((tid & ~63) < nitems) da_image_item<BQ, BF16, PPU>(xr, wr, true, rstd, tid, nitems, xp_lds, xs_lds);
+    // ---- 4. this wave's two rows, then the o_proj words behind them
+    WT w[R][P];
+    unsigned sz[P][R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        if constexpr (BQ == 3) w[i][p] = __builtin_amdgcn_raw_buffer_load_b96(qd, voff_w[p], (grow + i) * W4, 2);
+        else w[i][p] = __builtin_amdgcn_raw_buffer_load_b128(qd, voff_w[p], (grow + i) * W4, 2);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(szd, voff_s[p], gb * (G * R * 4), 0);
+      sz[p][0] = v.x; sz[p][1] = v.y;
+    }
+    issue_o();
+    __syncthreads();
+    DA_STAMP(3);
+    tag = gen + 1u;
+    if (tag == 0u) tag = 1u;
+    if (has) {
+      h2 xv[P][PAIRS];
+      float xs[P][NSUB], cf[P][NSUB];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int slot = p * 64 + lane;
+        const bool live = slot < nslots;
+        const int sl = min(slot, nslots - 1);
+        const u32x4* src = reinterpret_cast<const u32x4*>(xp_lds + static_cast<size_t>(sl) * SSTR);
+#pragma unroll
+        for (int q = 0; q < PAIRS / 4; ++q) {
+          const u32x4 v = src[q];
+          xv[p][4 * q + 0] = as_h2(live ? v.x : 0u);
+          xv[p][4 * q + 1] = as_h2(live ? v.y : 0u);
+          xv[p][4 * q + 2] = as_h2(live ? v.z : 0u);
+          xv[p][4 * q + 3] = as_h2(live ? v.w : 0u);
+        }
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+          const float2 t = xs_lds[sl * NSUB + s];
+          xs[p][s] = live ? t.x : 0.f;
+          cf[p][s] = live ? t.y : 0.f;
+        }
+      }
+      float acc[R] = {0.f, 0.f};
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        float d[R][NSUB];
+        WT wp[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) wp[i] = w[i][p];
+        dot_slot_rows<BQ, R>(wp, xv[p], d);
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          const float sc = sz_scale<BF16>(sz[p][i]), ze = sz_zero<BF16>(sz[p][i]);
+          if constexpr (NSUB == 2) {
+            const float t = fmaf(cf[p][1], d[i][1], cf[p][0] * d[i][0]);
+            acc[i] = fmaf(sc, t, acc[i]);
+            acc[i] = fmaf(ze, xs[p][0] + xs[p][1], acc[i]);
+          } else {
+            const float s2 = sc * cf[p][0];
+            acc[i] = fmaf(s2, d[i][0], acc[i]);
+            acc[i] = fmaf(ze, xs[p][0], acc[i]);
+          }
+        }
+      }
+      const float v0 = wave_sum2(acc[0], acc[1]);          // row 0 in lane 31, row 1 in lane 63
+      const float t0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v0), 31));
+      const float t1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v0), 63));
+      const unsigned val = static_cast<unsigned>(f32_to_act<BF16>(t0)) | (static_cast<unsigned>(f32_to_act<BF16>(t1)) << 16);
+      // sc0 store: write-through to this XCD's L2, where the group's attention members poll it
+      if (lane == 0) __hip_atomic_store(hand1 + lb, (static_cast<unsigned long long>(tag) << 32) | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    DA_STAMP(4);
+  } else {
+    // =========================================== phase 2: attention of head g * rep + r ===========================================
+    unsigned* raw32 = reinterpret_cast<unsigned*>(smem + DA_LDS_ATT);                    // q | k | v as they arrive: 3 x 64 words
+    float* q_s = reinterpret_cast<float*>(smem + DA_LDS_ATT + 768);
+    float* kn_s = q_s + HD;
+    float* vn_s = kn_s + HD;
+    float* gm = vn_s + HD;
+    float* gl = gm + NW;
+    float (*gacc)[HD + 8] = reinterpret_cast<float (*)[HD + 8]>(gl + NW);
+    constexpr float NEG = -1e30f;
+    constexpr int LP = HD / 8, PPW = 64 / LP, UB0 = 128 / (NW * PPW);                    // 16 lanes per position, 4 positions per wave, 2 rounds up front
+    const int h = g * rep + r;
+    const int d0 = (lane % LP) * 8, sub = lane / LP;
+    const unsigned short* kbase = a.kcache + static_cast<size_t>(g) * a.capacity * HD;
+    const unsigned short* vbase = a.vcache + static_cast<size_t>(g) * a.capacity * HD;
+    u32x4 k0[UB0], v0[UB0];
+#pragma unroll
+    for (int u = 0; u < UB0; ++u) {
+      const int tc = min(wave * PPW + u * NW * PPW + sub, a.capacity - 1);
+      k0[u] = *reinterpret_cast<const u32x4*>(kbase + static_cast<size_t>(tc) * HD + d0);
+      v0[u] = *reinterpret_cast<const u32x4*>(vbase + static_cast<size_t>(tc) * HD + d0);
+    }
+    const int pos = static_cast<int>(*a.pos);
+    issue_o();
+    tag = gen + 1u;
+    if (tag == 0u) tag = 1u;
+    // ---- hand-off 1: this head's q (64 granules), the group's k and v
+    if (wave < 3) {
+      const int base = wave == 0 ? r * (HD / 2) : (rep + wave - 1) * (HD / 2);
+      raw32[wave * 64 + lane] = sweep(hand1 + base + lane, tag, 1u);
+    }
+    __syncthreads();
+    DA_STAMP(5);
+    const unsigned short* raw16 = reinterpret_cast<const unsigned short*>(raw32);
+    if (tid < HD) {
+      const bool isk = tid >= HD / 2;
+      const int i = isk ? tid - HD / 2 : tid;
+      const unsigned short* src = raw16 + (isk ? HD : 0);
+      const int i1 = a.traditional ? 2 * i : i;
+      const int i2 = a.traditional ? 2 * i + 1 : i + HD / 2;
+      const float x1 = act_to_f32<BF16>(src[i1]), x2 = act_to_f32<BF16>(src[i2]);
+      const float rev = static_cast<float>(pos) * a.rope_scale * a.inv_freq[i] * 0.15915494309189535f;
+      const float fr = rev - floorf(rev);
+      const float sn = __builtin_amdgcn_sinf(fr), cs = __builtin_amdgcn_cosf(fr);
+      const unsigned short r1 = f32_to_act<BF16>(x1 * cs - x2 * sn), r2 = f32_to_act<BF16>(x1 * sn + x2 * cs);
+      if (isk) {
+        kn_s[i1] = act_to_f32<BF16>(r1);
+        kn_s[i2] = act_to_f32<BF16>(r2);
+        if (r == 0) {
+          unsigned short* dst = a.kcache + (static_cast<size_t>(g) * a.capacity + pos) * HD;
+          dst[i1] = r1;
+          dst[i2] = r2;
+        }
+      } else {
+        q_s[i1] = act_to_f32<BF16>(r1) * a.sm_scale;
+        q_s[i2] = act_to_f32<BF16>(r2) * a.sm_scale;
+      }
+    } else if (tid < 2 * HD) {
+      const int j = tid - HD;
+      const unsigned short vb = raw16[2 * HD + j];
+      vn_s[j] = act_to_f32<BF16>(vb);
+      if (r == 0) a.vcache[(static_cast<size_t>(g) * a.capacity + pos) * HD + j] = vb;
+    }
+    __syncthreads();
+    // ---- cached positions [0, pos): 16 lanes per position, online softmax per lane group (attn_decode_kernel, 16-wave form)
+    float qr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qr[j] = q_s[d0 + j];
+    float m = NEG, l = 0.f, acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    auto consume = [&](const u32x4& kq, const u32x4& vq, bool valid) {
+      const unsigned kw[4] = {kq.x, kq.y, kq.z, kq.w};
+      const unsigned vw[4] = {vq.x, vq.y, vq.z, vq.w};
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s = fmaf(qr[2 * j], act_lo<BF16>(kw[j]), s);
+        s = fmaf(qr[2 * j + 1], act_hi<BF16>(kw[j]), s);
+      }
+      s += dpp_f32<0xB1>(s);
+      s += dpp_f32<0x4E>(s);
+      s += dpp_f32<0x141>(s);
+      s += dpp_f32<0x140>(s);
+      const float mn = valid ? fmaxf(m, s) : m;
+      const float corr = __expf(m - mn);
+      const float p = valid ? __expf(s - mn) : 0.f;
+      l = l * corr + p;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[2 * j] = acc[2 * j] * corr + p * act_lo<BF16>(vw[j]);
+        acc[2 * j + 1] = acc[2 * j + 1] * corr + p * act_hi<BF16>(vw[j]);
+      }
+      m = mn;
+    };
+#pragma unroll
+    for (int u = 0; u < UB0; ++u) consume(k0[u], v0[u], wave * PPW + u * NW * PPW + sub < pos);
+    constexpr int UB = 2;
+    for (int t0 = UB0 * NW * PPW + wave * PPW; t0 < pos; t0 += NW * PPW * UB) {
+      u32x4 kv4[UB], vv4[UB];
+      bool valid[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int t = t0 + u * NW * PPW + sub;
+        valid[u] = t < pos;
+        const int tc = valid[u] ? t : pos - 1;
+        kv4[u] = *reinterpret_cast<const u32x4*>(kbase + static_cast<size_t>(tc) * HD + d0);
+        vv4[u] = *reinterpret_cast<const u32x4*>(vbase + static_cast<size_t>(tc) * HD + d0);
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) consume(kv4[u], vv4[u], valid[u]);
+    }
+    if (wave == 0 && sub == 0) {                             // the new token itself (its k, v are in LDS)
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s = fmaf(qr[j], kn_s[d0 + j], s);
+      s += dpp_f32<0xB1>(s);
+      s += dpp_f32<0x4E>(s);
+      s += dpp_f32<0x141>(s);
+      s += dpp_f32<0x140>(s);
+      const float mn = fmaxf(m, s);
+      const float corr = __expf(m - mn), p = __expf(s - mn);
+      l = l * corr + p;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = acc[j] * corr + p * vn_s[d0 + j];
+      m = mn;
+    }
+    {
+      auto merge = [&](float pm, float pl, const float (&pa)[8]) {
+        const float mn = fmaxf(m, pm);
+        const float c1 = __expf(m - mn), c2 = __expf(pm - mn);
+        l = l * c1 + pl * c2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = acc[j] * c1 + pa[j] * c2;
+        m = mn;
+      };
+      {
+        const bool hi = lane >= 32;
+        auto part = [&](float v) {
+          auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+          const unsigned r0 = rr[0], r1 = rr[1];
+          return __uint_as_float(hi ? r0 : r1);
+        };
+        float pa[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pa[j] = part(acc[j]);
+        const float pm = part(m), pl = part(l);
+        merge(pm, pl, pa);
+      }
+      {
+        const bool odd = (lane >> 4) & 1;
+        auto part = [&](float v) {
+          auto rr = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+          const unsigned r0 = rr[0], r1 = rr[1];
+          return __uint_as_float(odd ? r0 : r1);
+        };
+        float pa[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pa[j] = part(acc[j]);
+        const float pm = part(m), pl = part(l);
+        merge(pm, pl, pa);
+      }
+    }
+    if (lane == 0) { gm[wave] = m; gl[wave] = l; }
+    if (sub == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gacc[wave][d0 + j] = acc[j];
+    }
+    __syncthreads();
+    if (tid < HD) {
+      float M = NEG;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) M = fmaxf(M, gm[i]);
+      float num = 0.f, den = 0.f;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const float wgt = __expf(gm[i] - M);
+        num = fmaf(wgt, gacc[i][tid], num);
+        den = fmaf(wgt, gl[i], den);
+      }
+      const unsigned ob = f32_to_act<BF16>(num / den);
+      if (a.attn_out) a.attn_out[static_cast<size_t>(h) * HD + tid] = static_cast<unsigned short>(ob);
+      const unsigned nb2 = dpp_u32<0xB1>(ob);                // the odd neighbour's value on the even lane
+      if ((lane & 1) == 0)
+        __hip_atomic_store(hand2 + r * (HD / 2) + (tid >> 1), (static_cast<unsigned long long>(tag) << 32) | ob | (nb2 << 16),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    DA_STAMP(6);
+  }
+
+  // =========================================== phase 3: o_proj over this group's columns ===========================================
+  unsigned* raw3 = reinterpret_cast<unsigned*>(smem + DA_LDS_P3);
+  h2* xp3 = reinterpret_cast<h2*>(smem + DA_LDS_P3 + 2048);
+  if (wave < rep) raw3[wave * 64 + lane] = sweep(hand2 + wave * (HD / 2) + lane, tag, 2u);
+  __syncthreads();
+  DA_STAMP(7);
+  const unsigned short* raw3h = reinterpret_cast<const unsigned short*>(raw3);
+  auto phase3 = [&](auto BO_) {
+    constexpr int BO = decltype(BO_)::value;
+    using FO = Fmt<BO>;
+    using LO = Lds<BO>;
+    constexpr int PPU3 = (BO == 3) ? FO::UNIT_PAIRS : 2;
+    constexpr int TPU3 = FO::UNIT_PAIRS / PPU3;
+    float2* xs3 = reinterpret_cast<float2*>(reinterpret_cast<unsigned char*>(xp3) + static_cast<size_t>(spr) * LO::SSTR * 4);
+    const int nitems = (KC / FO::UNIT_VALS) * TPU3;
+    if ((tid & ~63) < nitems) {
+      unsigned xw[PPU3];
+      da_load_item<BO, PPU3>(raw3h, min(tid, nitems - 1), xw);
+      da_image_item<BO, BF16, PPU3>(xw, xw, false, 1.f, tid, nitems, xp3, xs3);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < DA_OP; ++p) {
+      const int rl = (p * NW + wave) * rpp + (lane >> lpr_l2);
+      if ((p * NW + wave) * rpp >= RPW) break;                // wave-uniform
+      const bool live = rl < RPW && oslot < spr;
+      float v = da_o_slot<BO, BF16>(ow[p], osc[p], oze[p], xp3, xs3, live ? oslot : 0);
+      v = live ? v : 0.f;
+      v += dpp_f32<0xB1>(v);
+      v += dpp_f32<0x4E>(v);
+      v += dpp_f32<0x141>(v);
+      if (lpr_l2 >= 4) v += dpp_f32<0x140>(v);
+      if (lpr_l2 >= 5) v += dpp_f32<0x142, 0xA>(v);
+      if (oslot == (1 << lpr_l2) - 1 && rl < RPW) {
+        const int row = r * RPW + rl;
+        da_gu64* accp = reinterpret_cast<da_gu64*>(reinterpret_cast<uintptr_t>(a.acc));
+        if (fabsf(v) < 2147483648.f) {
+          const long long fx = __float2ll_rn(v * 4294967296.f);
+          __hip_atomic_fetch_add(accp + row, static_cast<unsigned long long>(fx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          __hip_atomic_fetch_add(accp + D, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // NaN / Inf / out of range: the consumer makes x NaN
+        }
+      }
+    }
+  };
+  if (obits == 2) phase3(std::integral_constant<int, 2>{});
+  else if (obits == 3) phase3(std::integral_constant<int, 3>{});
+  else phase3(std::integral_constant<int, 4>{});
+  // member 0 advances the group's generation: every member has read it (nobody reaches this point before all of them published)
+  if (r == 0 && tid == 0) __hip_atomic_store(gen_p, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  DA_STAMP(8);
+}
+
+#define GBX_DEFINE_LAUNCH_DATTN(BQ, P_)                                                                                      \
+  template <> hipError_t launch_dattn_bits<BQ>(const DattnArgs& a, const DattnPlan& pl, bool bf16, hipStream_t stream) {     \
+    static DeviceOnce once;                                                                                                  \
+    if (pl.P != P_) return hipErrorInvalidValue;                                                                             \
+    if (once.pending()) {                                                                                                    \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dattn_kernel<BQ, P_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, DA_LDS_BYTES); \
+      if (e != hipSuccess) return e;                                                                                         \
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(dattn_kernel<BQ, P_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, DA_LDS_BYTES);           \
+      if (e != hipSuccess) return e;                                                                                         \
+      once.done();                                                                                                           \
+    }                                                                                                                        \
+    if (bf16) hipLaunchKernelGGL((dattn_kernel<BQ, P_, true>), dim3(DA_GROUPS * DA_MEMBERS), dim3(DA_NT), DA_LDS_BYTES, stream, a);   \
+    else hipLaunchKernelGGL((dattn_kernel<BQ, P_, false>), dim3(DA_GROUPS * DA_MEMBERS), dim3(DA_NT), DA_LDS_BYTES, stream, a);       \
+    return hipGetLastError();                                                                                                \
+  }
+
+}  // namespace gbx

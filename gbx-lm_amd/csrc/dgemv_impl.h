@@ -36,6 +36,11 @@ struct DgArgs {
   const unsigned short* norm_w;     // [K] RMSNorm weight or null
   const float* ssq_in;              // [DG_SSQ_SLOTS] partial sums of x^2 left by the producer of x, or null (computed here)
   float* ssq_out;                   // partial sums of y^2 of this launch (one per wave; KS == 4: one per workgroup), or null
+  // round 5 (the fused attention launch, dattn_impl.h, leaves o_proj's partial sums in a 2^-32 fixed-point accumulator):
+  const long long* x_acc;           // [K + 1] or null: x <- round(x + round(x_acc * 2^-32)) in the prologue (word K != 0: x <- NaN)
+  unsigned short* x_out;            // with x_acc: workgroup 0 writes the new x here (the residual stream the next launch adds to)
+  unsigned long long* zero_buf;     // or null: zero_n 8-byte words this launch clears (the accumulator, once its consumer has run)
+  int zero_n;
   int N;                            // output rows (SwiGLU: rows of ONE of the two matrices)
   int K;
   int log2g;                        // 6, 7 (2-bit) / 5, 6, 7 (3-, 4-bit): one (scale, zero) per lane and pass
@@ -225,6 +230,36 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(const DgArgs a) {
     const unsigned pk = carried ? 0u : KILL;
 #pragma unroll
     for (int i = 0; i < 4; ++i) pq[i] = __builtin_amdgcn_raw_buffer_load_b128(pd, static_cast<unsigned>(lane * 16 + 1024 * i) | pk, 0, 0);
+  }
+
+  if (a.zero_buf) {                                          // (kernel-argument uniform)
+    for (int i = static_cast<int>(blockIdx.x) * NT + tid; i < a.zero_n; i += static_cast<int>(gridDim.x) * NT) a.zero_buf[i] = 0ull;
+  }
+  if (a.x_acc) {
+    // x <- round(x + round(acc * 2^-32)): the o_proj output rounded once, the residual add rounded once (gbx_lm/models/qllama.py:138)
+    const bool poison = a.x_acc[K] != 0;
+#pragma unroll
+    for (int j = 0; j < UPT; ++j) {
+      const int it = min(tid + NT * j, nitems - 1);
+      const int u = it / TPU, t = it % TPU;
+      const bool live = (tid + NT * j) < nitems;
+#pragma unroll
+      for (int q = 0; q < XW; ++q) {
+        int idx;
+        if constexpr (BITS == 3) idx = u * F::UNIT_VALS + 2 * q;
+        else idx = u * F::UNIT_VALS + PPU * t + (q < PPU / 2 ? 2 * q : UP + 2 * (q - PPU / 2));
+        const u32x4 av = *reinterpret_cast<const u32x4*>(a.x_acc + idx);
+        const long long a0 = static_cast<long long>((static_cast<unsigned long long>(av.y) << 32) | av.x);
+        const long long a1 = static_cast<long long>((static_cast<unsigned long long>(av.w) << 32) | av.z);
+        const float o0 = round_bf16_or_f16(static_cast<float>(a0) * 2.3283064365386963e-10f, BF16);
+        const float o1 = round_bf16_or_f16(static_cast<float>(a1) * 2.3283064365386963e-10f, BF16);
+        float x0 = act_lo<BF16>(xr[j][q]) + o0, x1 = act_hi<BF16>(xr[j][q]) + o1;
+        if (poison) { x0 = __uint_as_float(0x7FC00000u); x1 = x0; }
+        const unsigned wv = static_cast<unsigned>(f32_to_act<BF16>(x0)) | (static_cast<unsigned>(f32_to_act<BF16>(x1)) << 16);
+        xr[j][q] = wv;
+        if (blockIdx.x == 0 && live && a.x_out) *reinterpret_cast<unsigned*>(a.x_out + idx) = wv;
+      }
+    }
   }
 
   DgBatch<BITS, P, R> ring[D];

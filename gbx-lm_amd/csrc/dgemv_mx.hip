@@ -108,6 +108,33 @@ __global__ __launch_bounds__(NW * 64) void dgemv_mx_kernel(const DgArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) pq[i] = __builtin_amdgcn_raw_buffer_load_b128(pd, static_cast<unsigned>(lane * 16 + 1024 * i) | pk, 0, 0);
   }
+  if (a.zero_buf) {
+    for (int i = static_cast<int>(blockIdx.x) * NT + tid; i < a.zero_n; i += static_cast<int>(gridDim.x) * NT) a.zero_buf[i] = 0ull;
+  }
+  if (a.x_acc) {
+    // x <- round(x + round(acc * 2^-32)) (dgemv_impl.h: the fused attention launch's o_proj sums; workgroup 0 writes the new stream)
+    const bool poison = a.x_acc[K] != 0;
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+      const int it = min(tid + NT * j, NIT - 1);
+      const bool live = (tid + NT * j) < NIT;
+      unsigned wv[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const u32x4 av = *reinterpret_cast<const u32x4*>(a.x_acc + 4 * it + 2 * q);
+        const long long a0 = static_cast<long long>((static_cast<unsigned long long>(av.y) << 32) | av.x);
+        const long long a1 = static_cast<long long>((static_cast<unsigned long long>(av.w) << 32) | av.z);
+        const float o0 = round_bf16_or_f16(static_cast<float>(a0) * 2.3283064365386963e-10f, BF16);
+        const float o1 = round_bf16_or_f16(static_cast<float>(a1) * 2.3283064365386963e-10f, BF16);
+        const unsigned xw = q == 0 ? xr[j].x : xr[j].y;
+        float x0 = act_lo<BF16>(xw) + o0, x1 = act_hi<BF16>(xw) + o1;
+        if (poison) { x0 = __uint_as_float(0x7FC00000u); x1 = x0; }
+        wv[q] = static_cast<unsigned>(f32_to_act<BF16>(x0)) | (static_cast<unsigned>(f32_to_act<BF16>(x1)) << 16);
+      }
+      xr[j] = u32x2{wv[0], wv[1]};
+      if (blockIdx.x == 0 && live && a.x_out) *reinterpret_cast<u32x2*>(a.x_out + 4 * it) = xr[j];
+    }
+  }
   DmxBatch<SP> ring[2];
   if constexpr (!LATE) issue(ring[0], batch_of(0));
 

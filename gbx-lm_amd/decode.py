@@ -32,7 +32,8 @@ class DecodeRunner:
         self.dtype = model.model.embed_tokens.weight.dtype
         self.batch = caches[0].keys.shape[0] if caches[0].keys is not None else 1
         self.tok = torch.zeros((self.batch,), dtype=torch.long, device=self.dev)
-        self.pos = torch.zeros((1,), dtype=torch.long, device=self.dev)
+        if getattr(self, "pos", None) is None:                   # (FusedDecodeRunner creates it first: its descriptors hold the address)
+            self.pos = torch.zeros((1,), dtype=torch.long, device=self.dev)
         self.logits = None
         self.graph = None
         a0 = model.model.layers[0].self_attn
@@ -353,6 +354,7 @@ class FusedDecodeRunner(DecodeRunner):
         D = model.args.hidden_size
         I = model.model.layers[0].mlp.gate_proj.output_dims
         mk = lambda n: torch.zeros((n,), dtype=dt, device=dev)
+        self.pos = torch.zeros((1,), dtype=torch.long, device=dev)
         nq, nkv = a0.n_heads * a0.head_dim, a0.n_kv_heads * a0.head_dim
         self.qkvb = mk(nq + 2 * nkv)             # q | k | v of the token: one buffer (one-segment q|k|v launch below), three views
         self.hb, self.qb, self.kb, self.vb = mk(D), self.qkvb[:nq], self.qkvb[nq:nq + nkv], self.qkvb[nq + nkv:]
@@ -387,6 +389,13 @@ class FusedDecodeRunner(DecodeRunner):
                             b.mlp.gate_proj.group_size >= 64 and
                             b.mlp.gate_proj.input_dims // (64 if b.mlp.gate_proj.bits == 2 else 32) <= 128
                             for b in model.model.layers))
+        # Round 5: RMSNorm + q|k|v + RoPE / cache append + attention + o_proj as ONE launch per block (gbx_dattn_forward: one kv head per
+        # XCD, hand-offs inside the XCD's L2, o_proj K-split by kv group into a fixed-point accumulator); the gate|up launch forms
+        # h + o in its prologue, the down launch clears the accumulator -- three launches per block instead of five.
+        self.use_dattn = (env.flag("GBX_DATTN") and not tp and self.attn_ws is None and not self.fuse_ao and env.flag("GBX_DGEMV") and
+                          env.flag("GBX_QKV_CAT"))
+        self.da = []                        # per layer: (dattn, gate|up, down) descriptors, or None (the five-launch block)
+        self.da_acc = self.da_state = None
         self.descs = []
         self.descs_ao = []
         self.dg = []                        # per layer: [qkv, o, gate|up, down] dgemv descriptors (None: the launch stays on gbx_qlinear_fused_forward)
@@ -428,7 +437,9 @@ class FusedDecodeRunner(DecodeRunner):
             # Round 4: the four launches on the decode-block GEMV (gbx_dgemv_forward: compact kernel arguments, 2 / 4 rows per
             # batch, vector epilogue) wherever it covers the shape; the RMSNorm statistic of h is carried from the launch that
             # writes h (o_proj / down_proj epilogue, one partial per workgroup) to the launch that normalises it (GBX_DG_SSQ).
+            ssq_prev_layer = self.ssq_prev
             self.dg.append(self._dgemv_descs(blk, qkv_mods[0] if len(qkv_mods) == 1 else None, qkv_ys[0], tp, r0, len(self.dg)))
+            self.da.append(self._dattn_descs(blk, qkv_mods[0] if len(qkv_mods) == 1 else None, caches[len(self.da)], ssq_prev_layer))
             if self.fuse_ao and p_gu is not None:
                 self.descs_ao.append((
                     # x = hb + round(acc) formed in the prologue, the new stream written to pb once
@@ -499,6 +510,53 @@ class FusedDecodeRunner(DecodeRunner):
         self.ssq_prev = ssq_dn if out[3] is not None else None
         return out
 
+    def _dattn_descs(self, blk, qkv_cat, cache, ssq_prev):
+        """(fused attention launch, gate|up with the accumulator prologue, down_proj that clears it) of one block, or None."""
+        from . import _lib as _l
+        at, mlp = blk.self_attn, blk.mlp
+        if (not self.use_dattn or qkv_cat is None or getattr(at, "q_norm", None) is not None or at.o_proj.bias is not None or
+                mlp.gate_proj.bias is not None or mlp.up_proj.bias is not None or mlp.down_proj.bias is not None or
+                cache.keys is None or cache.keys.shape[0] != 1 or not cache.keys.is_contiguous() or not cache.values.is_contiguous() or
+                not ops.dattn_supported(self.hb.numel(), at.n_heads, at.n_kv_heads, at.head_dim, qkv_cat, at.o_proj)):
+            return None
+        g_dn = self.dg[-1][3]
+        pl_gu = ops.dgemv_plan(mlp.gate_proj.output_dims, mlp.gate_proj.input_dims, mlp.gate_proj.bits, mlp.gate_proj.group_size,
+                               _l.GBX_DG_SWIGLU, True)
+        pl_dn = ops.dgemv_plan(mlp.down_proj.output_dims, mlp.down_proj.input_dims, mlp.down_proj.bits, mlp.down_proj.group_size,
+                               _l.GBX_DG_RESIDUAL, False)
+        if pl_gu is None or pl_dn is None or g_dn is None:
+            return None
+        dev = self.hb.device
+        D = self.hb.numel()
+        if self.da_acc is None:
+            self.da_acc = torch.zeros((D + 1,), dtype=torch.int64, device=dev)
+            self.da_state = ops.dattn_state(dev)
+        pk_qkv = ops.dgemv_pack(qkv_cat, 2)
+        pk_gu = ops.dgemv_pack(mlp.gate_proj, pl_gu[0], mlp.up_proj)
+        pk_dn = ops.dgemv_pack(mlp.down_proj, pl_dn[0])
+        self.dg_keep += [pk_qkv, pk_gu, pk_dn]
+        d_a = ops.make_dattn_desc(self.hb, blk.input_layernorm.weight, blk.input_layernorm.eps, qkv_cat, pk_qkv, cache.keys, cache.values,
+                                  at.rope.inv_freq, self.pos_buf(), at.o_proj, self.da_acc, self.da_state, at.n_heads, cache.capacity,
+                                  getattr(at.rope, "scale", 1.0), at.scale, at.rope.traditional, ssq_in=ssq_prev)
+        d_gu = ops.make_dgemv_desc(self.hb, mlp.gate_proj, self.actb, pk_gu, pl_gu[0], mod_up=mlp.up_proj,
+                                   norm_weight=blk.post_attention_layernorm.weight, eps=blk.post_attention_layernorm.eps,
+                                   x_acc=self.da_acc, x_out=self.pb)
+        # the statistic of the stream this launch writes goes to the next block's norm'd launch exactly as in the five-launch block
+        d_dn = ops.make_dgemv_desc(self.actb, mlp.down_proj, self.hb, pk_dn, pl_dn[0], residual=self.pb,
+                                   ssq_out=self.ssq_prev, zero_buf=self.da_acc)
+        return d_a, d_gu, d_dn
+
+    def pos_buf(self) -> torch.Tensor:
+        return self.pos
+
+    def dattn_check(self) -> None:
+        """Raise if a fused attention launch of this runner timed out on a hand-off (synchronises: call off the timed path)."""
+        if self.da_state is not None:
+            code = ops.dattn_status(self.da_state)
+            if code:
+                raise RuntimeError(f"gbx_dattn_forward: hand-off {code} timed out (workgroup placement broke the one-kv-group-per-XCD "
+                                   "bijection, or a member never ran); the results of this runner are invalid -- rerun with GBX_DATTN=0")
+
     def _forward(self):
         m = self.model.model
         dev = self.dev
@@ -513,6 +571,12 @@ class FusedDecodeRunner(DecodeRunner):
             at = blk.self_attn
             g_qkv, g_o, g_gu, g_dn = self.dg[li]
             run = lambda g, d: ops.dgemv(g, dev) if g is not None else ops.qlinear_fused(d, dev)
+            if self.da[li] is not None:
+                d_a, d_gu3, d_dn3 = self.da[li]
+                ops.dattn(d_a, dev)
+                ops.dgemv(d_gu3, dev)
+                ops.dgemv(d_dn3, dev)
+                continue
             run(g_qkv, d_qkv)
             if self.fuse_ao:
                 d_gu2, d_dn2 = self.descs_ao[li]

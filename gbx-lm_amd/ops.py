@@ -693,10 +693,14 @@ def dgemv_pack(mod, rows_per_batch: int, mod_up=None) -> torch.Tensor:
 
 def make_dgemv_desc(x: torch.Tensor, mod, y: torch.Tensor, packed: torch.Tensor, rows_per_batch: int, mod_up=None,
                     norm_weight: Optional[torch.Tensor] = None, eps: float = 0.0, residual: Optional[torch.Tensor] = None,
-                    ssq_in: Optional[torch.Tensor] = None, ssq_out: Optional[torch.Tensor] = None) -> "_lib.DgDesc":
+                    ssq_in: Optional[torch.Tensor] = None, ssq_out: Optional[torch.Tensor] = None,
+                    x_acc: Optional[torch.Tensor] = None, x_out: Optional[torch.Tensor] = None,
+                    zero_buf: Optional[torch.Tensor] = None) -> "_lib.DgDesc":
     """Descriptor of one decode-block GEMV launch (gbx_dgemv_forward): ``mod`` alone (optionally ``+ residual``), or
     ``silu(mod(x)) * mod_up(x)``.  ``ssq_out`` / ``ssq_in``: float32 [GBX_DG_SSQ_SLOTS] buffers that carry the RMSNorm
-    statistic from the launch that writes ``x`` to the launch that normalises it.  Tensors must stay alive and in place."""
+    statistic from the launch that writes ``x`` to the launch that normalises it.  ``x_acc`` (int64 [K + 1], the fused attention
+    launch's fixed-point o_proj sums) / ``x_out``: the prologue forms ``x + round(x_acc * 2^-32)`` and writes it to ``x_out``;
+    ``zero_buf`` (int64): cleared by this launch.  Tensors must stay alive and in place."""
     import ctypes
     for m in (mod,) + ((mod_up,) if mod_up is not None else ()):
         if m.bias is not None:
@@ -723,6 +727,15 @@ def make_dgemv_desc(x: torch.Tensor, mod, y: torch.Tensor, packed: torch.Tensor,
     d.N, d.K, d.bits, d.group_size, d.act_dtype = mod.output_dims, mod.input_dims, mod.bits, mod.group_size, _DT[x.dtype]
     d.rows_per_batch = rows_per_batch
     d.norm_eps = float(eps)
+    if x_acc is not None:
+        if x_acc.dtype != torch.int64 or x_acc.numel() != mod.input_dims + 1 or not x_acc.is_contiguous():
+            raise ValueError("x_acc is int64 [K + 1]")
+        d.x_acc = x_acc.data_ptr()
+        d.x_out = x_out.data_ptr() if x_out is not None else None
+    if zero_buf is not None:
+        if zero_buf.dtype != torch.int64 or not zero_buf.is_contiguous():
+            raise ValueError("zero_buf is a contiguous int64 tensor")
+        d.zero_buf, d.zero_n = zero_buf.data_ptr(), zero_buf.numel()
     if packed.dtype != torch.int32 or packed.numel() != (2 if mod_up is not None else 1) * mod.output_dims * (mod.input_dims // mod.group_size):
         raise ValueError("packed scales/zeros do not match the launch")
     return d
@@ -731,6 +744,78 @@ def make_dgemv_desc(x: torch.Tensor, mod, y: torch.Tensor, packed: torch.Tensor,
 def dgemv(desc, device) -> None:
     import ctypes
     _lib.check(_lib.lib().gbx_dgemv_forward(ctypes.byref(desc), _stream_ptr(device)))
+
+
+def dgemv_kernel_name(desc) -> str:
+    """Name of the kernel gbx_dgemv_forward launches for this descriptor, as rocprofv3 prints its template head (read back from
+    the library, gbx_dgemv_kernel_id: bench labels and profile filters never re-derive the dispatch)."""
+    import ctypes
+    k, nw, r = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+    _lib.check(_lib.lib().gbx_dgemv_kernel_id(ctypes.byref(desc), ctypes.byref(k), ctypes.byref(nw), ctypes.byref(r)))
+    return f"{'dgemv_mx_kernel' if k.value == 1 else 'dgemv_kernel'} (NW {nw.value}, R {r.value})"
+
+
+def dattn_supported(d_model: int, n_heads: int, n_kv: int, head_dim: int, qkv_mod, o_mod) -> bool:
+    """Does the fused attention launch (gbx_dattn_forward) cover this block?"""
+    L = _lib.lib()
+    if not hasattr(L, "gbx_dattn_plan"):
+        return False
+    return L.gbx_dattn_plan(d_model, n_heads, n_kv, head_dim, qkv_mod.bits, qkv_mod.group_size, o_mod.bits, o_mod.group_size) == _lib.GBX_OK
+
+
+def dattn_state(device) -> torch.Tensor:
+    """Hand-off state of the fused attention launch: zero-filled once, private to one stream (one decode runner)."""
+    return torch.zeros((_lib.lib().gbx_dattn_state_bytes(),), dtype=torch.uint8, device=device)
+
+
+def make_dattn_desc(x: torch.Tensor, norm_weight: torch.Tensor, eps: float, qkv_mod, qkv_packed: torch.Tensor, kcache: torch.Tensor,
+                    vcache: torch.Tensor, inv_freq: torch.Tensor, pos: torch.Tensor, o_mod, acc: torch.Tensor, state: torch.Tensor,
+                    n_heads: int, capacity: int, rope_scale: float, sm_scale: float, traditional: bool,
+                    ssq_in: Optional[torch.Tensor] = None, attn_out: Optional[torch.Tensor] = None) -> "_lib.DattnDesc":
+    """Descriptor of one fused attention launch: RMSNorm -> q|k|v (``qkv_mod``: the three projections' rows concatenated) -> RoPE +
+    cache append -> attention -> o_proj partial sums into ``acc`` (int64 [D + 1], 2^-32 fixed point)."""
+    import ctypes
+    D = x.numel()
+    for t in (x, norm_weight, qkv_mod.qweight, qkv_packed, kcache, vcache, inv_freq, pos, o_mod.qweight, o_mod.scales, o_mod.zeros, acc, state):
+        _require_cuda(t, "dattn tensor")
+    if qkv_mod.bias is not None or o_mod.bias is not None:
+        raise NotImplementedError("the fused attention launch carries no bias")
+    if acc.dtype != torch.int64 or acc.numel() != D + 1:
+        raise ValueError("acc is int64 [D + 1]")
+    if qkv_mod.output_dims != (n_heads + 16) * 128 or qkv_mod.input_dims != D or o_mod.output_dims != D or o_mod.input_dims != n_heads * 128:
+        raise ValueError("shapes do not describe a block with 8 kv heads of 128")
+    if kcache.shape[0] != 1 or kcache.shape[1] != 8 or kcache.shape[2] != capacity or kcache.shape[3] != 128 or not kcache.is_contiguous():
+        raise ValueError("kcache / vcache are [1, 8, capacity, 128]")
+    if qkv_packed.dtype != torch.int32 or qkv_packed.numel() != qkv_mod.output_dims * (D // qkv_mod.group_size):
+        raise ValueError("qkv_packed is gbx_dgemv_pack of the concatenated matrix, rows_per_batch 2")
+    d = _lib.DattnDesc()
+    d.struct_size = ctypes.sizeof(_lib.DattnDesc)
+    d.act_dtype = _DT[x.dtype]
+    d.x, d.norm_weight = x.data_ptr(), norm_weight.data_ptr()
+    d.ssq_in = ssq_in.data_ptr() if ssq_in is not None else None
+    d.qkv_qweight, d.qkv_sz = qkv_mod.qweight.data_ptr(), qkv_packed.data_ptr()
+    d.kcache, d.vcache, d.inv_freq, d.pos = kcache.data_ptr(), vcache.data_ptr(), inv_freq.data_ptr(), pos.data_ptr()
+    d.o_qweight, d.o_scales, d.o_zeros = o_mod.qweight.data_ptr(), o_mod.scales.data_ptr(), o_mod.zeros.data_ptr()
+    d.acc, d.state = acc.data_ptr(), state.data_ptr()
+    d.attn_out = attn_out.data_ptr() if attn_out is not None else None
+    d.D, d.n_heads, d.capacity = D, n_heads, capacity
+    d.qkv_bits, d.qkv_group_size, d.o_bits, d.o_group_size = qkv_mod.bits, qkv_mod.group_size, o_mod.bits, o_mod.group_size
+    d.traditional = 1 if traditional else 0
+    d.norm_eps, d.rope_scale, d.sm_scale = float(eps), float(rope_scale), float(sm_scale)
+    return d
+
+
+def dattn(desc, device) -> None:
+    import ctypes
+    _lib.check(_lib.lib().gbx_dattn_forward(ctypes.byref(desc), _stream_ptr(device)))
+
+
+def dattn_status(state: torch.Tensor) -> int:
+    """0, or the hand-off of a fused attention launch that timed out (synchronises; call off the timed path)."""
+    import ctypes
+    c = ctypes.c_int32(0)
+    _lib.check(_lib.lib().gbx_dattn_status(state.data_ptr(), ctypes.byref(c)))
+    return c.value
 
 
 class StreamProgram:

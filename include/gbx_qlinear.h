@@ -159,6 +159,13 @@ typedef struct gbx_dgemv {
   int32_t N, K, bits, group_size, act_dtype;
   int32_t rows_per_batch;      /* what sz was packed for (gbx_dgemv_plan) */
   float norm_eps;
+  /* round 5, with gbx_dattn_forward (below): o_proj's output arrives as 2^-32 fixed-point partial sums instead of a vector */
+  const int64_t* x_acc;        /* optional, with norm_weight and without ssq_in: [K + 1]; the prologue forms
+                                  x <- round(x + round(x_acc * 2^-32)) (qllama.py:96,138: o_proj's rounding, then the residual
+                                  add's); x_acc[K] != 0 (a non-finite partial sum) makes every x NaN */
+  void* x_out;                 /* optional with x_acc: [K], the new x (the residual stream), written once */
+  uint64_t* zero_buf;          /* optional: zero_n 8-byte words this launch clears (the accumulator, after its consumer) */
+  int32_t zero_n;
 } gbx_dgemv;
 
 /* rows_per_batch (2 / 4) the library prefers for this launch (with_norm: it will carry norm_weight) and the number of partial
@@ -172,6 +179,52 @@ int gbx_dgemv_plan(int32_t N, int32_t K, int32_t bits, int32_t group_size, int32
 int gbx_dgemv_pack(const void* scales0, const void* zeros0, const void* scales1, const void* zeros1, uint32_t* out,
                    int32_t N, int32_t G, int32_t rows_per_batch, void* hip_stream);
 int gbx_dgemv_forward(const gbx_dgemv* desc, void* hip_stream);
+/* The kernel gbx_dgemv_forward launches for this descriptor, for profiles and bench labels: 0 = dgemv_kernel (vector dot),
+ * 1 = dgemv_mx_kernel (FP4 x FP8 matrix cores); workgroup width and rows per batch through the optional out parameters.
+ * GBX_ERR_UNSUPPORTED as gbx_dgemv_forward would report it. */
+int gbx_dgemv_kernel_id(const gbx_dgemv* desc, int32_t* kernel, int32_t* waves_per_workgroup, int32_t* rows_per_batch);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused attention launch of a decoder block at M == 1 (round 5): input RMSNorm -> q | k | v projections -> RoPE + KV-cache
+ * append -> attention -> o_proj, ONE launch per block instead of three (qllama.py:137 norm, :76 q/k/v, :78-95 attention,
+ * :96 o_proj).  One kv head per XCD (n_kv_heads == 8, head_dim 128): the two hand-offs inside the launch (q|k|v -> attention ->
+ * o_proj) stay inside one XCD's L2; o_proj is K-split by kv group and its partial sums meet in `acc` as 2^-32 fixed-point
+ * integers (order-independent, bit-reproducible).  The consumer is the block's gate|up launch (gbx_dgemv.x_acc / x_out), the
+ * down_proj launch clears acc (gbx_dgemv.zero_buf).  Caches longer than the launch's single sweep stay on gbx_attn_decode_ws.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct gbx_dattn {
+  uint32_t struct_size;        /* sizeof(gbx_dattn) */
+  int32_t act_dtype;
+  const void* x;               /* [D] residual stream */
+  const void* norm_weight;     /* [D] input_layernorm weight */
+  const float* ssq_in;         /* optional: GBX_DG_SSQ_SLOTS partial sums of x^2 left by the launch that wrote x */
+  const uint32_t* qkv_qweight; /* [(n_heads + 2 * 8) * 128, D * qkv_bits / 32]: q_proj | k_proj | v_proj rows concatenated */
+  const uint32_t* qkv_sz;      /* gbx_dgemv_pack of that matrix, rows_per_batch 2 */
+  void* kcache;                /* [8, capacity, 128] (reference layout, models/cache.py:222-244, batch 1) */
+  void* vcache;
+  const float* inv_freq;       /* [64] RoPE inverse frequencies */
+  const int64_t* pos;          /* device scalar: index of the new token (cached positions [0, pos)) */
+  const uint32_t* o_qweight;   /* [D, n_heads * 128 * o_bits / 32] */
+  const void* o_scales;        /* [D, n_heads * 128 / o_group_size], act_dtype */
+  const void* o_zeros;
+  int64_t* acc;                /* [D + 1], zero on entry; receives o_proj . attention as 2^-32 fixed point (word D: non-finite marker) */
+  void* state;                 /* gbx_dattn_state_bytes() bytes, zero-filled ONCE by the caller, private to one stream */
+  void* attn_out;              /* optional [n_heads * 128]: the attention output before o_proj (tests) */
+  int32_t D, n_heads, capacity;
+  int32_t qkv_bits, qkv_group_size, o_bits, o_group_size;
+  int32_t traditional;
+  float norm_eps, rope_scale, sm_scale;
+} gbx_dattn;
+
+/* GBX_OK when the fused launch covers the shape (8 kv heads, head_dim 128, D <= 4096, n_heads a multiple of 8 up to 64, ...),
+ * GBX_ERR_UNSUPPORTED otherwise (the caller keeps gbx_dgemv_forward + gbx_attn_decode + gbx_dgemv_forward). */
+int gbx_dattn_plan(int32_t D, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int32_t qkv_bits, int32_t qkv_group_size,
+                   int32_t o_bits, int32_t o_group_size);
+size_t gbx_dattn_state_bytes(void);
+int gbx_dattn_forward(const gbx_dattn* desc, void* hip_stream);
+/* Synchronous read of the launch status word: *code = 0, or the hand-off that timed out (1: q|k|v, 2: attention output) -- then
+ * the results of that stream are garbage and the caller must fail.  Off the timed path (it synchronises the device). */
+int gbx_dattn_status(const void* state, int32_t* code);
 
 /* Load-time companion of the loader's scale/zero cast (gbx_lm/utils.py:841-843): out[p][g][i] = scale bits | zero bits << 16
  * (16-bit act-dtype patterns, copied verbatim) for the two rows a GEMV batch streams together:

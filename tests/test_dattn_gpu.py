@@ -1,0 +1,253 @@
+"""GPU: the fused attention launch of round 5 (gbx_dattn_forward: RMSNorm -> q|k|v -> RoPE + cache append -> attention -> o_proj
+partial sums, one kv head per XCD) and its two companions (gbx_dgemv.x_acc / x_out prologue, zero_buf), through the C-ABI.
+
+Reference: the same block computed in fp64 on gbx_dequantize weights with the reference graph's roundings
+(gbx_lm/models/qllama.py:68-96,131-141; mx.quantized_matmul at M == 1, quantized_linear_gba.py:195-203) -- the tolerance is the
+decode GEMV's (2e-2 of the value + 2e-2 of the vector's RMS), stated at each assert.  Integer / index work (the cache row the
+launch appends, the accumulator's fixed-point format, the generation tags over repeated launches) is checked exactly.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).double()
+
+
+def _deq(m):
+    from gbx_lm_amd import ops
+    return ops.dequantize(m.qweight, m.scales, m.zeros, m.group_size, m.bits, dtype=torch.float32).double()
+
+
+def _layer(cfg_name, bits_qkv, bits_o, group=128, seed=0):
+    from gbx_lm_amd import synthetic as S
+    cfg = dict(getattr(S, cfg_name), num_hidden_layers=1, vocab_size=512)
+    strat = S.make_strategy("S22", 1, group)
+    for p in strat["model.layers.0"]:
+        b = bits_o if p.endswith("o_proj") else bits_qkv
+        strat["model.layers.0"][p] = {"bits": [b], "group_size": {str(b): group}}
+    return S.build_model(cfg, strat, device=DEV, seed=seed), cfg
+
+
+def _cat_qkv(at):
+    from gbx_lm_amd.models.quantized_linear_gba import QuantizedLinear
+    mods = (at.q_proj, at.k_proj, at.v_proj)
+    cat = QuantizedLinear(at.q_proj.input_dims, sum(m.output_dims for m in mods), False, at.q_proj.group_size, at.q_proj.bits)
+    for nm in ("qweight", "scales", "zeros"):
+        cat._buffers[nm] = torch.cat([getattr(m, nm) for m in mods]).contiguous()
+    return cat
+
+
+def _reference(blk, h, pos, kc, vc):
+    """fp64 on dequantised weights, bf16 roundings where the reference graph holds a bf16 tensor.  Returns (q_rot, k_rot, v, attn, o)."""
+    from gbx_lm_amd.models.rope_utils import apply_rope
+    at = blk.self_attn
+    hd, nh, nkv = at.head_dim, at.n_heads, at.n_kv_heads
+    xf = h.double()
+    xn = _bf(xf * torch.rsqrt(xf.pow(2).mean() + blk.input_layernorm.eps) * blk.input_layernorm.weight.double())
+    q, k, v = _bf(_deq(at.q_proj) @ xn), _bf(_deq(at.k_proj) @ xn), _bf(_deq(at.v_proj) @ xn)
+    inv = at.rope.inv_freq.cpu()
+    sc = getattr(at.rope, "scale", 1.0)
+    qr = apply_rope(q.to(torch.bfloat16).cpu().view(1, nh, 1, hd), inv, pos, sc, at.rope.traditional).to(DEV).double().view(nh, hd)
+    kr = apply_rope(k.to(torch.bfloat16).cpu().view(1, nkv, 1, hd), inv, pos, sc, at.rope.traditional).to(DEV).double().view(nkv, hd)
+    K = torch.cat([kc[:, :pos].double(), kr[:, None]], 1)
+    V = torch.cat([vc[:, :pos].double(), v.view(nkv, 1, hd)], 1)
+    rep = nh // nkv
+    s = torch.einsum("hd,htd->ht", qr, K.repeat_interleave(rep, 0)) * at.scale
+    attn = _bf(torch.einsum("ht,htd->hd", torch.softmax(s, -1), V.repeat_interleave(rep, 0)).reshape(-1))
+    return kr, v.view(nkv, hd), attn
+
+
+def _close(got, want, what, rel=2e-2):
+    err = (got.double() - want).abs()
+    tol = rel * want.abs() + rel * want.pow(2).mean().sqrt()
+    assert (err <= tol).all(), f"{what}: {int((err > tol).sum())} of {want.numel()} outside tolerance, worst {err.max().item():.4g}"
+
+
+CASES = [
+    ("LLAMA3_8B", 2, 2, 40), ("LLAMA3_8B", 3, 3, 9), ("LLAMA3_8B", 4, 4, 131), ("LLAMA3_8B", 2, 4, 200), ("LLAMA3_8B", 4, 2, 0),
+    ("LLAMA32_3B", 2, 2, 17), ("LLAMA32_3B", 4, 4, 130), ("LLAMA32_3B", 3, 2, 64),
+]
+
+
+@pytest.mark.parametrize("cfg_name,bq,bo,ctx", CASES)
+def test_dattn_launch_vs_fp64(cfg_name, bq, bo, ctx):
+    from gbx_lm_amd import ops
+    model, cfg = _layer(cfg_name, bq, bo, seed=bq * 10 + bo)
+    blk = model.model.layers[0]
+    at = blk.self_attn
+    D, nh, nkv, hd = cfg["hidden_size"], at.n_heads, at.n_kv_heads, at.head_dim
+    cat = _cat_qkv(at)
+    assert ops.dattn_supported(D, nh, nkv, hd, cat, at.o_proj), "the BASELINE geometries must be covered"
+    cap = 256
+    gen = torch.Generator(device="cpu").manual_seed(ctx + 1)
+    h = (torch.randn(D, generator=gen) * 0.7).to(torch.bfloat16).to(DEV)
+    kc = (torch.randn(1, nkv, cap, hd, generator=gen) * 0.5).to(torch.bfloat16).to(DEV)
+    vc = (torch.randn(1, nkv, cap, hd, generator=gen)).to(torch.bfloat16).to(DEV)
+    kc0, vc0 = kc.clone(), vc.clone()
+    pos = torch.tensor([ctx], dtype=torch.long, device=DEV)
+    acc = torch.zeros(D + 1, dtype=torch.int64, device=DEV)
+    state = ops.dattn_state(DEV)
+    attn_out = torch.zeros(nh * hd, dtype=torch.bfloat16, device=DEV)
+    pk = ops.dgemv_pack(cat, 2)
+    d = ops.make_dattn_desc(h, blk.input_layernorm.weight, blk.input_layernorm.eps, cat, pk, kc, vc, at.rope.inv_freq, pos, at.o_proj,
+                            acc, state, nh, cap, getattr(at.rope, "scale", 1.0), at.scale, at.rope.traditional, attn_out=attn_out)
+    ops.dattn(d, DEV)
+    torch.cuda.synchronize()
+    assert ops.dattn_status(state) == 0, "a hand-off timed out"
+    kr, v, attn = _reference(blk, h, ctx, kc0[0], vc0[0])
+    # the appended cache row: RoPE(k) and v of the new token, everything else untouched (exact)
+    _close(kc[0, :, ctx], kr, "appended K row", rel=1e-2)
+    _close(vc[0, :, ctx], v, "appended V row", rel=2e-2)
+    keep = torch.ones(cap, dtype=torch.bool, device=DEV)
+    keep[ctx] = False
+    assert torch.equal(kc[0][:, keep], kc0[0][:, keep]) and torch.equal(vc[0][:, keep], vc0[0][:, keep]), "rows other than `pos` changed"
+    _close(attn_out, attn, "attention output")
+    # o_proj: against the launch's OWN attention output (isolates phase 3), fixed point -> float
+    o_got = acc[:D].double() * 2.0 ** -32
+    o_want = _deq(at.o_proj) @ attn_out.double()
+    _close(o_got, o_want, "o_proj partial sums", rel=1e-2)
+    assert int(acc[D].item()) == 0, "non-finite marker set on finite data"
+
+
+def test_dattn_repeated_launches_and_accumulator_protocol():
+    """Generation tags: 50 launches back to back on one state buffer (each must consume the hand-offs of ITS launch: the inputs change
+    every time); the accumulator ADDS (two launches without clearing = twice the sums, integer-exact); results are bit-reproducible."""
+    from gbx_lm_amd import ops
+    model, cfg = _layer("LLAMA3_8B", 2, 2, seed=3)
+    blk = model.model.layers[0]
+    at = blk.self_attn
+    D, nh, nkv, hd = cfg["hidden_size"], at.n_heads, at.n_kv_heads, at.head_dim
+    cat = _cat_qkv(at)
+    cap = 256
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    hs = (torch.randn(50, D, generator=gen)).to(torch.bfloat16).to(DEV)
+    h = hs[0].clone()
+    kc = torch.zeros(1, nkv, cap, hd, dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros_like(kc)
+    pos = torch.zeros(1, dtype=torch.long, device=DEV)
+    acc = torch.zeros(D + 1, dtype=torch.int64, device=DEV)
+    state = ops.dattn_state(DEV)
+    attn_out = torch.zeros(nh * hd, dtype=torch.bfloat16, device=DEV)
+    pk = ops.dgemv_pack(cat, 2)
+    d = ops.make_dattn_desc(h, blk.input_layernorm.weight, blk.input_layernorm.eps, cat, pk, kc, vc, at.rope.inv_freq, pos, at.o_proj,
+                            acc, state, nh, cap, getattr(at.rope, "scale", 1.0), at.scale, at.rope.traditional, attn_out=attn_out)
+    outs = []
+    for t in range(50):
+        h.copy_(hs[t])
+        pos.fill_(t)
+        acc.zero_()
+        ops.dattn(d, DEV)
+        outs.append((attn_out.clone(), acc.clone()))
+    torch.cuda.synchronize()
+    assert ops.dattn_status(state) == 0
+    # replay the last step from a copy of the cache as it was: identical bits (order-independent fixed-point sums)
+    kc2, vc2 = kc.clone(), vc.clone()
+    acc.zero_()
+    ops.dattn(d, DEV)
+    assert torch.equal(attn_out, outs[-1][0]) and torch.equal(acc, outs[-1][1]), "the launch is not bit-reproducible"
+    assert torch.equal(kc, kc2) and torch.equal(vc, vc2)
+    ops.dattn(d, DEV)                                          # no clearing: the sums add
+    assert torch.equal(acc[:D], 2 * outs[-1][1][:D])
+    # step t against the fp64 reference on the cache the earlier steps built
+    kr, v, attn = _reference(blk, hs[49], 49, kc2[0], vc2[0])
+    _close(outs[-1][0], attn, "attention output of step 49")
+
+
+@pytest.mark.parametrize("bits", [2, 4])
+def test_gateup_prologue_reads_the_accumulator(bits):
+    """gbx_dgemv with x_acc / x_out: x' = round(x + round(acc * 2^-32)) formed in the prologue must give the launch's output on x' and
+    write x' once; zero_buf clears; the non-finite marker turns x' into NaN."""
+    from gbx_lm_amd import _lib, ops
+    model, cfg = _layer("LLAMA3_8B", bits, bits, seed=7)
+    mlp = model.model.layers[0].mlp
+    nw = model.model.layers[0].post_attention_layernorm
+    D, I = cfg["hidden_size"], cfg["intermediate_size"]
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    x = torch.randn(D, generator=gen).to(torch.bfloat16).to(DEV)
+    o = (torch.randn(D, generator=gen) * 0.3).double()
+    acc = torch.zeros(D + 1, dtype=torch.int64, device=DEV)
+    acc[:D] = torch.round(o * 2.0 ** 32).to(torch.int64).to(DEV)
+    xo = torch.zeros(D, dtype=torch.bfloat16, device=DEV)
+    y = torch.zeros(I, dtype=torch.bfloat16, device=DEV)
+    y2 = torch.zeros_like(y)
+    pl = ops.dgemv_plan(I, D, bits, 128, _lib.GBX_DG_SWIGLU, True)
+    pk = ops.dgemv_pack(mlp.gate_proj, pl[0], mlp.up_proj)
+    d = ops.make_dgemv_desc(x, mlp.gate_proj, y, pk, pl[0], mod_up=mlp.up_proj, norm_weight=nw.weight, eps=nw.eps, x_acc=acc, x_out=xo)
+    ops.dgemv(d, DEV)
+    want_x = (x.double() + (acc[:D].double() * 2.0 ** -32).to(torch.bfloat16).double()).to(torch.bfloat16)
+    assert torch.equal(xo, want_x), "x_out is not round(x + round(acc * 2^-32))"
+    d2 = ops.make_dgemv_desc(want_x, mlp.gate_proj, y2, pk, pl[0], mod_up=mlp.up_proj, norm_weight=nw.weight, eps=nw.eps)
+    ops.dgemv(d2, DEV)
+    assert torch.equal(y, y2), "the accumulator prologue changed the launch's arithmetic"
+    # zero_buf on a residual launch
+    pl_dn = ops.dgemv_plan(D, I, bits, 128, _lib.GBX_DG_RESIDUAL, False)
+    pk_dn = ops.dgemv_pack(mlp.down_proj, pl_dn[0])
+    hb = torch.zeros(D, dtype=torch.bfloat16, device=DEV)
+    d3 = ops.make_dgemv_desc(y, mlp.down_proj, hb, pk_dn, pl_dn[0], residual=xo, zero_buf=acc)
+    ops.dgemv(d3, DEV)
+    assert int(acc.abs().sum().item()) == 0, "zero_buf left words behind"
+    d4 = ops.make_dgemv_desc(y, mlp.down_proj, torch.zeros_like(hb), pk_dn, pl_dn[0], residual=xo)
+    ops.dgemv(d4, DEV)
+    # non-finite marker
+    acc[D] = 1
+    ops.dgemv(d, DEV)
+    assert torch.isnan(xo.float()).all() and torch.isnan(y.float()).all()
+    with pytest.raises(ValueError):
+        bad = ops.make_dgemv_desc(x, mlp.gate_proj, y, pk, pl[0], mod_up=mlp.up_proj, norm_weight=nw.weight, eps=nw.eps, x_acc=acc, x_out=x)
+        ops.dgemv(bad, DEV)
+
+
+def test_dattn_plan_refuses_what_it_does_not_cover():
+    from gbx_lm_amd import _lib
+    L = _lib.lib()
+    ok = lambda *a: L.gbx_dattn_plan(*a) == _lib.GBX_OK
+    assert ok(4096, 32, 8, 128, 2, 128, 2, 128) and ok(3072, 24, 8, 128, 4, 128, 4, 128) and ok(4096, 32, 8, 128, 3, 64, 4, 32)
+    assert not ok(4096, 32, 4, 128, 2, 128, 2, 128), "4 kv heads: no XCD bijection"
+    assert not ok(2048, 32, 8, 64, 4, 128, 4, 128), "head_dim 64"
+    assert not ok(8192, 64, 8, 128, 2, 128, 2, 128), "rows longer than one lane pass at 2 bits"
+    assert not ok(4096, 32, 8, 128, 2, 32, 2, 128), "2-bit group 32: two (scale, zero) pairs per lane slot"
+
+
+def _hb(env_extra, layers=3, steps=12):
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "import bench\n"
+        "from gbx_lm_amd import synthetic as S\n"
+        "from gbx_lm_amd.decode import FusedDecodeRunner\n"
+        "cfg = dict(S.LLAMA3_8B, num_hidden_layers=%d, vocab_size=2048)\n"
+        "model = S.build_model(cfg, S.make_strategy('S22', %d, 128), device='cuda:0', seed=5)\n"
+        "caches = bench.make_caches(model, 1, 256, 'cuda:0')\n"
+        "r = FusedDecodeRunner(model, caches, use_graph=True)\n"
+        "print('DATTN', sum(d is not None for d in r.da))\n"
+        "for t in range(%d): lg = r.step(torch.tensor([(7 * t + 1) %% 2048], device='cuda:0'))\n"
+        "torch.cuda.synchronize()\n"
+        "r.dattn_check()\n"
+        "print('HB', r.hb.float().cpu().numpy().tobytes().hex())\n"
+        "print('KC', caches[-1].keys[0, :, :%d].float().cpu().numpy().tobytes().hex())\n" % (ROOT, layers, layers, steps, steps))
+    env = dict(os.environ, **env_extra)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return {l.split()[0]: l.split()[1] for l in out.stdout.splitlines() if l.startswith(("HB", "DATTN", "KC"))}
+
+
+def test_three_launch_block_agrees_with_five_launch_block():
+    """Three 8B-shaped layers of mixed widths, 12 teacher-forced steps through the graph-replayed runner: GBX_DATTN=1 (three launches
+    per block) against GBX_DATTN=0 (five).  The o_proj sum is formed in a different order (eight fixed-point partials instead of one
+    fp32 chain), so agreement is to a few bf16 ulps of the stream, not to the bit."""
+    new, old = _hb({"GBX_DATTN": "1"}), _hb({"GBX_DATTN": "0"})
+    assert int(new["DATTN"]) == 3 and int(old["DATTN"]) == 0
+    f = lambda d, k: np.frombuffer(bytes.fromhex(d[k]), dtype=np.float32)
+    a, b = f(new, "HB"), f(old, "HB")
+    assert np.abs(a - b).max() <= 0.05 * np.abs(b).mean() + 0.05 * np.abs(b).max(), "residual stream after 12 steps"
+    ka, kb = f(new, "KC"), f(old, "KC")
+    assert np.abs(ka - kb).max() <= 0.05 * np.abs(kb).mean() + 0.05 * np.abs(kb).max(), "last layer's cached keys"

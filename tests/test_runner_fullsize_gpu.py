@@ -59,15 +59,21 @@ def _ref_layer_fp64(model, h, pos, kcache, vcache):
     return _bf(h1 + _bf(deq(mlp.down_proj) @ act))
 
 
+@pytest.mark.parametrize("dattn", [0, 1])
 @pytest.mark.parametrize("bits", [2, 3, 4])
-def test_one_8b_layer_through_the_fused_runner_vs_fp64(bits):
+def test_one_8b_layer_through_the_fused_runner_vs_fp64(bits, dattn, monkeypatch):
     import bench
     from gbx_lm_amd import ops
     from gbx_lm_amd.decode import FusedDecodeRunner
+    monkeypatch.setenv("GBX_DATTN", str(dattn))               # 1: three launches per block (round 5), 0: five (round 4)
     model, cfg = _one_layer_model(bits)
     ctx = 9
     caches = bench.make_caches(model, 1, 256, DEV)
     runner = FusedDecodeRunner(model, caches, use_graph=True)
+    assert (runner.da[0] is not None) == bool(dattn), "the launch path under test"
+    if dattn:
+        d_a, d_gu3, d_dn3 = runner.da[0]
+        assert d_gu3.x_acc == d_a.acc and d_dn3.zero_buf == d_a.acc and d_gu3.x_out == d_dn3.residual
     # the launches under test are the decode-block GEMV ones (the bench's), all four, with the statistic carried into gate|up
     g_qkv, g_o, g_gu, g_dn = runner.dg[0]
     assert all(g is not None for g in (g_qkv, g_o, g_gu, g_dn)), "the 8B launches must run on gbx_dgemv_forward"
@@ -82,6 +88,7 @@ def test_one_8b_layer_through_the_fused_runner_vs_fp64(bits):
     kc, vc = c.keys[0, :, :ctx].clone(), c.values[0, :, :ctx].clone()
     runner.step(torch.tensor([tok], device=DEV))
     h_got = runner.hb.clone()                               # the residual stream after the layer (before the final norm)
+    runner.dattn_check()
     h0 = model.model.embed_tokens.weight[tok]
     want = _ref_layer_fp64(model, h0, ctx, kc, vc)
     err = (h_got.double() - want).abs()
