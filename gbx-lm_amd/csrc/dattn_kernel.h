@@ -12,9 +12,12 @@ typedef __attribute__((address_space(1))) unsigned da_gu32;
 // LDS map (bytes).  84 KB are requested so that a CU holds exactly one workgroup (the 256 workgroups then cover the 256 CUs).
 constexpr int DA_LDS_IMG1 = 0;                     // phase-1 activation image: Lds<BQ>::bytes(K <= 4096) <= 11.3 KB
 constexpr int DA_LDS_RED = 12 * 1024;              // 16 floats: RMSNorm partials
-constexpr int DA_LDS_ATT = 12 * 1024 + 256;        // attention scratch, 11.2 KB
-constexpr int DA_LDS_P3 = 24 * 1024;               // phase 3: 2 KB of raw attention output, then its operand image (<= 5.2 KB)
+constexpr int DA_LDS_P3 = 12 * 1024 + 256;         // phase 3: 2 KB of raw attention output, then its operand image (<= 5.2 KB)
+constexpr int DA_LDS_ATT = 24 * 1024;              // attention scratch: q | k | v words, rotated q / k / v, up to 64 softmax states (37.6 KB)
 constexpr int DA_LDS_BYTES = 84 * 1024;
+#ifndef DA_SWEEP4_MAX
+#define DA_SWEEP4_MAX 160      // contexts up to here are swept by 4 waves (one per SIMD), up to 320 by 8, longer ones by 16
+#endif
 
 #ifdef GBX_STAMPS
 #define DA_STAMP(i) do { if (lane == 0 && a.stamps) a.stamps[(static_cast<size_t>(blockIdx.x) * DA_NW + wave) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -146,7 +149,6 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
   const int r = static_cast<int>(blockIdx.x) >> 3;                                       // member of the group
   const int rep = a.rep, D = a.D;
   da_gu32* gen_p = reinterpret_cast<da_gu32*>(reinterpret_cast<uintptr_t>(a.state)) + g * 16;
-  const unsigned gen = __hip_atomic_load(gen_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   da_gu64* hand1 = reinterpret_cast<da_gu64*>(reinterpret_cast<uintptr_t>(a.hand)) + static_cast<size_t>(g) * DA_HAND_STRIDE;
   da_gu64* hand2 = hand1 + 1024;
   auto rsrc = [](const void* ptr, int bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, bytes, RS_FLAGS); };
@@ -228,50 +230,66 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
     constexpr int UP = F::UNIT_PAIRS;
     constexpr int PPU = (BQ == 3) ? UP : 2;
     constexpr int TPU = UP / PPU;
-    static_assert(P * 64 * (F::VPL / 2) <= NT * PPU, "one item per thread");
+    // The prologue runs on waves 0-7: the 16 waves of the workgroup start ~0.35 us apart and everything up to the image barrier
+    // used to wait for the LAST wave's activation loads; the early half carries two items per thread, the late half only joins
+    // barrier A ("x has landed": the cue to request rows without delaying x) and barrier B (image written).
+    constexpr int PW = 8, PT = PW * 64;
+    constexpr int IPT = (P * 64 * (F::VPL / 2) + PT * PPU - 1) / (PT * PPU);
     const int nitems = (K / F::UNIT_VALS) * TPU;
-    unsigned xr[PPU], wr[PPU];
-    {
-      const int it = min(tid, nitems - 1);
-      da_load_item<BQ, PPU>(a.x, it, xr);
-      da_load_item<BQ, PPU>(a.norm_w, it, wr);
-    }
+    const bool pro = wave < PW;
+    unsigned xr[IPT][PPU], wr[IPT][PPU];
     u32x4 pq[4] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
     const bool carried = a.ssq_in != nullptr;
-    {
+    if (pro) {
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) {
+        const int it = min(tid + PT * j, nitems - 1);
+        da_load_item<BQ, PPU>(a.x, it, xr[j]);
+        da_load_item<BQ, PPU>(a.norm_w, it, wr[j]);
+      }
       const __amdgpu_buffer_rsrc_t pd = rsrc(carried ? static_cast<const void*>(a.ssq_in) : static_cast<const void*>(a.x), RS_ALL);
       const unsigned pk = carried ? 0u : KILL;
 #pragma unroll
       for (int i = 0; i < 4; ++i) pq[i] = __builtin_amdgcn_raw_buffer_load_b128(pd, static_cast<unsigned>(lane * 16 + 1024 * i) | pk, 0, 0);
-    }
-    DA_STAMP(1);
-    // ---- 2. RMSNorm statistic
-    float tot;
-    if (carried) {
-      float s = 0.f;
+      DA_STAMP(1);
+      if (!carried) {
+        float ssq = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        s += (__uint_as_float(pq[i].x) + __uint_as_float(pq[i].y)) + (__uint_as_float(pq[i].z) + __uint_as_float(pq[i].w));
-      tot = wave_sum(s);
-    } else {
-      float ssq = 0.f;
-      const bool live = tid < nitems;
+        for (int j = 0; j < IPT; ++j) {
+          const bool live = tid + PT * j < nitems;
 #pragma unroll
-      for (int q = 0; q < PPU; ++q) {
-        const float lo = act_lo<BF16>(xr[q]), hi = act_hi<BF16>(xr[q]);
-        ssq += live ? fmaf(hi, hi, lo * lo) : 0.f;
+          for (int q = 0; q < PPU; ++q) {
+            const float lo = act_lo<BF16>(xr[j][q]), hi = act_hi<BF16>(xr[j][q]);
+            ssq += live ? fmaf(hi, hi, lo * lo) : 0.f;
+          }
+        }
+        ssq = wave_sum(ssq);
+        if (lane == 0) red_lds[wave] = ssq;
       }
-      ssq = wave_sum(ssq);
-      if (lane == 0) red_lds[wave] = ssq;
-      __syncthreads();
-      tot = 0.f;
-#pragma unroll
-      for (int i = 0; i < NW; ++i) tot += red_lds[i];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    const float rstd = rsqrtf(tot / static_cast<float>(K) + a.eps);
+    __syncthreads();                                           // barrier A: x, the norm weight and the statistic's partials have landed
+    const unsigned gen = __hip_atomic_load(gen_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // first needed at the publish
     DA_STAMP(2);
-    // ---- 3. image
-    if ((tid & ~63) < nitems) da_image_item<BQ, BF16, PPU>(xr, wr, true, rstd, tid, nitems, xp_lds, xs_lds);
+    if (pro) {
+      float tot;
+      if (carried) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          s += (__uint_as_float(pq[i].x) + __uint_as_float(pq[i].y)) + (__uint_as_float(pq[i].z) + __uint_as_float(pq[i].w));
+        tot = wave_sum(s);
+      } else {
+        tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) tot += red_lds[i];
+      }
+      const float rstd = rsqrtf(tot / static_cast<float>(K) + a.eps);
+      // ---- 3. image
+#pragma unroll
+      for (int j = 0; j < IPT; ++j)
+        if ((tid & ~63) + PT * j < nitems) da_image_item<BQ, BF16, PPU>(xr[j], wr[j], true, rstd, tid + PT * j, nitems, xp_lds, xs_lds);
+    }
     // ---- 4. this wave's two rows, then the o_proj words behind them
     WT w[R][P];
     unsigned sz[P][R];
@@ -288,8 +306,7 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
       const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(szd, voff_s[p], gb * (G * R * 4), 0);
       sz[p][0] = v.x; sz[p][1] = v.y;
     }
-    issue_o();
-    __syncthreads();
+    __syncthreads();                                           // barrier B: image written
     DA_STAMP(3);
     tag = gen + 1u;
     if (tag == 0u) tag = 1u;
@@ -347,6 +364,7 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
       if (lane == 0) __hip_atomic_store(hand1 + lb, (static_cast<unsigned long long>(tag) << 32) | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     DA_STAMP(4);
+    issue_o();                                                 // o_proj words: needed ~4 us from here, requested off the critical path
   } else {
     // =========================================== phase 2: attention of head g * rep + r ===========================================
     unsigned* raw32 = reinterpret_cast<unsigned*>(smem + DA_LDS_ATT);                    // q | k | v as they arrive: 3 x 64 words
@@ -354,23 +372,40 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
     float* kn_s = q_s + HD;
     float* vn_s = kn_s + HD;
     float* gm = vn_s + HD;
-    float* gl = gm + NW;
-    float (*gacc)[HD + 8] = reinterpret_cast<float (*)[HD + 8]>(gl + NW);
+    float* gl = gm + 64;
+    float (*gacc)[HD + 8] = reinterpret_cast<float (*)[HD + 8]>(gl + 64);
     constexpr float NEG = -1e30f;
-    constexpr int LP = HD / 8, PPW = 64 / LP, UB0 = 128 / (NW * PPW);                    // 16 lanes per position, 4 positions per wave, 2 rounds up front
+    constexpr int LP = HD / 8, PPW = 64 / LP, UB0 = 10;                                   // 16 lanes per position, 4 positions per wave and round
     const int h = g * rep + r;
     const int d0 = (lane % LP) * 8, sub = lane / LP;
+    // The sweep is vector-ALU work once K / V sit in registers, and every sweeping wave pays a fixed cost (q, state hand-over), so
+    // as FEW waves sweep as can hold the context in UB0 rounds of registers: 4 (one per SIMD) up to 160 positions, 8 up to 320,
+    // 16 beyond (then an online loop takes what the registers do not hold).  Round u of sweeping wave w covers positions
+    // (u * nws + w) * 4 + sub.  Everything is requested NOW, while the producers are busy (~4 us before q arrives).
+    const int pos = static_cast<int>(*a.pos);
+    const int nws = pos <= DA_SWEEP4_MAX ? 4 : (pos <= UB0 * 8 * PPW ? 8 : 16);
+    const int ppr = nws * PPW;
+    const bool sweeper = wave < nws;
+    const __amdgpu_buffer_rsrc_t kd = rsrc(a.kcache + static_cast<size_t>(g) * a.capacity * HD, a.capacity * HD * 2);
+    const __amdgpu_buffer_rsrc_t vd = rsrc(a.vcache + static_cast<size_t>(g) * a.capacity * HD, a.capacity * HD * 2);
     const unsigned short* kbase = a.kcache + static_cast<size_t>(g) * a.capacity * HD;
     const unsigned short* vbase = a.vcache + static_cast<size_t>(g) * a.capacity * HD;
     u32x4 k0[UB0], v0[UB0];
 #pragma unroll
     for (int u = 0; u < UB0; ++u) {
-      const int tc = min(wave * PPW + u * NW * PPW + sub, a.capacity - 1);
-      k0[u] = *reinterpret_cast<const u32x4*>(kbase + static_cast<size_t>(tc) * HD + d0);
-      v0[u] = *reinterpret_cast<const u32x4*>(vbase + static_cast<size_t>(tc) * HD + d0);
+      const int t = (u * nws + wave) * PPW + sub;
+      const unsigned off = static_cast<unsigned>(t * (HD * 2) + d0 * 2) | (t < pos ? 0u : KILL);
+      k0[u] = u32x4{0, 0, 0, 0};
+      v0[u] = u32x4{0, 0, 0, 0};
+      if (sweeper && u * ppr < pos) {                          // (wave-uniform) rounds wholly beyond the context issue nothing
+        k0[u] = __builtin_amdgcn_raw_buffer_load_b128(kd, off, 0, 0);
+        v0[u] = __builtin_amdgcn_raw_buffer_load_b128(vd, off, 0, 0);
+      }
     }
-    const int pos = static_cast<int>(*a.pos);
     issue_o();
+    const unsigned gen = __hip_atomic_load(gen_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float inv_f = a.inv_freq[tid & (HD / 2 - 1)];        // RoPE frequency of this thread's pair (threads [0, HD) rotate)
+    DA_STAMP(1);
     tag = gen + 1u;
     if (tag == 0u) tag = 1u;
     // ---- hand-off 1: this head's q (64 granules), the group's k and v
@@ -388,7 +423,7 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
       const int i1 = a.traditional ? 2 * i : i;
       const int i2 = a.traditional ? 2 * i + 1 : i + HD / 2;
       const float x1 = act_to_f32<BF16>(src[i1]), x2 = act_to_f32<BF16>(src[i2]);
-      const float rev = static_cast<float>(pos) * a.rope_scale * a.inv_freq[i] * 0.15915494309189535f;
+      const float rev = static_cast<float>(pos) * a.rope_scale * inv_f * 0.15915494309189535f;
       const float fr = rev - floorf(rev);
       const float sn = __builtin_amdgcn_sinf(fr), cs = __builtin_amdgcn_cosf(fr);
       const unsigned short r1 = f32_to_act<BF16>(x1 * cs - x2 * sn), r2 = f32_to_act<BF16>(x1 * sn + x2 * cs);
@@ -412,120 +447,148 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
     }
     __syncthreads();
     // ---- cached positions [0, pos): 16 lanes per position, online softmax per lane group (attn_decode_kernel, 16-wave form)
-    float qr[8];
+    // Packed fp32 arithmetic (v_pk_fma_f32: two lanes of work per issue slot -- this sweep is vector-ALU bound once the K / V rows
+    // sit in registers) and a two-pass softmax over the prefetched rounds: all scores first, ONE running-maximum update, then the
+    // exponentials and the value sums without a per-position rescale.
+    DA_STAMP(12);
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    auto unpack2 = [](unsigned w) { return f32x2{act_lo<BF16>(w), act_hi<BF16>(w)}; };
+    f32x2 q2[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) qr[j] = q_s[d0 + j];
-    float m = NEG, l = 0.f, acc[8];
+    for (int j = 0; j < 4; ++j) q2[j] = f32x2{q_s[d0 + 2 * j], q_s[d0 + 2 * j + 1]};
+    float m = NEG, l = 0.f;
+    f32x2 acc2[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    auto consume = [&](const u32x4& kq, const u32x4& vq, bool valid) {
-      const unsigned kw[4] = {kq.x, kq.y, kq.z, kq.w};
-      const unsigned vw[4] = {vq.x, vq.y, vq.z, vq.w};
-      float s = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        s = fmaf(qr[2 * j], act_lo<BF16>(kw[j]), s);
-        s = fmaf(qr[2 * j + 1], act_hi<BF16>(kw[j]), s);
-      }
+    for (int j = 0; j < 4; ++j) acc2[j] = f32x2{0.f, 0.f};
+    auto score = [&](const u32x4& kq) {
+      f32x2 t = unpack2(kq.x) * q2[0];
+      t = __builtin_elementwise_fma(unpack2(kq.y), q2[1], t);
+      t = __builtin_elementwise_fma(unpack2(kq.z), q2[2], t);
+      t = __builtin_elementwise_fma(unpack2(kq.w), q2[3], t);
+      float s = t.x + t.y;
       s += dpp_f32<0xB1>(s);
       s += dpp_f32<0x4E>(s);
       s += dpp_f32<0x141>(s);
       s += dpp_f32<0x140>(s);
-      const float mn = valid ? fmaxf(m, s) : m;
-      const float corr = __expf(m - mn);
-      const float p = valid ? __expf(s - mn) : 0.f;
-      l = l * corr + p;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[2 * j] = acc[2 * j] * corr + p * act_lo<BF16>(vw[j]);
-        acc[2 * j + 1] = acc[2 * j + 1] * corr + p * act_hi<BF16>(vw[j]);
-      }
-      m = mn;
+      return s;
     };
+    auto add_values = [&](const u32x4& vq, float p) {
+      const f32x2 p2 = f32x2{p, p};
+      acc2[0] = __builtin_elementwise_fma(p2, unpack2(vq.x), acc2[0]);
+      acc2[1] = __builtin_elementwise_fma(p2, unpack2(vq.y), acc2[1]);
+      acc2[2] = __builtin_elementwise_fma(p2, unpack2(vq.z), acc2[2]);
+      acc2[3] = __builtin_elementwise_fma(p2, unpack2(vq.w), acc2[3]);
+    };
+    auto rescale = [&](float corr) {
+      const f32x2 c2 = f32x2{corr, corr};
 #pragma unroll
-    for (int u = 0; u < UB0; ++u) consume(k0[u], v0[u], wave * PPW + u * NW * PPW + sub < pos);
-    constexpr int UB = 2;
-    for (int t0 = UB0 * NW * PPW + wave * PPW; t0 < pos; t0 += NW * PPW * UB) {
-      u32x4 kv4[UB], vv4[UB];
-      bool valid[UB];
+      for (int j = 0; j < 4; ++j) acc2[j] = acc2[j] * c2;
+    };
+#ifdef GBX_STAMPS     // diagnostic build only: when has every prefetched K / V row landed?
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DA_STAMP(15);
+#endif
+    if (sweeper) {
+      {
+        // Two straight-line halves of UB0 / 2 rounds each (the second only when the context reaches it): inside a half the rounds
+        // are independent chains the scheduler interleaves -- a branch per round made every round its own basic block and the
+        // single wave of a SIMD waited out each dot -> DPP -> max chain in turn.
+        constexpr int HB = UB0 / 2;
+        float sc[UB0];
+        const bool second = HB * ppr < pos;                                                   // (wave-uniform)
+        auto scores = [&](int u0) {
 #pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        const int t = t0 + u * NW * PPW + sub;
-        valid[u] = t < pos;
-        const int tc = valid[u] ? t : pos - 1;
-        kv4[u] = *reinterpret_cast<const u32x4*>(kbase + static_cast<size_t>(tc) * HD + d0);
-        vv4[u] = *reinterpret_cast<const u32x4*>(vbase + static_cast<size_t>(tc) * HD + d0);
+          for (int u = u0; u < u0 + HB; ++u) {
+            const float s = score(k0[u]);
+            sc[u] = ((u * nws + wave) * PPW + sub < pos) ? s : NEG;
+          }
+#pragma unroll
+          for (int u = u0; u < u0 + HB; ++u) m = fmaxf(m, sc[u]);
+        };
+        auto values = [&](int u0) {
+          float p[HB];
+#pragma unroll
+          for (int u = 0; u < HB; ++u) p[u] = sc[u0 + u] > 0.5f * NEG ? __expf(sc[u0 + u] - m) : 0.f;
+#pragma unroll
+          for (int u = 0; u < HB; ++u) { l += p[u]; add_values(v0[u0 + u], p[u]); }
+        };
+        scores(0);
+        if (second) scores(HB);
+        DA_STAMP(13);
+        values(0);
+        if (second) values(HB);
       }
-#pragma unroll
-      for (int u = 0; u < UB; ++u) consume(kv4[u], vv4[u], valid[u]);
-    }
-    if (wave == 0 && sub == 0) {                             // the new token itself (its k, v are in LDS)
-      float s = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s = fmaf(qr[j], kn_s[d0 + j], s);
-      s += dpp_f32<0xB1>(s);
-      s += dpp_f32<0x4E>(s);
-      s += dpp_f32<0x141>(s);
-      s += dpp_f32<0x140>(s);
-      const float mn = fmaxf(m, s);
-      const float corr = __expf(m - mn), p = __expf(s - mn);
-      l = l * corr + p;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = acc[j] * corr + p * vn_s[d0 + j];
-      m = mn;
-    }
-    {
-      auto merge = [&](float pm, float pl, const float (&pa)[8]) {
-        const float mn = fmaxf(m, pm);
-        const float c1 = __expf(m - mn), c2 = __expf(pm - mn);
-        l = l * c1 + pl * c2;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = acc[j] * c1 + pa[j] * c2;
+      DA_STAMP(14);
+      auto consume = [&](const u32x4& kq, const u32x4& vq, bool valid) {                     // online form: positions beyond the prefetch
+        const float s = score(kq);
+        const float mn = valid ? fmaxf(m, s) : m;
+        const float corr = __expf(m - mn);
+        const float p = valid ? __expf(s - mn) : 0.f;
+        l = l * corr + p;
+        rescale(corr);
+        add_values(vq, p);
         m = mn;
       };
-      {
-        const bool hi = lane >= 32;
-        auto part = [&](float v) {
-          auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-          const unsigned r0 = rr[0], r1 = rr[1];
-          return __uint_as_float(hi ? r0 : r1);
-        };
-        float pa[8];
+      constexpr int UB = 2;
+      for (int t0 = UB0 * ppr + wave * PPW; t0 < pos; t0 += ppr * UB) {
+        u32x4 kv4[UB], vv4[UB];
+        bool valid[UB];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pa[j] = part(acc[j]);
-        const float pm = part(m), pl = part(l);
-        merge(pm, pl, pa);
+        for (int u = 0; u < UB; ++u) {
+          const int t = t0 + u * ppr + sub;
+          valid[u] = t < pos;
+          const int tc = valid[u] ? t : pos - 1;
+          kv4[u] = *reinterpret_cast<const u32x4*>(kbase + static_cast<size_t>(tc) * HD + d0);
+          vv4[u] = *reinterpret_cast<const u32x4*>(vbase + static_cast<size_t>(tc) * HD + d0);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) consume(kv4[u], vv4[u], valid[u]);
       }
-      {
-        const bool odd = (lane >> 4) & 1;
-        auto part = [&](float v) {
-          auto rr = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-          const unsigned r0 = rr[0], r1 = rr[1];
-          return __uint_as_float(odd ? r0 : r1);
-        };
-        float pa[8];
+      if (wave == 0 && sub == 0) {                             // the new token itself (its k, v are in LDS)
+        float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pa[j] = part(acc[j]);
-        const float pm = part(m), pl = part(l);
-        merge(pm, pl, pa);
+        for (int j = 0; j < 4; ++j) s = fmaf(q2[j].x, kn_s[d0 + 2 * j], fmaf(q2[j].y, kn_s[d0 + 2 * j + 1], s));
+        s += dpp_f32<0xB1>(s);
+        s += dpp_f32<0x4E>(s);
+        s += dpp_f32<0x141>(s);
+        s += dpp_f32<0x140>(s);
+        const float mn = fmaxf(m, s);
+        const float corr = __expf(m - mn), p = __expf(s - mn);
+        l = l * corr + p;
+        rescale(corr);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc2[j] = __builtin_elementwise_fma(f32x2{p, p}, f32x2{vn_s[d0 + 2 * j], vn_s[d0 + 2 * j + 1]}, acc2[j]);
+        m = mn;
       }
-    }
-    if (lane == 0) { gm[wave] = m; gl[wave] = l; }
-    if (sub == 0) {
+      // one softmax state per (sweeping wave, lane group)
+      const int sidx = wave * PPW + sub;
+      if ((lane % LP) == 0) { gm[sidx] = m; gl[sidx] = l; }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) gacc[wave][d0 + j] = acc[j];
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x2*>(&gacc[sidx][d0 + 2 * j]) = acc2[j];
     }
+    DA_STAMP(8);
     __syncthreads();
     if (tid < HD) {
+      const int ns = nws * PPW;                              // 16, 32 or 64 states: chunks of 16, every chunk's LDS reads in flight together
       float M = NEG;
+      for (int c = 0; c < ns; c += 16) {
+        float t[16];
 #pragma unroll
-      for (int i = 0; i < NW; ++i) M = fmaxf(M, gm[i]);
+        for (int i = 0; i < 16; ++i) t[i] = gm[c + i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) M = fmaxf(M, t[i]);
+      }
       float num = 0.f, den = 0.f;
+      for (int c = 0; c < ns; c += 16) {
+        float tm[16], tl[16], ta[16];
 #pragma unroll
-      for (int i = 0; i < NW; ++i) {
-        const float wgt = __expf(gm[i] - M);
-        num = fmaf(wgt, gacc[i][tid], num);
-        den = fmaf(wgt, gl[i], den);
+        for (int i = 0; i < 16; ++i) { tm[i] = gm[c + i]; tl[i] = gl[c + i]; ta[i] = gacc[c + i][tid]; }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float wgt = __expf(tm[i] - M);
+          num = fmaf(wgt, ta[i], num);
+          den = fmaf(wgt, tl[i], den);
+        }
       }
       const unsigned ob = f32_to_act<BF16>(num / den);
       if (a.attn_out) a.attn_out[static_cast<size_t>(h) * HD + tid] = static_cast<unsigned short>(ob);
@@ -534,7 +597,7 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
         __hip_atomic_store(hand2 + r * (HD / 2) + (tid >> 1), (static_cast<unsigned long long>(tag) << 32) | ob | (nb2 << 16),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    DA_STAMP(6);
+    DA_STAMP(9);
   }
 
   // =========================================== phase 3: o_proj over this group's columns ===========================================
@@ -542,7 +605,7 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
   h2* xp3 = reinterpret_cast<h2*>(smem + DA_LDS_P3 + 2048);
   if (wave < rep) raw3[wave * 64 + lane] = sweep(hand2 + wave * (HD / 2) + lane, tag, 2u);
   __syncthreads();
-  DA_STAMP(7);
+  DA_STAMP(10);
   const unsigned short* raw3h = reinterpret_cast<const unsigned short*>(raw3);
   auto phase3 = [&](auto BO_) {
     constexpr int BO = decltype(BO_)::value;
@@ -558,6 +621,7 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
       da_image_item<BO, BF16, PPU3>(xw, xw, false, 1.f, tid, nitems, xp3, xs3);
     }
     __syncthreads();
+    DA_STAMP(11);
 #pragma unroll
     for (int p = 0; p < DA_OP; ++p) {
       const int rl = (p * NW + wave) * rpp + (lane >> lpr_l2);
@@ -587,7 +651,7 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
   else phase3(std::integral_constant<int, 4>{});
   // member 0 advances the group's generation: every member has read it (nobody reaches this point before all of them published)
   if (r == 0 && tid == 0) __hip_atomic_store(gen_p, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  DA_STAMP(8);
+  DA_STAMP(6);
 }
 
 #define GBX_DEFINE_LAUNCH_DATTN(BQ, P_)                                                                                      \

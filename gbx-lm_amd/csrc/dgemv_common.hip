@@ -78,6 +78,7 @@ bool dg_plan(int bits, int N, int K, int group, int epi, bool norm, int rows_per
   }
   size_t lds = (bits == 2 ? Lds<2>::bytes(K) : (bits == 3 ? Lds<3>::bytes(K) : Lds<4>::bytes(K))) + NW * sizeof(float) + 16;
   if (KS == 4) lds += static_cast<size_t>(NW / 4) * bpo * R * 4 * sizeof(float);
+  if (KS == 1 && norm) lds += static_cast<size_t>(K) * 2;              // x' of an x_acc launch (dgemv_impl.h)
   if (lds > 160 * 1024) return false;
   // partial sums of y^2 the launch can leave behind: one per wave (KS 1), one per workgroup when its row threads fit one wave (KS 4)
   int ssq_n = KS == 1 ? grid * NW : ((NW / 4) * bpo * R <= 64 ? grid : 0);

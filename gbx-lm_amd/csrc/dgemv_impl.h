@@ -195,32 +195,72 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(const DgArgs a) {
   const unsigned short* __restrict__ wg = norm ? a.norm_w : xg;
   constexpr int WPT = (KS == 1) ? UPT : 1;
   unsigned xr[UPT][XW], wr[WPT][XW];
-  auto load_item = [&](const unsigned short* base, int it, unsigned* out) {
+  // (the base pointer is global memory, or -- x_acc launches -- the LDS copy of x': `auto` keeps the address space)
+  auto load_item = [&](auto base, int it, unsigned* out) {
     const int u = it / TPU, t = it % TPU;
     if constexpr (BITS == 3) {
-      const u32x4* src = reinterpret_cast<const u32x4*>(base + static_cast<size_t>(u) * F::UNIT_VALS);
+      auto src = base + static_cast<size_t>(u) * F::UNIT_VALS;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { const u32x4 v = src[q]; out[4 * q] = v.x; out[4 * q + 1] = v.y; out[4 * q + 2] = v.z; out[4 * q + 3] = v.w; }
+      for (int q = 0; q < 4; ++q) { const u32x4 v = *(const u32x4*)(src + 8 * q); out[4 * q] = v.x; out[4 * q + 1] = v.y; out[4 * q + 2] = v.z; out[4 * q + 3] = v.w; }
     } else {
-      const unsigned short* pa = base + static_cast<size_t>(u) * F::UNIT_VALS + PPU * t;
-      const unsigned short* pb = pa + UP;
+      auto pa = base + static_cast<size_t>(u) * F::UNIT_VALS + PPU * t;
+      auto pb = pa + UP;
       if constexpr (PPU == 2) {
-        out[0] = *reinterpret_cast<const unsigned*>(pa);
-        out[1] = *reinterpret_cast<const unsigned*>(pb);
+        out[0] = *(const unsigned*)(pa);
+        out[1] = *(const unsigned*)(pb);
       } else if constexpr (PPU == 4) {
-        const u32x2 va = *reinterpret_cast<const u32x2*>(pa), vb = *reinterpret_cast<const u32x2*>(pb);
+        const u32x2 va = *(const u32x2*)(pa), vb = *(const u32x2*)(pb);
         out[0] = va.x; out[1] = va.y; out[2] = vb.x; out[3] = vb.y;
       } else {
-        const u32x4 va = *reinterpret_cast<const u32x4*>(pa), vb = *reinterpret_cast<const u32x4*>(pb);
+        const u32x4 va = *(const u32x4*)(pa), vb = *(const u32x4*)(pb);
         out[0] = va.x; out[1] = va.y; out[2] = va.z; out[3] = va.w; out[4] = vb.x; out[5] = vb.y; out[6] = vb.z; out[7] = vb.w;
       }
     }
   };
+  if constexpr (KS == 1) {
 #pragma unroll
-  for (int j = 0; j < UPT; ++j) {
-    const int it = min(tid + NT * j, nitems - 1);
-    load_item(xg, it, xr[j]);
-    if constexpr (KS == 1) load_item(wg, it, wr[j]);
+    for (int j = 0; j < UPT; ++j) load_item(wg, min(tid + NT * j, nitems - 1), wr[j]);
+  }
+  if (a.x_acc) {                                             // (kernel-argument uniform; launches with the RMSNorm prologue only)
+    // x' = round(x + round(acc * 2^-32)): o_proj's output rounded once, the residual add rounded once (gbx_lm/models/qllama.py:96,138),
+    // formed ONCE per workgroup by all its threads (a pair of values each) and parked in LDS, where the item loads below find it;
+    // workgroup 0 also writes it out as the new residual stream.  acc[K] != 0 (a non-finite partial sum upstream): x' = NaN.
+    unsigned* xl = reinterpret_cast<unsigned*>(red_lds + NW);
+    const unsigned* x32 = reinterpret_cast<const unsigned*>(a.x);
+    const bool poison = a.x_acc[K] != 0;
+    constexpr int XU = 4;
+    for (int base = 0; base < K / 2; base += NT * XU) {
+      unsigned hv[XU];
+      u32x4 av[XU];
+#pragma unroll
+      for (int i = 0; i < XU; ++i) {
+        const int wi = min(base + NT * i + tid, K / 2 - 1);
+        hv[i] = x32[wi];
+        av[i] = *reinterpret_cast<const u32x4*>(a.x_acc + 2 * wi);
+      }
+#pragma unroll
+      for (int i = 0; i < XU; ++i) {
+        const int wi = base + NT * i + tid;
+        const long long a0 = static_cast<long long>((static_cast<unsigned long long>(av[i].y) << 32) | av[i].x);
+        const long long a1 = static_cast<long long>((static_cast<unsigned long long>(av[i].w) << 32) | av[i].z);
+        const float o0 = round_bf16_or_f16(static_cast<float>(a0) * 2.3283064365386963e-10f, BF16);
+        const float o1 = round_bf16_or_f16(static_cast<float>(a1) * 2.3283064365386963e-10f, BF16);
+        float x0 = act_lo<BF16>(hv[i]) + o0, x1 = act_hi<BF16>(hv[i]) + o1;
+        if (poison) { x0 = __uint_as_float(0x7FC00000u); x1 = x0; }
+        const unsigned wv = static_cast<unsigned>(f32_to_act<BF16>(x0)) | (static_cast<unsigned>(f32_to_act<BF16>(x1)) << 16);
+        if (wi < K / 2) {
+          xl[wi] = wv;
+          if (blockIdx.x == 0 && a.x_out) reinterpret_cast<unsigned*>(a.x_out)[wi] = wv;
+        }
+      }
+    }
+    __syncthreads();
+    const __attribute__((address_space(3))) unsigned short* xs3 = (const __attribute__((address_space(3))) unsigned short*)(xl);
+#pragma unroll
+    for (int j = 0; j < UPT; ++j) load_item(xs3, min(tid + NT * j, nitems - 1), xr[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < UPT; ++j) load_item(xg, min(tid + NT * j, nitems - 1), xr[j]);
   }
   // partial sums of x^2 from the producer (every wave adds all of them itself: no barrier on this path)
   u32x4 pq[4] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
@@ -235,33 +275,6 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(const DgArgs a) {
   if (a.zero_buf) {                                          // (kernel-argument uniform)
     for (int i = static_cast<int>(blockIdx.x) * NT + tid; i < a.zero_n; i += static_cast<int>(gridDim.x) * NT) a.zero_buf[i] = 0ull;
   }
-  if (a.x_acc) {
-    // x <- round(x + round(acc * 2^-32)): the o_proj output rounded once, the residual add rounded once (gbx_lm/models/qllama.py:138)
-    const bool poison = a.x_acc[K] != 0;
-#pragma unroll
-    for (int j = 0; j < UPT; ++j) {
-      const int it = min(tid + NT * j, nitems - 1);
-      const int u = it / TPU, t = it % TPU;
-      const bool live = (tid + NT * j) < nitems;
-#pragma unroll
-      for (int q = 0; q < XW; ++q) {
-        int idx;
-        if constexpr (BITS == 3) idx = u * F::UNIT_VALS + 2 * q;
-        else idx = u * F::UNIT_VALS + PPU * t + (q < PPU / 2 ? 2 * q : UP + 2 * (q - PPU / 2));
-        const u32x4 av = *reinterpret_cast<const u32x4*>(a.x_acc + idx);
-        const long long a0 = static_cast<long long>((static_cast<unsigned long long>(av.y) << 32) | av.x);
-        const long long a1 = static_cast<long long>((static_cast<unsigned long long>(av.w) << 32) | av.z);
-        const float o0 = round_bf16_or_f16(static_cast<float>(a0) * 2.3283064365386963e-10f, BF16);
-        const float o1 = round_bf16_or_f16(static_cast<float>(a1) * 2.3283064365386963e-10f, BF16);
-        float x0 = act_lo<BF16>(xr[j][q]) + o0, x1 = act_hi<BF16>(xr[j][q]) + o1;
-        if (poison) { x0 = __uint_as_float(0x7FC00000u); x1 = x0; }
-        const unsigned wv = static_cast<unsigned>(f32_to_act<BF16>(x0)) | (static_cast<unsigned>(f32_to_act<BF16>(x1)) << 16);
-        xr[j][q] = wv;
-        if (blockIdx.x == 0 && live && a.x_out) *reinterpret_cast<unsigned*>(a.x_out + idx) = wv;
-      }
-    }
-  }
-
   DgBatch<BITS, P, R> ring[D];
 #ifndef DG_EXP_EARLY_LATE
 #define DG_EXP_EARLY_LATE 0      // experiment: rows of batch 0 the LATE form still requests ahead of the prologue

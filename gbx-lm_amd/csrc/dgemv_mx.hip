@@ -50,6 +50,12 @@ __global__ __launch_bounds__(NW * 64) void dgemv_mx_kernel(const DgArgs a) {
   const int K = a.K;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef GBX_STAMPS
+#define DMX_STAMP(i) do { if (lane == 0 && a.stamps) a.stamps[(static_cast<size_t>(blockIdx.x) * NW + wave) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define DMX_STAMP(i) do {} while (0)
+#endif
+  DMX_STAMP(0);
   const int W4 = K / 4;                                          // bytes per packed row (2 bits)
   const int G = K >> 7;
   const int ow = wave;
@@ -92,67 +98,81 @@ __global__ __launch_bounds__(NW * 64) void dgemv_mx_kernel(const DgArgs a) {
   const bool norm = a.norm_w != nullptr;
   const unsigned short* __restrict__ wg = norm ? a.norm_w : xg;
   constexpr int NIT = SP * 512;                                   // items of 4 values
-  constexpr int IPT = (NIT + NT - 1) / NT;
+  // Round 5: in a 16-wave workgroup the LATE (RMSNorm) prologue runs on waves 0-7 only.  The waves of a 1024-thread workgroup start
+  // ~0.35 us apart (profiles/r05_layer_timeline.txt) and everything up to the image barrier used to wait for the last one's loads;
+  // the early half now carries two items per thread, the late half only joins barrier A (= "x has landed": its cue to request
+  // batch 0 without delaying x) and barrier B (image written).
+  constexpr int PW = (NW == 16 && LATE) ? 8 : NW;
+  constexpr int PT = PW * 64;
+  constexpr int IPT = (NIT + PT - 1) / PT;
+  const bool pro = PW == NW ? true : wave < PW;                   // wave-uniform
   u32x2 xr[IPT], wr[IPT];
-#pragma unroll
-  for (int j = 0; j < IPT; ++j) {
-    const int it = min(tid + NT * j, NIT - 1);
-    xr[j] = *reinterpret_cast<const u32x2*>(xg + 4 * it);
-    wr[j] = *reinterpret_cast<const u32x2*>(wg + 4 * it);
-  }
+  u32x4 acv[IPT][2];
+  unsigned apoison = 0;
   u32x4 pq[4];
   const bool carried = norm && a.ssq_in != nullptr;
-  {
-    const __amdgpu_buffer_rsrc_t pd = rsrc(carried ? static_cast<const void*>(a.ssq_in) : static_cast<const void*>(a.x));
-    const unsigned pk = carried ? 0u : KILL;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) pq[i] = __builtin_amdgcn_raw_buffer_load_b128(pd, static_cast<unsigned>(lane * 16 + 1024 * i) | pk, 0, 0);
-  }
   if (a.zero_buf) {
     for (int i = static_cast<int>(blockIdx.x) * NT + tid; i < a.zero_n; i += static_cast<int>(gridDim.x) * NT) a.zero_buf[i] = 0ull;
   }
-  if (a.x_acc) {
-    // x <- round(x + round(acc * 2^-32)) (dgemv_impl.h: the fused attention launch's o_proj sums; workgroup 0 writes the new stream)
-    const bool poison = a.x_acc[K] != 0;
+  DmxBatch<SP> ring[2];
+  if (pro) {
+    // the fixed-point o_proj sums of an x_acc launch first (the longest of the prologue's round trips; unconditional issue: without
+    // x_acc the offsets are out of range and nothing is fetched)
+    {
+      const __amdgpu_buffer_rsrc_t ad = rsrc(a.x_acc ? static_cast<const void*>(a.x_acc) : static_cast<const void*>(a.x));
+      const unsigned ak = a.x_acc ? 0u : KILL;
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) {
+        const int it = min(tid + PT * j, NIT - 1);
+        acv[j][0] = __builtin_amdgcn_raw_buffer_load_b128(ad, static_cast<unsigned>(it * 32) | ak, 0, 0);
+        acv[j][1] = __builtin_amdgcn_raw_buffer_load_b128(ad, static_cast<unsigned>(it * 32 + 16) | ak, 0, 0);
+      }
+      apoison = __builtin_amdgcn_raw_buffer_load_b32(ad, static_cast<unsigned>(K * 8) | ak, 0, 0);
+    }
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
-      const int it = min(tid + NT * j, NIT - 1);
-      const bool live = (tid + NT * j) < NIT;
-      unsigned wv[2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const u32x4 av = *reinterpret_cast<const u32x4*>(a.x_acc + 4 * it + 2 * q);
-        const long long a0 = static_cast<long long>((static_cast<unsigned long long>(av.y) << 32) | av.x);
-        const long long a1 = static_cast<long long>((static_cast<unsigned long long>(av.w) << 32) | av.z);
-        const float o0 = round_bf16_or_f16(static_cast<float>(a0) * 2.3283064365386963e-10f, BF16);
-        const float o1 = round_bf16_or_f16(static_cast<float>(a1) * 2.3283064365386963e-10f, BF16);
-        const unsigned xw = q == 0 ? xr[j].x : xr[j].y;
-        float x0 = act_lo<BF16>(xw) + o0, x1 = act_hi<BF16>(xw) + o1;
-        if (poison) { x0 = __uint_as_float(0x7FC00000u); x1 = x0; }
-        wv[q] = static_cast<unsigned>(f32_to_act<BF16>(x0)) | (static_cast<unsigned>(f32_to_act<BF16>(x1)) << 16);
-      }
-      xr[j] = u32x2{wv[0], wv[1]};
-      if (blockIdx.x == 0 && live && a.x_out) *reinterpret_cast<u32x2*>(a.x_out + 4 * it) = xr[j];
+      const int it = min(tid + PT * j, NIT - 1);
+      xr[j] = *reinterpret_cast<const u32x2*>(xg + 4 * it);
+      wr[j] = *reinterpret_cast<const u32x2*>(wg + 4 * it);
     }
-  }
-  DmxBatch<SP> ring[2];
-  if constexpr (!LATE) issue(ring[0], batch_of(0));
-
-  // ---------------- 2. RMSNorm statistic (carried from the producer of x, or reduced here) ----------------
-  float rstd = 1.f;
-  if (norm) {
-    float tot;
-    if (carried) {
-      float s = 0.f;
+    {
+      const __amdgpu_buffer_rsrc_t pd = rsrc(carried ? static_cast<const void*>(a.ssq_in) : static_cast<const void*>(a.x));
+      const unsigned pk = carried ? 0u : KILL;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        s += (__uint_as_float(pq[i].x) + __uint_as_float(pq[i].y)) + (__uint_as_float(pq[i].z) + __uint_as_float(pq[i].w));
-      tot = wave_sum(s);
-    } else {
+      for (int i = 0; i < 4; ++i) pq[i] = __builtin_amdgcn_raw_buffer_load_b128(pd, static_cast<unsigned>(lane * 16 + 1024 * i) | pk, 0, 0);
+    }
+    if constexpr (!LATE) issue(ring[0], batch_of(0));             // (PW == NW here: every wave is a prologue wave)
+    DMX_STAMP(1);
+    if (a.x_acc) {
+      // x <- round(x + round(acc * 2^-32)) (dgemv_impl.h: the fused attention launch's o_proj sums; workgroup 0 writes the new stream)
+      const bool poison = apoison != 0u;
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) {
+        const int it = min(tid + PT * j, NIT - 1);
+        const bool live = (tid + PT * j) < NIT;
+        unsigned wv[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const u32x4 av = acv[j][q];
+          const long long a0 = static_cast<long long>((static_cast<unsigned long long>(av.y) << 32) | av.x);
+          const long long a1 = static_cast<long long>((static_cast<unsigned long long>(av.w) << 32) | av.z);
+          const float o0 = round_bf16_or_f16(static_cast<float>(a0) * 2.3283064365386963e-10f, BF16);
+          const float o1 = round_bf16_or_f16(static_cast<float>(a1) * 2.3283064365386963e-10f, BF16);
+          const unsigned xw = q == 0 ? xr[j].x : xr[j].y;
+          float x0 = act_lo<BF16>(xw) + o0, x1 = act_hi<BF16>(xw) + o1;
+          if (poison) { x0 = __uint_as_float(0x7FC00000u); x1 = x0; }
+          wv[q] = static_cast<unsigned>(f32_to_act<BF16>(x0)) | (static_cast<unsigned>(f32_to_act<BF16>(x1)) << 16);
+        }
+        xr[j] = u32x2{wv[0], wv[1]};
+        if (blockIdx.x == 0 && live && a.x_out) *reinterpret_cast<u32x2*>(a.x_out + 4 * it) = xr[j];
+      }
+    }
+    DMX_STAMP(8);
+    if (norm && !carried) {
       float ssq = 0.f;
 #pragma unroll
       for (int j = 0; j < IPT; ++j) {
-        const bool live = (tid + NT * j) < NIT;
+        const bool live = (tid + PT * j) < NIT;
         const unsigned w2[2] = {xr[j].x, xr[j].y};
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -162,18 +182,33 @@ __global__ __launch_bounds__(NW * 64) void dgemv_mx_kernel(const DgArgs a) {
       }
       ssq = wave_sum(ssq);
       if (lane == 0) red_lds[wave] = ssq;
-      __syncthreads();
+    }
+    if constexpr (PW != NW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // barrier A below says: the activations have landed
+  }
+  // ---------------- 2. RMSNorm statistic (carried from the producer of x, or reduced here); barrier A ----------------
+  if (PW != NW || (norm && !carried)) __syncthreads();
+  float rstd = 1.f;
+  if (pro && norm) {
+    float tot;
+    if (carried) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        s += (__uint_as_float(pq[i].x) + __uint_as_float(pq[i].y)) + (__uint_as_float(pq[i].z) + __uint_as_float(pq[i].w));
+      tot = wave_sum(s);
+    } else {
       tot = 0.f;
 #pragma unroll
-      for (int i = 0; i < NW; ++i) tot += red_lds[i];
+      for (int i = 0; i < PW; ++i) tot += red_lds[i];
     }
     rstd = rsqrtf(tot / static_cast<float>(K) + a.eps);
   }
+  DMX_STAMP(9);
   // ---------------- 3. the limb image: x' = x 2^-e per 32-value block, hi = fp8(x'), lo = fp8(x' - hi) ----------------
 #pragma unroll
   for (int j = 0; j < IPT; ++j) {
-    if ((tid & ~63) + NT * j < NIT) {                             // (wave-uniform) idle waves skip the arithmetic
-      const int it = tid + NT * j;
+    if (pro && (tid & ~63) + PT * j < NIT) {                      // (wave-uniform) idle waves skip the arithmetic
+      const int it = tid + PT * j;
       float v[4] = {act_lo<BF16>(xr[j].x), act_hi<BF16>(xr[j].x), act_lo<BF16>(xr[j].y), act_hi<BF16>(xr[j].y)};
       if (norm) {                                                 // one rounding to the activation dtype, like the reference's RMSNorm output
         v[0] = round_bf16_or_f16(v[0] * rstd * act_lo<BF16>(wr[j].x), BF16);
@@ -210,8 +245,10 @@ __global__ __launch_bounds__(NW * 64) void dgemv_mx_kernel(const DgArgs a) {
       }
     }
   }
+  DMX_STAMP(10);
   if constexpr (LATE) issue(ring[0], batch_of(0));
   __syncthreads();
+  DMX_STAMP(2);
   issue(ring[1], batch_of(1));
   if (batch_of(0) >= nbatch && !a.ssq_out) return;               // a wave without any batch was only here for the prologue
 
@@ -298,7 +335,9 @@ __global__ __launch_bounds__(NW * 64) void dgemv_mx_kernel(const DgArgs a) {
     issue(ring[1], batch_of(base + 3));
   }
   consume(ring[0], base);
+  DMX_STAMP(4);
   consume(ring[1], base + 1);
+  DMX_STAMP(6);
   if (a.ssq_out) {
     const float ws = wave_sum(sq);
     if (lane == 0) a.ssq_out[blockIdx.x * NW + wave] = ws;

@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r05
+[ -f scratch/stamps/libgbx_stamps.so ] || bash scratch/build_stamps.sh > gpurun_out/r05/build_stamps.log 2>&1
+GBX_QLINEAR_LIB=$PWD/scratch/stamps/libgbx_stamps.so python3 scratch/layer_timeline3.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r05/layer_timeline3.txt
+cat gpurun_out/r05/layer_timeline3.txt
