@@ -164,6 +164,19 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
     }
     return static_cast<unsigned>(x);
   };
+  // the same for two granules per lane (both in flight together)
+  auto sweep2 = [&](da_gu64* pa, da_gu64* pb, unsigned tag, unsigned code, unsigned& va, unsigned& vb) {
+    unsigned long long x, y;
+    for (unsigned spins = 0;;) {
+      x = __hip_atomic_load(pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      y = __hip_atomic_load(pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__all(static_cast<unsigned>(x >> 32) == tag && static_cast<unsigned>(y >> 32) == tag)) break;
+      if (++spins > DA_SPIN_LIMIT) { timeout(code); break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    va = static_cast<unsigned>(x);
+    vb = static_cast<unsigned>(y);
+  };
 
   // ---------------- o_proj: this workgroup's rows, this group's columns -- requested early, consumed in phase 3 ----------------
   const int obits = a.o_bits;
@@ -404,25 +417,23 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
     }
     issue_o();
     const unsigned gen = __hip_atomic_load(gen_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const float inv_f = a.inv_freq[tid & (HD / 2 - 1)];        // RoPE frequency of this thread's pair (threads [0, HD) rotate)
+    const float inv_f = a.inv_freq[lane];                      // RoPE frequency of this lane's pair (waves 0 and 1 rotate q and k)
     DA_STAMP(1);
     tag = gen + 1u;
     if (tag == 0u) tag = 1u;
-    // ---- hand-off 1: this head's q (64 granules), the group's k and v
-    if (wave < 3) {
-      const int base = wave == 0 ? r * (HD / 2) : (rep + wave - 1) * (HD / 2);
-      raw32[wave * 64 + lane] = sweep(hand1 + base + lane, tag, 1u);
-    }
-    __syncthreads();
-    DA_STAMP(5);
-    const unsigned short* raw16 = reinterpret_cast<const unsigned short*>(raw32);
-    if (tid < HD) {
-      const bool isk = tid >= HD / 2;
-      const int i = isk ? tid - HD / 2 : tid;
-      const unsigned short* src = raw16 + (isk ? HD : 0);
+    // ---- hand-off 1: this head's q (64 granules), the group's k and v -- polled by the threads that rotate / store them: wave 0
+    //      the q pairs, wave 1 the k pairs (element e lives in granule e / 2, half e % 2), wave 2 two values of v per lane
+    if (wave < 2) {
+      const bool isk = wave == 1;
+      const int i = lane;
       const int i1 = a.traditional ? 2 * i : i;
       const int i2 = a.traditional ? 2 * i + 1 : i + HD / 2;
-      const float x1 = act_to_f32<BF16>(src[i1]), x2 = act_to_f32<BF16>(src[i2]);
+      da_gu64* base = hand1 + (isk ? rep : r) * (HD / 2);
+      unsigned w1, w2;
+      sweep2(base + (i1 >> 1), base + (i2 >> 1), tag, 1u, w1, w2);
+      DA_STAMP(5);
+      const float x1 = act_to_f32<BF16>(static_cast<unsigned short>((i1 & 1) ? (w1 >> 16) : (w1 & 0xFFFFu)));
+      const float x2 = act_to_f32<BF16>(static_cast<unsigned short>((i2 & 1) ? (w2 >> 16) : (w2 & 0xFFFFu)));
       const float rev = static_cast<float>(pos) * a.rope_scale * inv_f * 0.15915494309189535f;
       const float fr = rev - floorf(rev);
       const float sn = __builtin_amdgcn_sinf(fr), cs = __builtin_amdgcn_cosf(fr);
@@ -439,11 +450,11 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
         q_s[i1] = act_to_f32<BF16>(r1) * a.sm_scale;
         q_s[i2] = act_to_f32<BF16>(r2) * a.sm_scale;
       }
-    } else if (tid < 2 * HD) {
-      const int j = tid - HD;
-      const unsigned short vb = raw16[2 * HD + j];
-      vn_s[j] = act_to_f32<BF16>(vb);
-      if (r == 0) a.vcache[(static_cast<size_t>(g) * a.capacity + pos) * HD + j] = vb;
+    } else if (wave == 2) {
+      const unsigned vw = sweep(hand1 + (rep + 1) * (HD / 2) + lane, tag, 1u);
+      vn_s[2 * lane] = act_lo<BF16>(vw);
+      vn_s[2 * lane + 1] = act_hi<BF16>(vw);
+      if (r == 0) *reinterpret_cast<unsigned*>(a.vcache + (static_cast<size_t>(g) * a.capacity + pos) * HD + 2 * lane) = vw;
     }
     __syncthreads();
     // ---- cached positions [0, pos): 16 lanes per position, online softmax per lane group (attn_decode_kernel, 16-wave form)
@@ -603,9 +614,6 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
   // =========================================== phase 3: o_proj over this group's columns ===========================================
   unsigned* raw3 = reinterpret_cast<unsigned*>(smem + DA_LDS_P3);
   h2* xp3 = reinterpret_cast<h2*>(smem + DA_LDS_P3 + 2048);
-  if (wave < rep) raw3[wave * 64 + lane] = sweep(hand2 + wave * (HD / 2) + lane, tag, 2u);
-  __syncthreads();
-  DA_STAMP(10);
   const unsigned short* raw3h = reinterpret_cast<const unsigned short*>(raw3);
   auto phase3 = [&](auto BO_) {
     constexpr int BO = decltype(BO_)::value;
@@ -615,10 +623,28 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
     constexpr int TPU3 = FO::UNIT_PAIRS / PPU3;
     float2* xs3 = reinterpret_cast<float2*>(reinterpret_cast<unsigned char*>(xp3) + static_cast<size_t>(spr) * LO::SSTR * 4);
     const int nitems = (KC / FO::UNIT_VALS) * TPU3;
-    if ((tid & ~63) < nitems) {
-      unsigned xw[PPU3];
-      da_load_item<BO, PPU3>(raw3h, min(tid, nitems - 1), xw);
-      da_image_item<BO, BF16, PPU3>(xw, xw, false, 1.f, tid, nitems, xp3, xs3);
+    if constexpr (BO == 3) {
+      // 3 bits: an image item is a whole 32-value unit -- the attention output goes through LDS as raw values first
+      if (wave < rep) raw3[wave * 64 + lane] = sweep(hand2 + wave * (HD / 2) + lane, tag, 2u);
+      __syncthreads();
+      DA_STAMP(10);
+      if ((tid & ~63) < nitems) {
+        unsigned xw[PPU3];
+        da_load_item<BO, PPU3>(raw3h, min(tid, nitems - 1), xw);
+        da_image_item<BO, BF16, PPU3>(xw, xw, false, 1.f, tid, nitems, xp3, xs3);
+      }
+    } else {
+      // 2 / 4 bits: an image item is two value pairs = two granules (unit u, pair t: granules u * UP + t and + UP / 2): the lanes
+      // that poll them write the image directly -- no staging of raw values, one barrier less
+      constexpr int UPG = FO::UNIT_PAIRS;                     // granules per unit
+      if ((tid & ~63) < nitems) {
+        const int it = min(tid, nitems - 1);
+        const int u = it / TPU3, t = it % TPU3;
+        unsigned xw[PPU3];
+        sweep2(hand2 + u * UPG + t, hand2 + u * UPG + UPG / 2 + t, tag, 2u, xw[0], xw[1]);
+        DA_STAMP(10);
+        da_image_item<BO, BF16, PPU3>(xw, xw, false, 1.f, tid, nitems, xp3, xs3);
+      }
     }
     __syncthreads();
     DA_STAMP(11);

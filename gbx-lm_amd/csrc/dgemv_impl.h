@@ -241,10 +241,8 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(const DgArgs a) {
 #pragma unroll
       for (int i = 0; i < XU; ++i) {
         const int wi = base + NT * i + tid;
-        const long long a0 = static_cast<long long>((static_cast<unsigned long long>(av[i].y) << 32) | av[i].x);
-        const long long a1 = static_cast<long long>((static_cast<unsigned long long>(av[i].w) << 32) | av[i].z);
-        const float o0 = round_bf16_or_f16(static_cast<float>(a0) * 2.3283064365386963e-10f, BF16);
-        const float o1 = round_bf16_or_f16(static_cast<float>(a1) * 2.3283064365386963e-10f, BF16);
+        const float o0 = round_bf16_or_f16(fx32_to_f32(av[i].x, av[i].y), BF16);
+        const float o1 = round_bf16_or_f16(fx32_to_f32(av[i].z, av[i].w), BF16);
         float x0 = act_lo<BF16>(hv[i]) + o0, x1 = act_hi<BF16>(hv[i]) + o1;
         if (poison) { x0 = __uint_as_float(0x7FC00000u); x1 = x0; }
         const unsigned wv = static_cast<unsigned>(f32_to_act<BF16>(x0)) | (static_cast<unsigned>(f32_to_act<BF16>(x1)) << 16);

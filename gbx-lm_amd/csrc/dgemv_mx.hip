@@ -154,10 +154,8 @@ __global__ __launch_bounds__(NW * 64) void dgemv_mx_kernel(const DgArgs a) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const u32x4 av = acv[j][q];
-          const long long a0 = static_cast<long long>((static_cast<unsigned long long>(av.y) << 32) | av.x);
-          const long long a1 = static_cast<long long>((static_cast<unsigned long long>(av.w) << 32) | av.z);
-          const float o0 = round_bf16_or_f16(static_cast<float>(a0) * 2.3283064365386963e-10f, BF16);
-          const float o1 = round_bf16_or_f16(static_cast<float>(a1) * 2.3283064365386963e-10f, BF16);
+          const float o0 = round_bf16_or_f16(fx32_to_f32(av.x, av.y), BF16);
+          const float o1 = round_bf16_or_f16(fx32_to_f32(av.z, av.w), BF16);
           const unsigned xw = q == 0 ? xr[j].x : xr[j].y;
           float x0 = act_lo<BF16>(xw) + o0, x1 = act_hi<BF16>(xw) + o1;
           if (poison) { x0 = __uint_as_float(0x7FC00000u); x1 = x0; }

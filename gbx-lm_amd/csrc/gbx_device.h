@@ -106,6 +106,13 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 __device__ __forceinline__ float pair_sum(float v) { return v + dpp_f32<0xB1>(v); }
 __device__ __forceinline__ float quad_sum(float v) { v += dpp_f32<0xB1>(v); return v + dpp_f32<0x4E>(v); }
 
+// 2^-32 fixed point (two's complement int64 as lo / hi words) -> fp32, one rounding: hi * 2^32 + lo is exact in fp64 below 2^53 and
+// fp64 adds / converts are single instructions on CDNA (the compiler's int64 -> float sequence is ~20)
+__device__ __forceinline__ float fx32_to_f32(unsigned lo, unsigned hi) {
+  const double d = __builtin_fma(static_cast<double>(static_cast<int>(hi)), 4294967296.0, static_cast<double>(lo));
+  return static_cast<float>(d) * 2.3283064365386963e-10f;
+}
+
 // exact 2^e as fp32, e in [-126, 127]
 __device__ __forceinline__ float exp2i(int e) { return __uint_as_float(static_cast<unsigned>(127 + e) << 23); }
 
