@@ -62,20 +62,25 @@ def cpu_baseline(model, cfg, timeout=240.0):
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
-def kernel_leg(model, reps=20):
+def kernel_leg(model, runner=None, reps=20):
     """Dominant hot-path kernel timed live with HIP events on the launch stream: the fused
     [RMSNorm + gate_proj + up_proj + SwiGLU] GEMV launch of the narrowest-bit layers -- exactly the launch the decode
     graph replays (20 % of a token) -- cycled over every such layer's own weights (>> 256 MiB, so the Infinity Cache
-    cannot serve them), IN ITS CHAIN POSITION: a graph of (o_proj launch, gate|up launch) pairs per layer is replayed, then the
-    same graph without the gate|up launches; the launch's duration is the difference per pair (boundary included).  (Replaying
-    the 33 MB launch back to back with itself reads 10-15 % longer than rocprofv3 shows it inside the token -- every launch then
-    starts on caches its predecessor has just swept -- and is reported as `us_back_to_back`.)
-    Algorithmic bytes per launch = both packed matrices + their scales/zeros + x + norm weight + out."""
-    from gbx_lm_amd import ops
+    cannot serve them), IN ITS CHAIN POSITION: a graph of (predecessor launch, gate|up launch) pairs per layer is replayed, then the
+    same graph without the gate|up launches; the launch's duration is the difference per pair (boundary included).  The
+    predecessor is what the decode runner launches in front of it: the fused attention launch (gbx_dattn_forward, round 5: the
+    runner's OWN descriptors are replayed, the gate|up launch then forms x from the fixed-point o_proj sums) or, in the
+    five-launch block, the o_proj launch.  (Replaying the 33 MB launch back to back with itself reads 10-15 % longer than
+    rocprofv3 shows it inside the token -- every launch then starts on caches its predecessor has just swept -- and is
+    reported as `us_back_to_back`.)  The kernel's name comes from the library (gbx_dgemv_kernel_id), not from a re-derivation here.
+    Algorithmic bytes per launch = both packed matrices + their scales/zeros + x + norm weight + out
+    (+ the 8-byte fixed-point sums the prologue reads in the three-launch block)."""
+    from gbx_lm_amd import env, ops
     from gbx_lm_amd import _lib as _l
     layers = list(model.model.layers)
     bits = min(blk.mlp.gate_proj.bits for blk in layers)
-    layers = [blk for blk in layers if blk.mlp.gate_proj.bits == bits and blk.mlp.up_proj.bits == bits]
+    idx = [i for i, blk in enumerate(layers) if blk.mlp.gate_proj.bits == bits and blk.mlp.up_proj.bits == bits]
+    layers = [layers[i] for i in idx]
     g0 = layers[0].mlp.gate_proj
     dev = g0.qweight.device
     dt = g0.scales.dtype
@@ -84,12 +89,24 @@ def kernel_leg(model, reps=20):
     x = torch.randn(g0.input_dims, device=dev).to(dt)               # the residual stream o_proj updates and gate|up normalises
     x0 = x.clone()
     act = torch.empty(g0.output_dims, device=dev, dtype=dt)
-    use_dg = os.environ.get("GBX_DGEMV", "1") == "1"
-    use_ssq = os.environ.get("GBX_DG_SSQ", "1") == "1"
+    use_dg = env.flag("GBX_DGEMV")
+    use_ssq = env.flag("GBX_DG_SSQ")
     pl = ops.dgemv_plan(g0.output_dims, g0.input_dims, g0.bits, g0.group_size, _l.GBX_DG_SWIGLU, True) if use_dg else None
     plo = ops.dgemv_plan(o0.output_dims, o0.input_dims, o0.bits, o0.group_size, _l.GBX_DG_RESIDUAL) if use_dg else None
     keep = []
-    if pl is not None and plo is not None:
+    acc_bytes = 0
+    pred = "o_proj"
+    da = getattr(runner, "da", None)
+    if da is not None and all(da[i] is not None for i in idx):
+        # the three-launch block: the runner's own (fused attention, gate|up) descriptors -- its weights, caches and buffers
+        o_descs = [da[i][0] for i in idx]
+        g_descs = [da[i][1] for i in idx]
+        x, x0 = runner.hb, runner.hb.clone()
+        kname = "gbx::" + ops.dgemv_kernel_name(g_descs[0])
+        acc_bytes = 8 * g0.input_dims
+        pred = "fused attention"
+        launch = lambda d, dv: ops.dattn(d, dv) if isinstance(d, _l.DattnDesc) else ops.dgemv(d, dv)
+    elif pl is not None and plo is not None:
         # exactly the launches the decode runner replays: gbx_dgemv_forward, the RMSNorm statistic carried from o_proj to gate|up
         ssq = torch.zeros(_l.GBX_DG_SSQ_SLOTS, dtype=torch.float32, device=dev) if (use_ssq and plo[1] > 0) else None
         o_descs, g_descs = [], []
@@ -100,13 +117,7 @@ def kernel_leg(model, reps=20):
             g_descs.append(ops.make_dgemv_desc(x, blk.mlp.gate_proj, act, pg, pl[0], mod_up=blk.mlp.up_proj,
                                                norm_weight=blk.post_attention_layernorm.weight.to(dt),
                                                eps=blk.post_attention_layernorm.eps, ssq_in=ssq))
-        # which kernel gbx_dgemv_forward runs for this launch (csrc/dgemv_mx.hip:dg_mx_wanted): 2-bit group-128 bf16 SwiGLU launches take the
-        # FP4 x FP8 matrix-core form unless GBX_DG_MX=0
-        kk = g0.input_dims
-        mx = (os.environ.get("GBX_DG_MX", "1") != "0" and bits == 2 and g0.group_size == 128 and dt == torch.bfloat16 and kk % 2048 == 0
-              and kk <= 8192 and pl[0] == 2)
-        kname = (f"gbx::dgemv_mx_kernel<SP{kk // 2048},NW16,SWIGLU,LATE> (v_mfma_scale_f32_16x16x128_f8f6f4 dot products)" if mx
-                 else f"gbx::dgemv_kernel<{bits},P1,KS1,NW16,R{pl[0]},SWIGLU,...>")
+        kname = "gbx::" + ops.dgemv_kernel_name(g_descs[0])
         launch = ops.dgemv
     else:
         o_descs, g_descs = [], []
@@ -146,7 +157,7 @@ def kernel_leg(model, reps=20):
     us = (us_pairs - us_o) / len(g_descs)
     descs = g_descs
     n, k, grp = g0.output_dims, g0.input_dims, g0.group_size
-    nbytes = 2 * (n * k * bits // 8 + 2 * n * (k // grp) * 2) + k * 2 + k * 2 + n * 2
+    nbytes = 2 * (n * k * bits // 8 + 2 * n * (k // grp) * 2) + k * 2 + k * 2 + n * 2 + acc_bytes
     achieved = nbytes / us / 1e3
     traffic = None            # PMC-derived HBM bytes per launch for this exact kernel/shape, if a profile run recorded it
     try:
@@ -162,7 +173,7 @@ def kernel_leg(model, reps=20):
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "floor": floor,
             "kernel": f"{kname} fused RMSNorm+gate_proj+up_proj+SwiGLU, 2 x [N={n}, K={k}] g={grp}",
             "bytes_per_launch": nbytes, "us_per_launch": us, "us_back_to_back": us_b2b / len(descs),
-            "method": "HIP events: graph of (o_proj, gate|up) pairs minus the same graph without gate|up, per pair",
+            "method": f"HIP events: graph of ({pred}, gate|up) pairs minus the same graph without gate|up, per pair",
             "launches_timed": reps * len(descs),
             "working_set_bytes": nbytes * len(descs)}
 
@@ -202,7 +213,7 @@ def dry_run(args, world, rank):
     """CPU rehearsal of the N > 1 control flow: gloo rendezvous, tp.shard_llama of the tiny model, the path's exchange
     pattern (one all-reduce of [B, D] after o_proj and after down_proj per layer) timed with the same barrier / max-over-
     ranks protocol, ONE JSON line from rank 0.  No QuantizedLinear math runs here (that needs the HIP extension)."""
-    from gbx_lm_amd import synthetic as S, tp
+    from gbx_lm_amd import env as genv, synthetic as S, tp
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -296,6 +307,8 @@ def decode_leg(model, cfg, dev, batch, context, steps, warmup, world=1, use_grap
     # shard: an argmax over it would start every rank on a different token id)
     runner.start_greedy(torch.argmax(full, -1))
     ms = time_decode(runner, steps, warmup, batch, world, dev) / steps
+    if hasattr(runner, "dattn_check"):
+        runner.dattn_check()
     ql_b, head_b, kv_b = token_bytes(model, context + warmup + steps // 2)
     nbytes = ql_b + head_b + kv_b * batch
     return {"tok_s": batch * 1e3 / ms, "ms_per_step": ms, "steps": steps, "context": context, "batch": batch,
@@ -409,7 +422,7 @@ def main():
     if world > 1:
         tp.shard_llama(model, rank, world)
         tp_allreduce = "rccl"
-        if os.environ.get("GBX_TP_P2P") == "1":
+        if genv.flag("GBX_TP_P2P"):
             # opt-in: one-shot push all-reduce through hipIpc inboxes (gbx_p2p_allreduce) instead of RCCL for the [B, D] exchanges
             if tp.enable_p2p(rank, world, cfg["hidden_size"] * 32, dev) is not None:
                 tp_allreduce = "p2p one-shot (gbx_p2p_allreduce)"
@@ -423,7 +436,7 @@ def main():
 
     # N > 1: the RCCL all-reduces are captured into the same HIP graph; GBX_TP_GRAPH=0 forces eager launches, and a capture
     # that raises (before any collective has been enqueued for real) falls back to them on every rank alike
-    use_graph = not args.no_graph and (world == 1 or os.environ.get("GBX_TP_GRAPH", "1") != "0")
+    use_graph = not args.no_graph and (world == 1 or genv.flag("GBX_TP_GRAPH"))
     graph_note = "hipGraph replay"
     Runner = FusedDecodeRunner if (fused_eligible(model) and args.batch == 1) else DecodeRunner
     try:
@@ -445,6 +458,11 @@ def main():
     runner.start_greedy(tok)                                        # greedy chain: argmax + next-token feed stay on the device
 
     ms = time_decode(runner, args.steps, args.warmup, args.batch, world, dev)
+    if hasattr(runner, "dattn_check"):
+        runner.dattn_check()            # a fused attention launch whose hand-off timed out voids the run (raises; off the timed path)
+    launches = [d is not None for d in getattr(runner, "da", [])]
+    block_note = ("3 launches per block (fused attention launch gbx_dattn_forward, gate|up, down)" if launches and all(launches) else
+                  (f"{sum(launches)} of {len(launches)} blocks on 3 launches, the rest on 5" if any(launches) else "5 launches per block"))
     ms_per_step = ms / args.steps
     tok_s = args.batch * 1e3 / ms_per_step
 
@@ -456,7 +474,7 @@ def main():
     cpu = None
     extra = None
     if rank == 0 and not args.no_kernel_leg:
-        roof = kernel_leg(model)
+        roof = kernel_leg(model, runner)
     if rank == 0 and world == 1 and not args.no_extra and args.model == "llama3-8b" and args.batch == 1:
         # the rest of the metric (BASELINE.json: "bpw-2.2 & 4.0", configs[3], configs[4] at TP 1) in the same line, bounded
         extra = {}
@@ -515,7 +533,7 @@ def main():
             "config": {"workload": f"{args.model} layer-mix {args.strategy} greedy decode batch={args.batch} "
                                    f"context={args.context} (BASELINE.json configs[{2 if args.batch == 1 else 4}])",
                        "global_batch": args.batch, "seq_len": args.context, "parallelism": f"tp{world}",
-                       "launch": graph_note, "decode_block": Runner.__name__, "bits_mix": args.strategy, "group_size": 128,
+                       "launch": graph_note, "decode_block": Runner.__name__, "block_launches": block_note, "bits_mix": args.strategy, "group_size": 128,
                        "tp_allreduce": tp_allreduce, "tp_head": "vocabulary-sharded" if getattr(model, "tp_vocab", None) else "full"},
             "roofline": roof,
             "cpu_baseline": cpu,

@@ -245,6 +245,7 @@ __global__ __launch_bounds__(NW * 64) void dgemv_mx_kernel(const DgArgs a) {
   }
   DMX_STAMP(10);
   if constexpr (LATE) issue(ring[0], batch_of(0));
+  DMX_STAMP(11);
   __syncthreads();
   DMX_STAMP(2);
   issue(ring[1], batch_of(1));

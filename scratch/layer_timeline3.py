@@ -111,3 +111,16 @@ for b in order:
     print(f"   block {b:3d} (group slot {b % 8}, member {b >> 3}): first wave start {wg_start[b]:5.2f}, last wave's loads issued {wg_issue[b]:5.2f}, barrier {wg_bar[b]:5.2f}, last publish {np.nanmax(rel[b, :, 4]):5.2f}")
 print("by member index r (median over the 8 groups): barrier passed")
 print("   " + "  ".join(f"{m}:{np.nanmedian(wg_bar[np.arange(256) >> 3 == m]):.2f}" for m in range(32)))
+
+for ki, (nm, cols) in enumerate([("dattn", None), ("gateup", (0, 1, 8, 9, 10, 11, 2, 4, 6)), ("down", (0, 1, 2, 3, 4, 6))]):
+    if cols is None:
+        continue
+    r = s[li * PER_LAYER + ki].astype(np.float64)
+    t0 = r[r[:, 0] > 0][:, 0].min()
+    rel = (r - t0) / 100.0
+    rel[r == 0] = np.nan
+    rel = rel.reshape(256, 16, 16)
+    print(f"{nm}, layer {li}: median over workgroups by wave index, stamps {cols}")
+    for w in range(16):
+        c = rel[:, w]
+        print(f"   wave {w:2d}: " + "  ".join(f"s{i}={np.nanmedian(c[:, i]):5.2f}" for i in cols) + f"   (end max {np.nanmax(c[:, 6]):5.2f})")
