@@ -154,14 +154,25 @@ class DattnDesc(ctypes.Structure):
                 ("qkv_qweight", ctypes.c_void_p), ("qkv_sz", ctypes.c_void_p), ("kcache", ctypes.c_void_p), ("vcache", ctypes.c_void_p),
                 ("inv_freq", ctypes.c_void_p), ("pos", ctypes.c_void_p), ("o_qweight", ctypes.c_void_p), ("o_scales", ctypes.c_void_p),
                 ("o_zeros", ctypes.c_void_p), ("acc", ctypes.c_void_p), ("state", ctypes.c_void_p), ("attn_out", ctypes.c_void_p),
+                ("x_acc", ctypes.c_void_p), ("x_out", ctypes.c_void_p), ("zero_buf", ctypes.c_void_p), ("zero_n", ctypes.c_int32),
                 ("D", ctypes.c_int32), ("n_heads", ctypes.c_int32), ("capacity", ctypes.c_int32),
                 ("qkv_bits", ctypes.c_int32), ("qkv_group_size", ctypes.c_int32), ("o_bits", ctypes.c_int32), ("o_group_size", ctypes.c_int32),
                 ("traditional", ctypes.c_int32), ("norm_eps", ctypes.c_float), ("rope_scale", ctypes.c_float), ("sm_scale", ctypes.c_float)]
 
 
+class DmlpDesc(ctypes.Structure):
+    """Mirror of ``gbx_dmlp`` (include/gbx_qlinear.h): the fused MLP launch of a decoder block at M == 1."""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("act_dtype", ctypes.c_int32),
+                ("x", ctypes.c_void_p), ("x_acc", ctypes.c_void_p), ("x_out", ctypes.c_void_p), ("norm_weight", ctypes.c_void_p),
+                ("gate_qweight", ctypes.c_void_p), ("up_qweight", ctypes.c_void_p), ("gate_up_sz", ctypes.c_void_p),
+                ("down_qweight", ctypes.c_void_p), ("down_sz", ctypes.c_void_p), ("acc_out", ctypes.c_void_p),
+                ("zero_buf", ctypes.c_void_p), ("state", ctypes.c_void_p), ("act_out", ctypes.c_void_p),
+                ("D", ctypes.c_int32), ("I", ctypes.c_int32), ("zero_n", ctypes.c_int32), ("norm_eps", ctypes.c_float)]
+
+
 GBX_DG_PLAIN, GBX_DG_RESIDUAL, GBX_DG_SWIGLU = 0, 1, 2
 GBX_DG_SSQ_SLOTS = 1024
-GBX_MIN_VERSION = 1200          # the header this binding mirrors
+GBX_MIN_VERSION = 1201          # the header this binding mirrors
 
 
 def _declare_optional(L) -> None:
@@ -177,6 +188,9 @@ def _declare_optional(L) -> None:
         "gbx_dattn_plan": [i32, i32, i32, i32, i32, i32, i32, i32],
         "gbx_dattn_forward": [ctypes.POINTER(DattnDesc), p],
         "gbx_dattn_status": [p, ctypes.POINTER(i32)],
+        "gbx_dmlp_plan": [i32, i32, i32, i32, i32, i32, i32],
+        "gbx_dmlp_forward": [ctypes.POINTER(DmlpDesc), p],
+        "gbx_acc_residual": [p, p, p, i32, p, p, p, p],
         "gbx_qlinear_kernel_id": [i64, i32, i32, i32, i32, i32],
         "gbx_qlinear_swiglu_forward": [p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, p],
         "gbx_qlinear_forward_partials": [p, p, p, p, p, ctypes.c_size_t, ctypes.POINTER(i32), i64, i32, i32, i32, i32, i32, p],

@@ -32,9 +32,9 @@ extern "C" void gbx_debug_stamp_reset(void) { gbx::g_stamp_launch = 0; }
 
 extern "C" {
 
-/* 1200: gbx_dgemv grows (x_acc, x_out, zero_buf, zero_n) + gbx_dattn_* + gbx_dgemv_kernel_id.  1101: + gbx_attn_decode_slices (an addition: nothing else changed).  1100: gbx_dgemv_* entry points; gbx_qlinear_fused (x_acc, x_out, zero_buf, zero_n since 1001) -- a consumer built against
+/* 1201: + gbx_dattn.x_acc / x_out / zero_buf, gbx_dmlp_*, gbx_acc_residual.  1200: gbx_dgemv grows (x_acc, x_out, zero_buf, zero_n) + gbx_dattn_* + gbx_dgemv_kernel_id.  1101: + gbx_attn_decode_slices (an addition: nothing else changed).  1100: gbx_dgemv_* entry points; gbx_qlinear_fused (x_acc, x_out, zero_buf, zero_n since 1001) -- a consumer built against
  * an older header must not pass its shorter struct to this library: check gbx_version() >= the header it compiled with. */
-int gbx_version(void) { return 1200; }
+int gbx_version(void) { return 1201; }
 
 const char* gbx_last_error(void) { return g_err; }
 
@@ -1076,6 +1076,15 @@ int gbx_dattn_forward(const gbx_dattn* d, void* hip_stream) {
   a.hand = static_cast<unsigned long long*>(d->state);
   a.state = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(d->state) + static_cast<size_t>(gbx::DA_GROUPS) * gbx::DA_HAND_STRIDE * 8);
   a.attn_out = static_cast<unsigned short*>(d->attn_out);
+  if (d->x_acc && (d->ssq_in || !aligned(d->x_acc, 16))) return fail(GBX_ERR_INVALID, "x_acc goes without ssq_in and must be 16-byte aligned");
+  if (d->x_out && (!d->x_acc || d->x_out == d->x || !aligned(d->x_out, 4))) return fail(GBX_ERR_INVALID, "x_out goes with x_acc and must not alias x");
+  if (d->zero_buf && (d->zero_n <= 0 || !aligned(d->zero_buf, 8) || reinterpret_cast<const void*>(d->zero_buf) == reinterpret_cast<const void*>(d->x_acc) ||
+                      reinterpret_cast<const void*>(d->zero_buf) == reinterpret_cast<const void*>(d->acc)))
+    return fail(GBX_ERR_INVALID, "zero_buf needs zero_n > 0, 8-byte alignment, and must be neither x_acc nor acc of this launch");
+  a.x_acc = reinterpret_cast<const long long*>(d->x_acc);
+  a.x_out = static_cast<unsigned short*>(d->x_out);
+  a.zero_buf = reinterpret_cast<unsigned long long*>(d->zero_buf);
+  a.zero_n = d->zero_buf ? d->zero_n : 0;
   a.D = d->D; a.rep = d->n_heads / 8; a.capacity = d->capacity; a.bpw = pl.bpw;
   a.qkv_log2g = log2_group(d->qkv_group_size); a.o_bits = d->o_bits; a.o_log2g = log2_group(d->o_group_size);
   a.traditional = d->traditional;
@@ -1085,6 +1094,63 @@ int gbx_dattn_forward(const gbx_dattn* d, void* hip_stream) {
 #endif
   hipError_t e = gbx::launch_dattn(a, pl, d->qkv_bits, d->act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));
   if (e != hipSuccess) return hip_fail(e, "gbx_dattn_forward launch");
+  return GBX_OK;
+}
+
+int gbx_dmlp_plan(int32_t D, int32_t I, int32_t gate_up_bits, int32_t gate_up_group_size, int32_t down_bits, int32_t down_group_size,
+                  int32_t act_dtype) {
+  int bpw, a4;
+  if (!gbx::dmlp_plan(D, I, gate_up_bits, gate_up_group_size, down_bits, down_group_size, act_dtype == GBX_BF16, &bpw, &a4))
+    return fail(GBX_ERR_UNSUPPORTED, "the fused MLP launch does not cover D=%d I=%d gate|up %d bits g%d, down %d bits g%d, dtype %d", D, I,
+                gate_up_bits, gate_up_group_size, down_bits, down_group_size, act_dtype);
+  return GBX_OK;
+}
+
+int gbx_dmlp_forward(const gbx_dmlp* d, void* hip_stream) {
+  if (!d) return fail(GBX_ERR_INVALID, "null descriptor");
+  if (d->struct_size != sizeof(gbx_dmlp)) return fail(GBX_ERR_INVALID, "gbx_dmlp.struct_size is %u, this library expects %zu (header / library mismatch)", d->struct_size, sizeof(gbx_dmlp));
+  int bpw, a4;
+  if (!gbx::dmlp_plan(d->D, d->I, 2, 128, 2, 128, d->act_dtype == GBX_BF16, &bpw, &a4))
+    return fail(GBX_ERR_UNSUPPORTED, "the fused MLP launch does not cover D=%d I=%d dtype %d (gbx_dmlp_plan)", d->D, d->I, d->act_dtype);
+  if (!d->x || !d->x_acc || !d->x_out || !d->norm_weight || !d->gate_qweight || !d->up_qweight || !d->gate_up_sz || !d->down_qweight || !d->down_sz ||
+      !d->acc_out || !d->state)
+    return fail(GBX_ERR_INVALID, "null device pointer");
+  if (!aligned(d->x, 16) || !aligned(d->x_acc, 16) || !aligned(d->x_out, 8) || !aligned(d->norm_weight, 16) || !aligned(d->gate_qweight, 16) ||
+      !aligned(d->up_qweight, 16) || !aligned(d->gate_up_sz, 16) || !aligned(d->down_qweight, 16) || !aligned(d->down_sz, 16) ||
+      !aligned(d->acc_out, 16) || !aligned(d->state, 64))
+    return fail(GBX_ERR_INVALID, "pointers must be 16-byte aligned (state: 64)");
+  if (d->x_out == d->x) return fail(GBX_ERR_INVALID, "x_out must not alias x (every workgroup reads x)");
+  if (reinterpret_cast<const void*>(d->acc_out) == reinterpret_cast<const void*>(d->x_acc)) return fail(GBX_ERR_INVALID, "acc_out must not be x_acc");
+  if (d->zero_buf && (d->zero_n <= 0 || !aligned(d->zero_buf, 8) || reinterpret_cast<const void*>(d->zero_buf) == reinterpret_cast<const void*>(d->x_acc) ||
+                      reinterpret_cast<const void*>(d->zero_buf) == reinterpret_cast<const void*>(d->acc_out)))
+    return fail(GBX_ERR_INVALID, "zero_buf needs zero_n > 0, 8-byte alignment, and must be neither x_acc nor acc_out of this launch");
+  gbx::DmlpArgs a{};
+  a.x = static_cast<const unsigned short*>(d->x);
+  a.x_acc = reinterpret_cast<const long long*>(d->x_acc);
+  a.x_out = static_cast<unsigned short*>(d->x_out);
+  a.norm_w = static_cast<const unsigned short*>(d->norm_weight);
+  a.gate_qw = d->gate_qweight; a.up_qw = d->up_qweight; a.gu_sz = d->gate_up_sz;
+  a.down_qw = d->down_qweight; a.down_sz = d->down_sz;
+  a.acc_out = reinterpret_cast<unsigned long long*>(d->acc_out);
+  a.zero_buf = reinterpret_cast<unsigned long long*>(d->zero_buf);
+  a.zero_n = d->zero_buf ? d->zero_n : 0;
+  a.hand = static_cast<unsigned long long*>(d->state);
+  a.state = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(d->state) + static_cast<size_t>(gbx::DA_GROUPS) * gbx::DA_HAND_STRIDE * 8);
+  a.act_out = static_cast<unsigned short*>(d->act_out);
+  a.K = d->D; a.I = d->I; a.D = d->D; a.bpw = bpw; a.a4 = a4;
+  a.eps = d->norm_eps;
+#ifdef GBX_STAMPS
+  a.stamps = gbx::stamp_region();
+#endif
+  hipError_t e = gbx::launch_dmlp(a, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_dmlp_forward launch");
+  return GBX_OK;
+}
+
+int gbx_acc_residual(const void* x, int64_t* acc, void* out, int32_t D, int64_t* zero0, int64_t* zero1, int64_t* zero2, void* hip_stream) {
+  if (!x || !acc || !out || D <= 0) return fail(GBX_ERR_INVALID, "null pointer or bad D");
+  hipError_t e = gbx::launch_acc_finish(x, acc, out, D, zero0, zero1, zero2, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_acc_residual launch");
   return GBX_OK;
 }
 

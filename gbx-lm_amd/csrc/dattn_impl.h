@@ -58,6 +58,11 @@ struct DattnArgs {
   unsigned long long* hand;         // [8][DA_HAND_STRIDE] granules
   unsigned* state;                  // [DA_STATE_WORDS]
   unsigned short* attn_out;         // optional [n_heads * 128]: the attention output (tests)
+  // the previous block's MLP launch (dmlp.hip) leaves down_proj's output as fixed-point sums too:
+  const long long* x_acc;           // [D + 1] or null: x <- round(x + round(x_acc * 2^-32)) in the producers' prologue (no ssq_in then)
+  unsigned short* x_out;            // with x_acc: the new x, written once
+  unsigned long long* zero_buf;     // or null: zero_n 8-byte words this launch clears
+  int zero_n;
   int D, rep, capacity, bpw;        // bpw: phase-1 batches per producer workgroup
   int qkv_log2g, o_bits, o_log2g, traditional;
   float eps, rope_scale, sm_scale;
@@ -74,6 +79,32 @@ struct DattnPlan {
 // false: this launch does not cover the shape (the caller keeps the five-launch block)
 bool dattn_plan(int D, int n_heads, int n_kv, int head_dim, int qkv_bits, int qkv_group, int o_bits, int o_group, DattnPlan* pl);
 hipError_t launch_dattn(const DattnArgs& a, const DattnPlan& pl, int qkv_bits, bool bf16, hipStream_t stream);
+// dmlp.hip: the MLP half of the block as one launch (gate | up + SwiGLU + XCD-local hand-off + down_proj partial sums)
+struct DmlpArgs {
+  const unsigned short* x;          // [K] the stream before o_proj's output is added
+  const long long* x_acc;           // [K + 1] o_proj sums, 2^-32 fixed point (word K: non-finite marker)
+  unsigned short* x_out;            // [K] x' = round(x + round(x_acc * 2^-32)), written once (workgroup 0)
+  const unsigned short* norm_w;     // [K] post-attention RMSNorm weight
+  const uint32_t* gate_qw;          // [I, K / 16]
+  const uint32_t* up_qw;            // [I, K / 16]
+  const uint32_t* gu_sz;            // [I][K / 128][2]: (scale | zero << 16) of (gate row n, up row n) (gbx_dgemv_pack, SwiGLU, 2 rows per batch)
+  const uint32_t* down_qw;          // [D, I / 16]
+  const uint32_t* down_sz;          // [D / 2][I / 128][2]: gbx_dgemv_pack of down_proj, 2 rows per batch
+  unsigned long long* acc_out;      // [D + 1] down_proj sums, 2^-32 fixed point (zero on entry)
+  unsigned long long* zero_buf;     // or null: zero_n words this launch clears
+  unsigned long long* hand;         // [8][DA_HAND_STRIDE] granules
+  unsigned* state;                  // [DA_STATE_WORDS]
+  unsigned short* act_out;          // optional [I]: the SwiGLU output (tests)
+  int K, I, D, zero_n, bpw, a4;     // bpw: gate|up batches per workgroup; waves [0, a4) own 4 of them, the others 2
+  float eps;
+#ifdef GBX_STAMPS
+  unsigned long long* stamps;
+#endif
+};
+
+bool dmlp_plan(int D, int I, int bits_gu, int group_gu, int bits_dn, int group_dn, bool bf16, int* bpw, int* a4);
+hipError_t launch_dmlp(const DmlpArgs& a, hipStream_t stream);
+hipError_t launch_acc_finish(const void* x, void* acc, void* out, int D, void* z0, void* z1, void* z2, hipStream_t stream);
 template <int BQ>
 hipError_t launch_dattn_bits(const DattnArgs& a, const DattnPlan& pl, bool bf16, hipStream_t stream);
 

@@ -178,6 +178,9 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
     vb = static_cast<unsigned>(y);
   };
 
+  if (a.zero_buf) {                                          // (kernel-argument uniform)
+    for (int i = static_cast<int>(blockIdx.x) * NT + tid; i < a.zero_n; i += static_cast<int>(gridDim.x) * NT) a.zero_buf[i] = 0ull;
+  }
   // ---------------- o_proj: this workgroup's rows, this group's columns -- requested early, consumed in phase 3 ----------------
   const int obits = a.o_bits;
   const int ovpl_l2 = obits == 2 ? 6 : 5;
@@ -254,11 +257,56 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
     u32x4 pq[4] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
     const bool carried = a.ssq_in != nullptr;
     if (pro) {
+      // the previous block's down_proj sums (x_acc launches) first: the longest round trip of the prologue; without x_acc the
+      // offsets are out of range and nothing is fetched
+      u32x4 acv[IPT][PPU];
+      unsigned apoison;
+      {
+        const __amdgpu_buffer_rsrc_t ad = rsrc(a.x_acc ? static_cast<const void*>(a.x_acc) : static_cast<const void*>(a.x), RS_ALL);
+        const unsigned ak = a.x_acc ? 0u : KILL;
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+          const int it = min(tid + PT * j, nitems - 1);
+          const int u = it / TPU, t = it % TPU;
+#pragma unroll
+          for (int q = 0; q < PPU; ++q) {
+            int idx;
+            if constexpr (BQ == 3) idx = u * F::UNIT_VALS + 2 * q;
+            else idx = u * F::UNIT_VALS + PPU * t + (q < PPU / 2 ? 2 * q : UP + 2 * (q - PPU / 2));
+            acv[j][q] = __builtin_amdgcn_raw_buffer_load_b128(ad, static_cast<unsigned>(idx * 8) | ak, 0, 0);
+          }
+        }
+        apoison = __builtin_amdgcn_raw_buffer_load_b32(ad, static_cast<unsigned>(K * 8) | ak, 0, 0);
+      }
 #pragma unroll
       for (int j = 0; j < IPT; ++j) {
         const int it = min(tid + PT * j, nitems - 1);
         da_load_item<BQ, PPU>(a.x, it, xr[j]);
         da_load_item<BQ, PPU>(a.norm_w, it, wr[j]);
+      }
+      if (a.x_acc) {                                           // x <- round(x + round(acc * 2^-32)); ONE producer workgroup writes it out
+        const bool poison = apoison != 0u;
+        const bool writer = blockIdx.x == static_cast<unsigned>(rep * DA_GROUPS) && a.x_out != nullptr;
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+          const int it = min(tid + PT * j, nitems - 1);
+          const int u = it / TPU, t = it % TPU;
+          const bool live = tid + PT * j < nitems;
+#pragma unroll
+          for (int q = 0; q < PPU; ++q) {
+            int idx;
+            if constexpr (BQ == 3) idx = u * F::UNIT_VALS + 2 * q;
+            else idx = u * F::UNIT_VALS + PPU * t + (q < PPU / 2 ? 2 * q : UP + 2 * (q - PPU / 2));
+            const u32x4 av = acv[j][q];
+            const float o0 = round_bf16_or_f16(fx32_to_f32(av.x, av.y), BF16);
+            const float o1 = round_bf16_or_f16(fx32_to_f32(av.z, av.w), BF16);
+            float x0 = act_lo<BF16>(xr[j][q]) + o0, x1 = act_hi<BF16>(xr[j][q]) + o1;
+            if (poison) { x0 = __uint_as_float(0x7FC00000u); x1 = x0; }
+            const unsigned wv = static_cast<unsigned>(f32_to_act<BF16>(x0)) | (static_cast<unsigned>(f32_to_act<BF16>(x1)) << 16);
+            xr[j][q] = wv;
+            if (writer && live) *reinterpret_cast<unsigned*>(a.x_out + idx) = wv;
+          }
+        }
       }
       const __amdgpu_buffer_rsrc_t pd = rsrc(carried ? static_cast<const void*>(a.ssq_in) : static_cast<const void*>(a.x), RS_ALL);
       const unsigned pk = carried ? 0u : KILL;

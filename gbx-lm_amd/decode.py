@@ -394,8 +394,12 @@ class FusedDecodeRunner(DecodeRunner):
         # h + o in its prologue, the down launch clears the accumulator -- three launches per block instead of five.
         self.use_dattn = (env.flag("GBX_DATTN") and not tp and self.attn_ws is None and not self.fuse_ao and env.flag("GBX_DGEMV") and
                           env.flag("GBX_QKV_CAT"))
-        self.da = []                        # per layer: (dattn, gate|up, down) descriptors, or None (the five-launch block)
-        self.da_acc = self.da_state = None
+        self.use_dmlp = self.use_dattn and env.flag("GBX_DMLP")
+        self.da = []                        # per layer: (dattn, gate|up, down) or (dattn, dmlp) descriptors, or None (the five-launch block)
+        self.da_pre = {}                    # layer -> (x, sums): pending fixed-point sums to finish into hb before a five-launch block
+        self.da_post = None                 # the same after the last block
+        self.acc_o = self.acc_d = self.hn = self.da_state = self.dm_state = None
+        self._pending = None
         self.descs = []
         self.descs_ao = []
         self.dg = []                        # per layer: [qkv, o, gate|up, down] dgemv descriptors (None: the launch stays on gbx_qlinear_fused_forward)
@@ -439,7 +443,7 @@ class FusedDecodeRunner(DecodeRunner):
             # writes h (o_proj / down_proj epilogue, one partial per workgroup) to the launch that normalises it (GBX_DG_SSQ).
             ssq_prev_layer = self.ssq_prev
             self.dg.append(self._dgemv_descs(blk, qkv_mods[0] if len(qkv_mods) == 1 else None, qkv_ys[0], tp, r0, len(self.dg)))
-            self.da.append(self._dattn_descs(blk, qkv_mods[0] if len(qkv_mods) == 1 else None, caches[len(self.da)], ssq_prev_layer))
+            self.da.append(self._fused_descs(len(self.da), blk, qkv_mods[0] if len(qkv_mods) == 1 else None, caches[len(self.da)], ssq_prev_layer))
             if self.fuse_ao and p_gu is not None:
                 self.descs_ao.append((
                     # x = hb + round(acc) formed in the prologue, the new stream written to pb once
@@ -451,6 +455,7 @@ class FusedDecodeRunner(DecodeRunner):
                 ))
             else:
                 self.fuse_ao = False
+        self.da_post, self._pending = self._pending, None
         super().__init__(model, caches, use_graph=use_graph)
 
     def _dgemv_descs(self, blk, qkv_cat, qkv_y, tp: bool, r0: bool, li: int):
@@ -510,40 +515,73 @@ class FusedDecodeRunner(DecodeRunner):
         self.ssq_prev = ssq_dn if out[3] is not None else None
         return out
 
-    def _dattn_descs(self, blk, qkv_cat, cache, ssq_prev):
-        """(fused attention launch, gate|up with the accumulator prologue, down_proj that clears it) of one block, or None."""
+    def _fused_descs(self, li, blk, qkv_cat, cache, ssq_prev):
+        """Descriptors of one block on the fused launches, or None (the five-launch block):
+        (fused attention, gate|up with the accumulator prologue, down_proj)  -- three launches, or
+        (fused attention, fused MLP)                                        -- two launches (gbx_dmlp_forward: 2-bit Llama-3-8B MLP shapes).
+        The stream enters a block either as a vector (``self._pending is None``) or as (vector, fixed-point down_proj sums) left
+        by the previous block's fused MLP launch; the fused attention launch takes both forms.  Accumulators alternate by block
+        parity so that a launch never clears a buffer another launch of the same kernel still reads or adds to."""
         from . import _lib as _l
         at, mlp = blk.self_attn, blk.mlp
-        if (not self.use_dattn or qkv_cat is None or getattr(at, "q_norm", None) is not None or at.o_proj.bias is not None or
-                mlp.gate_proj.bias is not None or mlp.up_proj.bias is not None or mlp.down_proj.bias is not None or
-                cache.keys is None or cache.keys.shape[0] != 1 or not cache.keys.is_contiguous() or not cache.values.is_contiguous() or
-                not ops.dattn_supported(self.hb.numel(), at.n_heads, at.n_kv_heads, at.head_dim, qkv_cat, at.o_proj)):
-            return None
-        g_dn = self.dg[-1][3]
-        pl_gu = ops.dgemv_plan(mlp.gate_proj.output_dims, mlp.gate_proj.input_dims, mlp.gate_proj.bits, mlp.gate_proj.group_size,
-                               _l.GBX_DG_SWIGLU, True)
-        pl_dn = ops.dgemv_plan(mlp.down_proj.output_dims, mlp.down_proj.input_dims, mlp.down_proj.bits, mlp.down_proj.group_size,
-                               _l.GBX_DG_RESIDUAL, False)
-        if pl_gu is None or pl_dn is None or g_dn is None:
-            return None
-        dev = self.hb.device
+        pending, self._pending = self._pending, None
         D = self.hb.numel()
-        if self.da_acc is None:
-            self.da_acc = torch.zeros((D + 1,), dtype=torch.int64, device=dev)
+        dev = self.hb.device
+        ok = (self.use_dattn and qkv_cat is not None and getattr(at, "q_norm", None) is None and at.o_proj.bias is None and
+              mlp.gate_proj.bias is None and mlp.up_proj.bias is None and mlp.down_proj.bias is None and
+              cache.keys is not None and cache.keys.shape[0] == 1 and cache.keys.is_contiguous() and cache.values.is_contiguous() and
+              ops.dattn_supported(D, at.n_heads, at.n_kv_heads, at.head_dim, qkv_cat, at.o_proj))
+        pl_gu = pl_dn = None
+        if ok:
+            pl_gu = ops.dgemv_plan(mlp.gate_proj.output_dims, mlp.gate_proj.input_dims, mlp.gate_proj.bits, mlp.gate_proj.group_size,
+                                   _l.GBX_DG_SWIGLU, True)
+            pl_dn = ops.dgemv_plan(mlp.down_proj.output_dims, mlp.down_proj.input_dims, mlp.down_proj.bits, mlp.down_proj.group_size,
+                                   _l.GBX_DG_RESIDUAL, False)
+            ok = pl_gu is not None and pl_dn is not None and self.dg[-1][3] is not None
+        if not ok:
+            if pending is not None:          # the five-launch block takes a plain vector: finish the pending sums into hb first
+                self.da_pre[li] = (pending[0], pending[1])
+            return None
+        if self.acc_o is None:
+            # o_proj / down_proj sums by block parity: [D + 1] views of two rows of D + 2 words (16-byte aligned rows)
+            self.acc_o_flat = torch.zeros((2 * (D + 2),), dtype=torch.int64, device=dev)
+            self.acc_d_flat = torch.zeros((2 * (D + 2),), dtype=torch.int64, device=dev)
+            self.acc_o = [self.acc_o_flat[q * (D + 2): q * (D + 2) + D + 1] for q in range(2)]
+            self.acc_d = [self.acc_d_flat[q * (D + 2): q * (D + 2) + D + 1] for q in range(2)]
+            self.hn = torch.zeros((D,), dtype=self.hb.dtype, device=dev)             # the stream a fused attention launch forms from (x, sums)
             self.da_state = ops.dattn_state(dev)
+            self.dm_state = ops.dattn_state(dev)
+        p = li & 1
         pk_qkv = ops.dgemv_pack(qkv_cat, 2)
+        self.dg_keep.append(pk_qkv)
+        x_in, acc_in = (pending if pending is not None else (self.hb, None))
+        d_a = ops.make_dattn_desc(x_in, blk.input_layernorm.weight, blk.input_layernorm.eps, qkv_cat, pk_qkv, cache.keys, cache.values,
+                                  at.rope.inv_freq, self.pos_buf(), at.o_proj, self.acc_o[p], self.da_state, at.n_heads, cache.capacity,
+                                  getattr(at.rope, "scale", 1.0), at.scale, at.rope.traditional,
+                                  ssq_in=ssq_prev if acc_in is None else None, x_acc=acc_in, x_out=self.hn if acc_in is not None else None,
+                                  zero_buf=self.acc_d[p])
+        h_buf = self.hn if acc_in is not None else x_in          # the stream before o_proj's output is added
+        use_mlp = (self.use_dmlp and ops.dmlp_supported(D, mlp.gate_proj, mlp.up_proj, mlp.down_proj, self.hb.dtype) and
+                   blk.post_attention_layernorm.weight.dtype == self.hb.dtype)
+        if use_mlp:
+            pk_gu = ops.dgemv_pack(mlp.gate_proj, 2, mlp.up_proj)
+            pk_dn = ops.dgemv_pack(mlp.down_proj, 2)
+            self.dg_keep += [pk_gu, pk_dn]
+            d_m = ops.make_dmlp_desc(h_buf, self.acc_o[p], self.pb, blk.post_attention_layernorm.weight, blk.post_attention_layernorm.eps,
+                                     mlp.gate_proj, mlp.up_proj, mlp.down_proj, pk_gu, pk_dn, self.acc_d[p], self.dm_state,
+                                     zero_buf=self.acc_o[1 - p])
+            self._pending = (self.pb, self.acc_d[p])
+            self.ssq_prev = None                                 # no down launch: no carried statistic for the next block
+            return d_a, d_m
         pk_gu = ops.dgemv_pack(mlp.gate_proj, pl_gu[0], mlp.up_proj)
         pk_dn = ops.dgemv_pack(mlp.down_proj, pl_dn[0])
-        self.dg_keep += [pk_qkv, pk_gu, pk_dn]
-        d_a = ops.make_dattn_desc(self.hb, blk.input_layernorm.weight, blk.input_layernorm.eps, qkv_cat, pk_qkv, cache.keys, cache.values,
-                                  at.rope.inv_freq, self.pos_buf(), at.o_proj, self.da_acc, self.da_state, at.n_heads, cache.capacity,
-                                  getattr(at.rope, "scale", 1.0), at.scale, at.rope.traditional, ssq_in=ssq_prev)
-        d_gu = ops.make_dgemv_desc(self.hb, mlp.gate_proj, self.actb, pk_gu, pl_gu[0], mod_up=mlp.up_proj,
+        self.dg_keep += [pk_gu, pk_dn]
+        d_gu = ops.make_dgemv_desc(h_buf, mlp.gate_proj, self.actb, pk_gu, pl_gu[0], mod_up=mlp.up_proj,
                                    norm_weight=blk.post_attention_layernorm.weight, eps=blk.post_attention_layernorm.eps,
-                                   x_acc=self.da_acc, x_out=self.pb)
+                                   x_acc=self.acc_o[p], x_out=self.pb)
         # the statistic of the stream this launch writes goes to the next block's norm'd launch exactly as in the five-launch block
         d_dn = ops.make_dgemv_desc(self.actb, mlp.down_proj, self.hb, pk_dn, pl_dn[0], residual=self.pb,
-                                   ssq_out=self.ssq_prev, zero_buf=self.da_acc)
+                                   ssq_out=self.ssq_prev, zero_buf=self.acc_o_flat)
         return d_a, d_gu, d_dn
 
     def pos_buf(self) -> torch.Tensor:
@@ -551,8 +589,8 @@ class FusedDecodeRunner(DecodeRunner):
 
     def dattn_check(self) -> None:
         """Raise if a fused attention launch of this runner timed out on a hand-off (synchronises: call off the timed path)."""
-        if self.da_state is not None:
-            code = ops.dattn_status(self.da_state)
+        for st in (self.da_state, self.dm_state):
+            code = ops.dattn_status(st) if st is not None else 0
             if code:
                 raise RuntimeError(f"gbx_dattn_forward: hand-off {code} timed out (workgroup placement broke the one-kv-group-per-XCD "
                                    "bijection, or a member never ran); the results of this runner are invalid -- rerun with GBX_DATTN=0")
@@ -571,11 +609,16 @@ class FusedDecodeRunner(DecodeRunner):
             at = blk.self_attn
             g_qkv, g_o, g_gu, g_dn = self.dg[li]
             run = lambda g, d: ops.dgemv(g, dev) if g is not None else ops.qlinear_fused(d, dev)
+            if li in self.da_pre:            # pending fixed-point sums -> hb (every accumulator is zero afterwards)
+                xs, accs = self.da_pre[li]
+                ops.acc_residual(xs, accs, self.hb, zero=[t for t in (self.acc_d[0], self.acc_d[1], self.acc_o[0], self.acc_o[1]) if t.data_ptr() != accs.data_ptr()])
             if self.da[li] is not None:
-                d_a, d_gu3, d_dn3 = self.da[li]
-                ops.dattn(d_a, dev)
-                ops.dgemv(d_gu3, dev)
-                ops.dgemv(d_dn3, dev)
+                ops.dattn(self.da[li][0], dev)
+                if len(self.da[li]) == 2:
+                    ops.dmlp(self.da[li][1], dev)
+                else:
+                    ops.dgemv(self.da[li][1], dev)
+                    ops.dgemv(self.da[li][2], dev)
                 continue
             run(g_qkv, d_qkv)
             if self.fuse_ao:
@@ -607,6 +650,9 @@ class FusedDecodeRunner(DecodeRunner):
             run(g_dn, d_dn)
             if self.tp_world > 1:            # ... and the stream returns to hb
                 all_reduce_(self.hb, blk.mlp.tp_group)
+        if self.da_post is not None:         # the last block's down_proj sums -> hb
+            xs, accs = self.da_post
+            ops.acc_residual(xs, accs, self.hb, zero=[t for t in (self.acc_d[0], self.acc_d[1], self.acc_o[0], self.acc_o[1]) if t.data_ptr() != accs.data_ptr()])
         ops.dense_gemv(self.hb, self.model.head_weight(), out=self.logits_buf.view(-1), norm_weight=m.norm.weight,
                        eps=m.norm.eps, argmax_keys=self.keys, index_offset=self.tp_vocab[0] if self.tp_vocab is not None else 0)
         if self.tp_vocab is None:

@@ -771,7 +771,9 @@ def dattn_state(device) -> torch.Tensor:
 def make_dattn_desc(x: torch.Tensor, norm_weight: torch.Tensor, eps: float, qkv_mod, qkv_packed: torch.Tensor, kcache: torch.Tensor,
                     vcache: torch.Tensor, inv_freq: torch.Tensor, pos: torch.Tensor, o_mod, acc: torch.Tensor, state: torch.Tensor,
                     n_heads: int, capacity: int, rope_scale: float, sm_scale: float, traditional: bool,
-                    ssq_in: Optional[torch.Tensor] = None, attn_out: Optional[torch.Tensor] = None) -> "_lib.DattnDesc":
+                    ssq_in: Optional[torch.Tensor] = None, attn_out: Optional[torch.Tensor] = None,
+                    x_acc: Optional[torch.Tensor] = None, x_out: Optional[torch.Tensor] = None,
+                    zero_buf: Optional[torch.Tensor] = None) -> "_lib.DattnDesc":
     """Descriptor of one fused attention launch: RMSNorm -> q|k|v (``qkv_mod``: the three projections' rows concatenated) -> RoPE +
     cache append -> attention -> o_proj partial sums into ``acc`` (int64 [D + 1], 2^-32 fixed point)."""
     import ctypes
@@ -798,11 +800,71 @@ def make_dattn_desc(x: torch.Tensor, norm_weight: torch.Tensor, eps: float, qkv_
     d.o_qweight, d.o_scales, d.o_zeros = o_mod.qweight.data_ptr(), o_mod.scales.data_ptr(), o_mod.zeros.data_ptr()
     d.acc, d.state = acc.data_ptr(), state.data_ptr()
     d.attn_out = attn_out.data_ptr() if attn_out is not None else None
+    if x_acc is not None:               # the previous block's fused MLP launch left down_proj's output as fixed-point sums
+        if x_acc.dtype != torch.int64 or x_acc.numel() != D + 1 or not x_acc.is_contiguous() or x_out is None or ssq_in is not None:
+            raise ValueError("x_acc is int64 [D + 1], comes with x_out and without ssq_in")
+        d.x_acc, d.x_out = x_acc.data_ptr(), x_out.data_ptr()
+    if zero_buf is not None:
+        if zero_buf.dtype != torch.int64 or not zero_buf.is_contiguous():
+            raise ValueError("zero_buf is a contiguous int64 tensor")
+        d.zero_buf, d.zero_n = zero_buf.data_ptr(), zero_buf.numel()
     d.D, d.n_heads, d.capacity = D, n_heads, capacity
     d.qkv_bits, d.qkv_group_size, d.o_bits, d.o_group_size = qkv_mod.bits, qkv_mod.group_size, o_mod.bits, o_mod.group_size
     d.traditional = 1 if traditional else 0
     d.norm_eps, d.rope_scale, d.sm_scale = float(eps), float(rope_scale), float(sm_scale)
     return d
+
+
+def dmlp_supported(d_model: int, gate, up, down, dtype) -> bool:
+    """Does the fused MLP launch (gbx_dmlp_forward) cover this block?"""
+    L = _lib.lib()
+    if not hasattr(L, "gbx_dmlp_plan") or any(m.bias is not None for m in (gate, up, down)):
+        return False
+    if (gate.bits, gate.group_size) != (up.bits, up.group_size) or gate.output_dims != up.output_dims or dtype not in _DT:
+        return False
+    return L.gbx_dmlp_plan(d_model, gate.output_dims, gate.bits, gate.group_size, down.bits, down.group_size, _DT[dtype]) == _lib.GBX_OK
+
+
+def make_dmlp_desc(x: torch.Tensor, x_acc: torch.Tensor, x_out: torch.Tensor, norm_weight: torch.Tensor, eps: float, gate, up, down,
+                   gate_up_packed: torch.Tensor, down_packed: torch.Tensor, acc_out: torch.Tensor, state: torch.Tensor,
+                   zero_buf: Optional[torch.Tensor] = None, act_out: Optional[torch.Tensor] = None) -> "_lib.DmlpDesc":
+    """Descriptor of one fused MLP launch: x' = x + round(x_acc * 2^-32) (written to ``x_out``) -> RMSNorm -> gate | up + SwiGLU ->
+    down_proj partial sums into ``acc_out`` (int64 [D + 1]).  ``gate_up_packed`` / ``down_packed``: dgemv_pack(gate, 2, up) / dgemv_pack(down, 2)."""
+    import ctypes
+    D, I = x.numel(), gate.output_dims
+    for t in (x, x_acc, x_out, norm_weight, gate.qweight, up.qweight, down.qweight, gate_up_packed, down_packed, acc_out, state):
+        _require_cuda(t, "dmlp tensor")
+    if x_acc.dtype != torch.int64 or acc_out.dtype != torch.int64 or x_acc.numel() != D + 1 or acc_out.numel() != D + 1:
+        raise ValueError("x_acc / acc_out are int64 [D + 1]")
+    if down.output_dims != D or down.input_dims != I or gate.input_dims != D:
+        raise ValueError("shapes do not describe an MLP block")
+    if gate_up_packed.numel() != 2 * I * (D // gate.group_size) or down_packed.numel() != D * (I // down.group_size):
+        raise ValueError("packed companions do not match (rows_per_batch 2)")
+    d = _lib.DmlpDesc()
+    d.struct_size = ctypes.sizeof(_lib.DmlpDesc)
+    d.act_dtype = _DT[x.dtype]
+    d.x, d.x_acc, d.x_out, d.norm_weight = x.data_ptr(), x_acc.data_ptr(), x_out.data_ptr(), norm_weight.data_ptr()
+    d.gate_qweight, d.up_qweight, d.gate_up_sz = gate.qweight.data_ptr(), up.qweight.data_ptr(), gate_up_packed.data_ptr()
+    d.down_qweight, d.down_sz = down.qweight.data_ptr(), down_packed.data_ptr()
+    d.acc_out, d.state = acc_out.data_ptr(), state.data_ptr()
+    if zero_buf is not None:
+        if zero_buf.dtype != torch.int64 or not zero_buf.is_contiguous():
+            raise ValueError("zero_buf is a contiguous int64 tensor")
+        d.zero_buf, d.zero_n = zero_buf.data_ptr(), zero_buf.numel()
+    d.act_out = act_out.data_ptr() if act_out is not None else None
+    d.D, d.I, d.norm_eps = D, I, float(eps)
+    return d
+
+
+def dmlp(desc, device) -> None:
+    import ctypes
+    _lib.check(_lib.lib().gbx_dmlp_forward(ctypes.byref(desc), _stream_ptr(device)))
+
+
+def acc_residual(x: torch.Tensor, acc: torch.Tensor, out: torch.Tensor, zero=()) -> None:
+    """out <- round(x + round(acc * 2^-32)); ``acc`` and up to three more [D + 1] accumulators are cleared (gbx_acc_residual)."""
+    z = [t.data_ptr() for t in zero] + [None] * (3 - len(zero))
+    _lib.check(_lib.lib().gbx_acc_residual(x.data_ptr(), acc.data_ptr(), out.data_ptr(), x.numel(), z[0], z[1], z[2], _stream_ptr(x.device)))
 
 
 def dattn(desc, device) -> None:

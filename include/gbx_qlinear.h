@@ -210,6 +210,11 @@ typedef struct gbx_dattn {
   int64_t* acc;                /* [D + 1], zero on entry; receives o_proj . attention as 2^-32 fixed point (word D: non-finite marker) */
   void* state;                 /* gbx_dattn_state_bytes() bytes, zero-filled ONCE by the caller, private to one stream */
   void* attn_out;              /* optional [n_heads * 128]: the attention output before o_proj (tests) */
+  /* after a block whose MLP ran as gbx_dmlp_forward the stream arrives as (x, fixed-point down_proj sums): */
+  const int64_t* x_acc;        /* optional [D + 1], without ssq_in: the launch normalises round(x + round(x_acc * 2^-32)) ... */
+  void* x_out;                 /* ... and writes that vector here once (must not alias x) */
+  uint64_t* zero_buf;          /* optional: zero_n 8-byte words this launch clears (an accumulator whose consumer has run) */
+  int32_t zero_n;
   int32_t D, n_heads, capacity;
   int32_t qkv_bits, qkv_group_size, o_bits, o_group_size;
   int32_t traditional;
@@ -222,9 +227,44 @@ int gbx_dattn_plan(int32_t D, int32_t n_heads, int32_t n_kv_heads, int32_t head_
                    int32_t o_bits, int32_t o_group_size);
 size_t gbx_dattn_state_bytes(void);
 int gbx_dattn_forward(const gbx_dattn* desc, void* hip_stream);
-/* Synchronous read of the launch status word: *code = 0, or the hand-off that timed out (1: q|k|v, 2: attention output) -- then
- * the results of that stream are garbage and the caller must fail.  Off the timed path (it synchronises the device). */
+/* Synchronous read of the launch status word: *code = 0, or the hand-off that timed out (1: q|k|v, 2: attention output, 3: the
+ * activations of gbx_dmlp_forward) -- then the results of that stream are garbage and the caller must fail.  Off the timed path
+ * (it synchronises the device).  Serves the state buffer of either fused launch. */
 int gbx_dattn_status(const void* state, int32_t* code);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused MLP launch of a decoder block at M == 1 (round 5): residual add of o_proj's fixed-point sums -> post-attention RMSNorm ->
+ * gate_proj | up_proj + SwiGLU -> down_proj, ONE launch (qllama.py:138-140, :115).  XCD g of the chip produces the activations
+ * [g I/8, (g+1) I/8) and consumes exactly that range as down_proj's input columns, so the one exchange inside the launch stays in
+ * that XCD's L2; the eight partial sums per output row meet in acc_out as 2^-32 fixed-point integers.  The NEXT launch forms the
+ * residual stream: gbx_dattn.x_acc / x_out of the next block, or gbx_acc_residual after the last one.
+ * Covered: 2 bits, group 128, bf16, D = 2048 / 4096, I a multiple of 1024 with I / 256 even in [32, 64] (Llama-3-8B: 14336).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct gbx_dmlp {
+  uint32_t struct_size;        /* sizeof(gbx_dmlp) */
+  int32_t act_dtype;           /* GBX_BF16 */
+  const void* x;               /* [D] the stream before o_proj's output is added */
+  const int64_t* x_acc;        /* [D + 1] o_proj sums (gbx_dattn.acc) */
+  void* x_out;                 /* [D] round(x + round(x_acc * 2^-32)), written once: the stream the next launch adds down_proj to */
+  const void* norm_weight;     /* [D] post_attention_layernorm weight */
+  const uint32_t* gate_qweight;/* [I, D / 16] */
+  const uint32_t* up_qweight;  /* [I, D / 16] */
+  const uint32_t* gate_up_sz;  /* gbx_dgemv_pack(gate, up) with rows_per_batch 2 */
+  const uint32_t* down_qweight;/* [D, I / 16] */
+  const uint32_t* down_sz;     /* gbx_dgemv_pack(down) with rows_per_batch 2 */
+  int64_t* acc_out;            /* [D + 1], zero on entry: down_proj sums, 2^-32 fixed point (word D: non-finite marker) */
+  uint64_t* zero_buf;          /* optional: zero_n 8-byte words this launch clears */
+  void* state;                 /* gbx_dattn_state_bytes() bytes of its OWN (not the attention launch's), zero-filled once */
+  void* act_out;               /* optional [I]: the SwiGLU output (tests) */
+  int32_t D, I, zero_n;
+  float norm_eps;
+} gbx_dmlp;
+int gbx_dmlp_plan(int32_t D, int32_t I, int32_t gate_up_bits, int32_t gate_up_group_size, int32_t down_bits, int32_t down_group_size,
+                  int32_t act_dtype);
+int gbx_dmlp_forward(const gbx_dmlp* desc, void* hip_stream);
+/* out[i] <- round(x[i] + round(acc[i] * 2^-32)) for i < D (acc[D] != 0: NaN), then acc and up to three more [D + 1] accumulators
+ * are cleared: the step between the last block's gbx_dmlp_forward and the output head.  bf16. */
+int gbx_acc_residual(const void* x, int64_t* acc, void* out, int32_t D, int64_t* zero0, int64_t* zero1, int64_t* zero2, void* hip_stream);
 
 /* Load-time companion of the loader's scale/zero cast (gbx_lm/utils.py:841-843): out[p][g][i] = scale bits | zero bits << 16
  * (16-bit act-dtype patterns, copied verbatim) for the two rows a GEMV batch streams together:

@@ -207,6 +207,98 @@ def test_gateup_prologue_reads_the_accumulator(bits):
         ops.dgemv(bad, DEV)
 
 
+@pytest.mark.parametrize("seed", [0, 1])
+def test_dmlp_launch_vs_fp64(seed):
+    """gbx_dmlp_forward on Llama-3-8B MLP shapes (2 bits): x' exact; the SwiGLU activations against fp64 on dequantised weights with
+    the reference graph's roundings (tolerance of the matrix-core form, as tests/test_dgemv_gpu.py: 2e-2 of the value + 2e-2 of the
+    RMS); down_proj's fixed-point sums against fp64 on the launch's OWN activations; zero_buf; bit-reproducible."""
+    from gbx_lm_amd import ops
+    model, cfg = _layer("LLAMA3_8B", 2, 2, seed=20 + seed)
+    blk = model.model.layers[0]
+    mlp, nw = blk.mlp, blk.post_attention_layernorm
+    D, I = cfg["hidden_size"], cfg["intermediate_size"]
+    assert ops.dmlp_supported(D, mlp.gate_proj, mlp.up_proj, mlp.down_proj, torch.bfloat16)
+    gen = torch.Generator(device="cpu").manual_seed(100 + seed)
+    x = torch.randn(D, generator=gen).to(torch.bfloat16).to(DEV)
+    o = (torch.randn(D, generator=gen) * 0.3).double()
+    acc_in = torch.zeros(D + 1, dtype=torch.int64, device=DEV)
+    acc_in[:D] = torch.round(o * 2.0 ** 32).to(torch.int64).to(DEV)
+    x_out = torch.zeros(D, dtype=torch.bfloat16, device=DEV)
+    acc_out = torch.zeros(D + 1, dtype=torch.int64, device=DEV)
+    junk = torch.full((D + 1,), 7, dtype=torch.int64, device=DEV)
+    act = torch.zeros(I, dtype=torch.bfloat16, device=DEV)
+    state = ops.dattn_state(DEV)
+    pk_gu, pk_dn = ops.dgemv_pack(mlp.gate_proj, 2, mlp.up_proj), ops.dgemv_pack(mlp.down_proj, 2)
+    d = ops.make_dmlp_desc(x, acc_in, x_out, nw.weight, nw.eps, mlp.gate_proj, mlp.up_proj, mlp.down_proj, pk_gu, pk_dn, acc_out, state,
+                           zero_buf=junk, act_out=act)
+    ops.dmlp(d, DEV)
+    torch.cuda.synchronize()
+    assert ops.dattn_status(state) == 0, "the hand-off timed out"
+    want_x = (x.double() + (acc_in[:D].double() * 2.0 ** -32).to(torch.bfloat16).double()).to(torch.bfloat16)
+    assert torch.equal(x_out, want_x), "x_out is not round(x + round(acc * 2^-32))"
+    assert int(junk.abs().sum().item()) == 0, "zero_buf left words behind"
+    xf = want_x.double()
+    xn = _bf(xf * torch.rsqrt(xf.pow(2).mean() + nw.eps) * nw.weight.double())
+    g, u = _bf(_deq(mlp.gate_proj) @ xn), _bf(_deq(mlp.up_proj) @ xn)
+    want_act = _bf(_bf(g / (1 + torch.exp(-g))) * u)
+    _close(act, want_act, "SwiGLU activations")
+    got = acc_out[:D].double() * 2.0 ** -32
+    want = _deq(mlp.down_proj) @ act.double()
+    _close(got, want, "down_proj sums")
+    assert int(acc_out[D].item()) == 0
+    first = acc_out.clone()
+    acc_out.zero_()
+    ops.dmlp(d, DEV)                                            # a second launch on the same state: next generation, identical bits
+    assert torch.equal(acc_out, first) and ops.dattn_status(state) == 0
+    # the step after the last block: sums -> stream, accumulators cleared
+    out = torch.zeros(D, dtype=torch.bfloat16, device=DEV)
+    z1 = torch.full((D + 1,), 3, dtype=torch.int64, device=DEV)
+    ops.acc_residual(x_out, acc_out, out, zero=[z1])
+    assert torch.equal(out, (x_out.double() + (first[:D].double() * 2.0 ** -32).to(torch.bfloat16).double()).to(torch.bfloat16))
+    assert int(acc_out.abs().sum().item()) == 0 and int(z1.abs().sum().item()) == 0
+
+
+def test_dattn_takes_the_stream_as_vector_plus_sums():
+    """gbx_dattn.x_acc / x_out: the launch on (x, sums) equals the launch on the finished vector, writes it once and clears zero_buf."""
+    from gbx_lm_amd import ops
+    model, cfg = _layer("LLAMA3_8B", 2, 2, seed=31)
+    blk = model.model.layers[0]
+    at = blk.self_attn
+    D, nh, nkv, hd = cfg["hidden_size"], at.n_heads, at.n_kv_heads, at.head_dim
+    cat = _cat_qkv(at)
+    cap, ctx = 256, 33
+    gen = torch.Generator(device="cpu").manual_seed(9)
+    x = torch.randn(D, generator=gen).to(torch.bfloat16).to(DEV)
+    dsum = (torch.randn(D, generator=gen) * 0.5).double()
+    xacc = torch.zeros(D + 1, dtype=torch.int64, device=DEV)
+    xacc[:D] = torch.round(dsum * 2.0 ** 32).to(torch.int64).to(DEV)
+    h = (x.double() + (xacc[:D].double() * 2.0 ** -32).to(torch.bfloat16).double()).to(torch.bfloat16)
+    kc = (torch.randn(1, nkv, cap, hd, generator=gen) * 0.5).to(torch.bfloat16).to(DEV)
+    vc = torch.randn(1, nkv, cap, hd, generator=gen).to(torch.bfloat16).to(DEV)
+    pos = torch.tensor([ctx], dtype=torch.long, device=DEV)
+    pk = ops.dgemv_pack(cat, 2)
+    outs = []
+    for mode in (0, 1):
+        acc = torch.zeros(D + 1, dtype=torch.int64, device=DEV)
+        state = ops.dattn_state(DEV)
+        ao = torch.zeros(nh * hd, dtype=torch.bfloat16, device=DEV)
+        k2, v2 = kc.clone(), vc.clone()
+        xo = torch.zeros(D, dtype=torch.bfloat16, device=DEV)
+        junk = torch.full((D + 1,), 5, dtype=torch.int64, device=DEV)
+        kw = dict(x_acc=xacc, x_out=xo, zero_buf=junk) if mode else {}
+        d = ops.make_dattn_desc(x if mode else h, blk.input_layernorm.weight, blk.input_layernorm.eps, cat, pk, k2, v2, at.rope.inv_freq, pos,
+                                at.o_proj, acc, state, nh, cap, getattr(at.rope, "scale", 1.0), at.scale, at.rope.traditional, attn_out=ao, **kw)
+        ops.dattn(d, DEV)
+        torch.cuda.synchronize()
+        assert ops.dattn_status(state) == 0
+        if mode:
+            assert torch.equal(xo, h), "x_out is not round(x + round(x_acc * 2^-32))"
+            assert int(junk.abs().sum().item()) == 0
+        outs.append((ao, acc, k2, v2))
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a_, b_), "the launch on (x, sums) differs from the launch on the finished vector"
+
+
 def test_dattn_plan_refuses_what_it_does_not_cover():
     from gbx_lm_amd import _lib
     L = _lib.lib()
@@ -218,36 +310,52 @@ def test_dattn_plan_refuses_what_it_does_not_cover():
     assert not ok(4096, 32, 8, 128, 2, 32, 2, 128), "2-bit group 32: two (scale, zero) pairs per lane slot"
 
 
-def _hb(env_extra, layers=3, steps=12):
+def _hb(env_extra, layers=3, steps=12, strategy="S22"):
     code = (
         "import sys, torch; sys.path.insert(0, %r)\n"
         "import bench\n"
         "from gbx_lm_amd import synthetic as S\n"
         "from gbx_lm_amd.decode import FusedDecodeRunner\n"
         "cfg = dict(S.LLAMA3_8B, num_hidden_layers=%d, vocab_size=2048)\n"
-        "model = S.build_model(cfg, S.make_strategy('S22', %d, 128), device='cuda:0', seed=5)\n"
+        "model = S.build_model(cfg, S.make_strategy('%s', %d, 128), device='cuda:0', seed=5)\n"
         "caches = bench.make_caches(model, 1, 256, 'cuda:0')\n"
         "r = FusedDecodeRunner(model, caches, use_graph=True)\n"
         "print('DATTN', sum(d is not None for d in r.da))\n"
+        "print('DMLP', sum(d is not None and len(d) == 2 for d in r.da))\n"
         "for t in range(%d): lg = r.step(torch.tensor([(7 * t + 1) %% 2048], device='cuda:0'))\n"
         "torch.cuda.synchronize()\n"
         "r.dattn_check()\n"
         "print('HB', r.hb.float().cpu().numpy().tobytes().hex())\n"
-        "print('KC', caches[-1].keys[0, :, :%d].float().cpu().numpy().tobytes().hex())\n" % (ROOT, layers, layers, steps, steps))
+        "print('KC', caches[-1].keys[0, :, :%d].float().cpu().numpy().tobytes().hex())\n" % (ROOT, layers, strategy, layers, steps, steps))
     env = dict(os.environ, **env_extra)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    return {l.split()[0]: l.split()[1] for l in out.stdout.splitlines() if l.startswith(("HB", "DATTN", "KC"))}
+    return {l.split()[0]: l.split()[1] for l in out.stdout.splitlines() if l.startswith(("HB", "DATTN", "DMLP", "KC"))}
 
 
 def test_three_launch_block_agrees_with_five_launch_block():
     """Three 8B-shaped layers of mixed widths, 12 teacher-forced steps through the graph-replayed runner: GBX_DATTN=1 (three launches
     per block) against GBX_DATTN=0 (five).  The o_proj sum is formed in a different order (eight fixed-point partials instead of one
     fp32 chain), so agreement is to a few bf16 ulps of the stream, not to the bit."""
-    new, old = _hb({"GBX_DATTN": "1"}), _hb({"GBX_DATTN": "0"})
-    assert int(new["DATTN"]) == 3 and int(old["DATTN"]) == 0
+    new, old = _hb({"GBX_DATTN": "1", "GBX_DMLP": "0"}), _hb({"GBX_DATTN": "0"})
+    assert int(new["DATTN"]) == 3 and int(old["DATTN"]) == 0 and int(new["DMLP"]) == 0
     f = lambda d, k: np.frombuffer(bytes.fromhex(d[k]), dtype=np.float32)
     a, b = f(new, "HB"), f(old, "HB")
     assert np.abs(a - b).max() <= 0.05 * np.abs(b).mean() + 0.05 * np.abs(b).max(), "residual stream after 12 steps"
     ka, kb = f(new, "KC"), f(old, "KC")
     assert np.abs(ka - kb).max() <= 0.05 * np.abs(kb).mean() + 0.05 * np.abs(kb).max(), "last layer's cached keys"
+
+
+def test_two_launch_block_agrees_with_five_launch_block():
+    """Five 8B-shaped layers, all 2 bits (S20) and the S22 mix on eight layers (4-, 3-, 3-bit blocks on three launches between 2-bit
+    blocks on two): the stream passes between blocks as (vector, fixed-point sums), accumulators alternate by parity, the last
+    block's sums are finished by gbx_acc_residual.  Agreement with the five-launch block to a few bf16 ulps of the stream."""
+    f = lambda d, k: np.frombuffer(bytes.fromhex(d[k]), dtype=np.float32)
+    for layers, strat, n_mlp in ((5, "S20", 5), (8, "S22", 3)):
+        new, old = _hb({"GBX_DATTN": "1", "GBX_DMLP": "1"}, layers, 12, strat), _hb({"GBX_DATTN": "0"}, layers, 12, strat)
+        assert int(new["DATTN"]) == layers and int(new["DMLP"]) == n_mlp, (new["DATTN"], new["DMLP"])
+        a, b = f(new, "HB"), f(old, "HB")
+        assert np.isfinite(a).all()
+        assert np.abs(a - b).max() <= 0.06 * np.abs(b).mean() + 0.06 * np.abs(b).max(), f"{strat}: residual stream after 12 steps"
+        ka, kb = f(new, "KC"), f(old, "KC")
+        assert np.abs(ka - kb).max() <= 0.06 * np.abs(kb).mean() + 0.06 * np.abs(kb).max(), f"{strat}: last layer's cached keys"

@@ -59,21 +59,25 @@ def _ref_layer_fp64(model, h, pos, kcache, vcache):
     return _bf(h1 + _bf(deq(mlp.down_proj) @ act))
 
 
-@pytest.mark.parametrize("dattn", [0, 1])
+@pytest.mark.parametrize("dattn", [0, 1, 2])
 @pytest.mark.parametrize("bits", [2, 3, 4])
 def test_one_8b_layer_through_the_fused_runner_vs_fp64(bits, dattn, monkeypatch):
     import bench
     from gbx_lm_amd import ops
     from gbx_lm_amd.decode import FusedDecodeRunner
-    monkeypatch.setenv("GBX_DATTN", str(dattn))               # 1: three launches per block (round 5), 0: five (round 4)
+    monkeypatch.setenv("GBX_DATTN", str(min(dattn, 1)))       # 0: five launches per block (round 4), 1: three, 2: two (2-bit blocks)
+    monkeypatch.setenv("GBX_DMLP", "1" if dattn == 2 else "0")
     model, cfg = _one_layer_model(bits)
     ctx = 9
     caches = bench.make_caches(model, 1, 256, DEV)
     runner = FusedDecodeRunner(model, caches, use_graph=True)
     assert (runner.da[0] is not None) == bool(dattn), "the launch path under test"
-    if dattn:
+    if dattn == 2 and bits == 2:
+        d_a, d_m = runner.da[0]
+        assert d_m.x_acc == d_a.acc and runner.da_post is not None, "attention + MLP as two launches, the sums finished after the last block"
+    elif dattn:
         d_a, d_gu3, d_dn3 = runner.da[0]
-        assert d_gu3.x_acc == d_a.acc and d_dn3.zero_buf == d_a.acc and d_gu3.x_out == d_dn3.residual
+        assert d_gu3.x_acc == d_a.acc and d_gu3.x_out == d_dn3.residual
     # the launches under test are the decode-block GEMV ones (the bench's), all four, with the statistic carried into gate|up
     g_qkv, g_o, g_gu, g_dn = runner.dg[0]
     assert all(g is not None for g in (g_qkv, g_o, g_gu, g_dn)), "the 8B launches must run on gbx_dgemv_forward"
