@@ -95,6 +95,7 @@ def kernel_leg(model, runner=None, reps=20):
     plo = ops.dgemv_plan(o0.output_dims, o0.input_dims, o0.bits, o0.group_size, _l.GBX_DG_RESIDUAL) if use_dg else None
     keep = []
     acc_bytes = 0
+    fused_mlp = False
     pred = "o_proj"
     da = getattr(runner, "da", None)
     if da is not None and all(da[i] is not None for i in idx):
@@ -102,10 +103,19 @@ def kernel_leg(model, runner=None, reps=20):
         o_descs = [da[i][0] for i in idx]
         g_descs = [da[i][1] for i in idx]
         x, x0 = runner.hb, runner.hb.clone()
-        kname = "gbx::" + ops.dgemv_kernel_name(g_descs[0])
         acc_bytes = 8 * g0.input_dims
         pred = "fused attention"
-        launch = lambda d, dv: ops.dattn(d, dv) if isinstance(d, _l.DattnDesc) else ops.dgemv(d, dv)
+        if isinstance(g_descs[0], _l.DmlpDesc):
+            # two-launch block: the dominant launch is the fused MLP launch (gate|up + SwiGLU + down_proj in one kernel)
+            dn = layers[0].mlp.down_proj
+            fused_mlp = True
+            kname = "gbx::dmlp_kernel<2> (FP4 x FP8 matrix cores; gate|up + SwiGLU + XCD-local hand-off + down_proj)"
+            acc_bytes += (dn.output_dims * dn.input_dims * dn.bits // 8 + 2 * dn.output_dims * (dn.input_dims // dn.group_size) * 2
+                          + 8 * dn.output_dims - g0.output_dims * 2)       # + down_proj's matrix, scales / zeros, its fixed-point sums; the activations never leave the chip
+        else:
+            kname = "gbx::" + ops.dgemv_kernel_name(g_descs[0])
+        launch = lambda d, dv: (ops.dattn(d, dv) if isinstance(d, _l.DattnDesc) else
+                                (ops.dmlp(d, dv) if isinstance(d, _l.DmlpDesc) else ops.dgemv(d, dv)))
     elif pl is not None and plo is not None:
         # exactly the launches the decode runner replays: gbx_dgemv_forward, the RMSNorm statistic carried from o_proj to gate|up
         ssq = torch.zeros(_l.GBX_DG_SSQ_SLOTS, dtype=torch.float32, device=dev) if (use_ssq and plo[1] > 0) else None
@@ -162,7 +172,7 @@ def kernel_leg(model, runner=None, reps=20):
     traffic = None            # PMC-derived HBM bytes per launch for this exact kernel/shape, if a profile run recorded it
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            rec = json.load(f).get(f"gateup_b{bits}_N{n}_K{k}_g{grp}")
+            rec = json.load(f).get(f"{'dmlp' if fused_mlp else 'gateup'}_b{bits}_N{n}_K{k}_g{grp}")
             traffic = rec["traffic_bytes_per_launch"] if rec else None
     except (OSError, ValueError, KeyError):
         traffic = None
@@ -171,9 +181,10 @@ def kernel_leg(model, runner=None, reps=20):
     floor = {"pure_stream_us": 5.7, "source": "profiles/r04_stream_floor.txt (29.4 MB of 1 KB rows, 16-wave workgroups, boundary included)"}
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "floor": floor,
-            "kernel": f"{kname} fused RMSNorm+gate_proj+up_proj+SwiGLU, 2 x [N={n}, K={k}] g={grp}",
+            "kernel": (f"{kname} residual+RMSNorm+gate_proj+up_proj+SwiGLU+down_proj, 2 x [N={n}, K={k}] + [N={k}, K={n}] g={grp}" if fused_mlp else
+                       f"{kname} fused RMSNorm+gate_proj+up_proj+SwiGLU, 2 x [N={n}, K={k}] g={grp}"),
             "bytes_per_launch": nbytes, "us_per_launch": us, "us_back_to_back": us_b2b / len(descs),
-            "method": f"HIP events: graph of ({pred}, gate|up) pairs minus the same graph without gate|up, per pair",
+            "method": f"HIP events: graph of ({pred}, {'fused MLP' if fused_mlp else 'gate|up'}) pairs minus the same graph without the second launch, per pair",
             "launches_timed": reps * len(descs),
             "working_set_bytes": nbytes * len(descs)}
 
@@ -461,7 +472,9 @@ def main():
     if hasattr(runner, "dattn_check"):
         runner.dattn_check()            # a fused attention launch whose hand-off timed out voids the run (raises; off the timed path)
     launches = [d is not None for d in getattr(runner, "da", [])]
-    block_note = ("3 launches per block (fused attention launch gbx_dattn_forward, gate|up, down)" if launches and all(launches) else
+    n2 = sum(1 for d in getattr(runner, "da", []) if d is not None and len(d) == 2)
+    block_note = ((f"{n2} blocks on 2 launches (gbx_dattn_forward, gbx_dmlp_forward), {len(launches) - n2} on 3 (gbx_dattn_forward, gate|up, down)"
+                   if n2 else "3 launches per block (fused attention launch gbx_dattn_forward, gate|up, down)") if launches and all(launches) else
                   (f"{sum(launches)} of {len(launches)} blocks on 3 launches, the rest on 5" if any(launches) else "5 launches per block"))
     ms_per_step = ms / args.steps
     tok_s = args.batch * 1e3 / ms_per_step
