@@ -1,7 +1,8 @@
 """A few decoded tokens of 8B S22 through FusedDecodeRunner WITHOUT a graph (eager launches): the workload of the PMC passes
 (rocprofv3 --pmc serialises every dispatch; a replayed graph of 70 launches per token takes minutes there)."""
 import sys, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from gbx_lm_amd import synthetic as S
 from gbx_lm_amd.decode import FusedDecodeRunner
