@@ -320,6 +320,9 @@ def decode_leg(model, cfg, dev, batch, context, steps, warmup, world=1, use_grap
     ms = time_decode(runner, steps, warmup, batch, world, dev) / steps
     if hasattr(runner, "dattn_check"):
         runner.dattn_check()
+    if world > 1:
+        from gbx_lm_amd import tp as _tp
+        _tp.p2p_check()
     ql_b, head_b, kv_b = token_bytes(model, context + warmup + steps // 2)
     nbytes = ql_b + head_b + kv_b * batch
     return {"tok_s": batch * 1e3 / ms, "ms_per_step": ms, "steps": steps, "context": context, "batch": batch,
@@ -466,11 +469,36 @@ def main():
     for t in range(args.context):
         full = runner.step(torch.full((args.batch,), t % vocab, device=dev, dtype=torch.long))
     tok = torch.argmax(full, -1)                                    # step() returns the gathered logits under a sharded head
+    tp_selfcheck = None
+    if world > 1:
+        # N > 1 self-check (so that the first real SCALE line is interpretable): the process group really has N ranks, every rank
+        # starts the greedy chain on the SAME token, and what the 64 all-reduces of a token cost on their own
+        assert dist.get_world_size() == world == args.gpus, (dist.get_world_size(), world, args.gpus)
+        toks = [torch.zeros_like(tok) for _ in range(world)]
+        dist.all_gather(toks, tok)
+        if not all(torch.equal(t, toks[0]) for t in toks):
+            raise RuntimeError(f"rank {rank}: the ranks disagree on the first greedy token: {[int(t.reshape(-1)[0]) for t in toks]}")
+        buf = torch.zeros((cfg["hidden_size"],), dtype=torch.bfloat16, device=dev)
+        for _ in range(8):
+            tp.all_reduce_(buf)
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(64):
+            tp.all_reduce_(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        tp_selfcheck = {"ranks": dist.get_world_size(), "first_token_agrees": True,
+                        "allreduce_us": e0.elapsed_time(e1) * 1e3 / 64, "allreduce_bytes": buf.numel() * 2,
+                        "note": "64 eager all-reduces of one [hidden] bf16 vector, back to back on rank 0's stream (a token has 64)"}
     runner.start_greedy(tok)                                        # greedy chain: argmax + next-token feed stay on the device
 
     ms = time_decode(runner, args.steps, args.warmup, args.batch, world, dev)
     if hasattr(runner, "dattn_check"):
         runner.dattn_check()            # a fused attention launch whose hand-off timed out voids the run (raises; off the timed path)
+    if world > 1:
+        tp_allreduce += "; " + tp.p2p_check()      # a one-shot all-reduce that gave up on a peer voids the run (raises -> non-zero exit)
     launches = [d is not None for d in getattr(runner, "da", [])]
     n2 = sum(1 for d in getattr(runner, "da", []) if d is not None and len(d) == 2)
     block_note = ((f"{n2} blocks on 2 launches (gbx_dattn_forward, gbx_dmlp_forward), {len(launches) - n2} on 3 (gbx_dattn_forward, gate|up, down)"
@@ -529,6 +557,8 @@ def main():
             leg = {"failed": f"{type(e).__name__}: {e}"[:200]}
         if rank == 0:
             extra = {"b32_decode_S22": leg}
+    if rank == 0 and world > 1:
+        extra = dict(extra or {}, tp_selfcheck=tp_selfcheck, allreduce_us=tp_selfcheck["allreduce_us"])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             cpu = cpu_baseline(model, cfg)

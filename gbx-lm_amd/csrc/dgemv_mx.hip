@@ -4,8 +4,11 @@
 // a wave owns whole rows, compact arguments, two-row batches, vector epilogue, carried RMSNorm statistic, weights requested behind
 // the activation image), but the per-weight arithmetic is gemv_mxd.hip's (round 3, experimental library): ONE packed row is the B
 // operand of v_mfma_scale_f32_16x16x128_f8f6f4 -- 16 consecutive 128-value groups as the 16 columns, a 2-bit field masked in place
-// in its nibble is the FP4 (E2M1) number q / 2 -- the activation vector is the A operand as two exact FP8 (E4M3) limbs with one
-// E8M0 exponent per 32 values, and the DIAGONAL of the 16 x 16 result holds the 16 per-group sums of x . q.
+// in its nibble is the FP4 (E2M1) number q / 2 -- the activation vector is the A operand as two FP8 (E4M3) limbs with one E8M0
+// exponent per 32 values (the block maximum is scaled into [128, 256): an element >= 2^-9 of its block's maximum is carried EXACTLY by
+// the two limbs, a smaller one with an absolute error <= 2^-17 of the block maximum -- tests/test_dgemv_gpu.py pins both; a NaN / Inf
+// activation turns its block's sum into NaN, which reaches every row through the zero-point term), and the DIAGONAL of the 16 x 16
+// result holds the 16 per-group sums of x . q.
 // Why now: with the launch overhead cut (dgemv), the widest launch (gate|up: 28 rows per SIMD) is bound by its vector-ALU work --
 // one v_and + one half-rate v_dot2c per pair of weights, ~3.4 k VALU instructions per SIMD = 4-5 us of a 9.1 us launch, the same
 // with the weight stream removed (profiles/r04_chain_floor.txt) -- and 4 MFMAs + ~12 VALU instructions per row replace ~70.
@@ -222,6 +225,7 @@ __global__ __launch_bounds__(NW * 64) void dgemv_mx_kernel(const DgArgs a) {
       sum += dpp_f32<0x4E>(sum); amax = max(amax, dpp_u32<0x4E>(amax));
       sum += dpp_f32<0x141>(sum); amax = max(amax, dpp_u32<0x141>(amax));
       // x' = x * 2^(134 - ea): the block maximum lands in [128, 256) (E4M3 holds up to 448); the instruction multiplies by 2^(scale - 127)
+      if (amax >= 0x7F800000u) sum = __uint_as_float(0x7FC00000u);   // Inf / NaN in the block: NaN through the zero-point term of every row (documented: DESIGN 3.1d)
       int ea = static_cast<int>(amax >> 23);
       ea = min(max(ea, 20), 240);
       const float up = exp2i(134 - ea);

@@ -168,6 +168,7 @@ __global__ __launch_bounds__(DA_NT) void dmlp_kernel(const DmlpArgs a) {
         sum += dpp_f32<0xB1>(sum); amax = max(amax, dpp_u32<0xB1>(amax));
         sum += dpp_f32<0x4E>(sum); amax = max(amax, dpp_u32<0x4E>(amax));
         sum += dpp_f32<0x141>(sum); amax = max(amax, dpp_u32<0x141>(amax));
+        if (amax >= 0x7F800000u) sum = __uint_as_float(0x7FC00000u);   // Inf / NaN in the block: NaN through the zero-point term of every row
         int ea = static_cast<int>(amax >> 23);
         ea = min(max(ea, 20), 240);
         const float up = exp2i(134 - ea);
@@ -320,6 +321,7 @@ __global__ __launch_bounds__(DA_NT) void dmlp_kernel(const DmlpArgs a) {
     sum += dpp_f32<0xB1>(sum); amax = max(amax, dpp_u32<0xB1>(amax));
     sum += dpp_f32<0x4E>(sum); amax = max(amax, dpp_u32<0x4E>(amax));
     sum += dpp_f32<0x141>(sum); amax = max(amax, dpp_u32<0x141>(amax));
+    if (amax >= 0x7F800000u) sum = __uint_as_float(0x7FC00000u);     // Inf / NaN in the block: NaN through the zero-point term of every row
     int ea = static_cast<int>(amax >> 23);
     ea = min(max(ea, 20), 240);
     const float up = exp2i(134 - ea);

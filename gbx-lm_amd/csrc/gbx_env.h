@@ -40,6 +40,7 @@ inline const EnvSwitch* env_table(int* n) {
       {"GBX_NO_BATCH_KERNEL", 0, "1: 2 <= M <= 32 on the split-K dequantising kernel instead of the no-dequant batch GEMM (diagnostic)"},
       {"GBX_PREFILL_TILE", 0, "prefill GEMM: force the tile (11 / 12 / 13) (tuning aid)"},
       {"GBX_DENSE_NO_8PHASE", 0, "1: the register-staged round-1 tile on dequantised weights instead of the 8-phase dense GEMM (A/B)"},
+      {"GBX_P2P_SPIN_LOG2", 26, "one-shot P2P all-reduce: log2 of the polls of one granule before a launch gives up and raises its error word (test hook: a small value makes the time-out path reachable in a test)"},
       {"GBX_P2P_FORCE_COARSE", 0, "test hook: gbx_p2p_inbox_create behaves as if fine-grained memory were unavailable"},
   };
   *n = static_cast<int>(sizeof(t) / sizeof(t[0]));

@@ -12,8 +12,11 @@
 //     e to finish call e), so call e + 1 never overwrites granules of call e - 1 that a peer may still be reading ... of call e - 1
 //     is finished by everyone once anyone has seen all of call e;
 //   * the epoch lives in device memory and is advanced by the launch itself (last workgroup out), so a captured HIP graph replays it.
-// Inboxes are exported / imported with hipIpc*; the spin is bounded (trap), never an endless wait.
+// Inboxes are exported / imported with hipIpc*; the spin is bounded: a launch that gives up raises the device-visible error word
+// (gbx_p2p_status, tp.P2PAllReduce.check -- called at every synchronisation point of bench.py and the tests) and returns; it never
+// traps and never waits endlessly.
 #include "gbx_device.h"
+#include "gbx_env.h"
 #include "kernels.h"
 #include <cstring>
 
@@ -27,6 +30,7 @@ struct P2PArgs {
   unsigned long long* inbox[P2P_MAX_WORLD];   // rank p's inbox as mapped in this process (own included)
   unsigned* state;                         // [0] epoch of the last finished call, [1] workgroups done in this call
   int n, rank, world, cap;                 // cap = granules per (parity, source) slab
+  unsigned spin_limit;                     // polls of one granule before the launch gives up (2^26 with s_sleep 8: tens of seconds)
 };
 
 typedef __attribute__((address_space(1))) unsigned long long p2p_g64;
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(const P2PArgs a) {
           // a peer that never arrived (tens of seconds: rank skew of a graph instantiate or a slow first launch is NOT that):
           // raise the device-visible error word (gbx_p2p_status) and leave with whatever is there -- never hang the queue,
           // never take the whole context down with a trap
-          if (++spins > (1u << 26)) { __hip_atomic_store(a.state + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+          if (++spins > a.spin_limit) { __hip_atomic_store(a.state + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
           __builtin_amdgcn_s_sleep(8);
         }
         w = static_cast<unsigned>(g);
@@ -90,6 +94,8 @@ hipError_t launch_p2p_allreduce(void* x, int n, int rank, int world, void* const
   for (int p = 0; p < world; ++p) a.inbox[p] = static_cast<unsigned long long*>(inbox[p]);
   a.state = static_cast<unsigned*>(state);
   a.n = n; a.rank = rank; a.world = world; a.cap = cap;
+  static const int spin_log2 = env_switch("GBX_P2P_SPIN_LOG2");
+  a.spin_limit = 1u << (spin_log2 < 4 ? 4 : (spin_log2 > 30 ? 30 : spin_log2));
   const int blocks = std::min(P2P_BLOCKS, (n / 2 + 255) / 256);
   if (bf16) hipLaunchKernelGGL((p2p_allreduce_kernel<true>), dim3(blocks), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((p2p_allreduce_kernel<false>), dim3(blocks), dim3(256), 0, s, a);

@@ -210,6 +210,15 @@ def enable_p2p(rank: int, world: int, max_elems: int, device, group=None) -> Opt
     return _p2p
 
 
+def p2p_check() -> str:
+    """Raise if a one-shot P2P all-reduce of this process gave up waiting for a peer (its result, and everything computed from it,
+    is invalid); returns a short status for reports.  Synchronous 4-byte read: call it at synchronisation points, off the timed path."""
+    if _p2p is None:
+        return "p2p off"
+    _p2p.check()
+    return "p2p ok (no time-out)"
+
+
 def all_reduce_(t: torch.Tensor, group=None) -> torch.Tensor:
     """Sum of the per-rank partial outputs of a K-split layer (the path's only exchange step)."""
     if (_p2p is not None and t.is_cuda and t.dtype in (torch.bfloat16, torch.float16) and t.is_contiguous()

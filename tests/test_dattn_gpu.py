@@ -258,6 +258,37 @@ def test_dmlp_launch_vs_fp64(seed):
     assert int(acc_out.abs().sum().item()) == 0 and int(z1.abs().sum().item()) == 0
 
 
+def test_dmlp_zero_and_non_finite_inputs():
+    """All-zero stream -> exact zero sums; a NaN / Inf anywhere in the stream -> the non-finite marker of acc_out is raised and the
+    next consumer (gbx_acc_residual here) produces NaN: the matrix-core form's documented rule for non-finite activations."""
+    from gbx_lm_amd import ops
+    model, cfg = _layer("LLAMA3_8B", 2, 2, seed=41)
+    blk = model.model.layers[0]
+    mlp, nw = blk.mlp, blk.post_attention_layernorm
+    D, I = cfg["hidden_size"], cfg["intermediate_size"]
+    pk_gu, pk_dn = ops.dgemv_pack(mlp.gate_proj, 2, mlp.up_proj), ops.dgemv_pack(mlp.down_proj, 2)
+    state = ops.dattn_state(DEV)
+    for bad in (None, float("nan"), float("inf")):
+        x = torch.zeros(D, dtype=torch.bfloat16, device=DEV)
+        if bad is not None:
+            x = torch.randn(D).to(torch.bfloat16).to(DEV)
+            x[D // 2 + 3] = bad
+        acc_in = torch.zeros(D + 1, dtype=torch.int64, device=DEV)
+        x_out = torch.zeros(D, dtype=torch.bfloat16, device=DEV)
+        acc_out = torch.zeros(D + 1, dtype=torch.int64, device=DEV)
+        d = ops.make_dmlp_desc(x, acc_in, x_out, nw.weight, nw.eps, mlp.gate_proj, mlp.up_proj, mlp.down_proj, pk_gu, pk_dn, acc_out, state)
+        ops.dmlp(d, DEV)
+        torch.cuda.synchronize()
+        assert ops.dattn_status(state) == 0
+        if bad is None:
+            assert int(acc_out.abs().sum().item()) == 0, "zero activations must give exactly zero sums"
+        else:
+            assert int(acc_out[D].item()) > 0, "non-finite marker not raised"
+            out = torch.zeros(D, dtype=torch.bfloat16, device=DEV)
+            ops.acc_residual(x_out, acc_out, out)
+            assert torch.isnan(out.float()).all()
+
+
 def test_dattn_takes_the_stream_as_vector_plus_sums():
     """gbx_dattn.x_acc / x_out: the launch on (x, sums) equals the launch on the finished vector, writes it once and clears zero_buf."""
     from gbx_lm_amd import ops

@@ -305,3 +305,94 @@ def test_dgemv_matrix_core_form_vs_oracle():
     env = dict(os.environ, GBX_DG_MX="2")
     out = subprocess.run([sys.executable, "-c", _MX_CHILD % root], env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0 and "MX_OK" in out.stdout, out.stderr[-3000:] + out.stdout[-500:]
+
+
+# ---- edge cases of the matrix-core form (review of round 4: it is the dominant kernel of the token): index map, non-finite inputs,
+#      the bound of the two-limb activation split, agreement with the vector form ----
+_MX_EDGE_CHILD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from gbx_lm_amd import ops, _lib
+from gbx_lm_amd.models.quantized_linear_gba import QuantizedLinear
+DEV = "cuda:0"
+def unit(n, k, seed):
+    g = torch.Generator().manual_seed(seed)
+    m = QuantizedLinear(k, n, False, 128, 2)
+    m._buffers["qweight"] = torch.randint(0, 2**32, (n, k // 16), dtype=torch.int64, generator=g).to(torch.int32).view(torch.uint32).to(DEV)
+    m._buffers["scales"] = torch.ones((n, k // 128), dtype=torch.bfloat16, device=DEV)
+    m._buffers["zeros"] = torch.zeros((n, k // 128), dtype=torch.bfloat16, device=DEV)
+    return m
+def run(m, x):
+    y = torch.zeros(m.output_dims, dtype=torch.bfloat16, device=DEV)
+    d = ops.make_dgemv_desc(x, m, y, ops.dgemv_pack(m, 2), 2)
+    assert ops.dgemv_kernel_name(d).startswith("dgemv_mx_kernel"), ops.dgemv_kernel_name(d)
+    ops.dgemv(d, x.device)
+    return y
+for k in (2048, 4096):                          # SP = 1, 2 spans: the shapes gbx_dgemv_forward puts on the matrix cores with the default
+    n = 64                                      # switches (K = 8192 rows are two lane passes long and run in 8-wave workgroups, vector form)
+    m = unit(n, k, k)
+    q = ops.unpack(m.qweight, 2).to(torch.float32)             # [n, k] integer fields (bit-exact unpack, tested elsewhere)
+    # (i) one-hot activations, unit scales: y[n] == q[n, k0] EXACTLY -- every position of the first span's first and last group,
+    #     of the last span's last group, and a stride through the rest: pins the operand slot map of dgemv_mx.hip:12-13
+    ks = list(range(0, 128)) + list(range(2048 - 128, 2048)) + list(range(k - 128, k)) + list(range(5, k, 97))
+    for k0 in ks:
+        for val in (1.0, -2.0, 0.00390625):
+            x = torch.zeros(k, dtype=torch.bfloat16, device=DEV); x[k0] = val
+            y = run(m, x)
+            assert torch.equal(y.float(), (q[:, k0] * val).to(torch.bfloat16).float()), (k, k0, val)
+    # (ii) all-zero x -> exact zeros; NaN / +-Inf anywhere -> every output non-finite (NaN: documented rule of the matrix-core form)
+    assert int(run(m, torch.zeros(k, dtype=torch.bfloat16, device=DEV)).abs().sum()) == 0
+    for bad in (float("nan"), float("inf"), float("-inf")):
+        x = torch.randn(k).to(torch.bfloat16).to(DEV); x[k // 3] = bad
+        assert not torch.isfinite(run(m, x).float()).any(), (k, bad)
+    # (iii) the two-limb split: an element >= 2^-9 of its 32-value block's maximum is carried exactly, a smaller one with an absolute
+    #       error <= 2^-17 of the block maximum (E4M3 limbs: 4 + 4 significant bits below a maximum scaled into [128, 256))
+    for j in range(0, 21):
+        x = torch.zeros(k, dtype=torch.bfloat16, device=DEV)
+        x[64] = 1.0                                             # block maximum
+        x[70] = 2.0 ** -j                                       # same block
+        y = run(m, x).double()
+        want = (q[:, 64] + q[:, 70] * 2.0 ** -j).double()
+        err = (y - want.to(torch.bfloat16).double()).abs().max().item()
+        lim = 0.0 if j <= 9 else 3 * 2.0 ** -17
+        ulp = 2.0 ** -7 * max(1.0, want.abs().max().item())     # one bf16 rounding of the output
+        assert err <= lim + ulp * (j > 9), (k, j, err)
+        if j <= 9:
+            assert torch.equal(y.float(), want.to(torch.bfloat16).float()), (k, j)
+    # wide in-block dynamic range, random signs: against fp64 with the bound 3 * 32 * 2^-17 * bmax per block + output rounding
+    g = torch.Generator().manual_seed(k + 1)
+    x = (torch.randn(k, generator=g) * torch.exp2(-torch.randint(0, 21, (k,), generator=g).float())).to(torch.bfloat16)
+    bmax = x.float().abs().view(-1, 32).max(1).values
+    y = run(m, x.to(DEV)).double().cpu()
+    want = q.double().cpu() @ x.double()
+    bound = 3 * 32 * 2.0 ** -17 * bmax.double().sum().item()
+    assert ((y - want).abs() <= bound + 2.0 ** -7 * want.abs() + 1e-6).all(), (k, (y - want).abs().max().item(), bound)
+# (iv) agreement with the vector form on ordinary inputs (random scales / zeros): <= 1 bf16 ulp of the larger of the two everywhere
+from oracle import gba_oracle as O
+for (n, k) in ((256, 4096), (128, 2048)):
+    d = O.synth_layer(n, k, 2, 128, seed=3)
+    m = QuantizedLinear(k, n, False, 128, 2)
+    m._buffers["qweight"] = torch.from_numpy(d["qweight"].view(np.int32)).view(torch.uint32).to(DEV)
+    m._buffers["scales"], m._buffers["zeros"] = d["scales"].to(DEV), d["zeros"].to(DEV)
+    x = torch.randn(k).to(torch.bfloat16).to(DEV)
+    y_mx = run(m, x).float()
+    y_v = ops.quantized_matmul(x[None], m.qweight, m.scales, m.zeros, True, 128, 2)[0].float()      # gemv_kernel (vector dot)
+    ulp = torch.maximum(y_mx.abs(), y_v.abs()) * 2.0 ** -7
+    rms = y_v.pow(2).mean().sqrt().item()
+    # both round an fp32-accurate sum: one rounding step apart where the sum sits at a rounding boundary, plus -- on sums that cancel to
+    # near zero -- the two forms' own accumulation error (2^-10 of the vector's RMS covers it; the oracle tolerance is 2e-2 of the RMS)
+    assert ((y_mx - y_v).abs() <= ulp + 2.0 ** -10 * rms).all(), (n, k, (y_mx - y_v).abs().max().item(), rms)
+    assert (y_mx == y_v).float().mean().item() > 0.8, (n, k, (y_mx == y_v).float().mean().item())
+    want = O.qlinear_ref(x.cpu()[None], d["qweight"], d["scales"], d["zeros"], 2, 128, acc=np.float64)[0]
+    tight = np.abs(y_mx.cpu().double().numpy() - want) <= 2.0 ** -7 * np.abs(want) + 2.0 ** -7 * np.sqrt((want ** 2).mean()) * 0.05
+    assert tight.mean() > 0.99, (n, k, tight.mean())
+print("MX_EDGE_OK")
+"""
+
+
+def test_dgemv_matrix_core_form_edge_cases():
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GBX_DG_MX="2")
+    out = subprocess.run([sys.executable, "-c", _MX_EDGE_CHILD % root], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0 and "MX_EDGE_OK" in out.stdout, out.stderr[-3000:] + out.stdout[-500:]

@@ -62,6 +62,7 @@ def _worker(rank, world, port, out):
             torch.cuda.synchronize()
             assert torch.equal(buf.float().cpu(), exp.to(torch.bfloat16).float())
             dist.barrier()
+        ar.check()                                             # no launch of this run gave up on a peer
         ar.close()
         out[rank] = worst_gloo
     finally:
@@ -125,3 +126,43 @@ def test_p2p_inbox_create_refuses_coarse_memory(monkeypatch):
     own, handle = ctypes.c_void_p(), ctypes.create_string_buffer(64)
     rc = _lib.lib().gbx_p2p_inbox_create(2, 4096, ctypes.byref(own), handle)
     assert rc == _lib.GBX_ERR_UNSUPPORTED and b"fine-grained" in _lib.lib().gbx_last_error()
+
+
+def _worker_timeout(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    os.environ["GBX_P2P_SPIN_LOG2"] = "10"               # give up after ~1000 polls instead of 2^26
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gbx_lm_amd import tp
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        ar = tp.enable_p2p(rank, world, 4096, dev)
+        assert ar is not None and tp.p2p_check() == "p2p ok (no time-out)"
+        x = torch.ones(4096, dtype=torch.bfloat16, device=dev)
+        raised = False
+        if rank == 0:                                        # the peer never pushes: rank 0's launch must give up and SAY so
+            tp.all_reduce_(x)
+            torch.cuda.synchronize()
+            try:
+                tp.p2p_check()
+            except RuntimeError as e:
+                raised = "timed out" in str(e)
+        dist.barrier()
+        out[rank] = raised
+        ar.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_p2p_timeout_is_raised_at_the_next_check():
+    """A peer that never arrives: the launch leaves with its error word set (no trap, no hang) and tp.p2p_check() -- which bench.py
+    and the TP tests call at every synchronisation point -- raises."""
+    world = 2
+    port = 28900 + (os.getpid() % 1000)
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_timeout, args=(world, port, out), nprocs=world, join=True)
+    assert out[0] is True and out[1] is False

@@ -12,16 +12,21 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, out, batch=1):
+def _worker(rank, world, port, out, batch=1, backend="gloo", graph=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    if backend == "nccl":                                       # one GPU per rank, RCCL over xGMI (needs >= 2 GPUs)
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{rank}"))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from gbx_lm_amd import synthetic as S, tp
         from gbx_lm_amd.decode import DecodeRunner, FusedDecodeRunner, fused_eligible
         from gbx_lm_amd.models.cache import KVCache
-        dev = "cuda:0"
+        dev = f"cuda:{rank}" if backend == "nccl" else "cuda:0"
         cfg = dict(S.TINY, num_hidden_layers=3, hidden_size=512, intermediate_size=1024, num_attention_heads=4,
                    num_key_value_heads=2)                      # head_dim 128; per-rank K: o_proj 256, down_proj 512
         strat = S.make_strategy("S22", 3, 64)
@@ -37,9 +42,9 @@ def _worker(rank, world, port, out, batch=1):
                 c.reserve(1, like, like)
                 caches.append(c)
             if batch > 1:                # the B > 1 runner: batch GEMMs, batched attention, all-reduce after o_proj / the MLP
-                r = DecodeRunner(model, caches, use_graph=False)
+                r = DecodeRunner(model, caches, use_graph=graph and getattr(model, "tp_world", 1) > 1)
                 return [r.step(torch.tensor([(t + 37 * b) % 512 for b in range(batch)], device=dev)).float().cpu().clone() for t in toks]
-            r = FusedDecodeRunner(model, caches, use_graph=False)
+            r = FusedDecodeRunner(model, caches, use_graph=graph and getattr(model, "tp_world", 1) > 1)   # graph: the collectives are captured
             lg = [r.step(torch.tensor([t], device=dev)).float().cpu().clone() for t in toks]
             # on-device greedy chain (vocabulary-sharded head: 64 argmax keys per rank are exchanged, never the logits)
             r.start_greedy(torch.argmax(lg[-1], -1))
@@ -61,6 +66,8 @@ def _worker(rank, world, port, out, batch=1):
         assert fused_eligible(shard)
         assert getattr(shard, "tp_vocab", None) is not None and shard.head_weight().shape[0] * world == full.head_weight().shape[0]
         got = run(shard)
+        torch.cuda.synchronize()
+        tp.p2p_check()                                          # (raises if a one-shot all-reduce gave up on a peer; "p2p off" here)
         out[rank] = max((g - w).abs().max().item() / (w.abs().max().item() + 1e-6) for g, w in zip(got, want))
         noise = 2.0 * max((g - w).abs().max().item() for g, w in zip(got, want))      # what sharding does to a logit, with margin
         # wherever the unsharded top-2 margin exceeds that noise the sharded run must pick the same token (every sequence, every step)
@@ -107,6 +114,22 @@ def test_tp2_batched_decode_runner_matches_unsharded():
     mgr = mp.get_context("spawn").Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out, 4), nprocs=world, join=True)
+    assert len(out) == world
+    for k, v in out.items():
+        assert v < 0.05, f"rank {k}: relative max |dlogit| = {v}"
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL with N > 1 needs two GPUs (the gpurun pool has one; the driver's 8-GPU node runs this)")
+@pytest.mark.parametrize("batch", [1, 4])
+def test_tp2_over_rccl_with_the_collectives_inside_the_graph(batch):
+    """The same comparison with one GPU per rank and torch.distributed's "nccl" backend (= RCCL over xGMI): the all-reduces after
+    o_proj / down_proj and the 512-byte argmax exchange of the vocabulary-sharded head are CAPTURED in the runner's HIP graph and
+    replayed -- the path bench.py --gpus N times.  Skips on single-GPU boxes."""
+    world = 2
+    port = 30100 + batch * 7 + (os.getpid() % 1000)
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out, batch, "nccl", True), nprocs=world, join=True)
     assert len(out) == world
     for k, v in out.items():
         assert v < 0.05, f"rank {k}: relative max |dlogit| = {v}"
