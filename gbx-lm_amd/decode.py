@@ -44,6 +44,7 @@ class DecodeRunner:
         # every workgroup then stages a quarter of the activations, the term that bounds it -- and leave fp32 slices that the
         # attention launch sums (gbx_attn_decode_slices); 11.5 -> 9.4 us per layer at B = 32
         self.qkv_cat = {}
+        self._qkv_probe = {}
         if self.batch > 1 and self.tp_world == 1 and env.flag("GBX_QKV_SLICES"):
             from .models.quantized_linear_gba import QuantizedLinear
             for li, layer in enumerate(model.model.layers):
@@ -56,6 +57,15 @@ class DecodeRunner:
                     cat = QuantizedLinear(at.q_proj.input_dims, sum(m.output_dims for m in mods), False, at.q_proj.group_size, at.q_proj.bits)
                     for nm in ("qweight", "scales", "zeros"):
                         cat._buffers[nm] = torch.cat([getattr(m, nm) for m in mods]).contiguous()
+                    # probe once per (bits, group, K, N) whether the k-split partials GEMM takes this batch and leaves few enough
+                    # slices for the attention launch to sum (<= 8): otherwise the concatenated copy would be dead memory and -- with
+                    # more slices -- the projection would run twice per step
+                    key = (cat.bits, cat.group_size, cat.input_dims, cat.output_dims)
+                    if key not in self._qkv_probe:
+                        parts = ops.quantized_matmul_partials(torch.zeros((self.batch, cat.input_dims), dtype=self.dtype, device=self.dev), cat)
+                        self._qkv_probe[key] = parts is not None and parts[1] <= 8
+                    if not self._qkv_probe[key]:
+                        continue
                     self.qkv_cat[li] = cat
         self.use_graph = use_graph
         if use_graph:
