@@ -36,6 +36,13 @@ bool dattn_plan(int D, int n_heads, int n_kv, int head_dim, int qkv_bits, int qk
   return true;
 }
 
+// the matrix-core form of the q|k|v rows and the o_proj slice (dattn_kernel<2, 1, true, 2>): bf16, D = 4096 (two spans), group 128 for
+// both matrices, 2-bit o_proj, four query heads per kv head
+bool dattn_mx_wanted(const DattnArgs& a, bool bf16) {
+  static const int on = env_switch("GBX_DATTN_MX");
+  return on && bf16 && a.D == 4096 && a.rep == 4 && a.qkv_log2g == 7 && a.o_bits == 2 && a.o_log2g == 7;
+}
+
 hipError_t launch_dattn(const DattnArgs& a, const DattnPlan& pl, int qkv_bits, bool bf16, hipStream_t stream) {
   switch (qkv_bits) {
     case 2: return launch_dattn_bits<2>(a, pl, bf16, stream);

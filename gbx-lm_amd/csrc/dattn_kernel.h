@@ -131,8 +131,16 @@ __device__ __forceinline__ float da_o_slot(const u32x4& w, unsigned sc_bits, uns
   }
 }
 
-template <int BQ, int P, bool BF16>
+typedef int da_v8i __attribute__((ext_vector_type(8)));
+typedef float da_v4f __attribute__((ext_vector_type(4)));
+
+// MX = 0: vector-ALU dots (any width).  MX = 2: the q|k|v rows (2 bits, group 128, K = 4096: two 2048-value spans) and the o_proj slice
+// (2 bits, group 128, rep = 4: four rows x four groups per operand) on the FP4 x FP8 matrix cores -- dgemv_mx.hip's arithmetic: the
+// producers' consume is vector-ALU bound (14 two-row batches per CU: the four wave groups of a SIMD publish 0.33 us apart) and so is
+// the o_proj slice (128 rows x 512 columns per CU: 0.64 us of v_and + v_dot2c).
+template <int BQ, int P, bool BF16, int MX = 0>
 __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
+  static_assert(MX == 0 || (MX == 2 && BQ == 2 && P == 1 && BF16), "matrix-core form: 2-bit rows of 4096 values, bf16");
   using F = Fmt<BQ>;
   using L = Lds<BQ>;
   using WT = typename SlotWords<BQ>::type;
@@ -196,7 +204,23 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
   const int oslot = lane & ((1 << lpr_l2) - 1);
   u32x4 ow[DA_OP];
   unsigned osc[DA_OP], oze[DA_OP];
+  // matrix-core form: operand lane (nn, kg) holds 8 bytes of (row nn / 4 of the operand's four, group nn % 4): two operands = 8 rows per wave
+  const int mnn = lane & 15, mkg = lane >> 4;
+  u32x2 owm[2];
   auto issue_o = [&]() {
+    if constexpr (MX != 0) {
+      const __amdgpu_buffer_rsrc_t od = rsrc(a.o_qw, D * W4o);
+      const __amdgpu_buffer_rsrc_t sd = rsrc(a.o_s, RS_ALL), zd = rsrc(a.o_z, RS_ALL);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = r * RPW + wave * 8 + 4 * j + (mnn >> 2);
+        owm[j] = __builtin_amdgcn_raw_buffer_load_b64(od, static_cast<unsigned>(row * W4o + (g * 4 + (mnn & 3)) * 32 + mkg * 8), 0, 0);
+        const unsigned so = static_cast<unsigned>((row * Go + g * 4 + (mnn & 3)) * 2);
+        osc[j] = __builtin_amdgcn_raw_buffer_load_b16(sd, so, 0, 0);
+        oze[j] = __builtin_amdgcn_raw_buffer_load_b16(zd, so, 0, 0);
+      }
+      return;
+    }
     const __amdgpu_buffer_rsrc_t od = rsrc(a.o_qw, D * W4o);
     const __amdgpu_buffer_rsrc_t sd = rsrc(a.o_s, RS_ALL), zd = rsrc(a.o_z, RS_ALL);
 #pragma unroll
@@ -214,6 +238,207 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
 
   unsigned tag;
   if (r >= rep) {
+    if constexpr (MX != 0) {
+    // ================= phase 1 on the matrix cores (dgemv_mx.hip's arithmetic; 2 bits, group 128, K = 4096 = two spans) =================
+    constexpr int SP = 2, NBLK = SP * 64;
+    unsigned char* img = smem + DA_LDS_IMG1;                       // [span][limb][piece][64 lanes][16 B]
+    float* bsum = reinterpret_cast<float*>(smem + DA_LDS_IMG1 + SP * 4096);
+    unsigned char* scl = reinterpret_cast<unsigned char*>(bsum + NBLK);
+    float* red_lds = reinterpret_cast<float*>(smem + DA_LDS_RED);
+    const int K = D, W4 = K / 4, G = K >> 7;
+    const int nb = (rep + 2) * (HD / 2);
+    const int lb = (r - rep) * a.bpw + wave;
+    const bool has = wave < a.bpw && lb < nb;
+    const int qrows = rep * HD;
+    const int lr = 2 * (has ? lb : 0);
+    const int grow = lr < qrows ? g * qrows + lr
+                                : (lr < qrows + HD ? DA_GROUPS * qrows + g * HD + (lr - qrows)
+                                                   : DA_GROUPS * qrows + DA_GROUPS * HD + g * HD + (lr - qrows - HD));
+    const int gb = grow >> 1;
+    const __amdgpu_buffer_rsrc_t qd = rsrc(a.qkv_qw, RS_ALL), szd = rsrc(a.qkv_sz, RS_ALL);
+    const unsigned killw = has ? 0u : KILL;
+    const unsigned voff_w = mnn * 32 + mkg * 8, voff_s = mnn * 8;
+    constexpr int NIT = SP * 512, PW = 8, PT = PW * 64, IPT = NIT / PT;
+    const bool pro = wave < PW;
+    const bool carried = a.ssq_in != nullptr;
+    u32x2 xr[IPT], wr[IPT];
+    u32x4 pq[4] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
+    if (pro) {
+      u32x4 acv[IPT][2];
+      const __amdgpu_buffer_rsrc_t ad = rsrc(a.x_acc ? static_cast<const void*>(a.x_acc) : static_cast<const void*>(a.x), RS_ALL);
+      const unsigned ak = a.x_acc ? 0u : KILL;
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) {
+        const int it = tid + PT * j;
+        acv[j][0] = __builtin_amdgcn_raw_buffer_load_b128(ad, static_cast<unsigned>(it * 32) | ak, 0, 0);
+        acv[j][1] = __builtin_amdgcn_raw_buffer_load_b128(ad, static_cast<unsigned>(it * 32 + 16) | ak, 0, 0);
+      }
+      const unsigned apoison = __builtin_amdgcn_raw_buffer_load_b32(ad, static_cast<unsigned>(K * 8) | ak, 0, 0);
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) {
+        const int it = tid + PT * j;
+        xr[j] = *reinterpret_cast<const u32x2*>(a.x + 4 * it);
+        wr[j] = *reinterpret_cast<const u32x2*>(a.norm_w + 4 * it);
+      }
+      {
+        const __amdgpu_buffer_rsrc_t pd = rsrc(carried ? static_cast<const void*>(a.ssq_in) : static_cast<const void*>(a.x), RS_ALL);
+        const unsigned pk = carried ? 0u : KILL;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pq[i] = __builtin_amdgcn_raw_buffer_load_b128(pd, static_cast<unsigned>(lane * 16 + 1024 * i) | pk, 0, 0);
+      }
+      DA_STAMP(1);
+      if (a.x_acc) {
+        const bool poison = apoison != 0u;
+        const bool writer = blockIdx.x == static_cast<unsigned>(rep * DA_GROUPS) && a.x_out != nullptr;
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+          unsigned wv[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const u32x4 av = acv[j][q];
+            const float o0 = round_bf16_or_f16(fx32_to_f32(av.x, av.y), BF16);
+            const float o1 = round_bf16_or_f16(fx32_to_f32(av.z, av.w), BF16);
+            const unsigned xw = q == 0 ? xr[j].x : xr[j].y;
+            float x0 = act_lo<BF16>(xw) + o0, x1 = act_hi<BF16>(xw) + o1;
+            if (poison) { x0 = __uint_as_float(0x7FC00000u); x1 = x0; }
+            wv[q] = static_cast<unsigned>(f32_to_act<BF16>(x0)) | (static_cast<unsigned>(f32_to_act<BF16>(x1)) << 16);
+          }
+          xr[j] = u32x2{wv[0], wv[1]};
+          if (writer) *reinterpret_cast<u32x2*>(a.x_out + 4 * (tid + PT * j)) = xr[j];
+        }
+      }
+      if (!carried) {
+        float ssq = 0.f;
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+          const unsigned w2[2] = {xr[j].x, xr[j].y};
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const float lo = act_lo<BF16>(w2[q]), hi = act_hi<BF16>(w2[q]);
+            ssq = fmaf(hi, hi, fmaf(lo, lo, ssq));
+          }
+        }
+        ssq = wave_sum(ssq);
+        if (lane == 0) red_lds[wave] = ssq;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();                                           // barrier A: x, the norm weight and the statistic's partials have landed
+    const unsigned gen = __hip_atomic_load(gen_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    DA_STAMP(2);
+    if (pro) {
+      float tot;
+      if (carried) {
+        float sp = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          sp += (__uint_as_float(pq[i].x) + __uint_as_float(pq[i].y)) + (__uint_as_float(pq[i].z) + __uint_as_float(pq[i].w));
+        tot = wave_sum(sp);
+      } else {
+        tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) tot += red_lds[i];
+      }
+      const float rstd = rsqrtf(tot / static_cast<float>(K) + a.eps);
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) {
+        const int it = tid + PT * j;
+        float v[4] = {act_lo<BF16>(xr[j].x), act_hi<BF16>(xr[j].x), act_lo<BF16>(xr[j].y), act_hi<BF16>(xr[j].y)};
+        v[0] = round_bf16_or_f16(v[0] * rstd * act_lo<BF16>(wr[j].x), BF16);
+        v[1] = round_bf16_or_f16(v[1] * rstd * act_hi<BF16>(wr[j].x), BF16);
+        v[2] = round_bf16_or_f16(v[2] * rstd * act_lo<BF16>(wr[j].y), BF16);
+        v[3] = round_bf16_or_f16(v[3] * rstd * act_hi<BF16>(wr[j].y), BF16);
+        float sum = (v[0] + v[1]) + (v[2] + v[3]);
+        unsigned amax = max(max(__float_as_uint(v[0]) & 0x7FFFFFFFu, __float_as_uint(v[1]) & 0x7FFFFFFFu),
+                            max(__float_as_uint(v[2]) & 0x7FFFFFFFu, __float_as_uint(v[3]) & 0x7FFFFFFFu));
+        sum += dpp_f32<0xB1>(sum); amax = max(amax, dpp_u32<0xB1>(amax));
+        sum += dpp_f32<0x4E>(sum); amax = max(amax, dpp_u32<0x4E>(amax));
+        sum += dpp_f32<0x141>(sum); amax = max(amax, dpp_u32<0x141>(amax));
+        if (amax >= 0x7F800000u) sum = __uint_as_float(0x7FC00000u);     // Inf / NaN in the block: NaN through the zero-point term of every row
+        int ea = static_cast<int>(amax >> 23);
+        ea = min(max(ea, 20), 240);
+        const float up = exp2i(134 - ea);
+        const int b = it >> 3, u = it & 7;
+        const int h = b >> 6, m = (b & 63) >> 2, kb = b & 3;
+        const int ga = 2 * (kb & 1) + (u >> 2);
+        unsigned char* dst = img + (h * 4 + (kb >> 1)) * 1024 + (m + 16 * ga) * 16 + 2 * (u & 3);
+        const float r0 = v[0] * up, r1 = v[1] * up, r2 = v[2] * up, r3 = v[3] * up;
+        const int pe = __builtin_amdgcn_cvt_pk_fp8_f32(r0, r2, 0, false);
+        const int po = __builtin_amdgcn_cvt_pk_fp8_f32(r1, r3, 0, false);
+        *reinterpret_cast<unsigned short*>(dst) = static_cast<unsigned short>(pe);
+        *reinterpret_cast<unsigned short*>(dst + 8) = static_cast<unsigned short>(po);
+        const int le = __builtin_amdgcn_cvt_pk_fp8_f32(r0 - __builtin_amdgcn_cvt_f32_fp8(pe, 0), r2 - __builtin_amdgcn_cvt_f32_fp8(pe, 1), 0, false);
+        const int lo = __builtin_amdgcn_cvt_pk_fp8_f32(r1 - __builtin_amdgcn_cvt_f32_fp8(po, 0), r3 - __builtin_amdgcn_cvt_f32_fp8(po, 1), 0, false);
+        *reinterpret_cast<unsigned short*>(dst + 2048) = static_cast<unsigned short>(le);
+        *reinterpret_cast<unsigned short*>(dst + 2048 + 8) = static_cast<unsigned short>(lo);
+        if (u == 0) { bsum[h * 64 + m + 16 * kb] = sum; scl[h * 64 + m + 16 * kb] = static_cast<unsigned char>(ea - 7); }
+      }
+    }
+    // this wave's two rows (one packed row per operand: 16 groups of 128 values per span)
+    u32x2 w[2][SP], sz[SP];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int h = 0; h < SP; ++h) w[i][h] = __builtin_amdgcn_raw_buffer_load_b64(qd, (voff_w + h * 512) | killw, (grow + i) * W4, 2);
+    }
+#pragma unroll
+    for (int h = 0; h < SP; ++h) sz[h] = __builtin_amdgcn_raw_buffer_load_b64(szd, (voff_s + h * 128) | killw, gb * (G * 8), 0);
+    __syncthreads();                                           // barrier B: image written
+    DA_STAMP(3);
+    tag = gen + 1u;
+    if (tag == 0u) tag = 1u;
+    if (has) {
+      da_v8i areg[SP][2];
+      int sa = 0;
+      float xsg[SP];
+      const bool diag = mkg == (mnn >> 2);
+#pragma unroll
+      for (int h = 0; h < SP; ++h) {
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+          const u32x4 p0 = *reinterpret_cast<const u32x4*>(img + (h * 4 + 0) * 1024 + l * 2048 + lane * 16);
+          const u32x4 p1 = *reinterpret_cast<const u32x4*>(img + (h * 4 + 1) * 1024 + l * 2048 + lane * 16);
+          areg[h][l][0] = p0.x; areg[h][l][1] = p0.y; areg[h][l][2] = p0.z; areg[h][l][3] = p0.w;
+          areg[h][l][4] = p1.x; areg[h][l][5] = p1.y; areg[h][l][6] = p1.z; areg[h][l][7] = p1.w;
+        }
+        sa |= static_cast<int>(scl[h * 64 + lane]) << (8 * h);
+        const float gs = (bsum[h * 64 + mnn] + bsum[h * 64 + mnn + 16]) + (bsum[h * 64 + mnn + 32] + bsum[h * 64 + mnn + 48]);
+        xsg[h] = diag ? gs : 0.f;
+      }
+      float dm[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dm[q] = (diag && (lane & 3) == q) ? 1.f : 0.f;
+      float acc[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float yv = 0.f;
+        auto span = [&](auto H) {
+          constexpr int h = decltype(H)::value;
+          da_v8i bv;
+          const unsigned w0 = w[i][h].x, w1 = w[i][h].y;
+          bv[0] = w0 & 0x33333333u; bv[1] = (w0 >> 2) & 0x33333333u; bv[2] = w1 & 0x33333333u; bv[3] = (w1 >> 2) & 0x33333333u;
+          bv[4] = 0; bv[5] = 0; bv[6] = 0; bv[7] = 0;
+          da_v4f z = {0.f, 0.f, 0.f, 0.f};
+          z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(areg[h][0], bv, z, 0, 4, h, sa, 0, 127);
+          z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(areg[h][1], bv, z, 0, 4, h, sa, 0, 127);
+          const float dsel = fmaf(z[0], dm[0], fmaf(z[1], dm[1], fmaf(z[2], dm[2], z[3] * dm[3])));
+          const unsigned szw = i == 0 ? sz[h].x : sz[h].y;
+          const float sc = sz_scale<BF16>(szw), ze = sz_zero<BF16>(szw);
+          yv += fmaf(ze, xsg[h], (sc + sc) * dsel);
+        };
+        span(std::integral_constant<int, 0>{});
+        span(std::integral_constant<int, 1>{});
+        acc[i] = yv;
+      }
+      const float v0 = wave_sum2(acc[0], acc[1]);
+      const float t0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v0), 31));
+      const float t1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v0), 63));
+      const unsigned val = static_cast<unsigned>(f32_to_act<BF16>(t0)) | (static_cast<unsigned>(f32_to_act<BF16>(t1)) << 16);
+      if (lane == 0) __hip_atomic_store(hand1 + lb, (static_cast<unsigned long long>(tag) << 32) | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    DA_STAMP(4);
+    issue_o();
+    } else {
     // =========================================== phase 1: the group's q | k | v rows ===========================================
     h2* xp_lds = reinterpret_cast<h2*>(smem + DA_LDS_IMG1);
     const int K = D;
@@ -426,6 +651,7 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
     }
     DA_STAMP(4);
     issue_o();                                                 // o_proj words: needed ~4 us from here, requested off the critical path
+    }
   } else {
     // =========================================== phase 2: attention of head g * rep + r ===========================================
     unsigned* raw32 = reinterpret_cast<unsigned*>(smem + DA_LDS_ATT);                    // q | k | v as they arrive: 3 x 64 words
@@ -466,6 +692,10 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
     issue_o();
     const unsigned gen = __hip_atomic_load(gen_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const float inv_f = a.inv_freq[lane];                      // RoPE frequency of this lane's pair (waves 0 and 1 rotate q and k)
+    // the rotation depends on the position only: ready before q / k arrive
+    const float rope_rev = static_cast<float>(pos) * a.rope_scale * inv_f * 0.15915494309189535f;
+    const float rope_fr = rope_rev - floorf(rope_rev);
+    const float sn = __builtin_amdgcn_sinf(rope_fr), cs = __builtin_amdgcn_cosf(rope_fr);
     DA_STAMP(1);
     tag = gen + 1u;
     if (tag == 0u) tag = 1u;
@@ -482,9 +712,6 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
       DA_STAMP(5);
       const float x1 = act_to_f32<BF16>(static_cast<unsigned short>((i1 & 1) ? (w1 >> 16) : (w1 & 0xFFFFu)));
       const float x2 = act_to_f32<BF16>(static_cast<unsigned short>((i2 & 1) ? (w2 >> 16) : (w2 & 0xFFFFu)));
-      const float rev = static_cast<float>(pos) * a.rope_scale * inv_f * 0.15915494309189535f;
-      const float fr = rev - floorf(rev);
-      const float sn = __builtin_amdgcn_sinf(fr), cs = __builtin_amdgcn_cosf(fr);
       const unsigned short r1 = f32_to_act<BF16>(x1 * cs - x2 * sn), r2 = f32_to_act<BF16>(x1 * sn + x2 * cs);
       if (isk) {
         kn_s[i1] = act_to_f32<BF16>(r1);
@@ -720,18 +947,123 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
       }
     }
   };
-  if (obits == 2) phase3(std::integral_constant<int, 2>{});
-  else if (obits == 3) phase3(std::integral_constant<int, 3>{});
-  else phase3(std::integral_constant<int, 4>{});
+  if constexpr (MX != 0) {
+    // ---- the o_proj slice on the matrix cores: 4 rows x 4 groups per operand, the attention output as two E4M3 limbs per value ----
+    unsigned char* img3 = smem + DA_LDS_P3;                        // [limb][piece][64 lanes][16 B]; operand row m holds group m % 4
+    float* bsum3 = reinterpret_cast<float*>(img3 + 4096);          // [m + 16 kb]
+    unsigned char* scl3 = reinterpret_cast<unsigned char*>(bsum3 + 64);
+    if (wave < 2) {                                                // 128 items of 4 values = two granules each
+      const int it = tid;
+      unsigned w0, w1;
+      sweep2(hand2 + 2 * it, hand2 + 2 * it + 1, tag, 2u, w0, w1);
+      DA_STAMP(10);
+      const float v[4] = {act_lo<BF16>(w0), act_hi<BF16>(w0), act_lo<BF16>(w1), act_hi<BF16>(w1)};
+      float sum = (v[0] + v[1]) + (v[2] + v[3]);
+      unsigned amax = max(max(__float_as_uint(v[0]) & 0x7FFFFFFFu, __float_as_uint(v[1]) & 0x7FFFFFFFu),
+                          max(__float_as_uint(v[2]) & 0x7FFFFFFFu, __float_as_uint(v[3]) & 0x7FFFFFFFu));
+      sum += dpp_f32<0xB1>(sum); amax = max(amax, dpp_u32<0xB1>(amax));
+      sum += dpp_f32<0x4E>(sum); amax = max(amax, dpp_u32<0x4E>(amax));
+      sum += dpp_f32<0x141>(sum); amax = max(amax, dpp_u32<0x141>(amax));
+      if (amax >= 0x7F800000u) sum = __uint_as_float(0x7FC00000u);
+      int ea = static_cast<int>(amax >> 23);
+      ea = min(max(ea, 20), 240);
+      const float up = exp2i(134 - ea);
+      const int b = it >> 3, u = it & 7;
+      const int gi = b >> 2, kb = b & 3;
+      const int ga = 2 * (kb & 1) + (u >> 2);
+      const float r0 = v[0] * up, r1 = v[1] * up, r2 = v[2] * up, r3 = v[3] * up;
+      const int pe = __builtin_amdgcn_cvt_pk_fp8_f32(r0, r2, 0, false);
+      const int po = __builtin_amdgcn_cvt_pk_fp8_f32(r1, r3, 0, false);
+      const int le = __builtin_amdgcn_cvt_pk_fp8_f32(r0 - __builtin_amdgcn_cvt_f32_fp8(pe, 0), r2 - __builtin_amdgcn_cvt_f32_fp8(pe, 1), 0, false);
+      const int lo = __builtin_amdgcn_cvt_pk_fp8_f32(r1 - __builtin_amdgcn_cvt_f32_fp8(po, 0), r3 - __builtin_amdgcn_cvt_f32_fp8(po, 1), 0, false);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {                                // the four operand rows that carry this group
+        const int m = gi + 4 * c;
+        unsigned char* dst = img3 + (kb >> 1) * 1024 + (m + 16 * ga) * 16 + 2 * (u & 3);
+        *reinterpret_cast<unsigned short*>(dst) = static_cast<unsigned short>(pe);
+        *reinterpret_cast<unsigned short*>(dst + 8) = static_cast<unsigned short>(po);
+        *reinterpret_cast<unsigned short*>(dst + 2048) = static_cast<unsigned short>(le);
+        *reinterpret_cast<unsigned short*>(dst + 2048 + 8) = static_cast<unsigned short>(lo);
+        if (u == 0) { bsum3[m + 16 * kb] = sum; scl3[m + 16 * kb] = static_cast<unsigned char>(ea - 7); }
+      }
+    }
+    __syncthreads();
+    DA_STAMP(11);
+    da_v8i a3[2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const u32x4 p0 = *reinterpret_cast<const u32x4*>(img3 + 0 * 1024 + l * 2048 + lane * 16);
+      const u32x4 p1 = *reinterpret_cast<const u32x4*>(img3 + 1 * 1024 + l * 2048 + lane * 16);
+      a3[l][0] = p0.x; a3[l][1] = p0.y; a3[l][2] = p0.z; a3[l][3] = p0.w;
+      a3[l][4] = p1.x; a3[l][5] = p1.y; a3[l][6] = p1.z; a3[l][7] = p1.w;
+    }
+    const int sa3 = static_cast<int>(scl3[lane]);
+    const bool diag = mkg == (mnn >> 2);
+    const float gs3 = (bsum3[mnn] + bsum3[mnn + 16]) + (bsum3[mnn + 32] + bsum3[mnn + 48]);
+    const float xsg3 = diag ? gs3 : 0.f;
+    float dm[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dm[q] = (diag && (lane & 3) == q) ? 1.f : 0.f;
+    da_gu64* accp = reinterpret_cast<da_gu64*>(reinterpret_cast<uintptr_t>(a.acc));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      da_v8i bv;
+      const unsigned w0 = owm[j].x, w1 = owm[j].y;
+      bv[0] = w0 & 0x33333333u; bv[1] = (w0 >> 2) & 0x33333333u; bv[2] = w1 & 0x33333333u; bv[3] = (w1 >> 2) & 0x33333333u;
+      bv[4] = 0; bv[5] = 0; bv[6] = 0; bv[7] = 0;
+      da_v4f z = {0.f, 0.f, 0.f, 0.f};
+      z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a3[0], bv, z, 0, 4, 0, sa3, 0, 127);
+      z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a3[1], bv, z, 0, 4, 0, sa3, 0, 127);
+      const float dsel = fmaf(z[0], dm[0], fmaf(z[1], dm[1], fmaf(z[2], dm[2], z[3] * dm[3])));
+      const float sc = act_to_f32<BF16>(static_cast<unsigned short>(osc[j])), ze = act_to_f32<BF16>(static_cast<unsigned short>(oze[j]));
+      float v = fmaf(ze, xsg3, (sc + sc) * dsel);                  // (row nn / 4, group nn % 4) on the diagonal lanes 20 (nn / 4) + nn % 4, 0 elsewhere
+      v += dpp_f32<0xB1>(v);
+      v += dpp_f32<0x4E>(v);                                       // the row's four groups: an aligned quad
+      if (diag && (mnn & 3) == 0) {
+        const int row = r * RPW + wave * 8 + 4 * j + (mnn >> 2);
+        if (fabsf(v) < 2147483648.f) {
+          const long long fx = __float2ll_rn(v * 4294967296.f);
+          __hip_atomic_fetch_add(accp + row, static_cast<unsigned long long>(fx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          __hip_atomic_fetch_add(accp + D, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+  } else {
+    if (obits == 2) phase3(std::integral_constant<int, 2>{});
+    else if (obits == 3) phase3(std::integral_constant<int, 3>{});
+    else phase3(std::integral_constant<int, 4>{});
+  }
   // member 0 advances the group's generation: every member has read it (nobody reaches this point before all of them published)
   if (r == 0 && tid == 0) __hip_atomic_store(gen_p, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   DA_STAMP(6);
 }
 
+bool dattn_mx_wanted(const DattnArgs& a, bool bf16);      // dattn_common.hip: GBX_DATTN_MX and the shapes the matrix-core form covers
+// the matrix-core instantiation exists for <2, 1> only (specialised in dattn_b2.hip)
+template <int BQ, int P_> struct DattnMx {
+  static constexpr bool has = false;
+  static hipError_t launch(const DattnArgs&, hipStream_t) { return hipErrorInvalidValue; }
+};
+#define GBX_DEFINE_LAUNCH_DATTN_MX(BQ, P_)                                                                                   \
+  template <> struct DattnMx<BQ, P_> {                                                                                       \
+    static constexpr bool has = true;                                                                                        \
+    static hipError_t launch(const DattnArgs& a, hipStream_t stream) {                                                       \
+      static DeviceOnce once;                                                                                                \
+      if (once.pending()) {                                                                                                  \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dattn_kernel<BQ, P_, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, DA_LDS_BYTES); \
+        if (e != hipSuccess) return e;                                                                                       \
+        once.done();                                                                                                         \
+      }                                                                                                                      \
+      hipLaunchKernelGGL((dattn_kernel<BQ, P_, true, 2>), dim3(DA_GROUPS * DA_MEMBERS), dim3(DA_NT), DA_LDS_BYTES, stream, a);       \
+      return hipGetLastError();                                                                                              \
+    }                                                                                                                        \
+  };
 #define GBX_DEFINE_LAUNCH_DATTN(BQ, P_)                                                                                      \
   template <> hipError_t launch_dattn_bits<BQ>(const DattnArgs& a, const DattnPlan& pl, bool bf16, hipStream_t stream) {     \
     static DeviceOnce once;                                                                                                  \
     if (pl.P != P_) return hipErrorInvalidValue;                                                                             \
+    if (DattnMx<BQ, P_>::has && dattn_mx_wanted(a, bf16)) return DattnMx<BQ, P_>::launch(a, stream);                         \
     if (once.pending()) {                                                                                                    \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dattn_kernel<BQ, P_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, DA_LDS_BYTES); \
       if (e != hipSuccess) return e;                                                                                         \

@@ -74,7 +74,7 @@ def _close(got, want, what, rel=2e-2):
 
 
 CASES = [
-    ("LLAMA3_8B", 2, 2, 40), ("LLAMA3_8B", 3, 3, 9), ("LLAMA3_8B", 4, 4, 131), ("LLAMA3_8B", 2, 4, 200), ("LLAMA3_8B", 4, 2, 0),
+    ("LLAMA3_8B", 2, 2, 40), ("LLAMA3_8B", 2, 2, 300), ("LLAMA3_8B", 3, 3, 9), ("LLAMA3_8B", 4, 4, 131), ("LLAMA3_8B", 2, 4, 200), ("LLAMA3_8B", 4, 2, 0),
     ("LLAMA32_3B", 2, 2, 17), ("LLAMA32_3B", 4, 4, 130), ("LLAMA32_3B", 3, 2, 64),
 ]
 
@@ -88,7 +88,7 @@ def test_dattn_launch_vs_fp64(cfg_name, bq, bo, ctx):
     D, nh, nkv, hd = cfg["hidden_size"], at.n_heads, at.n_kv_heads, at.head_dim
     cat = _cat_qkv(at)
     assert ops.dattn_supported(D, nh, nkv, hd, cat, at.o_proj), "the BASELINE geometries must be covered"
-    cap = 256
+    cap = 256 if ctx < 250 else 512
     gen = torch.Generator(device="cpu").manual_seed(ctx + 1)
     h = (torch.randn(D, generator=gen) * 0.7).to(torch.bfloat16).to(DEV)
     kc = (torch.randn(1, nkv, cap, hd, generator=gen) * 0.5).to(torch.bfloat16).to(DEV)
@@ -117,6 +117,17 @@ def test_dattn_launch_vs_fp64(cfg_name, bq, bo, ctx):
     o_want = _deq(at.o_proj) @ attn_out.double()
     _close(o_got, o_want, "o_proj partial sums", rel=1e-2)
     assert int(acc[D].item()) == 0, "non-finite marker set on finite data"
+
+
+def test_dattn_vector_form_when_the_matrix_core_form_is_switched_off():
+    """GBX_DATTN_MX=0 (read once per process: a child): the 2-bit 8B launch on the vector-ALU dots, same oracle check."""
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_dattn_gpu as t\n"
+            "t.test_dattn_launch_vs_fp64('LLAMA3_8B', 2, 2, 40)\n"
+            "t.test_dattn_launch_vs_fp64('LLAMA3_8B', 2, 2, 170)\n"
+            "print('VEC_OK')\n" % (ROOT, os.path.join(ROOT, "tests")))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GBX_DATTN_MX="0"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "VEC_OK" in out.stdout, out.stderr[-2000:]
 
 
 def test_dattn_repeated_launches_and_accumulator_protocol():
