@@ -229,6 +229,7 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(const DgArgs a) {
     const unsigned* x32 = reinterpret_cast<const unsigned*>(a.x);
     const bool poison = a.x_acc[K] != 0;
     constexpr int XU = 4;
+    float ssq_acc = 0.f;                                     // the statistic of x' rides on the same barrier as x' itself
     for (int base = 0; base < K / 2; base += NT * XU) {
       unsigned hv[XU];
       u32x4 av[XU];
@@ -249,9 +250,13 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(const DgArgs a) {
         if (wi < K / 2) {
           xl[wi] = wv;
           if (blockIdx.x == 0 && a.x_out) reinterpret_cast<unsigned*>(a.x_out)[wi] = wv;
+          const float lo = act_lo<BF16>(wv), hi = act_hi<BF16>(wv);
+          ssq_acc = fmaf(hi, hi, fmaf(lo, lo, ssq_acc));
         }
       }
     }
+    ssq_acc = wave_sum(ssq_acc);
+    if (lane == 0) red_lds[wave] = ssq_acc;
     __syncthreads();
     const __attribute__((address_space(3))) unsigned short* xs3 = (const __attribute__((address_space(3))) unsigned short*)(xl);
 #pragma unroll
@@ -298,6 +303,10 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(const DgArgs a) {
       for (int i = 0; i < 4; ++i)
         s += (__uint_as_float(pq[i].x) + __uint_as_float(pq[i].y)) + (__uint_as_float(pq[i].z) + __uint_as_float(pq[i].w));
       tot = wave_sum(s);
+    } else if (a.x_acc) {                                      // (reduced with x' above: one barrier for both)
+      tot = 0.f;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) tot += red_lds[i];
     } else {
       float ssq = 0.f;
 #pragma unroll
