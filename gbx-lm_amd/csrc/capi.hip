@@ -1040,7 +1040,8 @@ int gbx_dattn_plan(int32_t D, int32_t n_heads, int32_t n_kv_heads, int32_t head_
 }
 
 size_t gbx_dattn_state_bytes(void) {
-  return static_cast<size_t>(gbx::DA_GROUPS) * gbx::DA_HAND_STRIDE * 8 + static_cast<size_t>(gbx::DA_STATE_WORDS) * 4;
+  return static_cast<size_t>(gbx::DA_GROUPS) * gbx::DA_HAND_STRIDE * 8 + static_cast<size_t>(gbx::DA_STATE_WORDS) * 4 +
+         static_cast<size_t>(gbx::DA_PART_GRANULES) * 8;
 }
 
 int gbx_dattn_forward(const gbx_dattn* d, void* hip_stream) {
@@ -1076,6 +1077,12 @@ int gbx_dattn_forward(const gbx_dattn* d, void* hip_stream) {
   a.hand = static_cast<unsigned long long*>(d->state);
   a.state = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(d->state) + static_cast<size_t>(gbx::DA_GROUPS) * gbx::DA_HAND_STRIDE * 8);
   a.attn_out = static_cast<unsigned short*>(d->attn_out);
+  a.part = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(d->state) + static_cast<size_t>(gbx::DA_GROUPS) * gbx::DA_HAND_STRIDE * 8 +
+                                    static_cast<size_t>(gbx::DA_STATE_WORDS) * 4);
+  {
+    static const int coop_min = gbx::env_switch("GBX_DATTN_COOP_MIN");
+    a.coop_min = coop_min;
+  }
   if (d->x_acc && (d->ssq_in || !aligned(d->x_acc, 16))) return fail(GBX_ERR_INVALID, "x_acc goes without ssq_in and must be 16-byte aligned");
   if (d->x_out && (!d->x_acc || d->x_out == d->x || !aligned(d->x_out, 4))) return fail(GBX_ERR_INVALID, "x_out goes with x_acc and must not alias x");
   if (d->zero_buf && (d->zero_n <= 0 || !aligned(d->zero_buf, 8) || reinterpret_cast<const void*>(d->zero_buf) == reinterpret_cast<const void*>(d->x_acc) ||

@@ -40,6 +40,8 @@ constexpr int DA_OP = 2;                     // o_proj lane passes held in regis
 constexpr int DA_HAND_STRIDE = 2048;         // granules (8 bytes) per group: [0, 1024) phase 1, [1024, 2048) attention output
 constexpr int DA_STATE_WORDS = 64 * 16;      // u32: gen[g] at g * 16 (one 64-byte line each), status at 8 * 16, placement at 9 * 16
 constexpr unsigned DA_SPIN_LIMIT = 1u << 22;
+constexpr int DA_PART_STRIDE = 132;          // granules per partial softmax state: {tag, max}, {tag, denominator}, 128 x {tag, numerator}, 2 pad
+constexpr int DA_PART_GRANULES = DA_GROUPS * DA_MEMBERS * 4 * DA_PART_STRIDE;      // [group][member][head of the group <= 4]
 
 struct DattnArgs {
   const unsigned short* x;          // [D] residual stream
@@ -58,6 +60,7 @@ struct DattnArgs {
   unsigned long long* hand;         // [8][DA_HAND_STRIDE] granules
   unsigned* state;                  // [DA_STATE_WORDS]
   unsigned short* attn_out;         // optional [n_heads * 128]: the attention output (tests)
+  unsigned long long* part;         // [8][32][4][DA_PART_STRIDE] granules: partial softmax states of the cooperative sweep (long contexts)
   // the previous block's MLP launch (dmlp.hip) leaves down_proj's output as fixed-point sums too:
   const long long* x_acc;           // [D + 1] or null: x <- round(x + round(x_acc * 2^-32)) in the producers' prologue (no ssq_in then)
   unsigned short* x_out;            // with x_acc: the new x, written once
@@ -65,6 +68,7 @@ struct DattnArgs {
   int zero_n;
   int D, rep, capacity, bpw;        // bpw: phase-1 batches per producer workgroup
   int qkv_log2g, o_bits, o_log2g, traditional;
+  int coop_min;                     // contexts beyond this many cached positions: cooperative sweep (the group's producers, in chunks)
   float eps, rope_scale, sm_scale;
 #ifdef GBX_STAMPS
   unsigned long long* stamps;

@@ -9,19 +9,24 @@ namespace gbx {
 typedef __attribute__((address_space(1))) unsigned long long da_gu64;
 typedef __attribute__((address_space(1))) unsigned da_gu32;
 
-// LDS map (bytes).  84 KB are requested so that a CU holds exactly one workgroup (the 256 workgroups then cover the 256 CUs).
+// LDS map (bytes).  More than half of a CU's 160 KB is requested so that a CU holds exactly one workgroup (the 256 workgroups then cover the 256 CUs).
 constexpr int DA_LDS_IMG1 = 0;                     // phase-1 activation image: Lds<BQ>::bytes(K <= 4096) <= 11.3 KB
 constexpr int DA_LDS_RED = 12 * 1024;              // 16 floats: RMSNorm partials
 constexpr int DA_LDS_P3 = 12 * 1024 + 256;         // phase 3: 2 KB of raw attention output, then its operand image (<= 5.2 KB)
 constexpr int DA_LDS_ATT = 24 * 1024;              // attention scratch: q | k | v words, rotated q / k / v, up to 64 softmax states (37.6 KB)
-constexpr int DA_LDS_BYTES = 84 * 1024;
+constexpr int DA_LDS_DUMP = 100 * 1024;          // cooperative sweep, attention workgroups: 16 KB that the L2 prefetch's LDS-DMA overwrites (never read)
+constexpr int DA_LDS_BYTES = 116 * 1024;         // (the cooperative sweep's 128 partial states end at 98.1 KB)
 #ifndef DA_SWEEP4_MAX
 #define DA_SWEEP4_MAX 160      // contexts up to here are swept by 4 waves (one per SIMD), up to 320 by 8, longer ones by 16
 #endif
 
 #ifdef GBX_STAMPS
-#define DA_STAMP(i) do { if (lane == 0 && a.stamps) a.stamps[(static_cast<size_t>(blockIdx.x) * DA_NW + wave) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// diagnostic build: stamps are kept in LDS (behind the product's region) and flushed at the end of the launch -- a global store per
+// stamp would sit in the vector-memory queue and lengthen every s_waitcnt vmcnt that follows it
+#define DA_STAMP(i) do { if (lane == 0) reinterpret_cast<unsigned long long*>(smem + DA_LDS_BYTES)[wave * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define DA_STAMP_EXTRA 2048
 #else
+#define DA_STAMP_EXTRA 0
 #define DA_STAMP(i) do {} while (0)
 #endif
 
@@ -131,6 +136,30 @@ __device__ __forceinline__ float da_o_slot(const u32x4& w, unsigned sc_bits, uns
   }
 }
 
+typedef float da_f32x2 __attribute__((ext_vector_type(2)));
+template <bool BF16> __device__ __forceinline__ da_f32x2 da_unpack2(unsigned w) { return da_f32x2{act_lo<BF16>(w), act_hi<BF16>(w)}; }
+// q . k over the 16 lanes that share one cached position (8 features each); kf: the lane's 8 features of k as four fp32 pairs
+__device__ __forceinline__ float da_dot16(const da_f32x2 (&kf)[4], const da_f32x2 (&q2)[4]) {
+  da_f32x2 t = kf[0] * q2[0];
+  t = __builtin_elementwise_fma(kf[1], q2[1], t);
+  t = __builtin_elementwise_fma(kf[2], q2[2], t);
+  t = __builtin_elementwise_fma(kf[3], q2[3], t);
+  float s = t.x + t.y;
+  s += dpp_f32<0xB1>(s);
+  s += dpp_f32<0x4E>(s);
+  s += dpp_f32<0x141>(s);
+  s += dpp_f32<0x140>(s);
+  return s;
+}
+__device__ __forceinline__ void da_axpy8(const da_f32x2 (&vf)[4], float p, da_f32x2 (&acc2)[4]) {
+  const da_f32x2 p2 = da_f32x2{p, p};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc2[c] = __builtin_elementwise_fma(p2, vf[c], acc2[c]);
+}
+template <bool BF16> __device__ __forceinline__ void da_unpack8(const u32x4& w, da_f32x2 (&o)[4]) {
+  o[0] = da_unpack2<BF16>(w.x); o[1] = da_unpack2<BF16>(w.y); o[2] = da_unpack2<BF16>(w.z); o[3] = da_unpack2<BF16>(w.w);
+}
+
 typedef int da_v8i __attribute__((ext_vector_type(8)));
 typedef float da_v4f __attribute__((ext_vector_type(4)));
 
@@ -152,6 +181,9 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef GBX_STAMPS
+  if (lane < 16) reinterpret_cast<unsigned long long*>(smem + DA_LDS_BYTES)[wave * 16 + lane] = 0ull;
+#endif
   DA_STAMP(0);
   const int g = static_cast<int>(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);     // HW_REG_XCC_ID: this XCD = this kv group
   const int r = static_cast<int>(blockIdx.x) >> 3;                                       // member of the group
@@ -189,6 +221,13 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
   if (a.zero_buf) {                                          // (kernel-argument uniform)
     for (int i = static_cast<int>(blockIdx.x) * NT + tid; i < a.zero_n; i += static_cast<int>(gridDim.x) * NT) a.zero_buf[i] = 0ull;
   }
+  // Long contexts: ONE CU pulls a head's K / V at ~33 GB/s (0.5 KB per position: 160 positions hide behind phase 1, 650 take 10 us),
+  // so beyond coop_min positions (GBX_DATTN_COOP_MIN) the group's PRODUCERS sweep the context in chunks once their rows are published -- every chunk's
+  // K / V is read once for all `rep` heads -- and leave one partial softmax state per (producer, head); the head's workgroup only
+  // rotates / appends the new token and merges.  (The group's hand-offs stay XCD-local: flags are granules, states are sc0 stores.)
+  const int cpos = static_cast<int>(*a.pos);
+  const bool coop = cpos > a.coop_min && (rep == 3 || rep == 4);     // (two head pairs x 8 position sets; LDS sized for 4 heads)
+  const int cd0 = (lane & 15) * 8, csub = lane >> 4;          // 16 lanes per cached position, 8 features per lane
   // ---------------- o_proj: this workgroup's rows, this group's columns -- requested early, consumed in phase 3 ----------------
   const int obits = a.o_bits;
   const int ovpl_l2 = obits == 2 ? 6 : 5;
@@ -238,6 +277,8 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
 
   unsigned tag;
   if (r >= rep) {
+    // cooperative sweep: the RoPE frequency of this lane's q pair, fetched with the prologue's loads (one register through phase 1)
+    const float coop_invf = (coop && wave < rep) ? a.inv_freq[lane] : 0.f;
     if constexpr (MX != 0) {
     // ================= phase 1 on the matrix cores (dgemv_mx.hip's arithmetic; 2 bits, group 128, K = 4096 = two spans) =================
     constexpr int SP = 2, NBLK = SP * 64;
@@ -437,7 +478,6 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
       if (lane == 0) __hip_atomic_store(hand1 + lb, (static_cast<unsigned long long>(tag) << 32) | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     DA_STAMP(4);
-    issue_o();
     } else {
     // =========================================== phase 1: the group's q | k | v rows ===========================================
     h2* xp_lds = reinterpret_cast<h2*>(smem + DA_LDS_IMG1);
@@ -650,7 +690,165 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
       if (lane == 0) __hip_atomic_store(hand1 + lb, (static_cast<unsigned long long>(tag) << 32) | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     DA_STAMP(4);
-    issue_o();                                                 // o_proj words: needed ~4 us from here, requested off the critical path
+    }
+    // o_proj words: needed ~4 us from here, requested off the critical path.  (Loads return in order: under the cooperative sweep the
+    // chunk's K / V rows and the q poll go first, or they would queue behind these 32 KB per CU.)
+    if (!coop) issue_o();
+    if (coop) {
+      // ---------------- cooperative sweep: this producer's chunk of the context, all `rep` heads of the group ----------------
+      // A wave owns a PAIR of heads (the K / V unpacking is shared) and one of 8 "position sets"; round u of set s covers positions
+      // p0 + (u * 8 + s) * 4 + [0, 4), 16 lanes each.  RB rounds of K / V are requested NOW -- behind phase 1, whose weight stream already
+      // saturates this CU's fill path; the rows were pulled into this XCD's L2 by the group's idle attention workgroups meanwhile -- and
+      // re-requested as a ring; the softmax is two-pass per block of RB rounds (one rescale per block).
+      constexpr int RB = 4;
+      constexpr float NEG = -1e30f;
+      const int pi = r - rep, np = DA_MEMBERS - rep;
+      const int CH = (((cpos + np - 1) / np) + 3) & ~3;
+      const int p0 = pi * CH, p1 = min(cpos, p0 + CH);
+      constexpr int nps = 8, ppr = nps * 4, nst = nps * 4;      // position sets; positions per round; states per head
+      const int cpair = wave >> 3, cps = wave & 7;              // this wave's head pair and set
+      const int ja = 2 * cpair, jb = min(ja + 1, rep - 1);      // (three heads: the second pair computes its one head twice)
+      const int nr = p1 > p0 ? (p1 - p0 + ppr - 1) / ppr : 0;   // rounds (workgroup-uniform)
+      float* q_s = reinterpret_cast<float*>(smem + DA_LDS_ATT);          // [4][128] rotated, scaled q of the group's heads
+      float* gm = q_s + 4 * HD;                                          // [rep * nst <= 128] running maxima
+      float* gl = gm + 128;                                              // denominators
+      float* gw = gl + 128;                                              // merge weights
+      float (*gacc)[HD + 8] = reinterpret_cast<float (*)[HD + 8]>(gw + 128);       // [128][136]
+      const __amdgpu_buffer_rsrc_t kd = rsrc(a.kcache + static_cast<size_t>(g) * a.capacity * HD, a.capacity * HD * 2);
+      const __amdgpu_buffer_rsrc_t vd = rsrc(a.vcache + static_cast<size_t>(g) * a.capacity * HD, a.capacity * HD * 2);
+      const int tl0 = p0 + cps * 4 + csub;                      // this lane's position in round 0
+      u32x4 kc[RB], vc[RB];
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const int t = tl0 + u * ppr;
+        const unsigned off = static_cast<unsigned>(t * (HD * 2) + cd0 * 2) | (t < p1 ? 0u : KILL);
+        kc[u] = __builtin_amdgcn_raw_buffer_load_b128(kd, off, 0, 0);
+        vc[u] = __builtin_amdgcn_raw_buffer_load_b128(vd, off, 0, 0);
+      }
+      if (wave >= rep) issue_o();
+      if (wave < rep) {                                         // head `wave` of the group: its q pairs, rotated like the head's own workgroup does
+        const int i = lane;
+        const int i1 = a.traditional ? 2 * i : i;
+        const int i2 = a.traditional ? 2 * i + 1 : i + HD / 2;
+        da_gu64* base = hand1 + wave * (HD / 2);
+        unsigned w1, w2;
+        sweep2(base + (i1 >> 1), base + (i2 >> 1), tag, 4u, w1, w2);
+        const float rev = static_cast<float>(cpos) * a.rope_scale * coop_invf * 0.15915494309189535f;
+        const float fr = rev - floorf(rev);
+        const float sn = __builtin_amdgcn_sinf(fr), cs = __builtin_amdgcn_cosf(fr);
+        const float x1 = act_to_f32<BF16>(static_cast<unsigned short>((i1 & 1) ? (w1 >> 16) : (w1 & 0xFFFFu)));
+        const float x2 = act_to_f32<BF16>(static_cast<unsigned short>((i2 & 1) ? (w2 >> 16) : (w2 & 0xFFFFu)));
+        const unsigned short r1 = f32_to_act<BF16>(x1 * cs - x2 * sn), r2 = f32_to_act<BF16>(x1 * sn + x2 * cs);
+        q_s[wave * HD + i1] = act_to_f32<BF16>(r1) * a.sm_scale;
+        q_s[wave * HD + i2] = act_to_f32<BF16>(r2) * a.sm_scale;
+        issue_o();
+      }
+      __syncthreads();
+      DA_STAMP(12);
+      // position sets that hold a cached position at all (a short chunk leaves whole waves without work: they skip the sweep, and the
+      // merge below never reads their states)
+      const int nvs = nr > 1 ? nps : (nr == 1 ? (p1 - p0 + 3) >> 2 : 0);
+      if (cps < nvs) {
+        da_f32x2 qa[4], qb[4], acca[4], accb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          qa[c] = *reinterpret_cast<const da_f32x2*>(q_s + ja * HD + cd0 + 2 * c);
+          qb[c] = *reinterpret_cast<const da_f32x2*>(q_s + jb * HD + cd0 + 2 * c);
+          acca[c] = da_f32x2{0.f, 0.f};
+          accb[c] = da_f32x2{0.f, 0.f};
+        }
+        float ma = NEG, la = 0.f, mb = NEG, lb = 0.f;
+        for (int ub = 0; ub < nr; ub += RB) {
+          float sa[RB], sb[RB];
+#pragma unroll
+          for (int u = 0; u < RB; ++u) {
+            sa[u] = NEG;
+            sb[u] = NEG;
+            if (ub + u < nr) {                                  // (workgroup-uniform)
+              const int t = tl0 + (ub + u) * ppr;
+              da_f32x2 kf[4];
+              da_unpack8<BF16>(kc[u], kf);
+              const float s0 = da_dot16(kf, qa), s1 = da_dot16(kf, qb);
+              if (t < p1) { sa[u] = s0; sb[u] = s1; }
+              if (ub + u + RB < nr) {                           // this slot's next round
+                const int tn = t + RB * ppr;
+                kc[u] = __builtin_amdgcn_raw_buffer_load_b128(kd, static_cast<unsigned>(tn * (HD * 2) + cd0 * 2) | (tn < p1 ? 0u : KILL), 0, 0);
+              }
+            }
+          }
+          float na = ma, nb = mb;
+#pragma unroll
+          for (int u = 0; u < RB; ++u) { na = fmaxf(na, sa[u]); nb = fmaxf(nb, sb[u]); }
+          if (ub > 0) {                                         // one rescale per block (nothing to rescale in the first)
+            const float ca = __expf(ma - na), cb = __expf(mb - nb);
+            la *= ca;
+            lb *= cb;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { acca[c] = acca[c] * da_f32x2{ca, ca}; accb[c] = accb[c] * da_f32x2{cb, cb}; }
+          }
+          ma = na;
+          mb = nb;
+#pragma unroll
+          for (int u = 0; u < RB; ++u) {
+            if (ub + u < nr) {
+              const float pa = sa[u] > 0.5f * NEG ? __expf(sa[u] - ma) : 0.f;
+              const float pb = sb[u] > 0.5f * NEG ? __expf(sb[u] - mb) : 0.f;
+              da_f32x2 vf[4];
+              da_unpack8<BF16>(vc[u], vf);
+              la += pa;
+              lb += pb;
+              da_axpy8(vf, pa, acca);
+              da_axpy8(vf, pb, accb);
+              if (ub + u + RB < nr) {
+                const int tn = tl0 + (ub + u + RB) * ppr;
+                vc[u] = __builtin_amdgcn_raw_buffer_load_b128(vd, static_cast<unsigned>(tn * (HD * 2) + cd0 * 2) | (tn < p1 ? 0u : KILL), 0, 0);
+              }
+            }
+          }
+        }
+        const int sxa = ja * nst + cps * 4 + csub, sxb = jb * nst + cps * 4 + csub;
+        if ((lane & 15) == 0) { gm[sxa] = ma; gl[sxa] = la; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *reinterpret_cast<da_f32x2*>(&gacc[sxa][cd0 + 2 * c]) = acca[c];
+        if (jb != ja) {
+          if ((lane & 15) == 0) { gm[sxb] = mb; gl[sxb] = lb; }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) *reinterpret_cast<da_f32x2*>(&gacc[sxb][cd0 + 2 * c]) = accb[c];
+        }
+      }
+      __syncthreads();
+      DA_STAMP(13);
+      // merge the head's nvs * 4 states: wave j weighs them (lane = state) and sends {max, denominator}; then one (head, feature) per thread
+      da_gu64* pp0 = reinterpret_cast<da_gu64*>(reinterpret_cast<uintptr_t>(a.part)) + static_cast<size_t>(g * DA_MEMBERS + pi) * 4 * DA_PART_STRIDE;
+      const unsigned long long tg = static_cast<unsigned long long>(tag) << 32;
+      if (wave < rep) {
+        const bool live = lane < nvs * 4;
+        const float mv = live ? gm[wave * nst + lane] : NEG;
+        const float M = key2f(wave_max_u32(f2key(mv)));
+        const float wgt = live ? __expf(mv - M) : 0.f;
+        const float den = wave_sum(live ? wgt * gl[wave * nst + lane] : 0.f);
+        if (live) gw[wave * nst + lane] = wgt;
+        if (lane < 2) __hip_atomic_store(pp0 + wave * DA_PART_STRIDE + lane, tg | __float_as_uint(lane ? den : M), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      __syncthreads();
+      DA_STAMP(15);
+      {
+        const int j = tid >> 7, f = tid & 127;
+        if (j < rep) {
+          const int s0 = j * nst;
+          float num = 0.f;
+          for (int c = 0; c < nvs * 4; c += 4) {
+            float tw[4], ta[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { tw[i] = gw[s0 + c + i]; ta[i] = gacc[s0 + c + i][f]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) num = fmaf(tw[i], ta[i], num);
+          }
+          // every value leaves as its own {tag, value} granule (sc0: stays in this XCD's L2): no flag, no ordering between the stores
+          __hip_atomic_store(pp0 + j * DA_PART_STRIDE + 2 + f, tg | __float_as_uint(num), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+      DA_STAMP(14);
     }
   } else {
     // =========================================== phase 2: attention of head g * rep + r ===========================================
@@ -672,7 +870,7 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
     const int pos = static_cast<int>(*a.pos);
     const int nws = pos <= DA_SWEEP4_MAX ? 4 : (pos <= UB0 * 8 * PPW ? 8 : 16);
     const int ppr = nws * PPW;
-    const bool sweeper = wave < nws;
+    const bool sweeper = wave < nws && !coop;                  // (cooperative sweep: the producers own the cached positions)
     const __amdgpu_buffer_rsrc_t kd = rsrc(a.kcache + static_cast<size_t>(g) * a.capacity * HD, a.capacity * HD * 2);
     const __amdgpu_buffer_rsrc_t vd = rsrc(a.vcache + static_cast<size_t>(g) * a.capacity * HD, a.capacity * HD * 2);
     const unsigned short* kbase = a.kcache + static_cast<size_t>(g) * a.capacity * HD;
@@ -687,6 +885,19 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
       if (sweeper && u * ppr < pos) {                          // (wave-uniform) rounds wholly beyond the context issue nothing
         k0[u] = __builtin_amdgcn_raw_buffer_load_b128(kd, off, 0, 0);
         v0[u] = __builtin_amdgcn_raw_buffer_load_b128(vd, off, 0, 0);
+      }
+    }
+    if (coop) {
+      // Cooperative sweep: this workgroup is idle until q arrives, and its CU's fill path is free while the producers' is saturated by
+      // the weight stream -- so the group's `rep` attention workgroups pull the cached K / V rows (the first 1024 positions) into the
+      // XCD's L2 now, and the producers read their chunks from there once phase 1 is over.  LDS-DMA into a dump area: no registers, and
+      // nothing for the compiler to discard.  4-row piece n goes to workgroup n % rep, wave (n / rep) % 16.
+      const int npc = (min(pos, 1024) + 3) >> 2;
+      for (int n = r + rep * wave; n < npc; n += rep * NW) {
+        const int t = min(4 * n + csub, pos - 1);
+        const unsigned off = static_cast<unsigned>(t * (HD * 2) + cd0 * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(kd, (__attribute__((address_space(3))) void*)(smem + DA_LDS_DUMP + wave * 1024), 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(vd, (__attribute__((address_space(3))) void*)(smem + DA_LDS_DUMP + wave * 1024), 16, off, 0, 0, 0);
       }
     }
     issue_o();
@@ -732,6 +943,72 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
       if (r == 0) *reinterpret_cast<unsigned*>(a.vcache + (static_cast<size_t>(g) * a.capacity + pos) * HD + 2 * lane) = vw;
     }
     __syncthreads();
+    if (coop) {
+      // ---- cooperative sweep: this workgroup owns the new token and the merge of the producers' partial states of its head ----
+      // thread (f = tid % 128, pg = tid / 128) polls feature f of producers pg * 4 + [0, 4) -- 12 granules in flight -- and merges them;
+      // the eight partial results meet in LDS.
+      const int np = DA_MEMBERS - rep;
+      const float snew = wave_sum(fmaf(q_s[2 * lane], kn_s[2 * lane], q_s[2 * lane + 1] * kn_s[2 * lane + 1]));     // q . k of the new token
+      const int f = tid & (HD - 1), pg = tid >> 7;
+      da_gu64* pb = reinterpret_cast<da_gu64*>(reinterpret_cast<uintptr_t>(a.part)) + (static_cast<size_t>(g * DA_MEMBERS) * 4 + r) * DA_PART_STRIDE;
+      // lane l also polls ONE of the 8 {max, denominator} granules of its four producers (l % 4: producer, (l / 4) % 2: which); they are
+      // wave-uniform per producer and move to scalar registers once the tags match
+      da_gu64* pmd = pb + static_cast<size_t>(min(pg * 4 + (lane & 3), np - 1)) * (4 * DA_PART_STRIDE) + ((lane >> 2) & 1);
+      unsigned long long gq[4], gs;
+      for (unsigned spins = 0;;) {
+        gs = __hip_atomic_load(pmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          gq[i] = __hip_atomic_load(pb + static_cast<size_t>(min(pg * 4 + i, np - 1)) * (4 * DA_PART_STRIDE) + 2 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = static_cast<unsigned>(gs >> 32) == tag;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ok = ok && static_cast<unsigned>(gq[i] >> 32) == tag;
+        if (__all(ok)) break;
+        if (++spins > DA_SPIN_LIMIT) { timeout(5u); break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      DA_STAMP(8);
+      {
+        float pm[4], pd[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          pm[i] = __uint_as_float(__builtin_amdgcn_readlane(static_cast<unsigned>(gs), i));
+          pd[i] = __uint_as_float(__builtin_amdgcn_readlane(static_cast<unsigned>(gs), 4 + i));
+        }
+        float M = NEG;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (pg * 4 + i < np) M = fmaxf(M, pm[i]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float wgt = pg * 4 + i < np ? __expf(pm[i] - M) : 0.f;
+          num = fmaf(wgt, __uint_as_float(static_cast<unsigned>(gq[i])), num);
+          den = fmaf(wgt, pd[i], den);
+        }
+        if (f == 0) { gm[pg] = M; gl[pg] = den; }
+        gacc[pg][f] = num;
+      }
+      __syncthreads();
+      if (tid < HD) {
+        float M = snew;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) M = fmaxf(M, gm[i]);
+        const float wn = __expf(snew - M);
+        float num = wn * vn_s[tid], den = wn;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float wgt = __expf(gm[i] - M);
+          num = fmaf(wgt, gacc[i][tid], num);
+          den = fmaf(wgt, gl[i], den);
+        }
+        const unsigned ob = f32_to_act<BF16>(num / den);
+        if (a.attn_out) a.attn_out[static_cast<size_t>(h) * HD + tid] = static_cast<unsigned short>(ob);
+        const unsigned nb2 = dpp_u32<0xB1>(ob);
+        if ((lane & 1) == 0)
+          __hip_atomic_store(hand2 + r * (HD / 2) + (tid >> 1), (static_cast<unsigned long long>(tag) << 32) | ob | (nb2 << 16),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    } else {
     // ---- cached positions [0, pos): 16 lanes per position, online softmax per lane group (attn_decode_kernel, 16-wave form)
     // Packed fp32 arithmetic (v_pk_fma_f32: two lanes of work per issue slot -- this sweep is vector-ALU bound once the K / V rows
     // sit in registers) and a two-pass softmax over the prefetched rounds: all scores first, ONE running-maximum update, then the
@@ -882,6 +1159,7 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
       if ((lane & 1) == 0)
         __hip_atomic_store(hand2 + r * (HD / 2) + (tid >> 1), (static_cast<unsigned long long>(tag) << 32) | ob | (nb2 << 16),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     }
     DA_STAMP(9);
   }
@@ -1037,6 +1315,9 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
   // member 0 advances the group's generation: every member has read it (nobody reaches this point before all of them published)
   if (r == 0 && tid == 0) __hip_atomic_store(gen_p, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   DA_STAMP(6);
+#ifdef GBX_STAMPS
+  if (lane < 16 && a.stamps) a.stamps[(static_cast<size_t>(blockIdx.x) * DA_NW + wave) * 16 + lane] = reinterpret_cast<unsigned long long*>(smem + DA_LDS_BYTES)[wave * 16 + lane];
+#endif
 }
 
 bool dattn_mx_wanted(const DattnArgs& a, bool bf16);      // dattn_common.hip: GBX_DATTN_MX and the shapes the matrix-core form covers
@@ -1051,11 +1332,11 @@ template <int BQ, int P_> struct DattnMx {
     static hipError_t launch(const DattnArgs& a, hipStream_t stream) {                                                       \
       static DeviceOnce once;                                                                                                \
       if (once.pending()) {                                                                                                  \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dattn_kernel<BQ, P_, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, DA_LDS_BYTES); \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dattn_kernel<BQ, P_, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, DA_LDS_BYTES + DA_STAMP_EXTRA); \
         if (e != hipSuccess) return e;                                                                                       \
         once.done();                                                                                                         \
       }                                                                                                                      \
-      hipLaunchKernelGGL((dattn_kernel<BQ, P_, true, 2>), dim3(DA_GROUPS * DA_MEMBERS), dim3(DA_NT), DA_LDS_BYTES, stream, a);       \
+      hipLaunchKernelGGL((dattn_kernel<BQ, P_, true, 2>), dim3(DA_GROUPS * DA_MEMBERS), dim3(DA_NT), DA_LDS_BYTES + DA_STAMP_EXTRA, stream, a);       \
       return hipGetLastError();                                                                                              \
     }                                                                                                                        \
   };
@@ -1065,14 +1346,14 @@ template <int BQ, int P_> struct DattnMx {
     if (pl.P != P_) return hipErrorInvalidValue;                                                                             \
     if (DattnMx<BQ, P_>::has && dattn_mx_wanted(a, bf16)) return DattnMx<BQ, P_>::launch(a, stream);                         \
     if (once.pending()) {                                                                                                    \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dattn_kernel<BQ, P_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, DA_LDS_BYTES); \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dattn_kernel<BQ, P_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, DA_LDS_BYTES + DA_STAMP_EXTRA); \
       if (e != hipSuccess) return e;                                                                                         \
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(dattn_kernel<BQ, P_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, DA_LDS_BYTES);           \
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(dattn_kernel<BQ, P_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, DA_LDS_BYTES + DA_STAMP_EXTRA);           \
       if (e != hipSuccess) return e;                                                                                         \
       once.done();                                                                                                           \
     }                                                                                                                        \
-    if (bf16) hipLaunchKernelGGL((dattn_kernel<BQ, P_, true>), dim3(DA_GROUPS * DA_MEMBERS), dim3(DA_NT), DA_LDS_BYTES, stream, a);   \
-    else hipLaunchKernelGGL((dattn_kernel<BQ, P_, false>), dim3(DA_GROUPS * DA_MEMBERS), dim3(DA_NT), DA_LDS_BYTES, stream, a);       \
+    if (bf16) hipLaunchKernelGGL((dattn_kernel<BQ, P_, true>), dim3(DA_GROUPS * DA_MEMBERS), dim3(DA_NT), DA_LDS_BYTES + DA_STAMP_EXTRA, stream, a);   \
+    else hipLaunchKernelGGL((dattn_kernel<BQ, P_, false>), dim3(DA_GROUPS * DA_MEMBERS), dim3(DA_NT), DA_LDS_BYTES + DA_STAMP_EXTRA, stream, a);       \
     return hipGetLastError();                                                                                                \
   }
 

@@ -402,8 +402,9 @@ class FusedDecodeRunner(DecodeRunner):
         # Round 5: RMSNorm + q|k|v + RoPE / cache append + attention + o_proj as ONE launch per block (gbx_dattn_forward: one kv head per
         # XCD, hand-offs inside the XCD's L2, o_proj K-split by kv group into a fixed-point accumulator); the gate|up launch forms
         # h + o in its prologue, the down launch clears the accumulator -- three launches per block instead of five.
-        self.use_dattn = (env.flag("GBX_DATTN") and not tp and self.attn_ws is None and not self.fuse_ao and env.flag("GBX_DGEMV") and
-                          env.flag("GBX_QKV_CAT"))
+        # Long caches (the context split's territory): the launch's cooperative sweep covers them when a kv group has <= 4 query heads.
+        self.use_dattn = (env.flag("GBX_DATTN") and not tp and not self.fuse_ao and env.flag("GBX_DGEMV") and env.flag("GBX_QKV_CAT") and
+                          (self.attn_ws is None or a0.n_heads // a0.n_kv_heads <= 4))
         self.use_dmlp = self.use_dattn and env.flag("GBX_DMLP")
         self.da = []                        # per layer: (dattn, gate|up, down) or (dattn, dmlp) descriptors, or None (the five-launch block)
         self.da_pre = {}                    # layer -> (x, sums): pending fixed-point sums to finish into hb before a five-launch block

@@ -27,7 +27,7 @@ import bench  # noqa: E402
 
 cfg = S.LLAMA3_8B
 model = S.build_model(cfg, S.make_strategy("S22", cfg["num_hidden_layers"], 128), device=dev, seed=0)
-caches = bench.make_caches(model, 1, 512, dev)
+caches = bench.make_caches(model, 1, int(os.environ.get("CAPACITY", "512")), dev)
 L = _lib.lib()
 L.gbx_debug_stamp_reset.restype = None
 L.gbx_debug_stamp_reset()
@@ -47,8 +47,8 @@ runner.dattn_check()
 s = stamps.cpu().numpy().reshape(SLOTS, 4096, 16)
 END = {"dattn": 6, "dmlp": 7}
 labels = {
-    "dattn/producer": {0: "start", 1: "x, w, sums loads issued", 2: "barrier A (statistic)", 3: "barrier B (image; rows requested)", 4: "granule published", 10: "H2 received", 11: "o image built", 6: "end"},
-    "dattn/attention": {0: "start", 1: "K/V prefetch + o words issued", 5: "H1 received", 12: "RoPE done (barrier)", 13: "scores", 14: "values summed", 9: "output published", 10: "H2 received", 6: "end"},
+    "dattn/producer": {0: "start", 1: "x, w, sums loads issued", 2: "barrier A (statistic)", 3: "barrier B (image; rows requested)", 4: "granule published", 12: "coop: q rotated (barrier)", 5: "coop: staged scores", 7: "coop: sweep done", 8: "coop: states in LDS", 13: "coop: chunk swept (barrier)", 15: "coop: merge weights (barrier)", 14: "coop: states published", 10: "H2 received", 11: "o image built", 6: "end"},
+    "dattn/attention": {0: "start", 1: "K/V prefetch + o words issued", 5: "H1 received", 12: "RoPE done (barrier)", 13: "scores", 14: "values summed", 8: "merge input ready (coop: partial states received)", 9: "output published", 10: "H2 received", 6: "end"},
     "dmlp": {0: "start", 1: "sums, x, w loads issued", 9: "barrier A (statistic)", 10: "image written", 2: "barrier B", 3: "last gate|up rows requested", 4: "gate|up consumed, activations published", 5: "hand-off received (polling waves)", 6: "down image barrier", 7: "end"},
 }
 acc = {k: [] for k in labels}

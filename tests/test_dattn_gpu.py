@@ -76,6 +76,11 @@ def _close(got, want, what, rel=2e-2):
 CASES = [
     ("LLAMA3_8B", 2, 2, 40), ("LLAMA3_8B", 2, 2, 300), ("LLAMA3_8B", 3, 3, 9), ("LLAMA3_8B", 4, 4, 131), ("LLAMA3_8B", 2, 4, 200), ("LLAMA3_8B", 4, 2, 0),
     ("LLAMA32_3B", 2, 2, 17), ("LLAMA32_3B", 4, 4, 130), ("LLAMA32_3B", 3, 2, 64),
+    # beyond GBX_DATTN_COOP_MIN (384) positions the group's producers sweep the context in chunks (cooperative sweep): the first
+    # context that takes it, chunks that leave whole waves idle, ragged last chunks, a chunk longer than the register ring (beyond
+    # ~3.5 K positions), three query heads per kv head (the second head pair holds one head)
+    ("LLAMA3_8B", 2, 2, 385), ("LLAMA3_8B", 2, 2, 1500), ("LLAMA3_8B", 3, 4, 1023), ("LLAMA3_8B", 2, 2, 4000), ("LLAMA3_8B", 4, 2, 449),
+    ("LLAMA32_3B", 2, 2, 700), ("LLAMA32_3B", 4, 3, 2047), ("LLAMA32_3B", 3, 3, 390),
 ]
 
 
@@ -88,7 +93,9 @@ def test_dattn_launch_vs_fp64(cfg_name, bq, bo, ctx):
     D, nh, nkv, hd = cfg["hidden_size"], at.n_heads, at.n_kv_heads, at.head_dim
     cat = _cat_qkv(at)
     assert ops.dattn_supported(D, nh, nkv, hd, cat, at.o_proj), "the BASELINE geometries must be covered"
-    cap = 256 if ctx < 250 else 512
+    cap = 256
+    while cap <= ctx:
+        cap *= 2
     gen = torch.Generator(device="cpu").manual_seed(ctx + 1)
     h = (torch.randn(D, generator=gen) * 0.7).to(torch.bfloat16).to(DEV)
     kc = (torch.randn(1, nkv, cap, hd, generator=gen) * 0.5).to(torch.bfloat16).to(DEV)
@@ -128,6 +135,20 @@ def test_dattn_vector_form_when_the_matrix_core_form_is_switched_off():
             "print('VEC_OK')\n" % (ROOT, os.path.join(ROOT, "tests")))
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GBX_DATTN_MX="0"), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "VEC_OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_dattn_cooperative_sweep_at_short_contexts_and_on_the_vector_form():
+    """GBX_DATTN_COOP_MIN=8 (a child: read once per process) sends short contexts through the cooperative sweep -- chunks of four
+    positions, most producers with an empty chunk -- and GBX_DATTN_MX=0 puts the producers' phase 1 on the vector-ALU form before it."""
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_dattn_gpu as t\n"
+            "for case in (('LLAMA3_8B', 2, 2, 9), ('LLAMA3_8B', 2, 2, 40), ('LLAMA3_8B', 4, 3, 131), ('LLAMA32_3B', 2, 2, 17), ('LLAMA3_8B', 2, 2, 500)):\n"
+            "    t.test_dattn_launch_vs_fp64(*case)\n"
+            "print('COOP_OK')\n" % (ROOT, os.path.join(ROOT, "tests")))
+    for mx in ("1", "0"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GBX_DATTN_COOP_MIN="8", GBX_DATTN_MX=mx),
+                             capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and "COOP_OK" in out.stdout, out.stderr[-2000:]
 
 
 def test_dattn_repeated_launches_and_accumulator_protocol():

@@ -102,6 +102,33 @@ def test_one_8b_layer_through_the_fused_runner_vs_fp64(bits, dattn, monkeypatch)
     assert torch.isfinite(c.keys[0, :, ctx].float()).all() and torch.isfinite(c.values[0, :, ctx].float()).all()
 
 
+@pytest.mark.parametrize("bits", [2, 4])
+def test_long_cache_keeps_the_fused_launches(bits, monkeypatch):
+    """A cache of 2048 positions (the five-launch block would split the context over workgroups there): the fused attention launch
+    stays, with the kv group's producers sweeping the context in chunks; 1100 cached positions, against the fp64 layer."""
+    import bench
+    from gbx_lm_amd.decode import FusedDecodeRunner
+    monkeypatch.setenv("GBX_DATTN", "1")
+    monkeypatch.setenv("GBX_DMLP", "1")
+    model, cfg = _one_layer_model(bits)
+    ctx = 1100
+    caches = bench.make_caches(model, 1, 2048, DEV)
+    runner = FusedDecodeRunner(model, caches, use_graph=True)
+    assert runner.attn_ws is not None and runner.da[0] is not None, "long cache, fused launches"
+    for t in range(ctx):
+        runner.step(torch.tensor([(7 * t + 3) % 256], device=DEV))
+    tok = 77
+    c = caches[0]
+    kc, vc = c.keys[0, :, :ctx].clone(), c.values[0, :, :ctx].clone()
+    runner.step(torch.tensor([tok], device=DEV))
+    h_got = runner.hb.clone()
+    runner.dattn_check()
+    want = _ref_layer_fp64(model, model.model.embed_tokens.weight[tok], ctx, kc, vc)
+    err = (h_got.double() - want).abs()
+    tol = 2e-2 * want.abs() + 2e-2 * want.pow(2).mean().sqrt()
+    assert (err <= tol).all(), f"bits {bits}: {int((err > tol).sum())} of {want.numel()} outside tolerance, worst {err.max().item():.4g}"
+
+
 def _tokens(env_extra):
     code = (
         "import sys, torch; sys.path.insert(0, %r)\n"
