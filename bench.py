@@ -320,6 +320,7 @@ def decode_leg(model, cfg, dev, batch, context, steps, warmup, world=1, use_grap
     ms = time_decode(runner, steps, warmup, batch, world, dev) / steps
     if hasattr(runner, "dattn_check"):
         runner.dattn_check()
+    runner.norm_check()
     if world > 1:
         from gbx_lm_amd import tp as _tp
         _tp.p2p_check()
@@ -497,6 +498,7 @@ def main():
     ms = time_decode(runner, args.steps, args.warmup, args.batch, world, dev)
     if hasattr(runner, "dattn_check"):
         runner.dattn_check()            # a fused attention launch whose hand-off timed out voids the run (raises; off the timed path)
+    runner.norm_check()
     if world > 1:
         tp_allreduce += "; " + tp.p2p_check()      # a one-shot all-reduce that gave up on a peer voids the run (raises -> non-zero exit)
     launches = [d is not None for d in getattr(runner, "da", [])]

@@ -63,6 +63,9 @@ def lib() -> ctypes.CDLL:
             L.gbx_qlinear_partials_bytes.argtypes = [i64, i32, i32, i32, i32]
             L.gbx_qlinear_partials_bytes.restype = ctypes.c_size_t
         L.gbx_attn_workspace_bytes.restype = ctypes.c_size_t
+        if hasattr(L, 'gbx_norm_state_bytes'):
+            L.gbx_norm_state_bytes.argtypes = []
+            L.gbx_norm_state_bytes.restype = ctypes.c_size_t
         if hasattr(L, 'gbx_dattn_state_bytes'):
             L.gbx_dattn_state_bytes.argtypes = []
             L.gbx_dattn_state_bytes.restype = ctypes.c_size_t
@@ -172,7 +175,7 @@ class DmlpDesc(ctypes.Structure):
 
 GBX_DG_PLAIN, GBX_DG_RESIDUAL, GBX_DG_SWIGLU = 0, 1, 2
 GBX_DG_SSQ_SLOTS = 1024
-GBX_MIN_VERSION = 1201          # the header this binding mirrors
+GBX_MIN_VERSION = 1202          # the header this binding mirrors
 
 
 def _declare_optional(L) -> None:
@@ -195,6 +198,7 @@ def _declare_optional(L) -> None:
         "gbx_qlinear_swiglu_forward": [p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, p],
         "gbx_qlinear_forward_partials": [p, p, p, p, p, ctypes.c_size_t, ctypes.POINTER(i32), i64, i32, i32, i32, i32, i32, p],
         "gbx_add_rmsnorm_slices": [p, p, i32, p, p, i64, i32, f32, i32, p],
+        "gbx_add_rmsnorm_slices_xcd": [p, p, i32, p, p, i64, i32, f32, i32, p, p],
         "gbx_dense_forward": [p, p, p, p, i64, i32, i32, i32, p],
         "gbx_attn_decode": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, f32, f32, i32, i32, p],
         "gbx_attn_decode_batched": [p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, f32, i32, i32, p],

@@ -32,9 +32,9 @@ extern "C" void gbx_debug_stamp_reset(void) { gbx::g_stamp_launch = 0; }
 
 extern "C" {
 
-/* 1201: + gbx_dattn.x_acc / x_out / zero_buf, gbx_dmlp_*, gbx_acc_residual.  1200: gbx_dgemv grows (x_acc, x_out, zero_buf, zero_n) + gbx_dattn_* + gbx_dgemv_kernel_id.  1101: + gbx_attn_decode_slices (an addition: nothing else changed).  1100: gbx_dgemv_* entry points; gbx_qlinear_fused (x_acc, x_out, zero_buf, zero_n since 1001) -- a consumer built against
+/* 1202: + gbx_add_rmsnorm_slices_xcd, gbx_norm_state_bytes (additions).  1201: + gbx_dattn.x_acc / x_out / zero_buf, gbx_dmlp_*, gbx_acc_residual.  1200: gbx_dgemv grows (x_acc, x_out, zero_buf, zero_n) + gbx_dattn_* + gbx_dgemv_kernel_id.  1101: + gbx_attn_decode_slices (an addition: nothing else changed).  1100: gbx_dgemv_* entry points; gbx_qlinear_fused (x_acc, x_out, zero_buf, zero_n since 1001) -- a consumer built against
  * an older header must not pass its shorter struct to this library: check gbx_version() >= the header it compiled with. */
-int gbx_version(void) { return 1201; }
+int gbx_version(void) { return 1202; }
 
 const char* gbx_last_error(void) { return g_err; }
 
@@ -815,6 +815,24 @@ int gbx_add_rmsnorm_slices(void* h, const float* slices_ws, int32_t slices, cons
   if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
   hipError_t e = gbx::launch_add_rmsnorm_slices(h, slices_ws, slices, w, y, static_cast<int>(M), K, eps, act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));
   if (e != hipSuccess) return hip_fail(e, "gbx_add_rmsnorm_slices launch");
+  return GBX_OK;
+}
+
+size_t gbx_norm_state_bytes(void) { return gbx::slices_norm_state_bytes(); }
+
+int gbx_add_rmsnorm_slices_xcd(void* h, const float* slices_ws, int32_t slices, const void* w, void* y, int64_t M, int32_t K, float eps,
+                               int32_t act_dtype, void* state, void* hip_stream) {
+  if (M == 0) return GBX_OK;
+  if (!h || !slices_ws || !w || !y || !state) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (M < 0 || M > 65535 || K <= 0 || slices < 1) return fail(GBX_ERR_INVALID, "bad shape M=%lld K=%d slices=%d", (long long)M, K, slices);
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  if (!gbx::slices_norm_xcd_supported(static_cast<int>(M), K) || !aligned(h, 16) || !aligned(slices_ws, 16) || !aligned(w, 16) || !aligned(y, 16) ||
+      !aligned(state, 64))
+    return fail(GBX_ERR_UNSUPPORTED, "gbx_add_rmsnorm_slices_xcd needs K %% 512 == 0, K <= 4096, M <= 8 * (32 / (K / 512)) and aligned tensors (M = %lld, K = %d)",
+                (long long)M, K);
+  hipError_t e = gbx::launch_add_rmsnorm_slices_xcd(h, slices_ws, slices, w, y, static_cast<int>(M), K, eps, act_dtype == GBX_BF16, state,
+                                                    static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_add_rmsnorm_slices_xcd launch");
   return GBX_OK;
 }
 

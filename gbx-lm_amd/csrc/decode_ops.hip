@@ -1199,6 +1199,114 @@ hipError_t launch_add_rmsnorm_slices(void* h, const float* ws, int slices, const
   return hipGetLastError();
 }
 
+// The same launch spread over the whole chip (B = 32 decode: the one-workgroup-per-row form above pulls 8 slices x 16 KB = 128 KB
+// through ONE CU per row -- 4.9 us at that CU's fill rate -- and 224 of the 256 CUs idle).  A row is cut into K / 512 segments of 512
+// values, one single-wave workgroup each (8 values per lane); the row's statistic is the sum of the segments' partials, exchanged
+// through the L2 of ONE XCD: the workgroups of a row are placed on the same XCD by construction (group = HW_REG_XCC_ID, member =
+// blockIdx / 8, row = group + 8 * (member / segments): the fused attention launch's scheme, dattn_impl.h), so the partials leave as
+// workgroup-scope {tag, value} granule stores (write-through to that L2) and are polled with agent-scope loads (served by that L2).
+// A placement that is not a bijection leaves a row short of a segment and the launch raises its status word (bounded polls) instead
+// of returning a wrong row.  Tags come from a generation word per (group, row slot) that segment 0 advances when it has the row's
+// partials (every segment has read the word by then).  h is bit-identical to the launch above (same slice order, same roundings); the
+// statistic is summed in a different order (segment partials), so y may differ from it in the last place.
+constexpr int SN_STATUS_WORD = 256 * 16;                  // u32 index: gen words [256][16], then the status word
+constexpr int SN_HAND_BYTES = (256 * 16 + 16) * 4;        // granules [256 row slots][8 segments] start here
+constexpr unsigned SN_SPIN_LIMIT = 1u << 22;
+size_t slices_norm_state_bytes() { return static_cast<size_t>(SN_HAND_BYTES) + 256 * 8 * 8; }
+bool slices_norm_xcd_supported(int M, int K) {
+  if (K % 512 || K / 512 > 8 || K < 512) return false;
+  const int S = K / 512;
+  return M >= 1 && M <= 8 * (32 / S);
+}
+typedef __attribute__((address_space(1))) unsigned long long sn_gu64;
+typedef __attribute__((address_space(1))) unsigned sn_gu32;
+
+template <bool BF16>
+__global__ __launch_bounds__(64) void slices_norm_xcd_kernel(unsigned short* __restrict__ h, const float* __restrict__ ws, int slices, long long mn,
+                                                             const unsigned short* __restrict__ w, unsigned short* __restrict__ y, int M, int K,
+                                                             float eps, unsigned* state) {
+  const int lane = threadIdx.x;
+  const int g = static_cast<int>(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);       // HW_REG_XCC_ID
+  const int j = static_cast<int>(blockIdx.x) >> 3;
+  const int S = K >> 9;
+  const int rs = j / S, seg = j - rs * S;
+  const int row = g + 8 * rs;
+  if (row >= M || rs >= 32 / S) return;                       // (whole rows: every segment of a row takes the same branch)
+  sn_gu32* gen_p = reinterpret_cast<sn_gu32*>(reinterpret_cast<uintptr_t>(state)) + (g * 32 + rs) * 16;
+  sn_gu64* hand = reinterpret_cast<sn_gu64*>(reinterpret_cast<uintptr_t>(state) + SN_HAND_BYTES) + (g * 32 + rs) * 8;
+  const unsigned gen = __hip_atomic_load(gen_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const size_t off = static_cast<size_t>(row) * K + static_cast<size_t>(seg * 64 + lane) * 8;
+  // every slice is requested before the first add; the adds keep the order v = ws[0]; v += ws[s], s = 1.. (batch_finish_kernel)
+  const float* src = ws + off;
+  f32x4s a0 = *reinterpret_cast<const f32x4s*>(src), a1 = *reinterpret_cast<const f32x4s*>(src + 4);
+  const u32x4 hv0 = *reinterpret_cast<const u32x4*>(h + off);
+  const u32x4 wv = *reinterpret_cast<const u32x4*>(w + static_cast<size_t>(seg * 64 + lane) * 8);
+  for (int sl = 1; sl < slices; sl += 8) {
+    f32x4s t0[8], t1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float* sp = src + static_cast<size_t>(min(sl + i, slices - 1)) * mn;
+      t0[i] = *reinterpret_cast<const f32x4s*>(sp);
+      t1[i] = *reinterpret_cast<const f32x4s*>(sp + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (sl + i < slices) { a0 += t0[i]; a1 += t1[i]; }
+  }
+  const unsigned dw[4] = {static_cast<unsigned>(f32_to_act<BF16>(a0.x)) | (static_cast<unsigned>(f32_to_act<BF16>(a0.y)) << 16),
+                          static_cast<unsigned>(f32_to_act<BF16>(a0.z)) | (static_cast<unsigned>(f32_to_act<BF16>(a0.w)) << 16),
+                          static_cast<unsigned>(f32_to_act<BF16>(a1.x)) | (static_cast<unsigned>(f32_to_act<BF16>(a1.y)) << 16),
+                          static_cast<unsigned>(f32_to_act<BF16>(a1.z)) | (static_cast<unsigned>(f32_to_act<BF16>(a1.w)) << 16)};
+  const unsigned hw[4] = {hv0.x, hv0.y, hv0.z, hv0.w};
+  unsigned o[4];
+  float ssq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o[i] = static_cast<unsigned>(f32_to_act<BF16>(act_lo<BF16>(hw[i]) + act_lo<BF16>(dw[i]))) |
+           (static_cast<unsigned>(f32_to_act<BF16>(act_hi<BF16>(hw[i]) + act_hi<BF16>(dw[i]))) << 16);
+    const float v0 = act_lo<BF16>(o[i]), v1 = act_hi<BF16>(o[i]);
+    ssq = fmaf(v0, v0, fmaf(v1, v1, ssq));
+  }
+  *reinterpret_cast<u32x4*>(h + off) = u32x4{o[0], o[1], o[2], o[3]};
+  ssq = wave_sum(ssq);                                        // (wave-uniform)
+  unsigned tag = gen + 1u;
+  if (tag == 0u) tag = 1u;
+  if (lane == 0)
+    __hip_atomic_store(hand + seg, (static_cast<unsigned long long>(tag) << 32) | __float_as_uint(ssq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  unsigned long long gv;
+  for (unsigned spins = 0;;) {
+    gv = __hip_atomic_load(hand + min(lane, S - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__all(static_cast<unsigned>(gv >> 32) == tag)) break;
+    if (++spins > SN_SPIN_LIMIT) {
+      if (lane == 0) atomicOr(state + SN_STATUS_WORD, 1u);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  float tot = 0.f;
+  for (int i = 0; i < S; ++i) tot += __uint_as_float(static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<unsigned>(gv)), i)));
+  const float rstd = rsqrtf(tot / static_cast<float>(K) + eps);
+  const unsigned ww[4] = {wv.x, wv.y, wv.z, wv.w};
+  unsigned yo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    yo[i] = static_cast<unsigned>(f32_to_act<BF16>(act_lo<BF16>(o[i]) * rstd * act_lo<BF16>(ww[i]))) |
+            (static_cast<unsigned>(f32_to_act<BF16>(act_hi<BF16>(o[i]) * rstd * act_hi<BF16>(ww[i]))) << 16);
+  *reinterpret_cast<u32x4*>(y + off) = u32x4{yo[0], yo[1], yo[2], yo[3]};
+  if (seg == 0 && lane == 0) __hip_atomic_store(gen_p, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+hipError_t launch_add_rmsnorm_slices_xcd(void* h, const float* ws, int slices, const void* w, void* y, int M, int K, float eps, bool bf16,
+                                         void* state, hipStream_t s) {
+  auto H = static_cast<unsigned short*>(h);
+  auto W = static_cast<const unsigned short*>(w);
+  auto Y = static_cast<unsigned short*>(y);
+  const long long mn = static_cast<long long>(M) * K;
+  if (bf16) hipLaunchKernelGGL((slices_norm_xcd_kernel<true>), dim3(256), dim3(64), 0, s, H, ws, slices, mn, W, Y, M, K, eps, static_cast<unsigned*>(state));
+  else hipLaunchKernelGGL((slices_norm_xcd_kernel<false>), dim3(256), dim3(64), 0, s, H, ws, slices, mn, W, Y, M, K, eps, static_cast<unsigned*>(state));
+  return hipGetLastError();
+}
+
 // SwiGLU glue for batched decode: y = round(round(silu(g)) * u), the two roundings of `nn.silu(gate) * up` in the
 // activation dtype (qllama.py:115).  8 values (16 bytes) per thread.
 template <bool BF16>

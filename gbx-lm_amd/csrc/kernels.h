@@ -95,6 +95,11 @@ hipError_t launch_qgemm_partials(const void* x, const uint32_t* qw, const void* 
                                  int bits, int log2g, bool bf16, hipStream_t s);
 int qgemm_batch_slices(int M, int N, int K, int bits, int log2g);
 hipError_t launch_add_rmsnorm_slices(void* h, const float* ws, int slices, const void* w, void* y, int M, int K, float eps, bool bf16, hipStream_t s);
+// the same spread over the chip, the row statistic exchanged inside one XCD's L2 (decode_ops.hip); state: slices_norm_state_bytes() zeroed bytes
+size_t slices_norm_state_bytes();
+bool slices_norm_xcd_supported(int M, int K);
+hipError_t launch_add_rmsnorm_slices_xcd(void* h, const float* ws, int slices, const void* w, void* y, int M, int K, float eps, bool bf16,
+                                         void* state, hipStream_t s);
 hipError_t launch_prepack_tiles(const uint32_t* qw, const void* sc, const void* ze, const uint32_t* qw2, const void* sc2,
                                 const void* ze2, uint32_t* wt, uint32_t* szt, int N, int K, hipStream_t s);
 hipError_t launch_gemv_mfma(const void* x, const uint32_t* wt, const uint32_t* szt, void* y, int N, int K, const void* norm_w,

@@ -40,6 +40,8 @@ class DecodeRunner:
         self.n_heads, self.n_kv, self.hd = a0.n_heads, a0.n_kv_heads, a0.head_dim
         self.ar = torch.arange(self.capacity, device=self.dev)
         self.tp_world = getattr(model, "tp_world", 1)
+        # generation words of the chip-wide slice-sum + norm launches (batched decode): created before any capture
+        self.norm_state = ops.norm_state(self.dev) if (self.batch > 1 and self.dev.type == "cuda") else None
         # B > 1: q|k|v as ONE row-concatenated matrix (+7 MB per 2-bit 8B layer) so that the batch GEMM can split k across workgroups --
         # every workgroup then stages a quarter of the activations, the term that bounds it -- and leave fp32 slices that the
         # attention launch sums (gbx_attn_decode_slices); 11.5 -> 9.4 us per layer at B = 32
@@ -71,6 +73,12 @@ class DecodeRunner:
         if use_graph:
             self._capture()
 
+    def norm_check(self) -> None:
+        """Raise if a chip-wide slice-sum + norm launch of this runner ran out of polls (synchronises: call off the timed path)."""
+        if self.norm_state is not None and ops.norm_status(self.norm_state):
+            raise RuntimeError("gbx_add_rmsnorm_slices_xcd: a row's partial statistics did not meet (workgroup placement broke the "
+                               "blockIdx % 8 <-> XCD bijection); the results of this runner are invalid -- rerun with GBX_NORM_XCD=0")
+
     # one decode token, all shapes static, position read from device memory
     def _forward(self):
         m = self.model.model
@@ -86,7 +94,7 @@ class DecodeRunner:
             if delta is None:
                 x = ops.rmsnorm(h, norm.weight, norm.eps)
             elif isinstance(delta, tuple):           # fp32 slices of the previous block's k-split down projection
-                x = ops.add_rmsnorm_slices(h, delta[0], delta[1], norm.weight, norm.eps)
+                x = ops.add_rmsnorm_slices(h, delta[0], delta[1], norm.weight, norm.eps, self.norm_state)
             else:
                 x = ops.add_rmsnorm(h, delta, norm.weight, norm.eps)
             qn, kn = getattr(at, "q_norm", None), getattr(at, "k_norm", None)       # Qwen3: per-head norms before RoPE
@@ -135,7 +143,7 @@ class DecodeRunner:
             norm = layer.post_attention_layernorm
             parts = ops.quantized_matmul_partials(o.reshape(B, -1), at.o_proj) if (B > 1 and self.tp_world == 1) else None
             if parts is not None:                    # k split across workgroups, summed inside the add + norm launch
-                x = ops.add_rmsnorm_slices(h, parts[0], parts[1], norm.weight, norm.eps)
+                x = ops.add_rmsnorm_slices(h, parts[0], parts[1], norm.weight, norm.eps, self.norm_state)
             else:
                 o = at.o_proj(o.reshape(B, 1, -1))
                 if self.tp_world > 1:
@@ -158,7 +166,7 @@ class DecodeRunner:
             else:
                 delta = mlp(x).reshape(h.shape).contiguous()
         if isinstance(delta, tuple):
-            out = ops.add_rmsnorm_slices(h, delta[0], delta[1], m.norm.weight, m.norm.eps)
+            out = ops.add_rmsnorm_slices(h, delta[0], delta[1], m.norm.weight, m.norm.eps, self.norm_state)
         else:
             h = h + delta
             out = ops.rmsnorm(h, m.norm.weight, m.norm.eps)

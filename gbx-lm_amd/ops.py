@@ -525,12 +525,32 @@ def quantized_matmul_partials(x: torch.Tensor, mod):
     return ws, int(slices.value)
 
 
-def add_rmsnorm_slices(h: torch.Tensor, ws: torch.Tensor, slices: int, w: torch.Tensor, eps: float) -> torch.Tensor:
-    """h += round(sum of the fp32 slices) in place, returns RMSNorm(h) * w -- one launch (gbx_add_rmsnorm_slices)."""
+def norm_state(device) -> torch.Tensor:
+    """Zeroed state buffer of the chip-wide slice-sum + norm launches (gbx_norm_state_bytes): one per stream, created before any
+    graph capture (its generation words must survive replays)."""
+    return torch.zeros((_lib.lib().gbx_norm_state_bytes(),), dtype=torch.uint8, device=device)
+
+
+NORM_STATUS_OFFSET = 16384      # include/gbx_qlinear.h: GBX_NORM_STATUS_OFFSET
+
+
+def norm_status(state: torch.Tensor) -> int:
+    """0, or 1 after a launch on ``state`` whose polls ran out (synchronises: outside the timed path)."""
+    return int(state[NORM_STATUS_OFFSET:NORM_STATUS_OFFSET + 4].view(torch.int32).item())
+
+
+def add_rmsnorm_slices(h: torch.Tensor, ws: torch.Tensor, slices: int, w: torch.Tensor, eps: float, state: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """h += round(sum of the fp32 slices) in place, returns RMSNorm(h) * w -- one launch (gbx_add_rmsnorm_slices; with ``state`` and a
+    shape it covers, the chip-wide form gbx_add_rmsnorm_slices_xcd)."""
     k = h.shape[-1]
     assert h.is_contiguous() and ws.numel() >= slices * h.numel()
     y = torch.empty_like(h)
-    _lib.check(_lib.lib().gbx_add_rmsnorm_slices(h.data_ptr(), ws.data_ptr(), slices, w.data_ptr(), y.data_ptr(), h.numel() // k, k,
+    m = h.numel() // k
+    if state is not None and env.flag("GBX_NORM_XCD") and k % 512 == 0 and k <= 4096 and m <= 8 * (32 // (k // 512)):
+        _lib.check(_lib.lib().gbx_add_rmsnorm_slices_xcd(h.data_ptr(), ws.data_ptr(), slices, w.data_ptr(), y.data_ptr(), m, k, float(eps),
+                                                         _DT[h.dtype], state.data_ptr(), _stream_ptr(h.device)))
+        return y
+    _lib.check(_lib.lib().gbx_add_rmsnorm_slices(h.data_ptr(), ws.data_ptr(), slices, w.data_ptr(), y.data_ptr(), m, k,
                                                  float(eps), _DT[h.dtype], _stream_ptr(h.device)))
     return y
 

@@ -317,6 +317,20 @@ int gbx_qlinear_forward_partials(const void* x, const uint32_t* qweight, const v
 int gbx_add_rmsnorm_slices(void* h, const float* slices_ws, int32_t slices, const void* w, void* y, int64_t M, int32_t K, float eps,
                            int32_t act_dtype, void* hip_stream);
 
+/* gbx_add_rmsnorm_slices spread over the whole chip: a row is cut into K / 512 segments (one single-wave workgroup each) whose
+ * partial sums of squares meet in the L2 of one XCD (the row's workgroups share an XCD by construction; {tag, value} granules, bounded
+ * polls).  The one-workgroup-per-row form pulls slices * 4 * K bytes through one CU per row; at M = 32, K = 4096, 8 slices this form
+ * measures [see DESIGN 3.8] against 4.9 us.  h is bit-identical to gbx_add_rmsnorm_slices; y may differ in the last place (the statistic
+ * is summed per segment).  K % 512 == 0, K <= 4096, M <= 8 * (32 / (K / 512)), else GBX_ERR_UNSUPPORTED.
+ * state: gbx_norm_state_bytes() bytes, 64-byte aligned, zeroed ONCE by the caller and then owned by these launches (generation tags:
+ * one buffer serves every launch of a stream).  The 32-bit word at byte GBX_NORM_STATUS_OFFSET of state is 0, or 1 after a launch
+ * whose polls ran out (placement anomaly): the caller reads it outside the timed path.
+ * Replaces the same reference lines as gbx_add_rmsnorm_slices (gbx_lm/models/qllama.py:137-141: residual add + RMSNorm of the block). */
+size_t gbx_norm_state_bytes(void);
+int gbx_add_rmsnorm_slices_xcd(void* h, const float* slices_ws, int32_t slices, const void* w, void* y, int64_t M, int32_t K, float eps,
+                               int32_t act_dtype, void* state, void* hip_stream);
+#define GBX_NORM_STATUS_OFFSET 16384
+
 /* y[M,N] = x[M,K] . w[N,K]^T (+ bias[N] as a second rounding) for UNQUANTISED 16-bit weights on the matrix cores
  * (csrc/mfma_dense.hip: 256 x 256 tiles, LDS-DMA staging): the output head of a batch of decode rows (`nn.Linear lm_head` /
  * `embed_tokens.as_linear`, gbx_lm/models/qllama.py:194-198, M = batch: the weight matrix is streamed once for all rows)

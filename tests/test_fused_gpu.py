@@ -831,3 +831,48 @@ def test_dense_forward_matches_fp64(dtype, m, n, k):
     tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
     rms = ref.pow(2).mean().sqrt().item()
     assert y.shape == (m, n) and ((y.double() - ref).abs() <= tol * rms + tol * ref.abs()).all()
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,k,slices", [(32, 4096, 8), (5, 4096, 3), (32, 3072, 7), (17, 2048, 1), (40, 3072, 2), (64, 2048, 4), (1, 512, 2)])
+def test_chip_wide_slice_norm_vs_the_row_per_workgroup_launch(dt, m, k, slices):
+    """gbx_add_rmsnorm_slices_xcd (a row cut into 512-value segments over the whole chip, the statistic exchanged inside one XCD's L2)
+    against gbx_add_rmsnorm_slices: h bit-identical (same slice order and roundings), y equal up to one place of the output type (the
+    statistic is summed per segment), and y against an fp64 restatement.  One state buffer serves 40 launches back to back with
+    changing inputs (generation tags), and the status word stays 0."""
+    from gbx_lm_amd import ops
+    gen = torch.Generator().manual_seed(m * 7 + k + slices)
+    state = ops.norm_state(DEV)
+    w = (1 + 0.1 * torch.randn(k, generator=gen)).to(dt).to(DEV)
+    for it in range(40):
+        ws = (torch.randn(slices, m, k, generator=gen) * (0.5 + 0.1 * it)).to(DEV)
+        h0 = torch.randn(m, k, generator=gen).to(dt).to(DEV)
+        h1, h2 = h0.clone(), h0.clone()
+        y1 = ops.add_rmsnorm_slices(h1, ws, slices, w, 1e-5, state)
+        y2 = ops.add_rmsnorm_slices(h2, ws, slices, w, 1e-5)
+        assert torch.equal(h1, h2), f"launch {it}: the residual stream differs"
+        ulp = 2.0 ** (-7 if dt == torch.bfloat16 else -10)
+        assert ((y1.double() - y2.double()).abs() <= ulp * y2.double().abs() + 1e-30).all(), f"launch {it}: y differs by more than one place"
+    assert ops.norm_status(state) == 0
+    acc = ws[0].clone()
+    for s in range(1, slices):
+        acc += ws[s]
+    hh = (h0.float() + acc.to(dt).float()).to(dt)
+    assert torch.equal(h1, hh)
+    hf = hh.double()
+    want = hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + 1e-5) * w.double()
+    err = (y1.double() - want).abs()
+    assert (err <= 2 * ulp * want.abs() + 1e-6).all()
+
+
+def test_chip_wide_slice_norm_refuses_what_it_does_not_cover():
+    from gbx_lm_amd import _lib, ops
+    state = ops.norm_state(DEV)
+    for m, k in ((33, 4096), (4, 4608), (4, 768), (41, 3072)):
+        h = torch.zeros(m, k, dtype=torch.bfloat16, device=DEV)
+        ws = torch.zeros(1, m, k, device=DEV)
+        rc = _lib.lib().gbx_add_rmsnorm_slices_xcd(h.data_ptr(), ws.data_ptr(), 1, h.data_ptr(), h.data_ptr(), m, k, 1e-5, _lib.GBX_BF16, state.data_ptr(), None)
+        assert rc == _lib.GBX_ERR_UNSUPPORTED, (m, k, rc)
+        # the host wrapper keeps such shapes on the row-per-workgroup launch
+        y = ops.add_rmsnorm_slices(h, ws, 1, torch.ones(k, dtype=torch.bfloat16, device=DEV), 1e-5, state)
+        assert y.shape == h.shape
