@@ -278,7 +278,7 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
   unsigned tag;
   if (r >= rep) {
     // cooperative sweep: the RoPE frequency of this lane's q pair, fetched with the prologue's loads (one register through phase 1)
-    const float coop_invf = (coop && wave < rep) ? a.inv_freq[lane] : 0.f;
+    const float coop_invf = (coop && wave >= NW - rep) ? a.inv_freq[lane] : 0.f;
     if constexpr (MX != 0) {
     // ================= phase 1 on the matrix cores (dgemv_mx.hip's arithmetic; 2 bits, group 128, K = 4096 = two spans) =================
     constexpr int SP = 2, NBLK = SP * 64;
@@ -718,19 +718,24 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
       const __amdgpu_buffer_rsrc_t vd = rsrc(a.vcache + static_cast<size_t>(g) * a.capacity * HD, a.capacity * HD * 2);
       const int tl0 = p0 + cps * 4 + csub;                      // this lane's position in round 0
       u32x4 kc[RB], vc[RB];
+      auto issue_ring = [&]() {
 #pragma unroll
-      for (int u = 0; u < RB; ++u) {
-        const int t = tl0 + u * ppr;
-        const unsigned off = static_cast<unsigned>(t * (HD * 2) + cd0 * 2) | (t < p1 ? 0u : KILL);
-        kc[u] = __builtin_amdgcn_raw_buffer_load_b128(kd, off, 0, 0);
-        vc[u] = __builtin_amdgcn_raw_buffer_load_b128(vd, off, 0, 0);
-      }
-      if (wave >= rep) issue_o();
-      if (wave < rep) {                                         // head `wave` of the group: its q pairs, rotated like the head's own workgroup does
+        for (int u = 0; u < RB; ++u) {
+          const int t = tl0 + u * ppr;
+          const unsigned off = static_cast<unsigned>(t * (HD * 2) + cd0 * 2) | (t < p1 ? 0u : KILL);
+          kc[u] = __builtin_amdgcn_raw_buffer_load_b128(kd, off, 0, 0);
+          vc[u] = __builtin_amdgcn_raw_buffer_load_b128(vd, off, 0, 0);
+        }
+      };
+      // The LAST `rep` waves rotate q (one head each).  Loads return in order, so a polling wave asks for nothing before its poll -- its
+      // own rows would hold the first poll back by their latency; the last waves own the position sets that run out of positions first.
+      const int qh = wave - (NW - rep);
+      if (qh < 0) { issue_ring(); issue_o(); }
+      if (qh >= 0) {                                            // head qh of the group: its q pairs, rotated like the head's own workgroup does
         const int i = lane;
         const int i1 = a.traditional ? 2 * i : i;
         const int i2 = a.traditional ? 2 * i + 1 : i + HD / 2;
-        da_gu64* base = hand1 + wave * (HD / 2);
+        da_gu64* base = hand1 + qh * (HD / 2);
         unsigned w1, w2;
         sweep2(base + (i1 >> 1), base + (i2 >> 1), tag, 4u, w1, w2);
         const float rev = static_cast<float>(cpos) * a.rope_scale * coop_invf * 0.15915494309189535f;
@@ -739,8 +744,9 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
         const float x1 = act_to_f32<BF16>(static_cast<unsigned short>((i1 & 1) ? (w1 >> 16) : (w1 & 0xFFFFu)));
         const float x2 = act_to_f32<BF16>(static_cast<unsigned short>((i2 & 1) ? (w2 >> 16) : (w2 & 0xFFFFu)));
         const unsigned short r1 = f32_to_act<BF16>(x1 * cs - x2 * sn), r2 = f32_to_act<BF16>(x1 * sn + x2 * cs);
-        q_s[wave * HD + i1] = act_to_f32<BF16>(r1) * a.sm_scale;
-        q_s[wave * HD + i2] = act_to_f32<BF16>(r2) * a.sm_scale;
+        q_s[qh * HD + i1] = act_to_f32<BF16>(r1) * a.sm_scale;
+        q_s[qh * HD + i2] = act_to_f32<BF16>(r2) * a.sm_scale;
+        issue_ring();
         issue_o();
       }
       __syncthreads();
