@@ -37,7 +37,8 @@ constexpr int DA_MEMBERS = 32;               // workgroups per group
 constexpr int DA_NW = 16, DA_NT = DA_NW * 64;
 constexpr int DA_HD = 128;
 constexpr int DA_OP = 2;                     // o_proj lane passes held in registers
-constexpr int DA_HAND_STRIDE = 2048;         // granules (8 bytes) per group: [0, 1024) phase 1, [1024, 2048) attention output
+constexpr int DA_HAND_STRIDE = 2048;         // granules (8 bytes) per group: [0, 1024) phase 1, [1024, 1536) attention output, [1536, 1792) rotated q (cooperative sweep)
+constexpr int DA_HAND_QROT = 1536;
 constexpr int DA_STATE_WORDS = 64 * 16;      // u32: gen[g] at g * 16 (one 64-byte line each), status at 8 * 16, placement at 9 * 16
 constexpr unsigned DA_SPIN_LIMIT = 1u << 22;
 constexpr int DA_PART_STRIDE = 132;          // granules per partial softmax state: {tag, max}, {tag, denominator}, 128 x {tag, numerator}, 2 pad

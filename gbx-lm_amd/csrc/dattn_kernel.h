@@ -277,8 +277,6 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
 
   unsigned tag;
   if (r >= rep) {
-    // cooperative sweep: the RoPE frequency of this lane's q pair, fetched with the prologue's loads (one register through phase 1)
-    const float coop_invf = (coop && wave >= NW - rep) ? a.inv_freq[lane] : 0.f;
     if constexpr (MX != 0) {
     // ================= phase 1 on the matrix cores (dgemv_mx.hip's arithmetic; 2 bits, group 128, K = 4096 = two spans) =================
     constexpr int SP = 2, NBLK = SP * 64;
@@ -727,23 +725,18 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
           vc[u] = __builtin_amdgcn_raw_buffer_load_b128(vd, off, 0, 0);
         }
       };
-      // The LAST `rep` waves rotate q (one head each).  Loads return in order, so a polling wave asks for nothing before its poll -- its
+      // The LAST `rep` waves fetch the rotated q (one head each).  Loads return in order, so a polling wave asks for nothing before its poll -- its
       // own rows would hold the first poll back by their latency; the last waves own the position sets that run out of positions first.
       const int qh = wave - (NW - rep);
       if (qh < 0) { issue_ring(); issue_o(); }
-      if (qh >= 0) {                                            // head qh of the group: its q pairs, rotated like the head's own workgroup does
+      if (qh >= 0) {                                            // head qh of the group: its rotated q pairs
         const int i = lane;
         const int i1 = a.traditional ? 2 * i : i;
         const int i2 = a.traditional ? 2 * i + 1 : i + HD / 2;
-        da_gu64* base = hand1 + qh * (HD / 2);
-        unsigned w1, w2;
-        sweep2(base + (i1 >> 1), base + (i2 >> 1), tag, 4u, w1, w2);
-        const float rev = static_cast<float>(cpos) * a.rope_scale * coop_invf * 0.15915494309189535f;
-        const float fr = rev - floorf(rev);
-        const float sn = __builtin_amdgcn_sinf(fr), cs = __builtin_amdgcn_cosf(fr);
-        const float x1 = act_to_f32<BF16>(static_cast<unsigned short>((i1 & 1) ? (w1 >> 16) : (w1 & 0xFFFFu)));
-        const float x2 = act_to_f32<BF16>(static_cast<unsigned short>((i2 & 1) ? (w2 >> 16) : (w2 & 0xFFFFu)));
-        const unsigned short r1 = f32_to_act<BF16>(x1 * cs - x2 * sn), r2 = f32_to_act<BF16>(x1 * sn + x2 * cs);
+        // (the head's own workgroup has rotated q 0.5 us after the last q row is out -- this workgroup's poll starts behind its own rows --
+        //  and publishes the rotated pairs as 64 more granules)
+        const unsigned rw = sweep(hand1 + DA_HAND_QROT + qh * (HD / 2) + lane, tag, 4u);
+        const unsigned short r1 = static_cast<unsigned short>(rw & 0xFFFFu), r2 = static_cast<unsigned short>(rw >> 16);
         q_s[qh * HD + i1] = act_to_f32<BF16>(r1) * a.sm_scale;
         q_s[qh * HD + i2] = act_to_f32<BF16>(r2) * a.sm_scale;
         issue_ring();
@@ -941,6 +934,9 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
       } else {
         q_s[i1] = act_to_f32<BF16>(r1) * a.sm_scale;
         q_s[i2] = act_to_f32<BF16>(r2) * a.sm_scale;
+        if (coop)                                               // the group's producers sweep with it
+          __hip_atomic_store(hand1 + DA_HAND_QROT + r * (HD / 2) + lane, (static_cast<unsigned long long>(tag) << 32) | r1 | (static_cast<unsigned>(r2) << 16),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     } else if (wave == 2) {
       const unsigned vw = sweep(hand1 + (rep + 1) * (HD / 2) + lane, tag, 1u);
