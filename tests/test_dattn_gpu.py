@@ -19,8 +19,11 @@ DEV = "cuda:0"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+DT = torch.bfloat16           # activation dtype of the module's helpers (the fp16 test below swaps it)
+
+
 def _bf(x):
-    return x.to(torch.bfloat16).double()
+    return x.to(DT).double()
 
 
 def _deq(m):
@@ -35,7 +38,7 @@ def _layer(cfg_name, bits_qkv, bits_o, group=128, seed=0):
     for p in strat["model.layers.0"]:
         b = bits_o if p.endswith("o_proj") else bits_qkv
         strat["model.layers.0"][p] = {"bits": [b], "group_size": {str(b): group}}
-    return S.build_model(cfg, strat, device=DEV, seed=seed), cfg
+    return S.build_model(cfg, strat, device=DEV, seed=seed, act_dtype=DT), cfg
 
 
 def _cat_qkv(at):
@@ -57,8 +60,8 @@ def _reference(blk, h, pos, kc, vc):
     q, k, v = _bf(_deq(at.q_proj) @ xn), _bf(_deq(at.k_proj) @ xn), _bf(_deq(at.v_proj) @ xn)
     inv = at.rope.inv_freq.cpu()
     sc = getattr(at.rope, "scale", 1.0)
-    qr = apply_rope(q.to(torch.bfloat16).cpu().view(1, nh, 1, hd), inv, pos, sc, at.rope.traditional).to(DEV).double().view(nh, hd)
-    kr = apply_rope(k.to(torch.bfloat16).cpu().view(1, nkv, 1, hd), inv, pos, sc, at.rope.traditional).to(DEV).double().view(nkv, hd)
+    qr = apply_rope(q.to(DT).cpu().view(1, nh, 1, hd), inv, pos, sc, at.rope.traditional).to(DEV).double().view(nh, hd)
+    kr = apply_rope(k.to(DT).cpu().view(1, nkv, 1, hd), inv, pos, sc, at.rope.traditional).to(DEV).double().view(nkv, hd)
     K = torch.cat([kc[:, :pos].double(), kr[:, None]], 1)
     V = torch.cat([vc[:, :pos].double(), v.view(nkv, 1, hd)], 1)
     rep = nh // nkv
@@ -97,14 +100,14 @@ def test_dattn_launch_vs_fp64(cfg_name, bq, bo, ctx):
     while cap <= ctx:
         cap *= 2
     gen = torch.Generator(device="cpu").manual_seed(ctx + 1)
-    h = (torch.randn(D, generator=gen) * 0.7).to(torch.bfloat16).to(DEV)
-    kc = (torch.randn(1, nkv, cap, hd, generator=gen) * 0.5).to(torch.bfloat16).to(DEV)
-    vc = (torch.randn(1, nkv, cap, hd, generator=gen)).to(torch.bfloat16).to(DEV)
+    h = (torch.randn(D, generator=gen) * 0.7).to(DT).to(DEV)
+    kc = (torch.randn(1, nkv, cap, hd, generator=gen) * 0.5).to(DT).to(DEV)
+    vc = (torch.randn(1, nkv, cap, hd, generator=gen)).to(DT).to(DEV)
     kc0, vc0 = kc.clone(), vc.clone()
     pos = torch.tensor([ctx], dtype=torch.long, device=DEV)
     acc = torch.zeros(D + 1, dtype=torch.int64, device=DEV)
     state = ops.dattn_state(DEV)
-    attn_out = torch.zeros(nh * hd, dtype=torch.bfloat16, device=DEV)
+    attn_out = torch.zeros(nh * hd, dtype=DT, device=DEV)
     pk = ops.dgemv_pack(cat, 2)
     d = ops.make_dattn_desc(h, blk.input_layernorm.weight, blk.input_layernorm.eps, cat, pk, kc, vc, at.rope.inv_freq, pos, at.o_proj,
                             acc, state, nh, cap, getattr(at.rope, "scale", 1.0), at.scale, at.rope.traditional, attn_out=attn_out)
@@ -124,6 +127,18 @@ def test_dattn_launch_vs_fp64(cfg_name, bq, bo, ctx):
     o_want = _deq(at.o_proj) @ attn_out.double()
     _close(o_got, o_want, "o_proj partial sums", rel=1e-2)
     assert int(acc[D].item()) == 0, "non-finite marker set on finite data"
+
+
+def test_dattn_fp16_activations():
+    """The launch's fp16 instantiations (vector-ALU form; the matrix-core form is bf16 only): short context, the cooperative sweep,
+    3- and 4-bit rows."""
+    global DT
+    DT = torch.float16
+    try:
+        for case in (("LLAMA3_8B", 2, 2, 40), ("LLAMA3_8B", 2, 2, 500), ("LLAMA3_8B", 3, 4, 131), ("LLAMA32_3B", 4, 2, 450)):
+            test_dattn_launch_vs_fp64(*case)
+    finally:
+        DT = torch.bfloat16
 
 
 def test_dattn_vector_form_when_the_matrix_core_form_is_switched_off():
