@@ -160,6 +160,34 @@ def test_batched_runner_qkv_slices_switch_agrees():
     assert (outs[0] - outs[1]).abs().max().item() <= 0.05 * scale + 0.02 * outs[1].abs().max().item()
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_batched_runner_chip_wide_norm_switch_agrees(graph):
+    """DecodeRunner at B = 32 with the slice-sum + residual + RMSNorm launches spread over the chip (the default) against the
+    row-per-workgroup launch (GBX_NORM_XCD=0), eager and as a replayed graph (the generation words must survive replays): the residual
+    stream is bit-identical, the normalised rows agree to the last place, so the logits agree to rounding; the status word stays 0."""
+    import os
+    import bench
+    from gbx_lm_amd import ops, synthetic as S
+    from gbx_lm_amd.decode import DecodeRunner
+    cfg = dict(S.LLAMA3_8B, num_hidden_layers=2, vocab_size=2048)
+    model = S.build_model(cfg, S.make_strategy("S22", 2, 128), device=DEV, seed=12)
+    outs = []
+    for flag in ("1", "0"):
+        os.environ["GBX_NORM_XCD"] = flag
+        try:
+            r = DecodeRunner(model, bench.make_caches(model, 32, 64, DEV), use_graph=graph)
+            lg = [r.step((torch.arange(32, device=DEV) * 7 + 3 + t) % 2048).float().clone() for t in range(12)]
+            r.norm_check()
+            assert ops.norm_status(r.norm_state) == 0
+        finally:
+            os.environ.pop("GBX_NORM_XCD", None)
+        outs.append(torch.stack(lg))
+    assert torch.isfinite(outs[0]).all()
+    scale = outs[1].abs().mean().item()
+    assert (outs[0] - outs[1]).abs().max().item() <= 0.05 * scale + 0.02 * outs[1].abs().max().item()
+    assert (outs[0].argmax(-1) == outs[1].argmax(-1)).float().mean().item() > 0.97
+
+
 @pytest.mark.parametrize("hd,nh,nkv,traditional", [(128, 8, 2, False), (64, 4, 4, True), (128, 6, 2, True), (128, 4, 2, False)])
 def test_attn_decode_batched_matches_torch(hd, nh, nkv, traditional):
     """gbx_attn_decode_batched: B sequences at the same position, each against its own cache rows."""
