@@ -124,6 +124,14 @@ def exp_lib() -> ctypes.CDLL:
         L.gbx_attn_oproj_decode.argtypes = [p, p, p, p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, i32, i32, f32, f32, i32, i32, p]
         L.gbx_qlinear_prepack_tiles.argtypes = [p, p, p, p, p, p, p, p, i32, i32, i32, i32, p]
         L.gbx_gemv_tiled.argtypes = [p, p, p, p, i32, i32, i32, i32, p, f32, p, i32, i32, p]
+        if hasattr(L, 'gbx_exp_batch_mx_forward'):
+            L.gbx_exp_batch_mx_image_bytes.argtypes = [i32]
+            L.gbx_exp_batch_mx_image_bytes.restype = ctypes.c_size_t
+            L.gbx_exp_batch_mx_aux_bytes.argtypes = [i32]
+            L.gbx_exp_batch_mx_aux_bytes.restype = ctypes.c_size_t
+            L.gbx_exp_batch_mx_image.argtypes = [p, ctypes.c_int64, i32, p, p, p]
+            L.gbx_exp_batch_mx_forward.argtypes = [p, p, p, p, p, p, p, ctypes.c_int64, i32, i32, p]
+            L.gbx_exp_batch_mx_slices.argtypes = [i32, i32]
         _xlib = L
     return _xlib
 

@@ -169,6 +169,44 @@ int gbx_stream_run(const void* device_program, const void* host_program, int32_t
   return GBX_OK;
 }
 
+static int check_batch_mx(int64_t M, int32_t N, int32_t K) {
+  if (M < 1 || M > 32 || N <= 0 || K <= 0) return fail(GBX_ERR_INVALID, "bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+  if ((N % 128) || (K % 1024) || K > 16384)
+    return fail(GBX_ERR_UNSUPPORTED, "the FP4 x FP8 batch GEMM covers N %% 128 == 0, K %% 1024 == 0, K <= 16384 (2 bits, group 128, bf16; got N=%d K=%d)", N, K);
+  return GBX_OK;
+}
+
+size_t gbx_exp_batch_mx_image_bytes(int32_t K) { return (K > 0 && K % 128 == 0) ? gbx::batch_mx_image_bytes(K) : 0; }
+size_t gbx_exp_batch_mx_aux_bytes(int32_t K) { return (K > 0 && K % 128 == 0) ? gbx::batch_mx_aux_bytes(K) : 0; }
+
+int gbx_exp_batch_mx_image(const void* x, int64_t M, int32_t K, void* image, void* aux, void* hip_stream) {
+  int rc = check_batch_mx(M, 128, K);
+  if (rc) return rc;
+  if (!x || !image || !aux || !aligned(image, 16) || !aligned(aux, 16)) return fail(GBX_ERR_INVALID, "null or misaligned device pointer");
+  hipError_t e = gbx::launch_batch_mx_image(x, static_cast<int>(M), K, image, aux, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_exp_batch_mx_image launch");
+  return GBX_OK;
+}
+
+int gbx_exp_batch_mx_slices(int32_t N, int32_t K) {
+  if (N <= 0 || K <= 0 || (N % 128) || (K % 1024)) return 0;
+  return gbx::batch_mx_ksplit(N, K);
+}
+
+int gbx_exp_batch_mx_forward(const void* image, const void* aux, const uint32_t* qweight, const void* scales, const void* zeros, void* y,
+                             float* slices_ws, int64_t M, int32_t N, int32_t K, void* hip_stream) {
+  int rc = check_batch_mx(M, N, K);
+  if (rc) return rc;
+  if (!image || !aux || !qweight || !scales || !zeros) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (!aligned(image, 16) || !aligned(aux, 16) || !aligned(qweight, 16)) return fail(GBX_ERR_INVALID, "image, aux and qweight must be 16-byte aligned");
+  const int ks = gbx::batch_mx_ksplit(N, K);
+  if (ks < 1) return fail(GBX_ERR_UNSUPPORTED, "no k split of K = %d leaves an even number (<= 32) of groups per workgroup", K);
+  if (ks > 1 ? !slices_ws : !y) return fail(GBX_ERR_INVALID, "this shape %s", ks > 1 ? "splits k: slices_ws [gbx_exp_batch_mx_slices][M][N] fp32 needed" : "needs y");
+  hipError_t e = gbx::launch_batch_mx(image, aux, qweight, scales, zeros, y, slices_ws, ks, static_cast<int>(M), N, K, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_exp_batch_mx_forward launch");
+  return GBX_OK;
+}
+
 int gbx_qlinear_prepack_tiles(const uint32_t* qweight, const void* scales, const void* zeros,
                               const uint32_t* qweight_up, const void* scales_up, const void* zeros_up,
                               uint32_t* wt, uint32_t* szt, int32_t N, int32_t K, int32_t bits, int32_t group_size,

@@ -149,4 +149,12 @@ hipError_t launch_swiglu(const void* g, const void* u, void* y, long long n, boo
 hipError_t launch_stream(const void* dev_prog, const void* host_first_op, int op_begin, int op_end, bool bf16, hipStream_t s);
 hipError_t launch_rmsnorm(const void* x, const void* w, void* y, int M, int K, float eps, bool bf16, hipStream_t s);
 
+// batch_mx.hip (experimental library): the M <= 32 batch GEMM on the FP4 x FP8 matrix cores (2 bits, group 128, bf16)
+size_t batch_mx_image_bytes(int K);
+size_t batch_mx_aux_bytes(int K);
+hipError_t launch_batch_mx_image(const void* x, int M, int K, void* img, void* aux, hipStream_t s);
+hipError_t launch_batch_mx(const void* img, const void* aux, const uint32_t* qw, const void* sc, const void* ze, void* y, float* ws, int ksplit,
+                           int M, int N, int K, hipStream_t s);
+int batch_mx_ksplit(int N, int K);
+
 }  // namespace gbx

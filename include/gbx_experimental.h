@@ -57,6 +57,21 @@ int gbx_qlinear_prepack_tiles(const uint32_t* qweight, const void* scales, const
                               uint32_t* wt, uint32_t* szt, int32_t N, int32_t K, int32_t bits, int32_t group_size,
                               void* hip_stream);
 
+/* Round 5: the batched-decode GEMM (M <= 32 activation rows, 2 bits, group 128, bf16) on the FP4 x FP8 matrix cores -- the operand the
+ * round-3 / round-4 reviews asked to see measured at M = 32 (product path: gbx_qlinear_forward at 2 <= M <= 32, mfma_batch.hip; reference op
+ * mx.quantized_matmul at [B, 1, K], gbx_lm/models/quantized_linear_gba.py:195-203).  The activation tile is converted ONCE into two E4M3
+ * limbs + one E8M0 exponent per 32 values + per-group sums (gbx_exp_batch_mx_image: image_bytes(K) + aux_bytes(K) of caller memory; rows
+ * beyond M are zero); gbx_exp_batch_mx_forward then computes y[M, N] = x . dequant(W)^T with four scaled MFMAs per (16 weight rows,
+ * group).  N % 128 == 0, K % 1024 == 0.  Tolerance: the two-limb bound of dgemv_mx.hip. */
+size_t gbx_exp_batch_mx_image_bytes(int32_t K);
+size_t gbx_exp_batch_mx_aux_bytes(int32_t K);
+int gbx_exp_batch_mx_image(const void* x, int64_t M, int32_t K, void* image, void* aux, void* hip_stream);
+/* k ranges the launch splits this shape into (1: y [M, N] is written; > 1: fp32 slices slices_ws [ranges][M][N] for the consumer to sum,
+ * like gbx_qlinear_forward_partials; 0: shape not covered) */
+int gbx_exp_batch_mx_slices(int32_t N, int32_t K);
+int gbx_exp_batch_mx_forward(const void* image, const void* aux, const uint32_t* qweight, const void* scales, const void* zeros, void* y,
+                             float* slices_ws, int64_t M, int32_t N, int32_t K, void* hip_stream);
+
 /* y[N] = W x' for ONE activation row from the tiled form above; same result contract and the same optional fusions as
  * gbx_qlinear_fused_forward: x' = RMSNorm(x) * norm_weight (norm_weight != NULL), y <- residual + round(result)
  * (residual != NULL), or -- pair tiles, swiglu != 0 -- y[n] = silu(gate[n]) * up[n] with the reference's op-by-op
