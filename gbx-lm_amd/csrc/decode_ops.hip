@@ -280,6 +280,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnArgs a) {
 // bytes: 67 MB per layer at context 128).  Same arithmetic and layout as attn_decode_kernel.
 // NW waves per workgroup (4, or 8: round 4 -- at B = 32 / context 128-190 the four-wave form is a chain of 8 dependent sweep rounds with
 // four heads' arithmetic in each and one wave per SIMD: 9.4 us per layer; eight waves take half the rounds each, two per SIMD).
+#ifndef GQA_UB0_WIDE
+#define GQA_UB0_WIDE 2
+#endif
 template <bool BF16, int HD, int REP, bool STATIC, int NW = 4>
 __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(AttnArgs a) {
   constexpr int LP = HD / 8, PPW = 64 / LP, NG = NW * PPW, NT = NW * 64;
@@ -301,10 +304,31 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(AttnArgs a) {
     if (a.q) { a.q += b * a.n_heads * HD; a.k += b * a.n_kv * HD; a.v += b * a.n_kv * HD; }
     a.kcache += b * a.n_kv * a.capacity * HD; a.vcache += b * a.n_kv * a.capacity * HD;
   }
-  constexpr int UB0 = NW == 4 ? 4 : 2;                 // the same 64 speculative positions (head_dim 128) either way
+  constexpr int UB0 = NW == 4 ? 4 : GQA_UB0_WIDE;      // 64 speculative positions either way (round 5, slices requested first: 96 -> 9.5 us, 160 -> 11.1 us, 64 -> 8.6 us per launch at B = 32)
   const int d0 = (lane % LP) * 8, sub = lane / LP;
   const unsigned short* kbase = a.kcache + static_cast<size_t>(kvh) * a.capacity * HD;
   const unsigned short* vbase = a.vcache + static_cast<size_t>(kvh) * a.capacity * HD;
+  // Slice form (batched decode): loads return in order, and RoPE needs this thread's 2 x 8 slice values (12 KB per workgroup), not the
+  // 64 KB of speculative cache rows -- so the slices are requested FIRST (one (head, pair) item per thread when the workgroup is wide
+  // enough; the v values by the first HD threads) and summed when RoPE gets to them.
+  constexpr int NIT = (REP + 1) * (HD / 2);
+  const bool pre = !STATIC && a.qkv_ws != nullptr && NT >= NIT && NT >= HD;
+  float ps1[8], ps2[8], psv[8];
+  if (pre) {
+    const float* wsrow0 = a.qkv_ws + static_cast<size_t>(blockIdx.y) * ((a.n_heads + 2 * a.n_kv) * HD);
+    const int pp = min(tid, NIT - 1);
+    const int hh = pp / (HD / 2), i = pp % (HD / 2);
+    const int col = hh == REP ? a.n_heads * HD + kvh * HD : (hq0 + hh) * HD;
+    const int i1 = a.traditional ? 2 * i : i, i2 = a.traditional ? 2 * i + 1 : i + HD / 2;
+    const float* pv = wsrow0 + (a.n_heads + a.n_kv) * HD + kvh * HD + min(tid, HD - 1);
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) {
+      const size_t so = static_cast<size_t>(min(sl, a.qkv_slices - 1)) * a.qkv_mn;
+      ps1[sl] = wsrow0[col + i1 + so];
+      ps2[sl] = wsrow0[col + i2 + so];
+      psv[sl] = pv[so];
+    }
+  }
   u32x4 k0[UB0], v0[UB0];
 #pragma unroll
   for (int u = 0; u < UB0; ++u) {                   // first 4 * 4 * PPW positions requested before *pos is known
@@ -328,18 +352,27 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(AttnArgs a) {
   // (`col`: first column of this head inside the concatenated q | k | v row, for the slice form)
   const int qkv_n = (a.n_heads + 2 * a.n_kv) * HD;
   const float* wsrow = a.qkv_ws ? a.qkv_ws + static_cast<size_t>(blockIdx.y) * qkv_n : nullptr;
-  auto ldb = [&](int col, const unsigned short* src, const unsigned short* bias, int i) {
+  auto sum8 = [&](const float (&t)[8]) {              // v = ws[0]; v += ws[s], s = 1..: the summing launch's order, one rounding
+    float v = t[0];
+#pragma unroll
+    for (int sl = 1; sl < 8; ++sl)
+      if (sl < a.qkv_slices) v += t[sl];
+    return act_to_f32<BF16>(f32_to_act<BF16>(v));
+  };
+  // which: 0 = no preloaded values, 1 / 2 = this thread's first / second value of its pair, 3 = its v value
+  auto ldb = [&](int col, const unsigned short* src, const unsigned short* bias, int i, int which = 0) {
     float x;
-    if (wsrow) {                                    // every slice requested before the first add; v = ws[0]; v += ws[s], s = 1..
-      const float* p = wsrow + col + i;
-      float t[8];
+    if (wsrow) {                                    // every slice requested before the first add
+      if (which == 1) x = sum8(ps1);
+      else if (which == 2) x = sum8(ps2);
+      else if (which == 3) x = sum8(psv);
+      else {
+        const float* p = wsrow + col + i;
+        float t[8];
 #pragma unroll
-      for (int sl = 0; sl < 8; ++sl) t[sl] = p[static_cast<size_t>(min(sl, a.qkv_slices - 1)) * a.qkv_mn];
-      float v = t[0];
-#pragma unroll
-      for (int sl = 1; sl < 8; ++sl)
-        if (sl < a.qkv_slices) v += t[sl];
-      x = act_to_f32<BF16>(f32_to_act<BF16>(v));
+        for (int sl = 0; sl < 8; ++sl) t[sl] = p[static_cast<size_t>(min(sl, a.qkv_slices - 1)) * a.qkv_mn];
+        x = sum8(t);
+      }
     } else {
       x = act_to_f32<BF16>(src[i]);
     }
@@ -370,7 +403,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(AttnArgs a) {
     const int i2 = a.traditional ? 2 * i + 1 : i + HD / 2;
     const unsigned short* bsrc = !a.q_bias ? nullptr : isk ? a.k_bias + static_cast<size_t>(kvh) * HD : a.q_bias + (static_cast<size_t>(hq0) + hh) * HD;
     const int col = isk ? col_k : (hq0 + hh) * HD;
-    float x1 = ldb(col, src, bsrc, i1), x2 = ldb(col, src, bsrc, i2);
+    float x1 = ldb(col, src, bsrc, i1, pre ? 1 : 0), x2 = ldb(col, src, bsrc, i2, pre ? 2 : 0);     // (pre: one item per thread, p == tid)
     if (normed) {                                   // RMSNorm output rounded to the activation dtype, like the separate op
       const float rstd = rsqrtf(ssq_s[hh] / static_cast<float>(HD) + a.norm_eps);
       const unsigned short* w = isk ? a.kn_w : a.qn_w;
@@ -395,7 +428,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(AttnArgs a) {
     }
   }
   if (tid < HD) {
-    const unsigned short vb = f32_to_act<BF16>(ldb(col_v, a.v + static_cast<size_t>(kvh) * HD, a.v_bias ? a.v_bias + static_cast<size_t>(kvh) * HD : nullptr, tid));
+    const unsigned short vb = f32_to_act<BF16>(ldb(col_v, a.v + static_cast<size_t>(kvh) * HD, a.v_bias ? a.v_bias + static_cast<size_t>(kvh) * HD : nullptr, tid, pre ? 3 : 0));
     vn_s[tid] = act_to_f32<BF16>(vb);
     if (writer) a.vcache[(static_cast<size_t>(kvh) * a.capacity + pos) * HD + tid] = vb;
   }
