@@ -183,7 +183,7 @@ class DmlpDesc(ctypes.Structure):
 
 GBX_DG_PLAIN, GBX_DG_RESIDUAL, GBX_DG_SWIGLU = 0, 1, 2
 GBX_DG_SSQ_SLOTS = 1024
-GBX_MIN_VERSION = 1202          # the header this binding mirrors
+GBX_MIN_VERSION = 1300          # the header this binding mirrors
 
 
 def _declare_optional(L) -> None:
@@ -201,7 +201,8 @@ def _declare_optional(L) -> None:
         "gbx_dattn_status": [p, ctypes.POINTER(i32)],
         "gbx_dmlp_plan": [i32, i32, i32, i32, i32, i32, i32],
         "gbx_dmlp_forward": [ctypes.POINTER(DmlpDesc), p],
-        "gbx_acc_residual": [p, p, p, i32, p, p, p, p],
+        "gbx_acc_residual": [p, p, p, i32, i32, p, p, p, p],
+        "gbx_xcd_layout_check": [],
         "gbx_qlinear_kernel_id": [i64, i32, i32, i32, i32, i32],
         "gbx_qlinear_swiglu_forward": [p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, p],
         "gbx_qlinear_forward_partials": [p, p, p, p, p, ctypes.c_size_t, ctypes.POINTER(i32), i64, i32, i32, i32, i32, i32, p],

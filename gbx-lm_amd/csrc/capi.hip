@@ -32,9 +32,9 @@ extern "C" void gbx_debug_stamp_reset(void) { gbx::g_stamp_launch = 0; }
 
 extern "C" {
 
-/* 1202: + gbx_add_rmsnorm_slices_xcd, gbx_norm_state_bytes (additions).  1201: + gbx_dattn.x_acc / x_out / zero_buf, gbx_dmlp_*, gbx_acc_residual.  1200: gbx_dgemv grows (x_acc, x_out, zero_buf, zero_n) + gbx_dattn_* + gbx_dgemv_kernel_id.  1101: + gbx_attn_decode_slices (an addition: nothing else changed).  1100: gbx_dgemv_* entry points; gbx_qlinear_fused (x_acc, x_out, zero_buf, zero_n since 1001) -- a consumer built against
+/* 1300: gbx_acc_residual grows act_dtype; + gbx_xcd_layout_check, gbx_dblock_*; a timed-out hand-off poisons its accumulator.  1202: + gbx_add_rmsnorm_slices_xcd, gbx_norm_state_bytes (additions).  1201: + gbx_dattn.x_acc / x_out / zero_buf, gbx_dmlp_*, gbx_acc_residual.  1200: gbx_dgemv grows (x_acc, x_out, zero_buf, zero_n) + gbx_dattn_* + gbx_dgemv_kernel_id.  1101: + gbx_attn_decode_slices (an addition: nothing else changed).  1100: gbx_dgemv_* entry points; gbx_qlinear_fused (x_acc, x_out, zero_buf, zero_n since 1001) -- a consumer built against
  * an older header must not pass its shorter struct to this library: check gbx_version() >= the header it compiled with. */
-int gbx_version(void) { return 1202; }
+int gbx_version(void) { return 1300; }
 
 const char* gbx_last_error(void) { return g_err; }
 
@@ -1047,10 +1047,22 @@ int gbx_dgemv_forward(const gbx_dgemv* d, void* hip_stream) {
   return GBX_OK;
 }
 
+/* ---- the device check of every launch with XCD-local hand-offs (xcd_layout.hip): static checks + a census launch, once per device ---- */
+static int xcd_layout_gate(const char* who) {
+  hipError_t e = gbx::xcd_census();
+  if (e != hipSuccess) return hip_fail(e, who);
+  const char* why = gbx::xcd_layout_reason();
+  if (why[0]) return fail(GBX_ERR_UNSUPPORTED, "%s: this device does not take the launches with XCD-local hand-offs: %s", who, why);
+  return GBX_OK;
+}
+
+int gbx_xcd_layout_check(void) { return xcd_layout_gate("gbx_xcd_layout_check"); }
+
 /* ---- fused attention launch (dattn_impl.h) ---- */
 int gbx_dattn_plan(int32_t D, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int32_t qkv_bits, int32_t qkv_group_size,
                    int32_t o_bits, int32_t o_group_size) {
   gbx::DattnPlan pl;
+  if (int rc = xcd_layout_gate("gbx_dattn_plan")) return rc;
   if (!gbx::dattn_plan(D, n_heads, n_kv_heads, head_dim, qkv_bits, qkv_group_size, o_bits, o_group_size, &pl))
     return fail(GBX_ERR_UNSUPPORTED, "the fused attention launch does not cover D=%d heads=%d/%d head_dim=%d q|k|v %d bits g%d, o %d bits g%d",
                 D, n_heads, n_kv_heads, head_dim, qkv_bits, qkv_group_size, o_bits, o_group_size);
@@ -1100,6 +1112,8 @@ int gbx_dattn_forward(const gbx_dattn* d, void* hip_stream) {
   {
     static const int coop_min = gbx::env_switch("GBX_DATTN_COOP_MIN");
     a.coop_min = coop_min;
+    static const int spin_log2 = gbx::env_switch("GBX_DATTN_SPIN_LOG2");
+    a.spin_limit = 1u << (spin_log2 < 0 ? 0 : (spin_log2 > 30 ? 30 : spin_log2));
   }
   if (d->x_acc && (d->ssq_in || !aligned(d->x_acc, 16))) return fail(GBX_ERR_INVALID, "x_acc goes without ssq_in and must be 16-byte aligned");
   if (d->x_out && (!d->x_acc || d->x_out == d->x || !aligned(d->x_out, 4))) return fail(GBX_ERR_INVALID, "x_out goes with x_acc and must not alias x");
@@ -1116,6 +1130,19 @@ int gbx_dattn_forward(const gbx_dattn* d, void* hip_stream) {
   a.eps = d->norm_eps; a.rope_scale = d->rope_scale; a.sm_scale = d->sm_scale;
 #ifdef GBX_STAMPS
   a.stamps = gbx::stamp_region();
+  {
+    static const char* ps = getenv("GBX_PROBE_SRC");
+    static unsigned long long launch = 0;
+    if (ps) {
+      // a fresh 32 MB region of the pool per launch (24 regions: nothing of it is still in the L2s or the Infinity Cache)
+      a.probe_src = reinterpret_cast<const unsigned char*>(strtoull(ps, nullptr, 0)) + (launch++ % 24) * (static_cast<size_t>(32) << 20);
+      auto geti = [](const char* n, int dflt) { const char* v = getenv(n); return v ? atoi(v) : dflt; };
+      a.probe_mode = geti("GBX_PROBE_MODE", 1);
+      a.probe_kb_p = geti("GBX_PROBE_KB_P", 112);
+      a.probe_kb_a = geti("GBX_PROBE_KB_A", 90);
+      a.probe_kb_a0 = geti("GBX_PROBE_KB_A0", 32);
+    }
+  }
 #endif
   hipError_t e = gbx::launch_dattn(a, pl, d->qkv_bits, d->act_dtype == GBX_BF16, static_cast<hipStream_t>(hip_stream));
   if (e != hipSuccess) return hip_fail(e, "gbx_dattn_forward launch");
@@ -1125,6 +1152,7 @@ int gbx_dattn_forward(const gbx_dattn* d, void* hip_stream) {
 int gbx_dmlp_plan(int32_t D, int32_t I, int32_t gate_up_bits, int32_t gate_up_group_size, int32_t down_bits, int32_t down_group_size,
                   int32_t act_dtype) {
   int bpw, a4;
+  if (int rc = xcd_layout_gate("gbx_dmlp_plan")) return rc;
   if (!gbx::dmlp_plan(D, I, gate_up_bits, gate_up_group_size, down_bits, down_group_size, act_dtype == GBX_BF16, &bpw, &a4))
     return fail(GBX_ERR_UNSUPPORTED, "the fused MLP launch does not cover D=%d I=%d gate|up %d bits g%d, down %d bits g%d, dtype %d", D, I,
                 gate_up_bits, gate_up_group_size, down_bits, down_group_size, act_dtype);
@@ -1163,6 +1191,10 @@ int gbx_dmlp_forward(const gbx_dmlp* d, void* hip_stream) {
   a.state = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(d->state) + static_cast<size_t>(gbx::DA_GROUPS) * gbx::DA_HAND_STRIDE * 8);
   a.act_out = static_cast<unsigned short*>(d->act_out);
   a.K = d->D; a.I = d->I; a.D = d->D; a.bpw = bpw; a.a4 = a4;
+  {
+    static const int spin_log2 = gbx::env_switch("GBX_DATTN_SPIN_LOG2");
+    a.spin_limit = 1u << (spin_log2 < 0 ? 0 : (spin_log2 > 30 ? 30 : spin_log2));
+  }
   a.eps = d->norm_eps;
 #ifdef GBX_STAMPS
   a.stamps = gbx::stamp_region();
@@ -1172,9 +1204,10 @@ int gbx_dmlp_forward(const gbx_dmlp* d, void* hip_stream) {
   return GBX_OK;
 }
 
-int gbx_acc_residual(const void* x, int64_t* acc, void* out, int32_t D, int64_t* zero0, int64_t* zero1, int64_t* zero2, void* hip_stream) {
+int gbx_acc_residual(const void* x, int64_t* acc, void* out, int32_t D, int32_t act_dtype, int64_t* zero0, int64_t* zero1, int64_t* zero2, void* hip_stream) {
   if (!x || !acc || !out || D <= 0) return fail(GBX_ERR_INVALID, "null pointer or bad D");
-  hipError_t e = gbx::launch_acc_finish(x, acc, out, D, zero0, zero1, zero2, static_cast<hipStream_t>(hip_stream));
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  hipError_t e = gbx::launch_acc_finish(x, acc, out, D, act_dtype == GBX_BF16, zero0, zero1, zero2, static_cast<hipStream_t>(hip_stream));
   if (e != hipSuccess) return hip_fail(e, "gbx_acc_residual launch");
   return GBX_OK;
 }

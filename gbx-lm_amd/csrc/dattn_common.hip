@@ -1,10 +1,12 @@
 // Host side of the fused attention launch (dattn_impl.h): which shapes it covers, and the dispatch over the q|k|v bit width.
 #include "dattn_impl.h"
 #include "gbx_env.h"
+#include "kernels.h"
 
 namespace gbx {
 
 bool dattn_plan(int D, int n_heads, int n_kv, int head_dim, int qkv_bits, int qkv_group, int o_bits, int o_group, DattnPlan* pl) {
+  if (!xcd_layout_ok()) return false;                                     // 8 XCDs x 32 CUs, all available, round-robin placement (xcd_layout.hip)
   if (n_kv != DA_GROUPS || head_dim != DA_HD) return false;               // one kv head per XCD
   if (n_heads <= 0 || (n_heads % DA_GROUPS) != 0) return false;
   const int rep = n_heads / DA_GROUPS;

@@ -20,6 +20,9 @@
 //                        requested at the start of the launch and sit in registers; rep waves poll the attention granules, the
 //                        workgroup builds the operand image once, every lane owns one slot of one row; partial row sums go to
 //                        acc[row] as 2^-32 fixed-point integer adds (order-independent: the eight groups may finish in any order).
+// A hand-off that does not arrive within spin_limit polls (a placement that broke the bijection, a member that never ran) ends the wait:
+// the launch raises its status word AND the accumulator's non-finite marker acc[D], so the stream every later launch forms from these
+// sums is NaN -- the failure is in-band (NaN logits, NaN logprob of the token) even for a caller that never reads the status word.
 // Hand-off form (measured first, profiles/r05_xcd_barrier.txt P3): granule stores are workgroup-scope (sc0: write-through to the
 // XCD's L2, where the line stays), polls are agent-scope loads (sc1: past the L1, served by that same L2) -- 0.45 us per hand-off
 // against 1.05 us for the device-scope form, and correct by construction because producer and consumer share the L2 they
@@ -40,7 +43,7 @@ constexpr int DA_OP = 2;                     // o_proj lane passes held in regis
 constexpr int DA_HAND_STRIDE = 2048;         // granules (8 bytes) per group: [0, 1024) phase 1, [1024, 1536) attention output, [1536, 1792) rotated q (cooperative sweep)
 constexpr int DA_HAND_QROT = 1536;
 constexpr int DA_STATE_WORDS = 64 * 16;      // u32: gen[g] at g * 16 (one 64-byte line each), status at 8 * 16, placement at 9 * 16
-constexpr unsigned DA_SPIN_LIMIT = 1u << 22;
+constexpr unsigned DA_SPIN_LIMIT = 1u << 22;   // default of DattnArgs / DmlpArgs.spin_limit
 constexpr int DA_PART_STRIDE = 132;          // granules per partial softmax state: {tag, max}, {tag, denominator}, 128 x {tag, numerator}, 2 pad
 constexpr int DA_PART_GRANULES = DA_GROUPS * DA_MEMBERS * 4 * DA_PART_STRIDE;      // [group][member][head of the group <= 4]
 
@@ -70,9 +73,13 @@ struct DattnArgs {
   int D, rep, capacity, bpw;        // bpw: phase-1 batches per producer workgroup
   int qkv_log2g, o_bits, o_log2g, traditional;
   int coop_min;                     // contexts beyond this many cached positions: cooperative sweep (the group's producers, in chunks)
+  unsigned spin_limit;              // polls of one hand-off before the launch gives up (GBX_DATTN_SPIN_LOG2)
   float eps, rope_scale, sm_scale;
 #ifdef GBX_STAMPS
   unsigned long long* stamps;
+  // round-6 step 0 (ii): an LDS-DMA weight stream issued beside the hand-off chain (scratch/probe7, profiles/r06_block_probe.txt)
+  const unsigned char* probe_src;
+  int probe_mode, probe_kb_p, probe_kb_a, probe_kb_a0;
 #endif
 };
 
@@ -101,6 +108,7 @@ struct DmlpArgs {
   unsigned* state;                  // [DA_STATE_WORDS]
   unsigned short* act_out;          // optional [I]: the SwiGLU output (tests)
   int K, I, D, zero_n, bpw, a4;     // bpw: gate|up batches per workgroup; waves [0, a4) own 4 of them, the others 2
+  unsigned spin_limit;              // polls of the hand-off before the launch gives up (GBX_DATTN_SPIN_LOG2)
   float eps;
 #ifdef GBX_STAMPS
   unsigned long long* stamps;
@@ -109,7 +117,7 @@ struct DmlpArgs {
 
 bool dmlp_plan(int D, int I, int bits_gu, int group_gu, int bits_dn, int group_dn, bool bf16, int* bpw, int* a4);
 hipError_t launch_dmlp(const DmlpArgs& a, hipStream_t stream);
-hipError_t launch_acc_finish(const void* x, void* acc, void* out, int D, void* z0, void* z1, void* z2, hipStream_t stream);
+hipError_t launch_acc_finish(const void* x, void* acc, void* out, int D, bool bf16, void* z0, void* z1, void* z2, hipStream_t stream);
 template <int BQ>
 hipError_t launch_dattn_bits(const DattnArgs& a, const DattnPlan& pl, bool bf16, hipStream_t stream);
 

@@ -15,7 +15,11 @@ constexpr int DA_LDS_RED = 12 * 1024;              // 16 floats: RMSNorm partial
 constexpr int DA_LDS_P3 = 12 * 1024 + 256;         // phase 3: 2 KB of raw attention output, then its operand image (<= 5.2 KB)
 constexpr int DA_LDS_ATT = 24 * 1024;              // attention scratch: q | k | v words, rotated q / k / v, up to 64 softmax states (37.6 KB)
 constexpr int DA_LDS_DUMP = 100 * 1024;          // cooperative sweep, attention workgroups: 16 KB that the L2 prefetch's LDS-DMA overwrites (never read)
+#ifdef GBX_STAMPS
+constexpr int DA_LDS_BYTES = 156 * 1024;         // diagnostic build: room for the step-0 probe's LDS-DMA stream
+#else
 constexpr int DA_LDS_BYTES = 116 * 1024;         // (the cooperative sweep's 128 partial states end at 98.1 KB)
+#endif
 #ifndef DA_SWEEP4_MAX
 #define DA_SWEEP4_MAX 160      // contexts up to here are swept by 4 waves (one per SIMD), up to 320 by 8, longer ones by 16
 #endif
@@ -192,14 +196,20 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
   da_gu64* hand1 = reinterpret_cast<da_gu64*>(reinterpret_cast<uintptr_t>(a.hand)) + static_cast<size_t>(g) * DA_HAND_STRIDE;
   da_gu64* hand2 = hand1 + 1024;
   auto rsrc = [](const void* ptr, int bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, bytes, RS_FLAGS); };
-  auto timeout = [&](unsigned code) { if (lane == 0) a.state[8 * 16] = code; };
+  // a hand-off that never arrives: status word for the host, and the accumulator's non-finite marker so that the stream turns NaN in-band
+  auto timeout = [&](unsigned code) {
+    if (lane == 0) {
+      a.state[8 * 16] = code;
+      __hip_atomic_fetch_add(reinterpret_cast<da_gu64*>(reinterpret_cast<uintptr_t>(a.acc)) + a.D, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
   // one wave polls 64 granules until every tag matches; returns the lane's value
   auto sweep = [&](da_gu64* p, unsigned tag, unsigned code) -> unsigned {
     unsigned long long x;
     for (unsigned spins = 0;;) {
       x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           // sc1: past this CU's L1, served by the XCD's L2
       if (__all(static_cast<unsigned>(x >> 32) == tag)) break;
-      if (++spins > DA_SPIN_LIMIT) { timeout(code); break; }
+      if (++spins > a.spin_limit) { timeout(code); break; }
       __builtin_amdgcn_s_sleep(1);
     }
     return static_cast<unsigned>(x);
@@ -211,7 +221,7 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
       x = __hip_atomic_load(pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       y = __hip_atomic_load(pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (__all(static_cast<unsigned>(x >> 32) == tag && static_cast<unsigned>(y >> 32) == tag)) break;
-      if (++spins > DA_SPIN_LIMIT) { timeout(code); break; }
+      if (++spins > a.spin_limit) { timeout(code); break; }
       __builtin_amdgcn_s_sleep(1);
     }
     va = static_cast<unsigned>(x);
@@ -286,8 +296,10 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
     float* red_lds = reinterpret_cast<float*>(smem + DA_LDS_RED);
     const int K = D, W4 = K / 4, G = K >> 7;
     const int nb = (rep + 2) * (HD / 2);
-    const int lb = (r - rep) * a.bpw + wave;
-    const bool has = wave < a.bpw && lb < nb;
+    // batch lb = wave * producers + producer: EVERY producer owns a batch (nb >= producers), so every member of the group publishes at
+    // least one granule that the attention workgroups wait for -- the argument the generation advance at the end of the launch rests on
+    const int lb = wave * (DA_MEMBERS - rep) + (r - rep);
+    const bool has = lb < nb;
     const int qrows = rep * HD;
     const int lr = 2 * (has ? lb : 0);
     const int grow = lr < qrows ? g * qrows + lr
@@ -488,8 +500,10 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
     const int gshift = a.qkv_log2g - 5;
     // this wave's batch: local rows (2 lb, 2 lb + 1) of the group -> rows of the concatenated matrix
     const int nb = (rep + 2) * (HD / 2);
-    const int lb = (r - rep) * a.bpw + wave;
-    const bool has = wave < a.bpw && lb < nb;
+    // batch lb = wave * producers + producer: EVERY producer owns a batch (nb >= producers), so every member of the group publishes at
+    // least one granule that the attention workgroups wait for -- the argument the generation advance at the end of the launch rests on
+    const int lb = wave * (DA_MEMBERS - rep) + (r - rep);
+    const bool has = lb < nb;
     const int qrows = rep * HD;
     const int lr = 2 * (has ? lb : 0);
     const int grow = lr < qrows ? g * qrows + lr
@@ -692,6 +706,16 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
     // o_proj words: needed ~4 us from here, requested off the critical path.  (Loads return in order: under the cooperative sweep the
     // chunk's K / V rows and the q poll go first, or they would queue behind these 32 KB per CU.)
     if (!coop) issue_o();
+#ifdef GBX_STAMPS
+    if (a.probe_src && (a.probe_mode & 16) && !coop) __syncthreads();      // every wave of this workgroup has published: its granule stores are not behind the stream
+    if (a.probe_src && (a.probe_mode & 1) && !coop && !((a.probe_mode & 2) && wave < 2)) {
+      const __amdgpu_buffer_rsrc_t pd = rsrc(a.probe_src, RS_ALL);
+      const int w0 = (a.probe_mode & 2) ? wave - 2 : wave, nwv = (a.probe_mode & 2) ? NW - 2 : NW;
+      for (int n = w0; n < a.probe_kb_p; n += nwv)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(pd, (__attribute__((address_space(3))) void*)(smem + 24 * 1024 + n * 1024), 16, lane * 16,
+                                                 static_cast<int>((static_cast<size_t>(blockIdx.x) * 128 + n) * 1024), 0, 2);
+    }
+#endif
     if (coop) {
       // ---------------- cooperative sweep: this producer's chunk of the context, all `rep` heads of the group ----------------
       // A wave owns a PAIR of heads (the K / V unpacking is shared) and one of 8 "position sets"; round u of set s covers positions
@@ -900,6 +924,14 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
       }
     }
     issue_o();
+#ifdef GBX_STAMPS
+    if (a.probe_src && (a.probe_mode & 8) && !coop) {          // attention workgroups, early: behind the K / V prefetch and the o words
+      const __amdgpu_buffer_rsrc_t pd = rsrc(a.probe_src, RS_ALL);
+      for (int n = wave; n < a.probe_kb_a0; n += NW)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(pd, (__attribute__((address_space(3))) void*)(smem + 64 * 1024 + n * 1024), 16, lane * 16,
+                                                 static_cast<int>((static_cast<size_t>(blockIdx.x) * 128 + n) * 1024), 0, 2);
+    }
+#endif
     const unsigned gen = __hip_atomic_load(gen_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const float inv_f = a.inv_freq[lane];                      // RoPE frequency of this lane's pair (waves 0 and 1 rotate q and k)
     // the rotation depends on the position only: ready before q / k arrive
@@ -966,7 +998,7 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) ok = ok && static_cast<unsigned>(gq[i] >> 32) == tag;
         if (__all(ok)) break;
-        if (++spins > DA_SPIN_LIMIT) { timeout(5u); break; }
+        if (++spins > a.spin_limit) { timeout(5u); break; }
         __builtin_amdgcn_s_sleep(2);
       }
       DA_STAMP(8);
@@ -1164,6 +1196,14 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
     }
     }
     DA_STAMP(9);
+#ifdef GBX_STAMPS
+    if (a.probe_src && (a.probe_mode & 4) && !coop) {          // attention workgroups, behind their output granules
+      const __amdgpu_buffer_rsrc_t pd = rsrc(a.probe_src, RS_ALL);
+      for (int n = wave; n < a.probe_kb_a; n += NW)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(pd, (__attribute__((address_space(3))) void*)(smem + 64 * 1024 + (n % 90) * 1024), 16, lane * 16,
+                                                 static_cast<int>((static_cast<size_t>(blockIdx.x) * 128 + 32 + n) * 1024), 0, 2);
+    }
+#endif
   }
 
   // =========================================== phase 3: o_proj over this group's columns ===========================================
@@ -1314,7 +1354,9 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
     else if (obits == 3) phase3(std::integral_constant<int, 3>{});
     else phase3(std::integral_constant<int, 4>{});
   }
-  // member 0 advances the group's generation: every member has read it (nobody reaches this point before all of them published)
+  // member 0 advances the group's generation: every member has read it -- member 0 passes phase 3 only after every attention workgroup's
+  // output granules, an attention workgroup publishes only after every producer's granules, every producer owns at least one batch
+  // (interleaved batch order above) and reads the generation before it publishes
   if (r == 0 && tid == 0) __hip_atomic_store(gen_p, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   DA_STAMP(6);
 #ifdef GBX_STAMPS

@@ -1247,6 +1247,7 @@ constexpr int SN_HAND_BYTES = (256 * 16 + 16) * 4;        // granules [256 row s
 constexpr unsigned SN_SPIN_LIMIT = 1u << 22;
 size_t slices_norm_state_bytes() { return static_cast<size_t>(SN_HAND_BYTES) + 256 * 8 * 8; }
 bool slices_norm_xcd_supported(int M, int K) {
+  if (!xcd_layout_ok()) return false;          // a row's segments meet in ONE XCD's L2: 8 XCDs, round-robin placement (xcd_layout.hip)
   if (K % 512 || K / 512 > 8 || K < 512) return false;
   const int S = K / 512;
   return M >= 1 && M <= 8 * (32 / S);

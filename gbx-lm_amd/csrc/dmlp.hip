@@ -309,7 +309,13 @@ __global__ __launch_bounds__(DA_NT) void dmlp_kernel(const DmlpArgs a) {
       xa = __hip_atomic_load(hand + 2 * it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       xb = __hip_atomic_load(hand + 2 * it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (__all(static_cast<unsigned>(xa >> 32) == tag && static_cast<unsigned>(xb >> 32) == tag)) break;
-      if (++spins > DA_SPIN_LIMIT) { if (lane == 0) a.state[8 * 16] = 3u; break; }
+      if (++spins > a.spin_limit) {                               // status word + the accumulator's non-finite marker: the stream turns NaN in-band
+        if (lane == 0) {
+          a.state[8 * 16] = 3u;
+          __hip_atomic_fetch_add(reinterpret_cast<dml_gu64*>(reinterpret_cast<uintptr_t>(a.acc_out)) + a.D, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        break;
+      }
       __builtin_amdgcn_s_sleep(1);
     }
     DML_STAMP(5);
@@ -397,6 +403,7 @@ __global__ __launch_bounds__(DA_NT) void dmlp_kernel(const DmlpArgs a) {
 }
 
 // ---- the last block's down_proj sums -> the residual stream the output head reads; every accumulator of the token is left zero ----
+template <bool BF16>
 __global__ __launch_bounds__(1024) void acc_finish_kernel(const unsigned short* __restrict__ x, unsigned long long* __restrict__ acc,
                                                           unsigned short* __restrict__ out, int D, unsigned long long* z0,
                                                           unsigned long long* z1, unsigned long long* z2) {
@@ -405,10 +412,10 @@ __global__ __launch_bounds__(1024) void acc_finish_kernel(const unsigned short* 
   for (int i = threadIdx.x; i <= D; i += blockDim.x) {
     if (i < D) {
       const unsigned long long av = acc[i];
-      const float o = round_bf16_or_f16(fx32_to_f32(static_cast<unsigned>(av), static_cast<unsigned>(av >> 32)), true);
-      float v = act_to_f32<true>(x[i]) + o;
+      const float o = round_bf16_or_f16(fx32_to_f32(static_cast<unsigned>(av), static_cast<unsigned>(av >> 32)), BF16);
+      float v = act_to_f32<BF16>(x[i]) + o;
       if (poison) v = __uint_as_float(0x7FC00000u);
-      out[i] = f32_to_act<true>(v);
+      out[i] = f32_to_act<BF16>(v);
     }
     acc[i] = 0ull;
     if (z0) z0[i] = 0ull;
@@ -418,8 +425,9 @@ __global__ __launch_bounds__(1024) void acc_finish_kernel(const unsigned short* 
 }
 
 bool dmlp_plan(int D, int I, int bits_gu, int group_gu, int bits_dn, int group_dn, bool bf16, int* bpw, int* a4) {
+  if (!xcd_layout_ok()) return false;                                       // 8 XCDs x 32 CUs, all available, round-robin placement (xcd_layout.hip)
   if (!bf16 || bits_gu != 2 || bits_dn != 2 || group_gu != 128 || group_dn != 128) return false;
-  if (D != 4096 && D != 2048) return false;                                 // one or two 2048-value spans
+  if (D != 4096) return false;                                              // two 2048-value spans (the one-span instantiation had no caller: dropped)
   if (I <= 0 || (I % (8 * 128)) != 0) return false;
   const int IX = I / 8;
   if (IX > 2048 || IX < 256) return false;                                  // one span of down's operand; at least one polling wave
@@ -438,19 +446,22 @@ hipError_t launch_dmlp(const DmlpArgs& a, hipStream_t stream) {
   if (once.pending()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dmlp_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, DM_LDS_BYTES);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(dmlp_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, DM_LDS_BYTES);
-    if (e != hipSuccess) return e;
     once.done();
   }
-  if (a.K == 4096) hipLaunchKernelGGL((dmlp_kernel<2>), dim3(DA_GROUPS * DA_MEMBERS), dim3(DA_NT), DM_LDS_BYTES, stream, a);
-  else hipLaunchKernelGGL((dmlp_kernel<1>), dim3(DA_GROUPS * DA_MEMBERS), dim3(DA_NT), DM_LDS_BYTES, stream, a);
+  if (a.K != 4096) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((dmlp_kernel<2>), dim3(DA_GROUPS * DA_MEMBERS), dim3(DA_NT), DM_LDS_BYTES, stream, a);
   return hipGetLastError();
 }
 
-hipError_t launch_acc_finish(const void* x, void* acc, void* out, int D, void* z0, void* z1, void* z2, hipStream_t stream) {
-  hipLaunchKernelGGL(acc_finish_kernel, dim3(1), dim3(1024), 0, stream, static_cast<const unsigned short*>(x),
-                     static_cast<unsigned long long*>(acc), static_cast<unsigned short*>(out), D, static_cast<unsigned long long*>(z0),
-                     static_cast<unsigned long long*>(z1), static_cast<unsigned long long*>(z2));
+hipError_t launch_acc_finish(const void* x, void* acc, void* out, int D, bool bf16, void* z0, void* z1, void* z2, hipStream_t stream) {
+  if (bf16)
+    hipLaunchKernelGGL(acc_finish_kernel<true>, dim3(1), dim3(1024), 0, stream, static_cast<const unsigned short*>(x),
+                       static_cast<unsigned long long*>(acc), static_cast<unsigned short*>(out), D, static_cast<unsigned long long*>(z0),
+                       static_cast<unsigned long long*>(z1), static_cast<unsigned long long*>(z2));
+  else
+    hipLaunchKernelGGL(acc_finish_kernel<false>, dim3(1), dim3(1024), 0, stream, static_cast<const unsigned short*>(x),
+                       static_cast<unsigned long long*>(acc), static_cast<unsigned short*>(out), D, static_cast<unsigned long long*>(z0),
+                       static_cast<unsigned long long*>(z1), static_cast<unsigned long long*>(z2));
   return hipGetLastError();
 }
 

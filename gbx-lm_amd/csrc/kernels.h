@@ -98,6 +98,11 @@ hipError_t launch_add_rmsnorm_slices(void* h, const float* ws, int slices, const
 // the same spread over the chip, the row statistic exchanged inside one XCD's L2 (decode_ops.hip); state: slices_norm_state_bytes() zeroed bytes
 size_t slices_norm_state_bytes();
 bool slices_norm_xcd_supported(int M, int K);
+// xcd_layout.hip: what the launches with XCD-local hand-offs require of the device (256 CUs in one partition, no CU mask, consecutive
+// workgroups dealt round-robin over the 8 XCDs -- the last one MEASURED by a census launch).  reason: "" = fine.
+const char* xcd_layout_reason();
+bool xcd_layout_ok();
+hipError_t xcd_census();          // synchronous, once per device; never call it inside a stream capture
 hipError_t launch_add_rmsnorm_slices_xcd(void* h, const float* ws, int slices, const void* w, void* y, int M, int K, float eps, bool bf16,
                                          void* state, hipStream_t s);
 hipError_t launch_prepack_tiles(const uint32_t* qw, const void* sc, const void* ze, const uint32_t* qw2, const void* sc2,

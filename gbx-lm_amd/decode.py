@@ -41,7 +41,7 @@ class DecodeRunner:
         self.ar = torch.arange(self.capacity, device=self.dev)
         self.tp_world = getattr(model, "tp_world", 1)
         # generation words of the chip-wide slice-sum + norm launches (batched decode): created before any capture
-        self.norm_state = ops.norm_state(self.dev) if (self.batch > 1 and self.dev.type == "cuda") else None
+        self.norm_state = ops.norm_state(self.dev) if (self.batch > 1 and self.dev.type == "cuda" and ops.xcd_layout_ok(self.dev)) else None
         # B > 1: q|k|v as ONE row-concatenated matrix (+7 MB per 2-bit 8B layer) so that the batch GEMM can split k across workgroups --
         # every workgroup then stages a quarter of the activations, the term that bounds it -- and leave fp32 slices that the
         # attention launch sums (gbx_attn_decode_slices); 11.5 -> 9.4 us per layer at B = 32
@@ -411,8 +411,12 @@ class FusedDecodeRunner(DecodeRunner):
         # XCD, hand-offs inside the XCD's L2, o_proj K-split by kv group into a fixed-point accumulator); the gate|up launch forms
         # h + o in its prologue, the down launch clears the accumulator -- three launches per block instead of five.
         # Long caches (the context split's territory): the launch's cooperative sweep covers them when a kv group has <= 4 query heads.
+        # (long caches with 1 or 2 query heads per kv head have no cooperative sweep: ONE workgroup per head would pull the whole context)
+        # A model whose hand-offs timed out once (decode_fallback) stays on the five-launch block; so does a device that fails the
+        # layout check (partition mode, CU mask, a dispatcher that does not deal workgroups round-robin over the XCDs).
         self.use_dattn = (env.flag("GBX_DATTN") and not tp and not self.fuse_ao and env.flag("GBX_DGEMV") and env.flag("GBX_QKV_CAT") and
-                          (self.attn_ws is None or a0.n_heads // a0.n_kv_heads <= 4))
+                          (self.attn_ws is None or a0.n_heads // a0.n_kv_heads in (3, 4)) and
+                          not getattr(model, "_fused_handoff_disabled", False) and ops.xcd_layout_ok(dev))
         self.use_dmlp = self.use_dattn and env.flag("GBX_DMLP")
         self.da = []                        # per layer: (dattn, gate|up, down) or (dattn, dmlp) descriptors, or None (the five-launch block)
         self.da_pre = {}                    # layer -> (x, sums): pending fixed-point sums to finish into hb before a five-launch block
@@ -605,6 +609,11 @@ class FusedDecodeRunner(DecodeRunner):
 
     def pos_buf(self) -> torch.Tensor:
         return self.pos
+
+    def fault_words(self):
+        """The status words of this runner's fused launches as one-element int32 device views (non-zero: a hand-off timed out and the
+        stream was poisoned).  generate_step copies them to the host next to every token and calls decode_fallback on a non-zero one."""
+        return [ops.dattn_status_word(st) for st in (self.da_state, self.dm_state) if st is not None]
 
     def dattn_check(self) -> None:
         """Raise if a fused attention launch of this runner timed out on a hand-off (synchronises: call off the timed path)."""
@@ -852,6 +861,41 @@ def _rope_at(x: torch.Tensor, rope, pos: torch.Tensor) -> torch.Tensor:
     if dims < x.shape[-1]:
         out = torch.cat([out, x[..., dims:]], dim=-1)
     return out
+
+
+def decode_fault_words(model):
+    """Device status words that ``generate_step`` reads next to every token (empty: this model's decode has no in-launch hand-offs)."""
+    runner = getattr(model, "_decode_runner", None)
+    fw = getattr(runner, "fault_words", None)
+    return fw() if fw is not None else []
+
+
+def decode_fallback(model, code: int) -> None:
+    """A fused launch of this model gave up on a hand-off (status ``code``; its stream is NaN from there on): drop the runner and keep
+    this model on the five-launch block from now on.  The caller rewinds the KV offsets and replays the step."""
+    import warnings
+    if not getattr(model, "_fused_handoff_disabled", False):
+        warnings.warn(f"gbx_lm_amd: a fused decode launch timed out on hand-off {code} (another tenant on the GPU, a CU mask, or a "
+                      "workgroup placement that broke the one-kv-group-per-XCD bijection); this model decodes on the five-launch block "
+                      "from here on and the step is replayed")
+    model._fused_handoff_disabled = True
+    model._decode_runner = None
+    torch.cuda.synchronize()
+
+
+def decode_step_checked(model, y: torch.Tensor, prompt_cache: List[KVCache]) -> torch.Tensor:
+    """``decode_step`` for loops that synchronise on every token anyway (EMINF reads the logits on the host): the fault words are read
+    right behind the step and a faulted step is replayed on the five-launch block before its logits reach the caller."""
+    off = prompt_cache[0].offset
+    logits = decode_step(model, y, prompt_cache)
+    for w in decode_fault_words(model):
+        code = int(w.item())
+        if code:
+            decode_fallback(model, code)
+            for c in prompt_cache:
+                c.offset = off
+            return decode_step(model, y, prompt_cache)
+    return logits
 
 
 def decode_step(model, y: torch.Tensor, prompt_cache: List[KVCache]) -> torch.Tensor:

@@ -124,7 +124,7 @@ def eminf_generate(model, tokenizer, input_ids: List[int], input_ids_no_gen: Opt
         tokenizer = TokenizerWrapper(tokenizer)
     detok = tokenizer.detokenizer
     detok.reset()
-    fast = getattr(model, "decode_step", None)
+    fast = getattr(model, "decode_step_checked", None) or getattr(model, "decode_step", None)   # (hand-off faults are replayed: decode.py)
     for _ in range(max_tokens):
         tok, _ = _eminf_sample(logits, alpha, num_steps, threshold, rng)
         generated.append(tok)
@@ -151,7 +151,7 @@ def eminf_generate_step(model, tokenizer, input_ids: List[int], input_ids_no_gen
     logits, cache, dev = _eminf_prefill(model, prompt_cache, input_ids, input_ids_no_gen, use_cache, max_kv_size)
     if not isinstance(tokenizer, TokenizerWrapper):
         tokenizer = TokenizerWrapper(tokenizer)
-    fast = getattr(model, "decode_step", None)
+    fast = getattr(model, "decode_step_checked", None) or getattr(model, "decode_step", None)   # (hand-off faults are replayed: decode.py)
     for _ in range(max_tokens):
         tok, best_logits = _eminf_sample(logits, alpha, num_steps, threshold, rng)
         if tok == getattr(tokenizer, "eos_token_id", None) or tok in tokenizer.eos_token_ids:

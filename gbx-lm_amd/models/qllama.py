@@ -258,6 +258,21 @@ class Model(nn.Module):
         from ..decode import decode_step
         return decode_step(self, y, prompt_cache)
 
+    def decode_step_checked(self, y: torch.Tensor, prompt_cache) -> torch.Tensor:
+        """``decode_step`` that checks the fused launches' status words behind the step (callers that synchronise per token: EMINF)."""
+        from ..decode import decode_step_checked
+        return decode_step_checked(self, y, prompt_cache)
+
+    def decode_fault_words(self):
+        """Device status words of the decode runner's fused launches; generate_step reads them next to every token (decode.py)."""
+        from ..decode import decode_fault_words
+        return decode_fault_words(self)
+
+    def decode_fallback(self, code: int) -> None:
+        """A fused decode launch timed out on a hand-off: this model decodes on the five-launch block from here on (decode.py)."""
+        from ..decode import decode_fallback
+        decode_fallback(self, code)
+
     def sanitize(self, weights: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """Drop precomputed rotary tables some exporters leave in the checkpoint (qllama.py:201-205)."""
         return {k: v for k, v in weights.items() if "self_attn.rotary_emb.inv_freq" not in k}

@@ -525,6 +525,32 @@ def quantized_matmul_partials(x: torch.Tensor, mod):
     return ws, int(slices.value)
 
 
+_XCD_LAYOUT = {}
+
+
+def xcd_layout_ok(device) -> bool:
+    """Does this device take the launches with XCD-local hand-offs (gbx_xcd_layout_check: 256 CUs in one partition, no CU mask, and a
+    census launch that finds consecutive workgroups on 8 different XCDs)?  Checked once per device, outside any capture; False keeps
+    every caller on the launch-per-op block."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        return False
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _XCD_LAYOUT:
+        L = _lib.lib()
+        ok = False
+        if hasattr(L, "gbx_xcd_layout_check") and not torch.cuda.is_current_stream_capturing():
+            with torch.cuda.device(idx):
+                ok = L.gbx_xcd_layout_check() == _lib.GBX_OK
+            if not ok:
+                import warnings
+                warnings.warn("gbx_lm_amd: " + L.gbx_last_error().decode("utf-8", "replace") + " -- decoding on the launch-per-op block")
+        elif torch.cuda.is_current_stream_capturing():
+            return False                       # (not cached: ask again outside the capture)
+        _XCD_LAYOUT[idx] = ok
+    return _XCD_LAYOUT[idx]
+
+
 def norm_state(device) -> torch.Tensor:
     """Zeroed state buffer of the chip-wide slice-sum + norm launches (gbx_norm_state_bytes): one per stream, created before any
     graph capture (its generation words must survive replays)."""
@@ -884,12 +910,21 @@ def dmlp(desc, device) -> None:
 def acc_residual(x: torch.Tensor, acc: torch.Tensor, out: torch.Tensor, zero=()) -> None:
     """out <- round(x + round(acc * 2^-32)); ``acc`` and up to three more [D + 1] accumulators are cleared (gbx_acc_residual)."""
     z = [t.data_ptr() for t in zero] + [None] * (3 - len(zero))
-    _lib.check(_lib.lib().gbx_acc_residual(x.data_ptr(), acc.data_ptr(), out.data_ptr(), x.numel(), z[0], z[1], z[2], _stream_ptr(x.device)))
+    _lib.check(_lib.lib().gbx_acc_residual(x.data_ptr(), acc.data_ptr(), out.data_ptr(), x.numel(), _DT[x.dtype], z[0], z[1], z[2], _stream_ptr(x.device)))
 
 
 def dattn(desc, device) -> None:
     import ctypes
     _lib.check(_lib.lib().gbx_dattn_forward(ctypes.byref(desc), _stream_ptr(device)))
+
+
+DATTN_STATUS_BYTE_OFFSET = 8 * 2048 * 8 + 8 * 16 * 4     # dattn_impl.h: DA_GROUPS * DA_HAND_STRIDE granules, then state word 8 * 16
+
+
+def dattn_status_word(state: torch.Tensor) -> torch.Tensor:
+    """The launch status word inside a fused launch's state buffer as a one-element int32 view (device memory: copy it to the host
+    together with the token, gbx_lm_amd.utils.generate_step does)."""
+    return state[DATTN_STATUS_BYTE_OFFSET:DATTN_STATUS_BYTE_OFFSET + 4].view(torch.int32)
 
 
 def dattn_status(state: torch.Tensor) -> int:

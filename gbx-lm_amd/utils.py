@@ -325,42 +325,86 @@ def generate_step(prompt: torch.Tensor, model: nn.Module, *, max_tokens: int = 2
             prompt_progress_callback(prompt_processed_tokens, total_prompt_tokens)
             prompt_processed_tokens += prefill_step_size
             y = y[prefill_step_size:]
+        first_in, first_off = y, (prompt_cache[0].offset if prompt_cache else 0)
         y, logprobs, h_states = _step(y, hidden_states=with_hidden_states)
 
     # One-token lookahead like the reference's mx.async_eval (utils.py:323-338): step n+1 is enqueued BEFORE token n is read on the
     # host.  On one in-order stream a plain ``y.item()`` would queue its copy behind step n+1 and wait for it, so the id goes to a
     # pinned host word right after its own step (async copy + event) and the host waits for that event only.
-    ring, slot = [], [0]
+    # The status words of the decode runner's fused launches (in-launch hand-offs that can time out: another tenant on the GPU, a CU
+    # mask) travel with the id: a non-zero word means the step's stream was poisoned (NaN logits) -- the model then falls back to the
+    # five-launch block for good and the step is REPLAYED, so the caller never sees a token of a faulted step.
+    ring, fring, slot = [], [], [0]
+    fault_words = getattr(model, "decode_fault_words", None) if fast_decode is not None else None
+
+    class _HandoffFault(Exception):
+        pass
 
     def _to_host(t):
         if not t.is_cuda:
-            return t, None
+            return t, None, None
         if not ring:
             ring.extend(torch.empty((1,), dtype=torch.long, pin_memory=True) for _ in range(3))   # (two ids are in flight at most)
-        pinned = ring[slot[0] % 3]
-        slot[0] += 1
+            fring.extend(torch.zeros((4,), dtype=torch.int32, pin_memory=True) for _ in range(3))
+        pinned, fpin = ring[slot[0] % 3], None
         pinned.copy_(t.reshape(-1)[:1], non_blocking=True)
+        words = fault_words() if fault_words is not None else []
+        if words:
+            fpin = fring[slot[0] % 3][:len(words)]
+            for i, w in enumerate(words):
+                fpin[i:i + 1].copy_(w, non_blocking=True)
+        slot[0] += 1
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(t.device))
-        return pinned, ev
+        return pinned, ev, fpin
 
     def _read(pending):
-        host, ev = pending
+        host, ev, fpin = pending
         if ev is not None:
             ev.synchronize()
+        if fpin is not None and bool(fpin.any()):
+            raise _HandoffFault(int(fpin[fpin != 0][0]))
         return int(host.item())
 
+    def _rewind(off):
+        for c in prompt_cache:
+            c.offset = off
+
     n = 0
+    # (input, cache offset before it) of the decode step that produced ``y``; None when ``y`` came out of the prompt pass
+    made_by = (first_in, first_off) if (first_in is not None and first_in.numel() == 1 and fast_decode is not None) else None
     pending = _to_host(y)
     while True:
         if n != max_tokens:
+            ahead_off = prompt_cache[0].offset if prompt_cache else 0
             next_y, next_logprobs, _ = _step(y)
             next_pending = _to_host(next_y)
         if n == 0:
             prompt_progress_callback(total_prompt_tokens, total_prompt_tokens)
         if n == max_tokens:
             break
-        yield _read(pending), logprobs, h_states
+        try:
+            tok = _read(pending)
+        except _HandoffFault as fault:
+            # in flight: the step that produced ``y`` (when it was a decode step) and the look-ahead step fed by it.  Either may be the
+            # faulted one (the words are sticky): both are replayed on the five-launch block, from the cache offset they started at.
+            model.decode_fallback(int(fault.args[0]))
+            if made_by is not None:
+                _rewind(made_by[1])
+                y, logprobs, h_states = _step(made_by[0])
+            else:
+                _rewind(ahead_off)
+            pending = _to_host(y)
+            if n != max_tokens:
+                ahead_off = prompt_cache[0].offset if prompt_cache else 0
+                next_y, next_logprobs, _ = _step(y)
+                next_pending = _to_host(next_y)
+            try:
+                tok = _read(pending)
+            except _HandoffFault as again:
+                raise RuntimeError(f"decode hand-off {again.args[0]} timed out again after the fall-back to the five-launch block") from None
+        yield tok, logprobs, h_states
+        made_by = (y, ahead_off)
         y, logprobs, pending = next_y, next_logprobs, next_pending
         n += 1
 

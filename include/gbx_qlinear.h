@@ -227,9 +227,13 @@ int gbx_dattn_plan(int32_t D, int32_t n_heads, int32_t n_kv_heads, int32_t head_
                    int32_t o_bits, int32_t o_group_size);
 size_t gbx_dattn_state_bytes(void);
 int gbx_dattn_forward(const gbx_dattn* desc, void* hip_stream);
-/* Synchronous read of the launch status word: *code = 0, or the hand-off that timed out (1: q|k|v, 2: attention output, 3: the
- * activations of gbx_dmlp_forward) -- then the results of that stream are garbage and the caller must fail.  Off the timed path
- * (it synchronises the device).  Serves the state buffer of either fused launch. */
+/* Synchronous read of the launch status word: *code = 0, or the hand-off that timed out (1: q|k|v granules, 2: attention output,
+ * 3: the activations of gbx_dmlp_forward / gbx_dblock_forward, 4: the rotated q of the cooperative sweep, 5: the partial softmax
+ * states of the cooperative sweep, 6: gbx_dblock_forward's arrival line, 7: its leader flags, 8: its x' granules, 9: a context
+ * beyond what gbx_dblock_forward sweeps).  A launch that gives up ALSO raises the non-finite marker of the accumulator it adds to,
+ * so the residual stream -- and with it the logits and the token's logprob -- turn NaN in-band; the caller must still fail or fall
+ * back (gbx-lm_amd/decode.py rebuilds its runner on the five-launch block and replays the step).  Off the timed path (it
+ * synchronises the device).  Serves the state buffer of any of the fused launches. */
 int gbx_dattn_status(const void* state, int32_t* code);
 
 /* ------------------------------------------------------------------------------------------------
@@ -238,7 +242,7 @@ int gbx_dattn_status(const void* state, int32_t* code);
  * [g I/8, (g+1) I/8) and consumes exactly that range as down_proj's input columns, so the one exchange inside the launch stays in
  * that XCD's L2; the eight partial sums per output row meet in acc_out as 2^-32 fixed-point integers.  The NEXT launch forms the
  * residual stream: gbx_dattn.x_acc / x_out of the next block, or gbx_acc_residual after the last one.
- * Covered: 2 bits, group 128, bf16, D = 2048 / 4096, I a multiple of 1024 with I / 256 even in [32, 64] (Llama-3-8B: 14336).
+ * Covered: 2 bits, group 128, bf16, D = 4096, I a multiple of 1024 with I / 256 even in [32, 64] (Llama-3-8B: 14336).
  * ------------------------------------------------------------------------------------------------ */
 typedef struct gbx_dmlp {
   uint32_t struct_size;        /* sizeof(gbx_dmlp) */
@@ -263,8 +267,15 @@ int gbx_dmlp_plan(int32_t D, int32_t I, int32_t gate_up_bits, int32_t gate_up_gr
                   int32_t act_dtype);
 int gbx_dmlp_forward(const gbx_dmlp* desc, void* hip_stream);
 /* out[i] <- round(x[i] + round(acc[i] * 2^-32)) for i < D (acc[D] != 0: NaN), then acc and up to three more [D + 1] accumulators
- * are cleared: the step between the last block's gbx_dmlp_forward and the output head.  bf16. */
-int gbx_acc_residual(const void* x, int64_t* acc, void* out, int32_t D, int64_t* zero0, int64_t* zero1, int64_t* zero2, void* hip_stream);
+ * are cleared: the step between the last block's gbx_dmlp_forward and the output head.  act_dtype: GBX_F16 / GBX_BF16 (since 1300). */
+int gbx_acc_residual(const void* x, int64_t* acc, void* out, int32_t D, int32_t act_dtype, int64_t* zero0, int64_t* zero1, int64_t* zero2,
+                     void* hip_stream);
+/* The device check behind every launch with XCD-local hand-offs (gbx_dattn_*, gbx_dmlp_*, gbx_dblock_*, gbx_add_rmsnorm_slices_xcd):
+ * 256 CUs in one partition, no CU mask on the process, and -- measured once per device by a census launch of the same geometry --
+ * consecutive workgroups on 8 different XCDs, one workgroup per CU.  GBX_OK, or GBX_ERR_UNSUPPORTED with the reason in
+ * gbx_last_error() (the *_plan functions then refuse too and the caller keeps the five-launch block).  Synchronous: not inside a
+ * stream capture.  (since 1300) */
+int gbx_xcd_layout_check(void);
 
 /* Load-time companion of the loader's scale/zero cast (gbx_lm/utils.py:841-843): out[p][g][i] = scale bits | zero bits << 16
  * (16-bit act-dtype patterns, copied verbatim) for the two rows a GEMV batch streams together:

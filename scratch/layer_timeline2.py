@@ -20,6 +20,9 @@ os.environ["GBX_STAMP_PTR"] = str(stamps.data_ptr())
 os.environ["GBX_STAMP_SLOTS"] = str(SLOTS)
 os.environ["GBX_DATTN"] = "1"
 os.environ["GBX_DMLP"] = "1"
+if os.environ.get("GBX_PROBE_MODE"):      # round-6 step 0 (ii): an LDS-DMA stream beside dattn's hand-off chain (stamps build only)
+    pool = torch.full(((24 * 32 + 40) << 20,), 1, dtype=torch.uint8, device=dev)
+    os.environ["GBX_PROBE_SRC"] = str(pool.data_ptr())
 
 from gbx_lm_amd import _lib, synthetic as S  # noqa: E402
 from gbx_lm_amd.decode import FusedDecodeRunner  # noqa: E402

@@ -45,7 +45,7 @@ def test_no_stray_switch_reads():
     getenv / os.environ read of a GBX_ name outside them is either one of the documented diagnostic-build / experimental-library
     names or a bug (a switch without a row of documentation, or one read with different truthiness in two places)."""
     import glob
-    allowed_raw = {"GBX_STAMP_PTR", "GBX_STAMP_SLOTS",                        # -DGBX_STAMPS diagnostic builds (DESIGN.md section 8 preamble)
+    allowed_raw = {"GBX_STAMP_PTR", "GBX_STAMP_SLOTS", "GBX_PROBE_SRC",       # -DGBX_STAMPS diagnostic builds (DESIGN.md section 8 preamble)
                    "GBX_GEMV_MX", "GBX_GEMV_MXD", "GBX_MXD_DEEP", "GBX_CHAIN_FLOOR"}   # libgbx_experimental.so's own opt-ins (gemv_mx.hip, gemv_mxd.hip)
     for f in glob.glob(os.path.join(ROOT, "gbx-lm_amd", "csrc", "*.h*")):
         if f.endswith("gbx_env.h"):
