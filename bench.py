@@ -98,6 +98,9 @@ def kernel_leg(model, runner=None, reps=20):
     fused_mlp = False
     pred = "o_proj"
     da = getattr(runner, "da", None)
+    db = getattr(runner, "db", None)
+    if db is not None and all(db[i] is not None for i in idx) and runner.caches[0].offset <= runner.db_max_ctx:
+        return _block_leg(model, runner, idx, reps)
     if da is not None and all(da[i] is not None for i in idx):
         # the three-launch block: the runner's own (fused attention, gate|up) descriptors -- its weights, caches and buffers
         o_descs = [da[i][0] for i in idx]
@@ -187,6 +190,69 @@ def kernel_leg(model, runner=None, reps=20):
             "method": f"HIP events: graph of ({pred}, {'fused MLP' if fused_mlp else 'gate|up'}) pairs minus the same graph without the second launch, per pair",
             "launches_timed": reps * len(descs),
             "working_set_bytes": nbytes * len(descs)}
+
+
+def _block_leg(model, runner, idx, reps):
+    """Round 6: the dominant launch is the WHOLE 2-bit block (gbx::dblock_kernel: norm -> q|k|v -> attention -> o_proj -> chip-wide release ->
+    norm -> gate|up from LDS -> down_proj).  Timed in its chain position: the runner's own one-launch descriptors of the 2-bit layers, in
+    layer order, as one graph (every launch's predecessor is the previous block's launch, as in the token), HIP events on the launch
+    stream; one tiny accumulator-clearing launch closes the chain so that every replay starts from zero sums.  The duration per launch
+    includes its boundary.  Algorithmic bytes per launch = the seven packed matrices + their scales / zeros + the cached K / V rows the
+    attention reads + the stream / norm-weight vectors + the two fixed-point accumulators (written and read once each)."""
+    from gbx_lm_amd import ops
+    dev = runner.hb.device
+    layers = [model.model.layers[i] for i in idx]
+    descs = [runner.db[i] for i in idx]
+    ctx = runner.caches[0].offset
+    accs = [t for t in (runner.acc_d[0], runner.acc_d[1], runner.acc_o[0], runner.acc_o[1])]
+    tmp = torch.zeros_like(runner.hb)
+
+    def chain():
+        for d in descs:
+            ops.dblock(d, dev)
+        ops.acc_residual(runner.pb, accs[0], tmp, zero=accs[1:])
+
+    hb0 = runner.hb.clone()
+    chain()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        chain()
+    g.replay()
+    torch.cuda.synchronize()
+    best = float("inf")
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
+    runner.dattn_check()
+    runner.hb.copy_(hb0)
+    us = best / len(descs)
+    blk = layers[0]
+    mods = (blk.self_attn.q_proj, blk.self_attn.k_proj, blk.self_attn.v_proj, blk.self_attn.o_proj, blk.mlp.gate_proj, blk.mlp.up_proj, blk.mlp.down_proj)
+    D = runner.hb.numel()
+    wbytes = sum(m.qweight.numel() * 4 + m.scales.numel() * 2 + m.zeros.numel() * 2 for m in mods)
+    kv = 2 * (ctx + 1) * blk.self_attn.n_kv_heads * blk.self_attn.head_dim * 2
+    nbytes = wbytes + kv + 4 * D * 2 + 2 * 2 * (D + 1) * 8
+    achieved = nbytes / us / 1e3
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            rec = json.load(f).get("dblock_b2_D4096_I14336")
+            traffic = rec["traffic_bytes_per_launch"] if rec else None
+    except (OSError, ValueError, KeyError):
+        traffic = None
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+            "kernel": "gbx::dblock_kernel (one launch per 2-bit decoder block: RMSNorm + q|k|v + RoPE/append + attention + o_proj + chip-wide release + "
+                      "RMSNorm + gate|up from LDS + SwiGLU + down_proj; FP4 x FP8 matrix cores), Llama-3-8B shapes, g=128",
+            "bytes_per_launch": nbytes, "us_per_launch": us, "context": ctx,
+            "method": "HIP events: one graph of the runner's own one-launch descriptors of every 2-bit layer in layer order (+ one accumulator-clearing "
+                      "launch), per launch, boundary included",
+            "launches_timed": reps * len(descs), "working_set_bytes": nbytes * len(descs)}
 
 
 def _free_port():

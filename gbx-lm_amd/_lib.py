@@ -63,6 +63,9 @@ def lib() -> ctypes.CDLL:
             L.gbx_qlinear_partials_bytes.argtypes = [i64, i32, i32, i32, i32]
             L.gbx_qlinear_partials_bytes.restype = ctypes.c_size_t
         L.gbx_attn_workspace_bytes.restype = ctypes.c_size_t
+        if hasattr(L, 'gbx_dblock_state_bytes'):
+            L.gbx_dblock_state_bytes.argtypes = []
+            L.gbx_dblock_state_bytes.restype = ctypes.c_size_t
         if hasattr(L, 'gbx_norm_state_bytes'):
             L.gbx_norm_state_bytes.argtypes = []
             L.gbx_norm_state_bytes.restype = ctypes.c_size_t
@@ -181,6 +184,22 @@ class DmlpDesc(ctypes.Structure):
                 ("D", ctypes.c_int32), ("I", ctypes.c_int32), ("zero_n", ctypes.c_int32), ("norm_eps", ctypes.c_float)]
 
 
+class DblockDesc(ctypes.Structure):
+    """Mirror of ``gbx_dblock`` (include/gbx_qlinear.h): a whole 2-bit decoder block at M == 1 as one launch."""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("act_dtype", ctypes.c_int32),
+                ("x", ctypes.c_void_p), ("norm_weight", ctypes.c_void_p), ("ssq_in", ctypes.c_void_p),
+                ("qkv_qweight", ctypes.c_void_p), ("qkv_sz", ctypes.c_void_p), ("kcache", ctypes.c_void_p), ("vcache", ctypes.c_void_p),
+                ("inv_freq", ctypes.c_void_p), ("pos", ctypes.c_void_p), ("o_qweight", ctypes.c_void_p), ("o_scales", ctypes.c_void_p),
+                ("o_zeros", ctypes.c_void_p), ("acc_o", ctypes.c_void_p), ("x_acc", ctypes.c_void_p), ("x_out", ctypes.c_void_p),
+                ("attn_out", ctypes.c_void_p),
+                ("norm2_weight", ctypes.c_void_p), ("gate_qweight", ctypes.c_void_p), ("up_qweight", ctypes.c_void_p),
+                ("gate_up_sz", ctypes.c_void_p), ("down_qweight", ctypes.c_void_p), ("down_sz", ctypes.c_void_p),
+                ("acc_d", ctypes.c_void_p), ("x2_out", ctypes.c_void_p), ("act_out", ctypes.c_void_p),
+                ("zero_buf0", ctypes.c_void_p), ("zero_buf1", ctypes.c_void_p), ("state", ctypes.c_void_p),
+                ("zero_n0", ctypes.c_int32), ("zero_n1", ctypes.c_int32), ("capacity", ctypes.c_int32), ("traditional", ctypes.c_int32),
+                ("norm_eps", ctypes.c_float), ("norm2_eps", ctypes.c_float), ("rope_scale", ctypes.c_float), ("sm_scale", ctypes.c_float)]
+
+
 GBX_DG_PLAIN, GBX_DG_RESIDUAL, GBX_DG_SWIGLU = 0, 1, 2
 GBX_DG_SSQ_SLOTS = 1024
 GBX_MIN_VERSION = 1300          # the header this binding mirrors
@@ -203,6 +222,10 @@ def _declare_optional(L) -> None:
         "gbx_dmlp_forward": [ctypes.POINTER(DmlpDesc), p],
         "gbx_acc_residual": [p, p, p, i32, i32, p, p, p, p],
         "gbx_xcd_layout_check": [],
+        "gbx_dblock_plan": [i32] * 14,
+        "gbx_dblock_forward": [ctypes.POINTER(DblockDesc), p],
+        "gbx_dblock_status": [p, ctypes.POINTER(i32)],
+        "gbx_dblock_max_context": [],
         "gbx_qlinear_kernel_id": [i64, i32, i32, i32, i32, i32],
         "gbx_qlinear_swiglu_forward": [p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, p],
         "gbx_qlinear_forward_partials": [p, p, p, p, p, ctypes.c_size_t, ctypes.POINTER(i32), i64, i32, i32, i32, i32, i32, p],

@@ -1212,6 +1212,97 @@ int gbx_acc_residual(const void* x, int64_t* acc, void* out, int32_t D, int32_t 
   return GBX_OK;
 }
 
+int gbx_dblock_plan(int32_t D, int32_t I, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int32_t qkv_bits, int32_t qkv_group_size,
+                    int32_t o_bits, int32_t o_group_size, int32_t gate_up_bits, int32_t gate_up_group_size, int32_t down_bits,
+                    int32_t down_group_size, int32_t act_dtype) {
+  if (int rc = xcd_layout_gate("gbx_dblock_plan")) return rc;
+  if (!gbx::dblock_plan(D, I, n_heads, n_kv_heads, head_dim, qkv_bits, qkv_group_size, o_bits, o_group_size, gate_up_bits, gate_up_group_size,
+                        down_bits, down_group_size, act_dtype == GBX_BF16))
+    return fail(GBX_ERR_UNSUPPORTED, "the one-launch block covers 2 bits, group 128, bf16, D = 4096, 32 / 8 heads of 128, I = 14336 (got D=%d I=%d heads=%d/%d hd=%d "
+                "bits %d/%d/%d/%d groups %d/%d/%d/%d dtype %d)", D, I, n_heads, n_kv_heads, head_dim, qkv_bits, o_bits, gate_up_bits, down_bits,
+                qkv_group_size, o_group_size, gate_up_group_size, down_group_size, act_dtype);
+  return GBX_OK;
+}
+
+size_t gbx_dblock_state_bytes(void) { return gbx::dblock_state_bytes(); }
+int32_t gbx_dblock_max_context(void) { return gbx::dblock_max_ctx(); }
+
+int gbx_dblock_forward(const gbx_dblock* d, void* hip_stream) {
+  if (!d) return fail(GBX_ERR_INVALID, "null descriptor");
+  if (d->struct_size != sizeof(gbx_dblock)) return fail(GBX_ERR_INVALID, "gbx_dblock.struct_size is %u, this library expects %zu (header / library mismatch)", d->struct_size, sizeof(gbx_dblock));
+  if (d->act_dtype != GBX_BF16) return fail(GBX_ERR_UNSUPPORTED, "the one-launch block is bf16");
+  if (!gbx::xcd_layout_ok()) return fail(GBX_ERR_UNSUPPORTED, "gbx_dblock_forward: %s (gbx_dblock_plan)", gbx::xcd_layout_reason());
+  if (!d->x || !d->norm_weight || !d->qkv_qweight || !d->qkv_sz || !d->kcache || !d->vcache || !d->inv_freq || !d->pos || !d->o_qweight || !d->o_scales ||
+      !d->o_zeros || !d->acc_o || !d->norm2_weight || !d->gate_qweight || !d->up_qweight || !d->gate_up_sz || !d->down_qweight || !d->down_sz || !d->acc_d ||
+      !d->x2_out || !d->state)
+    return fail(GBX_ERR_INVALID, "null device pointer");
+  const void* al16[] = {d->x, d->norm_weight, d->qkv_qweight, d->qkv_sz, d->kcache, d->vcache, d->o_qweight, d->acc_o, d->norm2_weight, d->gate_qweight,
+                        d->up_qweight, d->gate_up_sz, d->down_qweight, d->down_sz, d->acc_d, d->x2_out, d->ssq_in, d->x_acc, d->x_out};
+  for (const void* p : al16)
+    if (p && !aligned(p, 16)) return fail(GBX_ERR_INVALID, "every tensor of gbx_dblock must be 16-byte aligned");
+  if (!aligned(d->state, 64)) return fail(GBX_ERR_INVALID, "state must be 64-byte aligned");
+  if (d->capacity <= 0) return fail(GBX_ERR_INVALID, "capacity must be positive");
+  if (d->x_acc && d->ssq_in) return fail(GBX_ERR_INVALID, "x_acc goes without ssq_in");
+  if (d->x_acc && (!d->x_out || d->x_out == d->x)) return fail(GBX_ERR_INVALID, "x_acc needs x_out (the leaders read the stream back), not aliasing x");
+  if (!d->x_acc && d->x_out) return fail(GBX_ERR_INVALID, "x_out goes with x_acc");
+  // (x2_out MAY be x: every read of x sits in front of a workgroup's ARRIVE, the one write of x2_out behind the chip-wide release)
+  if (d->x2_out == d->x_out) return fail(GBX_ERR_INVALID, "x2_out must not alias x_out (the leaders read x_out back while one of them writes x2_out)");
+  if (reinterpret_cast<const void*>(d->acc_o) == reinterpret_cast<const void*>(d->acc_d) || reinterpret_cast<const void*>(d->x_acc) == reinterpret_cast<const void*>(d->acc_o) ||
+      reinterpret_cast<const void*>(d->x_acc) == reinterpret_cast<const void*>(d->acc_d))
+    return fail(GBX_ERR_INVALID, "acc_o, acc_d and x_acc are three different accumulators");
+  const uint64_t* zb[2] = {d->zero_buf0, d->zero_buf1};
+  const int32_t zn[2] = {d->zero_n0, d->zero_n1};
+  for (int i = 0; i < 2; ++i)
+    // (acc_d itself MAY be a zero_buf: it is cleared with write-through stores before this workgroup's ARRIVE and added to only behind the
+    //  chip-wide release, which waits for every workgroup's ARRIVE -- the two-launch block clears it in its first launch the same way)
+    if (zb[i] && (zn[i] <= 0 || !aligned(zb[i], 8) || reinterpret_cast<const void*>(zb[i]) == reinterpret_cast<const void*>(d->x_acc) ||
+                  reinterpret_cast<const void*>(zb[i]) == reinterpret_cast<const void*>(d->acc_o)))
+      return fail(GBX_ERR_INVALID, "a zero_buf needs zero_n > 0, 8-byte alignment, and must be neither x_acc nor acc_o of this launch");
+  gbx::DblockArgs a{};
+  a.x = static_cast<const unsigned short*>(d->x);
+  a.norm_w = static_cast<const unsigned short*>(d->norm_weight);
+  a.ssq_in = d->ssq_in;
+  a.qkv_qw = d->qkv_qweight; a.qkv_sz = d->qkv_sz;
+  a.kcache = static_cast<unsigned short*>(d->kcache); a.vcache = static_cast<unsigned short*>(d->vcache);
+  a.inv_freq = d->inv_freq;
+  a.pos = reinterpret_cast<const long long*>(d->pos);
+  a.o_qw = d->o_qweight; a.o_s = static_cast<const unsigned short*>(d->o_scales); a.o_z = static_cast<const unsigned short*>(d->o_zeros);
+  a.acc_o = reinterpret_cast<unsigned long long*>(d->acc_o);
+  a.x_acc = reinterpret_cast<const long long*>(d->x_acc);
+  a.x_out = static_cast<unsigned short*>(d->x_out);
+  a.attn_out = static_cast<unsigned short*>(d->attn_out);
+  a.norm2_w = static_cast<const unsigned short*>(d->norm2_weight);
+  a.gate_qw = d->gate_qweight; a.up_qw = d->up_qweight; a.gu_sz = d->gate_up_sz; a.down_qw = d->down_qweight; a.down_sz = d->down_sz;
+  a.acc_d = reinterpret_cast<unsigned long long*>(d->acc_d);
+  a.x2_out = static_cast<unsigned short*>(d->x2_out);
+  a.act_out = static_cast<unsigned short*>(d->act_out);
+  a.hand = static_cast<unsigned long long*>(d->state);
+  a.state = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(d->state) + gbx::dblock_status_offset() - 8 * 16 * 4);
+  a.zero0 = reinterpret_cast<unsigned long long*>(d->zero_buf0); a.zero_n0 = d->zero_buf0 ? d->zero_n0 : 0;
+  a.zero1 = reinterpret_cast<unsigned long long*>(d->zero_buf1); a.zero_n1 = d->zero_buf1 ? d->zero_n1 : 0;
+  a.capacity = d->capacity; a.traditional = d->traditional; a.max_ctx = gbx::dblock_max_ctx();
+  {
+    static const int spin_log2 = gbx::env_switch("GBX_DATTN_SPIN_LOG2");
+    a.spin_limit = 1u << (spin_log2 < 0 ? 0 : (spin_log2 > 30 ? 30 : spin_log2));
+  }
+  a.eps1 = d->norm_eps; a.eps2 = d->norm2_eps; a.rope_scale = d->rope_scale; a.sm_scale = d->sm_scale;
+#ifdef GBX_STAMPS
+  a.stamps = gbx::stamp_region();
+#endif
+  hipError_t e = gbx::launch_dblock(a, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_dblock_forward launch");
+  return GBX_OK;
+}
+
+int gbx_dblock_status(const void* state, int32_t* code) {
+  if (!state || !code) return fail(GBX_ERR_INVALID, "null pointer");
+  unsigned v = 0;
+  hipError_t e = hipMemcpy(&v, static_cast<const unsigned char*>(state) + gbx::dblock_status_offset(), 4, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return hip_fail(e, "gbx_dblock_status");
+  *code = static_cast<int32_t>(v);
+  return GBX_OK;
+}
+
 int gbx_dattn_status(const void* state, int32_t* code) {
   if (!state || !code) return fail(GBX_ERR_INVALID, "null pointer");
   unsigned v = 0;

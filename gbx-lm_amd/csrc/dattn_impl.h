@@ -118,6 +118,55 @@ struct DmlpArgs {
 bool dmlp_plan(int D, int I, int bits_gu, int group_gu, int bits_dn, int group_dn, bool bf16, int* bpw, int* a4);
 hipError_t launch_dmlp(const DmlpArgs& a, hipStream_t stream);
 hipError_t launch_acc_finish(const void* x, void* acc, void* out, int D, bool bf16, void* z0, void* z1, void* z2, hipStream_t stream);
+// dblock.hip (round 6): the whole 2-bit block -- both launches above -- as ONE launch with a chip-wide release between o_proj's sums and the MLP
+struct DblockArgs {
+  // attention half (DattnArgs)
+  const unsigned short* x;          // [D] residual stream
+  const unsigned short* norm_w;     // [D] input RMSNorm weight
+  const float* ssq_in;              // carried statistic of x, or null
+  const uint32_t* qkv_qw;           // q | k | v rows concatenated
+  const uint32_t* qkv_sz;
+  unsigned short* kcache;           // [8, capacity, 128]
+  unsigned short* vcache;
+  const float* inv_freq;
+  const long long* pos;
+  const uint32_t* o_qw;
+  const unsigned short* o_s;
+  const unsigned short* o_z;
+  unsigned long long* acc_o;        // [D + 1] o_proj sums (zero on entry)
+  const long long* x_acc;           // [D + 1] or null: the previous block's down_proj sums
+  unsigned short* x_out;            // with x_acc: x <- round(x + round(x_acc * 2^-32)), written once (write-through: the leaders read it back)
+  unsigned short* attn_out;         // optional (tests)
+  // MLP half (DmlpArgs)
+  const unsigned short* norm2_w;    // [D] post-attention RMSNorm weight
+  const uint32_t* gate_qw;
+  const uint32_t* up_qw;
+  const uint32_t* gu_sz;
+  const uint32_t* down_qw;
+  const uint32_t* down_sz;
+  unsigned long long* acc_d;        // [D + 1] down_proj sums (zero on entry)
+  unsigned short* x2_out;           // [D] x' = round(h + round(o_proj sums)): the stream the next launch adds down_proj's output to
+  unsigned short* act_out;          // optional (tests)
+  // plumbing
+  unsigned long long* hand;         // [8][DB_HAND_STRIDE] granules
+  unsigned* state;
+  unsigned long long* zero0;        // or null: zero_n0 words this launch clears (write-through stores)
+  unsigned long long* zero1;
+  int zero_n0, zero_n1;
+  int capacity, traditional, max_ctx;
+  unsigned spin_limit;
+  float eps1, eps2, rope_scale, sm_scale;
+#ifdef GBX_STAMPS
+  unsigned long long* stamps;
+#endif
+};
+bool dblock_plan(int D, int I, int n_heads, int n_kv, int head_dim, int qkv_bits, int qkv_group, int o_bits, int o_group, int gu_bits, int gu_group,
+                 int dn_bits, int dn_group, bool bf16);
+size_t dblock_state_bytes();
+size_t dblock_status_offset();
+int dblock_max_ctx();
+hipError_t launch_dblock(const DblockArgs& a, hipStream_t stream);
+
 template <int BQ>
 hipError_t launch_dattn_bits(const DattnArgs& a, const DattnPlan& pl, bool bf16, hipStream_t stream);
 

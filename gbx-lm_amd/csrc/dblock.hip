@@ -1,0 +1,981 @@
+// A whole 2-bit decoder block at M == 1 as ONE launch ("dblock", round 6):
+//
+//   [x = round(h + round(previous down_proj sums))] -> RMSNorm -> q | k | v rows of ONE kv group per XCD -> RoPE + KV-cache append -> attention
+//      -> o_proj over that group's 512 input columns -> fixed-point partial sums into acc_o[D]
+//      -> CHIP-WIDE RELEASE: per-XCD arrival line -> 8 leader flags -> each XCD's leader workgroup turns (h, sums) into x' = round(h + round(o)),
+//         its statistic and RMSNorm(x') ONCE and publishes it XCD-locally as 2048 tagged granules
+//      -> every workgroup builds the two-limb FP8 operand image from the granules it polled
+//      -> gate | up rows of ONE eighth of the intermediate vector per XCD, consumed FROM LDS, + SwiGLU -> XCD-local hand-off of those
+//         I / 8 activations -> down_proj over exactly that eighth of its input columns -> fixed-point partial sums into acc_d[D]
+//
+// replaces the two launches of round 5 (gbx_dattn_forward + gbx_dmlp_forward; dattn_impl.h, dmlp.hip) for the block they both cover:
+//   mx.quantized_matmul at M == 1 (gbx_lm/models/quantized_linear_gba.py:195-203), seven times, at the call sites of
+//   gbx_lm/models/qllama.py:76 (q, k, v), :96 (o_proj), :115 (gate, up, down), with the block's norms and residual adds (:137-141) and the
+//   attention between them (:78-95).
+//
+// Why one launch (profiles/r06_block_probe.txt): in the two-launch block HBM is idle for ~19 of 27.4 us -- two 3 us prologues, the 5 us
+// attention latency chain, the hand-off tails, two boundaries -- while the MLP's 47.7 MB depend on nothing.  Here a CU pulls its
+// gate | up rows (60 activations = 135 KB for a producer workgroup) into LDS by LDS-DMA DURING the attention chain and consumes them from
+// LDS (~1.5 us) once x' exists.  What the probe established and this kernel is built on:
+//   * one memory queue per CU, served in order: a poll issued behind a stream waits for the stream.  So a CU's stream must END before the
+//     hand-off it waits for is due.  Windows: W0 attention workgroups at launch start (idle until q arrives); W1 producers between
+//     "every granule of this workgroup is out" (a workgroup barrier behind the publish: granule STORES queue behind DMA too) and the
+//     attention output (+0.3 us on H2 at 72-88 KB); W2 everyone between ARRIVE and x' (3.1 us: up to ~56 KB drains in time);
+//     W3 down_proj's words (56 KB per CU, registers) behind x', landing during the LDS consume.
+//   * the release costs 3.1 us after the last arrival (0.3 arrival line, 1.1 the one cross-XCD hop, 0.85 sums + statistic, 0.8 publish +
+//     poll) -- what the removed boundary + the second prologue cost (1.6 + 2.9 us); the gain is the stream that no longer follows it.
+//   * the leader (member 0 of each XCD, an attention workgroup) carries no stream while it runs the release: it owns 16 activations, all
+//     fetched in W0; the other attention workgroups own 32, producers 60 (16 + 3 * 32 + 28 * 60 = 1792 = I / 8).
+// Arithmetic: identical to the two launches (dattn_kernel<2, 1, true, 2> + dmlp_kernel<2>: FP4 x FP8 matrix cores, fixed-point sums,
+// the same roundings in the same places), so results agree with them bit for bit wherever the summation order is the same.
+// Covered: 2 bits, group 128, bf16, D = 4096, 32 query / 8 kv heads of 128, I = 14336, contexts up to `max_ctx` cached positions (the
+// head's own workgroup sweeps; beyond that the runner replays the two-launch block with its cooperative sweep).
+#include "dattn_impl.h"
+#include "gbx_env.h"
+#include "kernels.h"
+#include <type_traits>
+
+namespace gbx {
+
+typedef int db_v8i __attribute__((ext_vector_type(8)));
+typedef float db_v4f __attribute__((ext_vector_type(4)));
+typedef float db_f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) unsigned long long db_gu64;
+typedef __attribute__((address_space(1))) unsigned db_gu32;
+
+// LDS map (bytes)
+constexpr int DB_LDS_IMG = 0;                      // phase-1 operand image, later the gate|up operand image: 8 KB + 512 B sums + 128 B scales
+constexpr int DB_LDS_RED = 9 * 1024;               // 16 floats
+constexpr int DB_LDS_P3 = 9 * 1024 + 256;          // o_proj operand image, later down_proj's: 4 KB + 256 B + 64 B
+constexpr int DB_LDS_ATT = 16 * 1024;              // attention workgroups: q | k | v words, rotated q / k / v, softmax states (37.6 KB)
+constexpr int DB_LDS_ROWS_P = 16 * 1024;           // producers: gate rows | up rows | scale-zero pairs of 60 activations (135 KB)
+constexpr int DB_LDS_ROWS_A = 56 * 1024;           // attention workgroups: the same for 32 (16) activations (72 / 36 KB)
+constexpr int DB_LDS_BYTES = 152 * 1024;
+#ifdef GBX_STAMPS
+#define DB_STAMP(i) do { if (lane == 0) reinterpret_cast<unsigned long long*>(smem + DB_LDS_BYTES)[wave * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define DB_STAMP_EXTRA 2048
+#else
+#define DB_STAMP(i) do {} while (0)
+#define DB_STAMP_EXTRA 0
+#endif
+
+constexpr int DB_D = 4096, DB_I = 14336, DB_REP = 4, DB_HD = 128, DB_IX = DB_I / 8;
+constexpr int DB_ACT_LEADER = 16, DB_ACT_ATT = 32, DB_ACT_PROD = 60;
+static_assert(DB_ACT_LEADER + (DB_REP - 1) * DB_ACT_ATT + (DA_MEMBERS - DB_REP) * DB_ACT_PROD == DB_IX, "the XCD's eighth of the intermediate vector");
+constexpr int DB_W0_PIECES = 36;                   // attention workgroups, launch start (the leader's whole share)
+constexpr int DB_W1_PIECES = 84;                   // producers, behind their publish barrier: 14 waves x 6 pieces of 1 KB
+// hand-off granules per group (8 bytes each)
+constexpr int DB_H_P1 = 0;                         // 384 phase-1 granules
+constexpr int DB_H_ATT = 512;                      // 256 attention-output granules
+constexpr int DB_H_ARR = 768;                      // 32 arrival granules
+constexpr int DB_H_X = 1024;                       // 2048 granules of RMSNorm(x')
+constexpr int DB_H_ACT = 3072;                     // 896 activation granules
+constexpr int DB_HAND_STRIDE = 4096;
+// state words (u32): gen[g] at g * 16, status at 8 * 16 (as the two-launch kernels: gbx_dattn_status serves all), leader flag of XCD g at (16 + 2 g) * 16
+constexpr int DB_STATE_WORDS = 64 * 16;
+constexpr int DB_MAX_CTX = 384;
+
+template <int DUMMY>
+__global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
+  constexpr bool BF16 = true;
+  constexpr int NT = DA_NT, NW = DA_NW, HD = DB_HD, REP = DB_REP, D = DB_D;
+  constexpr int SP = 2, NBLK = SP * 64;
+  constexpr unsigned KILL = 0x80000000u;
+  constexpr int RS_FLAGS = 0x00020000, RS_ALL = 0x7FFFFFFF;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef GBX_STAMPS
+  if (lane < 16) reinterpret_cast<unsigned long long*>(smem + DB_LDS_BYTES)[wave * 16 + lane] = 0ull;
+#endif
+  DB_STAMP(0);
+  const int g = static_cast<int>(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);     // HW_REG_XCC_ID: this XCD = kv group = eighth of the MLP
+  const int r = static_cast<int>(blockIdx.x) >> 3;                                       // member of the group
+  db_gu32* gen_p = reinterpret_cast<db_gu32*>(reinterpret_cast<uintptr_t>(a.state)) + g * 16;
+  db_gu32* flag_p = reinterpret_cast<db_gu32*>(reinterpret_cast<uintptr_t>(a.state)) + 16 * 16;     // flag of XCD j at + 32 j
+  db_gu64* hand = reinterpret_cast<db_gu64*>(reinterpret_cast<uintptr_t>(a.hand)) + static_cast<size_t>(g) * DB_HAND_STRIDE;
+  db_gu64* hand1 = hand + DB_H_P1, *hand2 = hand + DB_H_ATT, *harr = hand + DB_H_ARR, *hx = hand + DB_H_X, *hact = hand + DB_H_ACT;
+  db_gu64* acc_o = reinterpret_cast<db_gu64*>(reinterpret_cast<uintptr_t>(a.acc_o));
+  db_gu64* acc_d = reinterpret_cast<db_gu64*>(reinterpret_cast<uintptr_t>(a.acc_d));
+  auto rsrc = [](const void* ptr, int bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, bytes, RS_FLAGS); };
+  // a hand-off that never arrives: status word for the host + the non-finite markers of BOTH accumulators (whichever the consumer reads)
+  auto timeout = [&](unsigned code) {
+    if (lane == 0) {
+      a.state[8 * 16] = code;
+      __hip_atomic_fetch_add(acc_o + D, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(acc_d + D, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  auto sweep = [&](db_gu64* p, unsigned tag, unsigned code) -> unsigned {
+    unsigned long long x;
+    for (unsigned spins = 0;;) {
+      x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__all(static_cast<unsigned>(x >> 32) == tag)) break;
+      if (++spins > a.spin_limit) { timeout(code); break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    return static_cast<unsigned>(x);
+  };
+  auto sweep2 = [&](db_gu64* pa, db_gu64* pb, unsigned tag, unsigned code, unsigned& va, unsigned& vb) {
+    unsigned long long x, y;
+    for (unsigned spins = 0;;) {
+      x = __hip_atomic_load(pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      y = __hip_atomic_load(pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__all(static_cast<unsigned>(x >> 32) == tag && static_cast<unsigned>(y >> 32) == tag)) break;
+      if (++spins > a.spin_limit) { timeout(code); break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    va = static_cast<unsigned>(x);
+    vb = static_cast<unsigned>(y);
+  };
+
+  // Accumulators this launch clears for later launches.  Write-through (agent-scope) stores: a dirty zero line left in this XCD's L2 would be
+  // written back at the end of the launch OVER the memory-side atomic sums another part of this launch may add to the same words.
+  if (a.zero0) {
+    db_gu64* z = reinterpret_cast<db_gu64*>(reinterpret_cast<uintptr_t>(a.zero0));
+    for (int i = static_cast<int>(blockIdx.x) * NT + tid; i < a.zero_n0; i += static_cast<int>(gridDim.x) * NT) __hip_atomic_store(z + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (a.zero1) {
+    db_gu64* z = reinterpret_cast<db_gu64*>(reinterpret_cast<uintptr_t>(a.zero1));
+    for (int i = static_cast<int>(blockIdx.x) * NT + tid; i < a.zero_n1; i += static_cast<int>(gridDim.x) * NT) __hip_atomic_store(z + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const int cpos = static_cast<int>(*a.pos);
+  const int mnn = lane & 15, mkg = lane >> 4;               // matrix-core operand lane: (row / group nn, 8-byte piece kg)
+  const bool diag = mkg == (mnn >> 2);
+  float dm[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dm[q] = (diag && (lane & 3) == q) ? 1.f : 0.f;
+
+  // ---- this workgroup's share of the XCD's gate | up activations, and where its rows live in LDS
+  const int nact = r == 0 ? DB_ACT_LEADER : (r < REP ? DB_ACT_ATT : DB_ACT_PROD);
+  const int act0 = r == 0 ? 0 : (r < REP ? DB_ACT_LEADER + (r - 1) * DB_ACT_ATT : DB_ACT_LEADER + (REP - 1) * DB_ACT_ATT + (r - REP) * DB_ACT_PROD);
+  const int n0g = g * DB_IX + act0;                         // first gate / up row of this workgroup
+  unsigned char* rows = smem + (r < REP ? DB_LDS_ROWS_A : DB_LDS_ROWS_P);
+  const int npieces = 2 * nact + (nact >> 2);               // 1-KB pieces: gate rows, up rows, four activations' scale-zero pairs
+  const __amdgpu_buffer_rsrc_t gqd = rsrc(a.gate_qw, RS_ALL), uqd = rsrc(a.up_qw, RS_ALL), gszd = rsrc(a.gu_sz, RS_ALL);
+  // pieces [p0, p1) by the waves [w0, NW): LDS-DMA, 16 bytes per lane, nothing held in registers
+  auto dma = [&](int p0, int p1, int w0) {
+    if (wave < w0) return;
+    for (int p = p0 + (wave - w0); p < p1; p += NW - w0) {
+      auto dst = (__attribute__((address_space(3))) void*)(rows + p * 1024);
+      if (p < nact) __builtin_amdgcn_raw_ptr_buffer_load_lds(gqd, dst, 16, lane * 16, (n0g + p) * 1024, 0, 2);
+      else if (p < 2 * nact) __builtin_amdgcn_raw_ptr_buffer_load_lds(uqd, dst, 16, lane * 16, (n0g + p - nact) * 1024, 0, 2);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(gszd, dst, 16, lane * 16, n0g * 256 + (p - 2 * nact) * 1024, 0, 0);
+    }
+  };
+  int pieces_done = 0;
+
+  // ---------------- o_proj: this workgroup's 128 rows, this group's 512 columns -- requested early, consumed in phase 3 ----------------
+  constexpr int KO = REP * HD * DA_GROUPS;                  // 4096
+  constexpr int W4o = KO / 4;                               // bytes per packed o_proj row
+  constexpr int Go = KO >> 7;
+  constexpr int RPW = D / DA_MEMBERS;                       // 128 rows per workgroup (o_proj and down_proj)
+  u32x2 owm[2];
+  unsigned osc[2], oze[2];
+  auto issue_o = [&]() {
+    const __amdgpu_buffer_rsrc_t od = rsrc(a.o_qw, D * W4o);
+    const __amdgpu_buffer_rsrc_t sd = rsrc(a.o_s, RS_ALL), zd = rsrc(a.o_z, RS_ALL);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = r * RPW + wave * 8 + 4 * j + (mnn >> 2);
+      owm[j] = __builtin_amdgcn_raw_buffer_load_b64(od, static_cast<unsigned>(row * W4o + (g * 4 + (mnn & 3)) * 32 + mkg * 8), 0, 0);
+      const unsigned so = static_cast<unsigned>((row * Go + g * 4 + (mnn & 3)) * 2);
+      osc[j] = __builtin_amdgcn_raw_buffer_load_b16(sd, so, 0, 0);
+      oze[j] = __builtin_amdgcn_raw_buffer_load_b16(zd, so, 0, 0);
+    }
+  };
+
+  // one 4-value item of a two-limb FP8 operand image (dgemv_mx.hip): values v, item `it` of a [span h][limb][piece][64 lanes][16 B] image
+  auto image_item = [&](const float (&v)[4], int it, bool two_span, unsigned char* img, float* bsum, unsigned char* scl) {
+    float sum = (v[0] + v[1]) + (v[2] + v[3]);
+    unsigned amax = max(max(__float_as_uint(v[0]) & 0x7FFFFFFFu, __float_as_uint(v[1]) & 0x7FFFFFFFu),
+                        max(__float_as_uint(v[2]) & 0x7FFFFFFFu, __float_as_uint(v[3]) & 0x7FFFFFFFu));
+    sum += dpp_f32<0xB1>(sum); amax = max(amax, dpp_u32<0xB1>(amax));
+    sum += dpp_f32<0x4E>(sum); amax = max(amax, dpp_u32<0x4E>(amax));
+    sum += dpp_f32<0x141>(sum); amax = max(amax, dpp_u32<0x141>(amax));
+    if (amax >= 0x7F800000u) sum = __uint_as_float(0x7FC00000u);     // Inf / NaN in the block: NaN through the zero-point term of every row
+    int ea = static_cast<int>(amax >> 23);
+    ea = min(max(ea, 20), 240);
+    const float up = exp2i(134 - ea);
+    const int b = it >> 3, u = it & 7;
+    const int h = two_span ? (b >> 6) : 0, m = (b & 63) >> 2, kb = b & 3;
+    const int ga = 2 * (kb & 1) + (u >> 2);
+    unsigned char* dst = img + (h * 4 + (kb >> 1)) * 1024 + (m + 16 * ga) * 16 + 2 * (u & 3);
+    const float r0 = v[0] * up, r1 = v[1] * up, r2 = v[2] * up, r3 = v[3] * up;
+    const int pe = __builtin_amdgcn_cvt_pk_fp8_f32(r0, r2, 0, false);
+    const int po = __builtin_amdgcn_cvt_pk_fp8_f32(r1, r3, 0, false);
+    *reinterpret_cast<unsigned short*>(dst) = static_cast<unsigned short>(pe);
+    *reinterpret_cast<unsigned short*>(dst + 8) = static_cast<unsigned short>(po);
+    const int le = __builtin_amdgcn_cvt_pk_fp8_f32(r0 - __builtin_amdgcn_cvt_f32_fp8(pe, 0), r2 - __builtin_amdgcn_cvt_f32_fp8(pe, 1), 0, false);
+    const int lo = __builtin_amdgcn_cvt_pk_fp8_f32(r1 - __builtin_amdgcn_cvt_f32_fp8(po, 0), r3 - __builtin_amdgcn_cvt_f32_fp8(po, 1), 0, false);
+    *reinterpret_cast<unsigned short*>(dst + 2048) = static_cast<unsigned short>(le);
+    *reinterpret_cast<unsigned short*>(dst + 2048 + 8) = static_cast<unsigned short>(lo);
+    if (u == 0) { bsum[h * 64 + m + 16 * kb] = sum; scl[h * 64 + m + 16 * kb] = static_cast<unsigned char>(ea - 7); }
+  };
+
+  unsigned char* img = smem + DB_LDS_IMG;
+  float* bsum = reinterpret_cast<float*>(smem + DB_LDS_IMG + SP * 4096);
+  unsigned char* scl = reinterpret_cast<unsigned char*>(bsum + NBLK);
+  float* red_lds = reinterpret_cast<float*>(smem + DB_LDS_RED);
+
+  unsigned tag;
+  if (cpos > a.max_ctx) timeout(9u);                            // (the runner replays the two-launch block beyond max_ctx: never reached through it)
+  if (r >= REP) {
+    // ================= phase 1 on the matrix cores (dattn_kernel<2, 1, true, 2>): this producer's rows of the group's q | k | v =================
+    constexpr int K = D, W4 = K / 4, G = K >> 7;
+    constexpr int nb = (REP + 2) * (HD / 2);
+    const int lb = wave * (DA_MEMBERS - REP) + (r - REP);       // every producer owns a batch (dattn_kernel.h)
+    const bool has = lb < nb;
+    constexpr int qrows = REP * HD;
+    const int lr = 2 * (has ? lb : 0);
+    const int grow = lr < qrows ? g * qrows + lr
+                                : (lr < qrows + HD ? DA_GROUPS * qrows + g * HD + (lr - qrows)
+                                                   : DA_GROUPS * qrows + DA_GROUPS * HD + g * HD + (lr - qrows - HD));
+    const int gb = grow >> 1;
+    const __amdgpu_buffer_rsrc_t qd = rsrc(a.qkv_qw, RS_ALL), szd = rsrc(a.qkv_sz, RS_ALL);
+    const unsigned killw = has ? 0u : KILL;
+    const unsigned voff_w = mnn * 32 + mkg * 8, voff_s = mnn * 8;
+    constexpr int NIT = SP * 512, PW = 8, PT = PW * 64, IPT = NIT / PT;
+    const bool pro = wave < PW;
+    const bool carried = a.ssq_in != nullptr;
+    u32x2 xr[IPT], wr[IPT];
+    u32x4 pq[4] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
+    if (pro) {
+      u32x4 acv[IPT][2];
+      const __amdgpu_buffer_rsrc_t ad = rsrc(a.x_acc ? static_cast<const void*>(a.x_acc) : static_cast<const void*>(a.x), RS_ALL);
+      const unsigned ak = a.x_acc ? 0u : KILL;
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) {
+        const int it = tid + PT * j;
+        acv[j][0] = __builtin_amdgcn_raw_buffer_load_b128(ad, static_cast<unsigned>(it * 32) | ak, 0, 0);
+        acv[j][1] = __builtin_amdgcn_raw_buffer_load_b128(ad, static_cast<unsigned>(it * 32 + 16) | ak, 0, 0);
+      }
+      const unsigned apoison = __builtin_amdgcn_raw_buffer_load_b32(ad, static_cast<unsigned>(K * 8) | ak, 0, 0);
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) {
+        const int it = tid + PT * j;
+        xr[j] = *reinterpret_cast<const u32x2*>(a.x + 4 * it);
+        wr[j] = *reinterpret_cast<const u32x2*>(a.norm_w + 4 * it);
+      }
+      {
+        const __amdgpu_buffer_rsrc_t pd = rsrc(carried ? static_cast<const void*>(a.ssq_in) : static_cast<const void*>(a.x), RS_ALL);
+        const unsigned pk = carried ? 0u : KILL;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pq[i] = __builtin_amdgcn_raw_buffer_load_b128(pd, static_cast<unsigned>(lane * 16 + 1024 * i) | pk, 0, 0);
+      }
+      DB_STAMP(1);
+      if (a.x_acc) {
+        const bool poison = apoison != 0u;
+        const bool writer = blockIdx.x == static_cast<unsigned>(REP * DA_GROUPS) && a.x_out != nullptr;
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+          unsigned wv[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const u32x4 av = acv[j][q];
+            const float o0 = round_bf16_or_f16(fx32_to_f32(av.x, av.y), BF16);
+            const float o1 = round_bf16_or_f16(fx32_to_f32(av.z, av.w), BF16);
+            const unsigned xw = q == 0 ? xr[j].x : xr[j].y;
+            float x0 = act_lo<BF16>(xw) + o0, x1 = act_hi<BF16>(xw) + o1;
+            if (poison) { x0 = __uint_as_float(0x7FC00000u); x1 = x0; }
+            wv[q] = static_cast<unsigned>(f32_to_act<BF16>(x0)) | (static_cast<unsigned>(f32_to_act<BF16>(x1)) << 16);
+          }
+          xr[j] = u32x2{wv[0], wv[1]};
+          // the stream this block starts from: the XCD leaders read it back (cross-XCD) behind the chip-wide release -- write-through store
+          if (writer)
+            __hip_atomic_store(reinterpret_cast<db_gu64*>(reinterpret_cast<uintptr_t>(a.x_out)) + (tid + PT * j),
+                               static_cast<unsigned long long>(wv[0]) | (static_cast<unsigned long long>(wv[1]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (!carried) {
+        float ssq = 0.f;
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+          const unsigned w2[2] = {xr[j].x, xr[j].y};
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const float lo = act_lo<BF16>(w2[q]), hi = act_hi<BF16>(w2[q]);
+            ssq = fmaf(hi, hi, fmaf(lo, lo, ssq));
+          }
+        }
+        ssq = wave_sum(ssq);
+        if (lane == 0) red_lds[wave] = ssq;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();                                           // barrier A: x, the norm weight and the statistic's partials have landed
+    const unsigned gen = __hip_atomic_load(gen_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (pro) {
+      float tot;
+      if (carried) {
+        float sp = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          sp += (__uint_as_float(pq[i].x) + __uint_as_float(pq[i].y)) + (__uint_as_float(pq[i].z) + __uint_as_float(pq[i].w));
+        tot = wave_sum(sp);
+      } else {
+        tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) tot += red_lds[i];
+      }
+      const float rstd = rsqrtf(tot / static_cast<float>(K) + a.eps1);
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) {
+        const int it = tid + PT * j;
+        float v[4] = {act_lo<BF16>(xr[j].x), act_hi<BF16>(xr[j].x), act_lo<BF16>(xr[j].y), act_hi<BF16>(xr[j].y)};
+        v[0] = round_bf16_or_f16(v[0] * rstd * act_lo<BF16>(wr[j].x), BF16);
+        v[1] = round_bf16_or_f16(v[1] * rstd * act_hi<BF16>(wr[j].x), BF16);
+        v[2] = round_bf16_or_f16(v[2] * rstd * act_lo<BF16>(wr[j].y), BF16);
+        v[3] = round_bf16_or_f16(v[3] * rstd * act_hi<BF16>(wr[j].y), BF16);
+        image_item(v, it, true, img, bsum, scl);
+      }
+    }
+    u32x2 w[2][SP], sz[SP];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int h = 0; h < SP; ++h) w[i][h] = __builtin_amdgcn_raw_buffer_load_b64(qd, (voff_w + h * 512) | killw, (grow + i) * W4, 2);
+    }
+#pragma unroll
+    for (int h = 0; h < SP; ++h) sz[h] = __builtin_amdgcn_raw_buffer_load_b64(szd, (voff_s + h * 128) | killw, gb * (G * 8), 0);
+    __syncthreads();                                           // barrier B: image written
+    DB_STAMP(2);
+    tag = gen + 1u;
+    if (tag == 0u) tag = 1u;
+    if (has) {
+      db_v8i areg[SP][2];
+      int sa = 0;
+      float xsg[SP];
+#pragma unroll
+      for (int h = 0; h < SP; ++h) {
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+          const u32x4 p0 = *reinterpret_cast<const u32x4*>(img + (h * 4 + 0) * 1024 + l * 2048 + lane * 16);
+          const u32x4 p1 = *reinterpret_cast<const u32x4*>(img + (h * 4 + 1) * 1024 + l * 2048 + lane * 16);
+          areg[h][l][0] = p0.x; areg[h][l][1] = p0.y; areg[h][l][2] = p0.z; areg[h][l][3] = p0.w;
+          areg[h][l][4] = p1.x; areg[h][l][5] = p1.y; areg[h][l][6] = p1.z; areg[h][l][7] = p1.w;
+        }
+        sa |= static_cast<int>(scl[h * 64 + lane]) << (8 * h);
+        const float gs = (bsum[h * 64 + mnn] + bsum[h * 64 + mnn + 16]) + (bsum[h * 64 + mnn + 32] + bsum[h * 64 + mnn + 48]);
+        xsg[h] = diag ? gs : 0.f;
+      }
+      float accr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float yv = 0.f;
+        auto span = [&](auto H) {
+          constexpr int h = decltype(H)::value;
+          db_v8i bv;
+          const unsigned w0 = w[i][h].x, w1 = w[i][h].y;
+          bv[0] = w0 & 0x33333333u; bv[1] = (w0 >> 2) & 0x33333333u; bv[2] = w1 & 0x33333333u; bv[3] = (w1 >> 2) & 0x33333333u;
+          bv[4] = 0; bv[5] = 0; bv[6] = 0; bv[7] = 0;
+          db_v4f z = {0.f, 0.f, 0.f, 0.f};
+          z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(areg[h][0], bv, z, 0, 4, h, sa, 0, 127);
+          z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(areg[h][1], bv, z, 0, 4, h, sa, 0, 127);
+          const float dsel = fmaf(z[0], dm[0], fmaf(z[1], dm[1], fmaf(z[2], dm[2], z[3] * dm[3])));
+          const unsigned szw = i == 0 ? sz[h].x : sz[h].y;
+          const float sc = sz_scale<BF16>(szw), ze = sz_zero<BF16>(szw);
+          yv += fmaf(ze, xsg[h], (sc + sc) * dsel);
+        };
+        span(std::integral_constant<int, 0>{});
+        span(std::integral_constant<int, 1>{});
+        accr[i] = yv;
+      }
+      const float v0 = wave_sum2(accr[0], accr[1]);
+      const float t0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v0), 31));
+      const float t1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v0), 63));
+      const unsigned val = static_cast<unsigned>(f32_to_act<BF16>(t0)) | (static_cast<unsigned>(f32_to_act<BF16>(t1)) << 16);
+      if (lane == 0) __hip_atomic_store(hand1 + lb, (static_cast<unsigned long long>(tag) << 32) | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    DB_STAMP(3);
+    issue_o();
+    // W1: every granule of this workgroup is out (granule stores would queue behind the stream); waves 0 / 1 poll the attention output
+    // next and issue nothing (their polls would come back behind their own pieces)
+    __syncthreads();
+    dma(0, DB_W1_PIECES, 2);
+    pieces_done = DB_W1_PIECES;
+  } else {
+    // =========================================== phase 2: attention of head g * REP + r (dattn_kernel.h) ===========================================
+    unsigned* raw32 = reinterpret_cast<unsigned*>(smem + DB_LDS_ATT);
+    float* q_s = reinterpret_cast<float*>(smem + DB_LDS_ATT + 768);
+    float* kn_s = q_s + HD;
+    float* vn_s = kn_s + HD;
+    float* gm = vn_s + HD;
+    float* gl = gm + 64;
+    float (*gacc)[HD + 8] = reinterpret_cast<float (*)[HD + 8]>(gl + 64);
+    (void)raw32;
+    constexpr float NEG = -1e30f;
+    constexpr int LP = HD / 8, PPW = 64 / LP, UB0 = 10;
+    const int h = g * REP + r;
+    const int d0 = (lane % LP) * 8, sub = lane / LP;
+    const int pos = cpos;
+    const int nws = pos <= 160 ? 4 : (pos <= UB0 * 8 * PPW ? 8 : 16);
+    const int ppr = nws * PPW;
+    const bool sweeper = wave < nws;
+    const __amdgpu_buffer_rsrc_t kd = rsrc(a.kcache + static_cast<size_t>(g) * a.capacity * HD, a.capacity * HD * 2);
+    const __amdgpu_buffer_rsrc_t vd = rsrc(a.vcache + static_cast<size_t>(g) * a.capacity * HD, a.capacity * HD * 2);
+    const unsigned short* kbase = a.kcache + static_cast<size_t>(g) * a.capacity * HD;
+    const unsigned short* vbase = a.vcache + static_cast<size_t>(g) * a.capacity * HD;
+    u32x4 k0[UB0], v0[UB0];
+#pragma unroll
+    for (int u = 0; u < UB0; ++u) {
+      const int t = (u * nws + wave) * PPW + sub;
+      const unsigned off = static_cast<unsigned>(t * (HD * 2) + d0 * 2) | (t < pos ? 0u : KILL);
+      k0[u] = u32x4{0, 0, 0, 0};
+      v0[u] = u32x4{0, 0, 0, 0};
+      if (sweeper && u * ppr < pos) {
+        k0[u] = __builtin_amdgcn_raw_buffer_load_b128(kd, off, 0, 0);
+        v0[u] = __builtin_amdgcn_raw_buffer_load_b128(vd, off, 0, 0);
+      }
+    }
+    issue_o();
+    // W0: this CU is idle until q arrives (~4 us): its first gate | up pieces go behind the K / V prefetch now (the leader's whole share).
+    // Long contexts keep the queue for K / V; the pieces then move to W2 (the leader: behind its publish).
+    if (pos <= 192) {
+      pieces_done = min(npieces, DB_W0_PIECES);
+      dma(0, pieces_done, 0);
+    }
+    const unsigned gen = __hip_atomic_load(gen_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float inv_f = a.inv_freq[lane];
+    const float rope_rev = static_cast<float>(pos) * a.rope_scale * inv_f * 0.15915494309189535f;
+    const float rope_fr = rope_rev - floorf(rope_rev);
+    const float sn = __builtin_amdgcn_sinf(rope_fr), cs = __builtin_amdgcn_cosf(rope_fr);
+    DB_STAMP(1);
+    tag = gen + 1u;
+    if (tag == 0u) tag = 1u;
+    if (wave < 2) {
+      const bool isk = wave == 1;
+      const int i = lane;
+      const int i1 = a.traditional ? 2 * i : i;
+      const int i2 = a.traditional ? 2 * i + 1 : i + HD / 2;
+      db_gu64* base = hand1 + (isk ? REP : r) * (HD / 2);
+      unsigned w1, w2;
+      sweep2(base + (i1 >> 1), base + (i2 >> 1), tag, 1u, w1, w2);
+      DB_STAMP(2);
+      const float x1 = act_to_f32<BF16>(static_cast<unsigned short>((i1 & 1) ? (w1 >> 16) : (w1 & 0xFFFFu)));
+      const float x2 = act_to_f32<BF16>(static_cast<unsigned short>((i2 & 1) ? (w2 >> 16) : (w2 & 0xFFFFu)));
+      const unsigned short r1 = f32_to_act<BF16>(x1 * cs - x2 * sn), r2 = f32_to_act<BF16>(x1 * sn + x2 * cs);
+      if (isk) {
+        kn_s[i1] = act_to_f32<BF16>(r1);
+        kn_s[i2] = act_to_f32<BF16>(r2);
+        if (r == 0) {
+          unsigned short* dst = a.kcache + (static_cast<size_t>(g) * a.capacity + pos) * HD;
+          dst[i1] = r1;
+          dst[i2] = r2;
+        }
+      } else {
+        q_s[i1] = act_to_f32<BF16>(r1) * a.sm_scale;
+        q_s[i2] = act_to_f32<BF16>(r2) * a.sm_scale;
+      }
+    } else if (wave == 2) {
+      const unsigned vw = sweep(hand1 + (REP + 1) * (HD / 2) + lane, tag, 1u);
+      vn_s[2 * lane] = act_lo<BF16>(vw);
+      vn_s[2 * lane + 1] = act_hi<BF16>(vw);
+      if (r == 0) *reinterpret_cast<unsigned*>(a.vcache + (static_cast<size_t>(g) * a.capacity + pos) * HD + 2 * lane) = vw;
+    }
+    __syncthreads();
+    db_f32x2 q2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q2[j] = db_f32x2{q_s[d0 + 2 * j], q_s[d0 + 2 * j + 1]};
+    float m = NEG, l = 0.f;
+    db_f32x2 acc2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc2[j] = db_f32x2{0.f, 0.f};
+    auto unpack2 = [](unsigned w) { return db_f32x2{act_lo<BF16>(w), act_hi<BF16>(w)}; };
+    auto score = [&](const u32x4& kq) {
+      db_f32x2 t = unpack2(kq.x) * q2[0];
+      t = __builtin_elementwise_fma(unpack2(kq.y), q2[1], t);
+      t = __builtin_elementwise_fma(unpack2(kq.z), q2[2], t);
+      t = __builtin_elementwise_fma(unpack2(kq.w), q2[3], t);
+      float s = t.x + t.y;
+      s += dpp_f32<0xB1>(s);
+      s += dpp_f32<0x4E>(s);
+      s += dpp_f32<0x141>(s);
+      s += dpp_f32<0x140>(s);
+      return s;
+    };
+    auto add_values = [&](const u32x4& vq, float p) {
+      const db_f32x2 p2 = db_f32x2{p, p};
+      acc2[0] = __builtin_elementwise_fma(p2, unpack2(vq.x), acc2[0]);
+      acc2[1] = __builtin_elementwise_fma(p2, unpack2(vq.y), acc2[1]);
+      acc2[2] = __builtin_elementwise_fma(p2, unpack2(vq.z), acc2[2]);
+      acc2[3] = __builtin_elementwise_fma(p2, unpack2(vq.w), acc2[3]);
+    };
+    auto rescale = [&](float corr) {
+      const db_f32x2 c2 = db_f32x2{corr, corr};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc2[j] = acc2[j] * c2;
+    };
+    if (sweeper) {
+      {
+        constexpr int HB = UB0 / 2;
+        float sc[UB0];
+        const bool second = HB * ppr < pos;
+        auto scores = [&](int u0) {
+#pragma unroll
+          for (int u = u0; u < u0 + HB; ++u) {
+            const float s = score(k0[u]);
+            sc[u] = ((u * nws + wave) * PPW + sub < pos) ? s : NEG;
+          }
+#pragma unroll
+          for (int u = u0; u < u0 + HB; ++u) m = fmaxf(m, sc[u]);
+        };
+        auto values = [&](int u0) {
+          float p[HB];
+#pragma unroll
+          for (int u = 0; u < HB; ++u) p[u] = sc[u0 + u] > 0.5f * NEG ? __expf(sc[u0 + u] - m) : 0.f;
+#pragma unroll
+          for (int u = 0; u < HB; ++u) { l += p[u]; add_values(v0[u0 + u], p[u]); }
+        };
+        scores(0);
+        if (second) scores(HB);
+        values(0);
+        if (second) values(HB);
+      }
+      auto consume1 = [&](const u32x4& kq, const u32x4& vq, bool valid) {
+        const float s = score(kq);
+        const float mn = valid ? fmaxf(m, s) : m;
+        const float corr = __expf(m - mn);
+        const float p = valid ? __expf(s - mn) : 0.f;
+        l = l * corr + p;
+        rescale(corr);
+        add_values(vq, p);
+        m = mn;
+      };
+      constexpr int UB = 2;
+      for (int t0 = UB0 * ppr + wave * PPW; t0 < pos; t0 += ppr * UB) {
+        u32x4 kv4[UB], vv4[UB];
+        bool valid[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int t = t0 + u * ppr + sub;
+          valid[u] = t < pos;
+          const int tc = valid[u] ? t : pos - 1;
+          kv4[u] = *reinterpret_cast<const u32x4*>(kbase + static_cast<size_t>(tc) * HD + d0);
+          vv4[u] = *reinterpret_cast<const u32x4*>(vbase + static_cast<size_t>(tc) * HD + d0);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) consume1(kv4[u], vv4[u], valid[u]);
+      }
+      if (wave == 0 && sub == 0) {                             // the new token itself
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s = fmaf(q2[j].x, kn_s[d0 + 2 * j], fmaf(q2[j].y, kn_s[d0 + 2 * j + 1], s));
+        s += dpp_f32<0xB1>(s);
+        s += dpp_f32<0x4E>(s);
+        s += dpp_f32<0x141>(s);
+        s += dpp_f32<0x140>(s);
+        const float mn = fmaxf(m, s);
+        const float corr = __expf(m - mn), p = __expf(s - mn);
+        l = l * corr + p;
+        rescale(corr);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc2[j] = __builtin_elementwise_fma(db_f32x2{p, p}, db_f32x2{vn_s[d0 + 2 * j], vn_s[d0 + 2 * j + 1]}, acc2[j]);
+        m = mn;
+      }
+      const int sidx = wave * PPW + sub;
+      if ((lane % LP) == 0) { gm[sidx] = m; gl[sidx] = l; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<db_f32x2*>(&gacc[sidx][d0 + 2 * j]) = acc2[j];
+    }
+    __syncthreads();
+    if (tid < HD) {
+      const int ns = nws * PPW;
+      float M = NEG;
+      for (int c = 0; c < ns; c += 16) {
+        float t[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[i] = gm[c + i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) M = fmaxf(M, t[i]);
+      }
+      float num = 0.f, den = 0.f;
+      for (int c = 0; c < ns; c += 16) {
+        float tm[16], tl[16], ta[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { tm[i] = gm[c + i]; tl[i] = gl[c + i]; ta[i] = gacc[c + i][tid]; }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float wgt = __expf(tm[i] - M);
+          num = fmaf(wgt, ta[i], num);
+          den = fmaf(wgt, tl[i], den);
+        }
+      }
+      const unsigned ob = f32_to_act<BF16>(num / den);
+      if (a.attn_out) a.attn_out[static_cast<size_t>(h) * HD + tid] = static_cast<unsigned short>(ob);
+      const unsigned nb2 = dpp_u32<0xB1>(ob);
+      if ((lane & 1) == 0)
+        __hip_atomic_store(hand2 + r * (HD / 2) + (tid >> 1), (static_cast<unsigned long long>(tag) << 32) | ob | (nb2 << 16),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    DB_STAMP(3);
+  }
+
+  // =========================================== phase 3: o_proj over this group's columns (matrix cores) ===========================================
+  {
+    unsigned char* img3 = smem + DB_LDS_P3;
+    float* bsum3 = reinterpret_cast<float*>(img3 + 4096);
+    unsigned char* scl3 = reinterpret_cast<unsigned char*>(bsum3 + 64);
+    if (wave < 2) {
+      const int it = tid;
+      unsigned w0, w1;
+      sweep2(hand2 + 2 * it, hand2 + 2 * it + 1, tag, 2u, w0, w1);
+      DB_STAMP(4);
+      const float v[4] = {act_lo<BF16>(w0), act_hi<BF16>(w0), act_lo<BF16>(w1), act_hi<BF16>(w1)};
+      float sum = (v[0] + v[1]) + (v[2] + v[3]);
+      unsigned amax = max(max(__float_as_uint(v[0]) & 0x7FFFFFFFu, __float_as_uint(v[1]) & 0x7FFFFFFFu),
+                          max(__float_as_uint(v[2]) & 0x7FFFFFFFu, __float_as_uint(v[3]) & 0x7FFFFFFFu));
+      sum += dpp_f32<0xB1>(sum); amax = max(amax, dpp_u32<0xB1>(amax));
+      sum += dpp_f32<0x4E>(sum); amax = max(amax, dpp_u32<0x4E>(amax));
+      sum += dpp_f32<0x141>(sum); amax = max(amax, dpp_u32<0x141>(amax));
+      if (amax >= 0x7F800000u) sum = __uint_as_float(0x7FC00000u);
+      int ea = static_cast<int>(amax >> 23);
+      ea = min(max(ea, 20), 240);
+      const float up = exp2i(134 - ea);
+      const int b = it >> 3, u = it & 7;
+      const int gi = b >> 2, kb = b & 3;
+      const int ga = 2 * (kb & 1) + (u >> 2);
+      const float r0 = v[0] * up, r1 = v[1] * up, r2 = v[2] * up, r3 = v[3] * up;
+      const int pe = __builtin_amdgcn_cvt_pk_fp8_f32(r0, r2, 0, false);
+      const int po = __builtin_amdgcn_cvt_pk_fp8_f32(r1, r3, 0, false);
+      const int le = __builtin_amdgcn_cvt_pk_fp8_f32(r0 - __builtin_amdgcn_cvt_f32_fp8(pe, 0), r2 - __builtin_amdgcn_cvt_f32_fp8(pe, 1), 0, false);
+      const int lo = __builtin_amdgcn_cvt_pk_fp8_f32(r1 - __builtin_amdgcn_cvt_f32_fp8(po, 0), r3 - __builtin_amdgcn_cvt_f32_fp8(po, 1), 0, false);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {                                // the four operand rows that carry this group
+        const int m = gi + 4 * c;
+        unsigned char* dst = img3 + (kb >> 1) * 1024 + (m + 16 * ga) * 16 + 2 * (u & 3);
+        *reinterpret_cast<unsigned short*>(dst) = static_cast<unsigned short>(pe);
+        *reinterpret_cast<unsigned short*>(dst + 8) = static_cast<unsigned short>(po);
+        *reinterpret_cast<unsigned short*>(dst + 2048) = static_cast<unsigned short>(le);
+        *reinterpret_cast<unsigned short*>(dst + 2048 + 8) = static_cast<unsigned short>(lo);
+        if (u == 0) { bsum3[m + 16 * kb] = sum; scl3[m + 16 * kb] = static_cast<unsigned char>(ea - 7); }
+      }
+    }
+    __syncthreads();
+    db_v8i a3[2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const u32x4 p0 = *reinterpret_cast<const u32x4*>(img3 + 0 * 1024 + l * 2048 + lane * 16);
+      const u32x4 p1 = *reinterpret_cast<const u32x4*>(img3 + 1 * 1024 + l * 2048 + lane * 16);
+      a3[l][0] = p0.x; a3[l][1] = p0.y; a3[l][2] = p0.z; a3[l][3] = p0.w;
+      a3[l][4] = p1.x; a3[l][5] = p1.y; a3[l][6] = p1.z; a3[l][7] = p1.w;
+    }
+    const int sa3 = static_cast<int>(scl3[lane]);
+    const float gs3 = (bsum3[mnn] + bsum3[mnn + 16]) + (bsum3[mnn + 32] + bsum3[mnn + 48]);
+    const float xsg3 = diag ? gs3 : 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      db_v8i bv;
+      const unsigned w0 = owm[j].x, w1 = owm[j].y;
+      bv[0] = w0 & 0x33333333u; bv[1] = (w0 >> 2) & 0x33333333u; bv[2] = w1 & 0x33333333u; bv[3] = (w1 >> 2) & 0x33333333u;
+      bv[4] = 0; bv[5] = 0; bv[6] = 0; bv[7] = 0;
+      db_v4f z = {0.f, 0.f, 0.f, 0.f};
+      z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a3[0], bv, z, 0, 4, 0, sa3, 0, 127);
+      z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a3[1], bv, z, 0, 4, 0, sa3, 0, 127);
+      const float dsel = fmaf(z[0], dm[0], fmaf(z[1], dm[1], fmaf(z[2], dm[2], z[3] * dm[3])));
+      const float sc = act_to_f32<BF16>(static_cast<unsigned short>(osc[j])), ze = act_to_f32<BF16>(static_cast<unsigned short>(oze[j]));
+      float v = fmaf(ze, xsg3, (sc + sc) * dsel);
+      v += dpp_f32<0xB1>(v);
+      v += dpp_f32<0x4E>(v);
+      if (diag && (mnn & 3) == 0) {
+        const int row = r * RPW + wave * 8 + 4 * j + (mnn >> 2);
+        if (fabsf(v) < 2147483648.f) {
+          const long long fx = __float2ll_rn(v * 4294967296.f);
+          __hip_atomic_fetch_add(acc_o + row, static_cast<unsigned long long>(fx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          __hip_atomic_fetch_add(acc_o + D, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+  }
+  DB_STAMP(5);
+  // =========================================== the chip-wide release ===========================================
+  // ARRIVE: this workgroup's sums (memory-side atomics) have been acknowledged, its zero stores and the stream it wrote have left the CU
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (wave == 0 && lane == 0)
+    __hip_atomic_store(harr + r, (static_cast<unsigned long long>(tag) << 32) | static_cast<unsigned>(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  DB_STAMP(6);
+  // W2: the rest of this workgroup's gate | up pieces (<= 56 KB: drained before x' is due).  The leader carries no stream during the release.
+  if (r != 0) { dma(pieces_done, npieces, 0); pieces_done = npieces; }
+  if (r == 0) {
+    if (wave == 0) {
+      sweep(harr + (lane & 31), tag, 6u);                          // the XCD's 32 arrivals
+      DB_STAMP(13);
+      if (lane == 0) __hip_atomic_store(flag_p + g * 32, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (unsigned spins = 0;;) {                                 // the 8 XCDs' flags: the one cross-XCD hop of the block
+        const unsigned v = __hip_atomic_load(flag_p + (lane & 7) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all(v == tag)) break;
+        if (++spins > a.spin_limit) { timeout(7u); break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      DB_STAMP(14);
+    }
+    __syncthreads();
+    // every o_proj sum of the chip is in memory: x' = round(h + round(o)), its statistic, RMSNorm(x') -- ONCE per XCD, 4 values per thread
+    const __amdgpu_buffer_rsrc_t ad = rsrc(a.acc_o, (D + 1) * 8);
+    const u32x4 s0 = __builtin_amdgcn_raw_buffer_load_b128(ad, static_cast<unsigned>(tid * 32), 0, 16);          // aux 16: sc1 (the sums never were in an L2)
+    const u32x4 s1 = __builtin_amdgcn_raw_buffer_load_b128(ad, static_cast<unsigned>(tid * 32 + 16), 0, 16);
+    const unsigned apoison = __builtin_amdgcn_raw_buffer_load_b32(ad, static_cast<unsigned>(D * 8), 0, 16);
+    const unsigned short* hsrc = a.x_acc ? a.x_out : a.x;          // the stream before o_proj's output: written THIS launch when x_acc is set
+    unsigned long long hv;
+    if (a.x_acc) hv = __hip_atomic_load(reinterpret_cast<const db_gu64*>(reinterpret_cast<uintptr_t>(hsrc)) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else hv = *reinterpret_cast<const unsigned long long*>(hsrc + 4 * tid);
+    const u32x2 wv2 = *reinterpret_cast<const u32x2*>(a.norm2_w + 4 * tid);
+    const bool poison = apoison != 0u;
+    const unsigned hw[2] = {static_cast<unsigned>(hv), static_cast<unsigned>(hv >> 32)};
+    const u32x4 sv[2] = {s0, s1};
+    unsigned xw[2];
+    float ssq = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float o0 = round_bf16_or_f16(fx32_to_f32(sv[q].x, sv[q].y), BF16);
+      const float o1 = round_bf16_or_f16(fx32_to_f32(sv[q].z, sv[q].w), BF16);
+      float x0 = act_lo<BF16>(hw[q]) + o0, x1 = act_hi<BF16>(hw[q]) + o1;
+      if (poison) { x0 = __uint_as_float(0x7FC00000u); x1 = x0; }
+      xw[q] = static_cast<unsigned>(f32_to_act<BF16>(x0)) | (static_cast<unsigned>(f32_to_act<BF16>(x1)) << 16);
+      const float lo = act_lo<BF16>(xw[q]), hi = act_hi<BF16>(xw[q]);
+      ssq += fmaf(hi, hi, lo * lo);
+    }
+    if (blockIdx.x == 0 && a.x2_out) *reinterpret_cast<u32x2*>(a.x2_out + 4 * tid) = u32x2{xw[0], xw[1]};
+    ssq = wave_sum(ssq);
+    if (lane == 0) red_lds[wave] = ssq;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) tot += red_lds[i];
+    const float rstd = rsqrtf(tot / static_cast<float>(D) + a.eps2);
+    const unsigned y0 = static_cast<unsigned>(f32_to_act<BF16>(round_bf16_or_f16(act_lo<BF16>(xw[0]) * rstd * act_lo<BF16>(wv2.x), BF16))) |
+                        (static_cast<unsigned>(f32_to_act<BF16>(round_bf16_or_f16(act_hi<BF16>(xw[0]) * rstd * act_hi<BF16>(wv2.x), BF16))) << 16);
+    const unsigned y1 = static_cast<unsigned>(f32_to_act<BF16>(round_bf16_or_f16(act_lo<BF16>(xw[1]) * rstd * act_lo<BF16>(wv2.y), BF16))) |
+                        (static_cast<unsigned>(f32_to_act<BF16>(round_bf16_or_f16(act_hi<BF16>(xw[1]) * rstd * act_hi<BF16>(wv2.y), BF16))) << 16);
+    __hip_atomic_store(hx + 2 * tid, (static_cast<unsigned long long>(tag) << 32) | y0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(hx + 2 * tid + 1, (static_cast<unsigned long long>(tag) << 32) | y1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    DB_STAMP(15);
+    if (pieces_done < npieces) { dma(pieces_done, npieces, 0); pieces_done = npieces; }      // (long contexts: the leader's share, behind its publish)
+  }
+  // ---- every workgroup: thread t polls the two granules of image item t (4 values of RMSNorm(x')) and writes the gate | up operand image
+  {
+    unsigned w0, w1;
+    sweep2(hx + 2 * tid, hx + 2 * tid + 1, tag, 8u, w0, w1);
+    DB_STAMP(7);
+    const float v[4] = {act_lo<BF16>(w0), act_hi<BF16>(w0), act_lo<BF16>(w1), act_hi<BF16>(w1)};
+    image_item(v, tid, true, img, bsum, scl);
+  }
+  // down_proj's operand image: rows / scale bytes of groups beyond this XCD's 14 are never written below (dmlp.hip)
+  unsigned char* img2 = smem + DB_LDS_P3;
+  float* bsum2 = reinterpret_cast<float*>(img2 + 4096);
+  unsigned char* scl2 = reinterpret_cast<unsigned char*>(bsum2 + 64);
+  // (phase 3's reads of this region ended at the ARRIVE barrier)
+  if (tid < 256) *reinterpret_cast<u32x4*>(img2 + tid * 16) = u32x4{0, 0, 0, 0};
+  else if (tid < 256 + 20) *reinterpret_cast<u32x4*>(img2 + 4096 + (tid - 256) * 16) = u32x4{0, 0, 0, 0};
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's LDS-DMA pieces have landed
+  __syncthreads();                                               // image written, every piece of every wave in LDS
+  DB_STAMP(8);
+
+  // ---------------- W3: down_proj's words of this wave's 8 rows, this XCD's columns (registers; consumed behind the hand-off) ----------------
+  constexpr int W4d = DB_I / 4;                                  // bytes per packed down row
+  constexpr int Gd = DB_I >> 7;
+  constexpr int ng = DB_IX >> 7;                                 // 14 groups of this XCD's slice
+  const unsigned voff_w = mnn * 32 + mkg * 8;
+  u32x2 dw[8], dsz[4];
+  {
+    const __amdgpu_buffer_rsrc_t dd = rsrc(a.down_qw, RS_ALL), dsd = rsrc(a.down_sz, RS_ALL);
+    const unsigned killd = mnn < ng ? 0u : KILL;
+    const int row0 = r * RPW + wave * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      dw[i] = __builtin_amdgcn_raw_buffer_load_b64(dd, (voff_w + static_cast<unsigned>(g * (DB_IX / 4))) | killd, (row0 + i) * W4d, 2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      dsz[q] = __builtin_amdgcn_raw_buffer_load_b64(dsd, static_cast<unsigned>((g * ng + mnn) * 8) | killd, ((row0 >> 1) + q) * (Gd * 8), 0);
+  }
+  // ---------------- gate | up from LDS on the matrix cores (dmlp.hip's arithmetic), SwiGLU, two activations per granule ----------------
+  {
+    const int a4 = nact > 32 ? (nact - 32) >> 1 : 0;             // waves [0, a4) own 4 activations, the next (nact - 4 a4) / 2 waves own 2
+    const int a2 = (nact - 4 * a4) >> 1;
+    const int nloc = wave < a4 ? 4 : (wave < a4 + a2 ? 2 : 0);
+    const int al0 = wave < a4 ? 4 * wave : 4 * a4 + 2 * (wave - a4);       // first activation of this wave, workgroup-local
+    const unsigned char* grow_l = rows, *urow_l = rows + nact * 1024, *sz_l = rows + 2 * nact * 1024;
+    const unsigned voff_s = mnn * 8;
+    db_v8i areg[SP][2];
+    int sa = 0;
+    float xsg[SP];
+#pragma unroll
+    for (int h = 0; h < SP; ++h) {
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        const u32x4 p0 = *reinterpret_cast<const u32x4*>(img + (h * 4 + 0) * 1024 + l * 2048 + lane * 16);
+        const u32x4 p1 = *reinterpret_cast<const u32x4*>(img + (h * 4 + 1) * 1024 + l * 2048 + lane * 16);
+        areg[h][l][0] = p0.x; areg[h][l][1] = p0.y; areg[h][l][2] = p0.z; areg[h][l][3] = p0.w;
+        areg[h][l][4] = p1.x; areg[h][l][5] = p1.y; areg[h][l][6] = p1.z; areg[h][l][7] = p1.w;
+      }
+      sa |= static_cast<int>(scl[h * 64 + lane]) << (8 * h);
+      const float gs = (bsum[h * 64 + mnn] + bsum[h * 64 + mnn + 16]) + (bsum[h * 64 + mnn + 32] + bsum[h * 64 + mnn + 48]);
+      xsg[h] = diag ? gs : 0.f;
+    }
+    unsigned short actv[4] = {0, 0, 0, 0};
+    struct Batch { u32x2 w[2][SP]; u32x2 sz[SP]; };
+    auto fetch = [&](Batch& b, int j) {
+      const int al = min(al0 + (j < nloc ? j : 0), nact - 1);      // (waves without a batch read a valid row and drop it)
+#pragma unroll
+      for (int h = 0; h < SP; ++h) {
+        b.w[0][h] = *reinterpret_cast<const u32x2*>(grow_l + al * 1024 + h * 512 + voff_w);
+        b.w[1][h] = *reinterpret_cast<const u32x2*>(urow_l + al * 1024 + h * 512 + voff_w);
+        b.sz[h] = *reinterpret_cast<const u32x2*>(sz_l + al * 256 + h * 128 + voff_s);
+      }
+    };
+    auto consume = [&](const Batch& cur, int j) {
+      if (j >= nloc) return;                                     // wave-uniform
+      db_v4f c[2][SP];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        auto span = [&](auto H) {
+          constexpr int h = decltype(H)::value;
+          db_v8i bv;
+          const unsigned w0 = cur.w[i][h].x, w1 = cur.w[i][h].y;
+          bv[0] = w0 & 0x33333333u; bv[1] = (w0 >> 2) & 0x33333333u; bv[2] = w1 & 0x33333333u; bv[3] = (w1 >> 2) & 0x33333333u;
+          bv[4] = 0; bv[5] = 0; bv[6] = 0; bv[7] = 0;
+          db_v4f z = {0.f, 0.f, 0.f, 0.f};
+          z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(areg[h][0], bv, z, 0, 4, h, sa, 0, 127);
+          c[i][h] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(areg[h][1], bv, z, 0, 4, h, sa, 0, 127);
+        };
+        span(std::integral_constant<int, 0>{});
+        span(std::integral_constant<int, 1>{});
+      }
+      float accv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float yv = 0.f;
+#pragma unroll
+        for (int h = 0; h < SP; ++h) {
+          const float dsel = fmaf(c[i][h][0], dm[0], fmaf(c[i][h][1], dm[1], fmaf(c[i][h][2], dm[2], c[i][h][3] * dm[3])));
+          const unsigned szw = i == 0 ? cur.sz[h].x : cur.sz[h].y;
+          const float sc = sz_scale<BF16>(szw), ze = sz_zero<BF16>(szw);
+          yv += fmaf(ze, xsg[h], (sc + sc) * dsel);
+        }
+        accv[i] = yv;
+      }
+      const float v0 = wave_sum2(accv[0], accv[1]);
+      const float t0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v0), 31));
+      const float t1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v0), 63));
+      const float gt = round_bf16_or_f16(t0, BF16), up = round_bf16_or_f16(t1, BF16);
+      const float sl = round_bf16_or_f16(gt / (1.f + __expf(-gt)), BF16);
+      actv[j] = f32_to_act<BF16>(sl * up);
+    };
+    auto publish = [&](int q) {                                  // activations (act0 + al0) + 2 q, + 1 -> one granule (sc0: stays in this XCD's L2)
+      if (2 * q >= nloc) return;
+      const unsigned val = static_cast<unsigned>(actv[2 * q]) | (static_cast<unsigned>(actv[2 * q + 1]) << 16);
+      if (lane == 0) {
+        __hip_atomic_store(hact + ((act0 + al0) >> 1) + q, (static_cast<unsigned long long>(tag) << 32) | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (a.act_out) *reinterpret_cast<unsigned*>(a.act_out + n0g + al0 + 2 * q) = val;
+      }
+    };
+    Batch ring[2];
+    fetch(ring[0], 0);
+    fetch(ring[1], 1);
+    consume(ring[0], 0);
+    fetch(ring[0], 2);
+    consume(ring[1], 1);
+    publish(0);
+    fetch(ring[1], 3);
+    consume(ring[0], 2);
+    consume(ring[1], 3);
+    publish(1);
+  }
+  DB_STAMP(9);
+  // ---------------- hand-off: the XCD's 1792 activations, polled by the lanes that convert them (two granules = one 4-value item) ----------------
+  constexpr int nit2 = DB_IX >> 2;                               // 448 items: waves 0..6
+  if ((tid & ~63) < nit2) {
+    const int it = min(tid, nit2 - 1);
+    unsigned w0, w1;
+    sweep2(hact + 2 * it, hact + 2 * it + 1, tag, 3u, w0, w1);
+    DB_STAMP(10);
+    const float v[4] = {act_lo<BF16>(w0), act_hi<BF16>(w0), act_lo<BF16>(w1), act_hi<BF16>(w1)};
+    // (image_item's DPP steps need the whole wave: the clamped duplicates of the last wave recompute item nit2 - 1 and write the same bytes)
+    image_item(v, it, false, img2, bsum2, scl2);
+  }
+  __syncthreads();
+  DB_STAMP(11);
+  // ---------------- down_proj over this XCD's columns: one packed row slice per scaled-MFMA operand, 2 limbs ----------------
+  {
+    db_v8i a2[2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const u32x4 p0 = *reinterpret_cast<const u32x4*>(img2 + 0 * 1024 + l * 2048 + lane * 16);
+      const u32x4 p1 = *reinterpret_cast<const u32x4*>(img2 + 1 * 1024 + l * 2048 + lane * 16);
+      a2[l][0] = p0.x; a2[l][1] = p0.y; a2[l][2] = p0.z; a2[l][3] = p0.w;
+      a2[l][4] = p1.x; a2[l][5] = p1.y; a2[l][6] = p1.z; a2[l][7] = p1.w;
+    }
+    const bool lg = mnn < ng;
+    const int sa2 = static_cast<int>(scl2[lane]);
+    const float gs2 = (bsum2[mnn] + bsum2[mnn + 16]) + (bsum2[mnn + 32] + bsum2[mnn + 48]);
+    const float xsg2 = (diag && lg) ? gs2 : 0.f;
+    float yv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      db_v8i bv;
+      const unsigned w0 = dw[i].x, w1 = dw[i].y;
+      bv[0] = w0 & 0x33333333u; bv[1] = (w0 >> 2) & 0x33333333u; bv[2] = w1 & 0x33333333u; bv[3] = (w1 >> 2) & 0x33333333u;
+      bv[4] = 0; bv[5] = 0; bv[6] = 0; bv[7] = 0;
+      db_v4f z = {0.f, 0.f, 0.f, 0.f};
+      z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a2[0], bv, z, 0, 4, 0, sa2, 0, 127);
+      z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a2[1], bv, z, 0, 4, 0, sa2, 0, 127);
+      const float dsel = fmaf(z[0], dm[0], fmaf(z[1], dm[1], fmaf(z[2], dm[2], z[3] * dm[3])));
+      const unsigned szw = (i & 1) ? dsz[i >> 1].y : dsz[i >> 1].x;
+      const float sc = sz_scale<BF16>(szw), ze = sz_zero<BF16>(szw);
+      yv[i] = lg ? fmaf(ze, xsg2, (sc + sc) * dsel) : 0.f;
+    }
+    const int row0 = r * RPW + wave * 8;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float v = wave_sum2(yv[2 * q], yv[2 * q + 1]);       // row 2 q in lane 31, row 2 q + 1 in lane 63
+      if ((lane & 31) == 31) {
+        const int row = row0 + 2 * q + (lane >> 5);
+        if (fabsf(v) < 2147483648.f) {
+          const long long fx = __float2ll_rn(v * 4294967296.f);
+          __hip_atomic_fetch_add(acc_d + row, static_cast<unsigned long long>(fx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          __hip_atomic_fetch_add(acc_d + D, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+  }
+  // member 0 advances the group's generation: every member has read it long before (the chip-wide release sits between)
+  if (r == 0 && tid == 0) __hip_atomic_store(gen_p, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  DB_STAMP(12);
+#ifdef GBX_STAMPS
+  if (lane < 16 && a.stamps) a.stamps[(static_cast<size_t>(blockIdx.x) * DA_NW + wave) * 16 + lane] = reinterpret_cast<unsigned long long*>(smem + DB_LDS_BYTES)[wave * 16 + lane];
+#endif
+}
+
+size_t dblock_state_bytes() { return static_cast<size_t>(DA_GROUPS) * DB_HAND_STRIDE * 8 + static_cast<size_t>(DB_STATE_WORDS) * 4; }
+size_t dblock_status_offset() { return static_cast<size_t>(DA_GROUPS) * DB_HAND_STRIDE * 8 + 8 * 16 * 4; }
+int dblock_max_ctx() { return DB_MAX_CTX; }
+
+bool dblock_plan(int D, int I, int n_heads, int n_kv, int head_dim, int qkv_bits, int qkv_group, int o_bits, int o_group, int gu_bits, int gu_group,
+                 int dn_bits, int dn_group, bool bf16) {
+  if (!xcd_layout_ok()) return false;
+  if (!bf16 || D != DB_D || I != DB_I || n_heads != DB_REP * DA_GROUPS || n_kv != DA_GROUPS || head_dim != DB_HD) return false;
+  if (qkv_bits != 2 || o_bits != 2 || gu_bits != 2 || dn_bits != 2) return false;
+  if (qkv_group != 128 || o_group != 128 || gu_group != 128 || dn_group != 128) return false;
+  return true;
+}
+
+hipError_t launch_dblock(const DblockArgs& a, hipStream_t stream) {
+  static DeviceOnce once;
+  if (once.pending()) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dblock_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS_BYTES + DB_STAMP_EXTRA);
+    if (e != hipSuccess) return e;
+    int per_cu = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dblock_kernel<0>, DA_NT, DB_LDS_BYTES + DB_STAMP_EXTRA);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) return hipErrorLaunchOutOfResources;         // (the 256 workgroups must all be resident: one per CU)
+    once.done();
+  }
+  hipLaunchKernelGGL((dblock_kernel<0>), dim3(DA_GROUPS * DA_MEMBERS), dim3(DA_NT), DB_LDS_BYTES + DB_STAMP_EXTRA, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace gbx

@@ -418,6 +418,15 @@ class FusedDecodeRunner(DecodeRunner):
                           (self.attn_ws is None or a0.n_heads // a0.n_kv_heads in (3, 4)) and
                           not getattr(model, "_fused_handoff_disabled", False) and ops.xcd_layout_ok(dev))
         self.use_dmlp = self.use_dattn and env.flag("GBX_DMLP")
+        # Round 6: the whole 2-bit block as ONE launch (gbx_dblock_forward) while the context is short enough for the head's own workgroup
+        # to sweep it; beyond gbx_dblock_max_context() cached positions the same descriptors replay as the two launches above (a second
+        # captured graph, chosen on the host by the position it knows anyway).
+        self.use_dblock = self.use_dmlp and env.flag("GBX_DBLOCK")
+        self.db = []                        # per layer: the one-launch descriptor, or None
+        self.db_state = None
+        self.db_max_ctx = 0
+        self.long_mode = False              # True while capturing / running the graph of contexts beyond db_max_ctx
+        self._graphs = {}                   # (chain, long) -> (graph, logits)
         self.da = []                        # per layer: (dattn, gate|up, down) or (dattn, dmlp) descriptors, or None (the five-launch block)
         self.da_pre = {}                    # layer -> (x, sums): pending fixed-point sums to finish into hb before a five-launch block
         self.da_post = None                 # the same after the last block
@@ -467,6 +476,7 @@ class FusedDecodeRunner(DecodeRunner):
             ssq_prev_layer = self.ssq_prev
             self.dg.append(self._dgemv_descs(blk, qkv_mods[0] if len(qkv_mods) == 1 else None, qkv_ys[0], tp, r0, len(self.dg)))
             self.da.append(self._fused_descs(len(self.da), blk, qkv_mods[0] if len(qkv_mods) == 1 else None, caches[len(self.da)], ssq_prev_layer))
+            self.db.append(self._block_desc(blk, qkv_mods[0] if len(qkv_mods) == 1 else None, self.da[-1]))
             if self.fuse_ao and p_gu is not None:
                 self.descs_ao.append((
                     # x = hb + round(acc) formed in the prologue, the new stream written to pb once
@@ -479,7 +489,10 @@ class FusedDecodeRunner(DecodeRunner):
             else:
                 self.fuse_ao = False
         self.da_post, self._pending = self._pending, None
-        super().__init__(model, caches, use_graph=use_graph)
+        super().__init__(model, caches, use_graph=False)       # (graphs are captured per mode, the first time a step needs one)
+        self.use_graph = use_graph
+        if use_graph:
+            self._graph_for(False, self._wants_long(caches[0].offset))
 
     def _dgemv_descs(self, blk, qkv_cat, qkv_y, tp: bool, r0: bool, li: int):
         """dgemv descriptors of one block's four launches (None where the shape is not covered or dgemv is switched off)."""
@@ -607,18 +620,82 @@ class FusedDecodeRunner(DecodeRunner):
                                    ssq_out=self.ssq_prev, zero_buf=self.acc_o_flat)
         return d_a, d_gu, d_dn
 
+    def _block_desc(self, blk, qkv_cat, fused):
+        """The one-launch descriptor of a block whose (fused attention, fused MLP) pair exists and whose shapes gbx_dblock covers."""
+        if not self.use_dblock or fused is None or len(fused) != 2 or qkv_cat is None:
+            return None
+        at, mlp = blk.self_attn, blk.mlp
+        if not ops.dblock_supported(self.hb.numel(), at.n_heads, at.n_kv_heads, at.head_dim, qkv_cat, at.o_proj, mlp.gate_proj, mlp.up_proj,
+                                    mlp.down_proj, self.hb.dtype):
+            return None
+        if self.db_state is None:
+            self.db_state = ops.dblock_state(self.hb.device)
+            self.db_max_ctx = ops.dblock_max_context()
+        return ops.make_dblock_desc(fused[0], fused[1], self.db_state)
+
     def pos_buf(self) -> torch.Tensor:
         return self.pos
+
+    # ---- captured graphs by (greedy chain?, long context?): the one-launch block up to db_max_ctx cached positions, the two-launch block
+    #      (cooperative sweep) beyond; each is captured the first time a step needs it, at the position the step is at ----
+    def _wants_long(self, off: int) -> bool:
+        return self.db_state is not None and off > self.db_max_ctx
+
+    def _graph_for(self, chain: bool, long: bool):
+        """(graph, logits) of the mode, capturing it first if need be.  The warm-up passes of a capture run real steps at the current
+        position: they write cache rows >= the current offset only and leave every accumulator zero; keys / position / offsets are restored."""
+        slot = (chain, long)
+        if slot not in self._graphs:
+            off = self.caches[0].offset
+            saved = (self.graph, self.logits, self.chain, self.long_mode)
+            keys0, pos0 = self.keys.clone(), self.pos.clone()
+            akeys0 = self.all_keys.clone() if self.tp_vocab is not None else None
+            self.chain, self.long_mode = chain, long
+            self._capture()
+            self._graphs[slot] = (self.graph, self.logits)
+            self.graph, self.logits, self.chain, self.long_mode = saved
+            if self.graph is None:                                   # (what callers and tests look at: the first captured graph and the static logits)
+                self.graph, self.logits = self._graphs[slot]
+            for c in self.caches:
+                c.offset = off
+            self.keys.copy_(keys0)
+            self.pos.copy_(pos0)
+            if akeys0 is not None:
+                self.all_keys.copy_(akeys0)
+        return self._graphs[slot]
+
+    def _step_local(self, token: torch.Tensor) -> torch.Tensor:
+        off = self.caches[0].offset
+        self._check_room(off)
+        long = self._wants_long(off)
+        if self.use_graph:
+            graph, out = self._graph_for(False, long)
+            self.tok.copy_(token.reshape(-1))
+            self.pos.fill_(off)
+            graph.replay()
+        else:
+            self.tok.copy_(token.reshape(-1))
+            self.pos.fill_(off)
+            self.long_mode = long
+            with torch.no_grad():
+                out = self.logits = self._forward()
+            self.long_mode = False
+        for c in self.caches:
+            c.offset = off + 1
+        return out
 
     def fault_words(self):
         """The status words of this runner's fused launches as one-element int32 device views (non-zero: a hand-off timed out and the
         stream was poisoned).  generate_step copies them to the host next to every token and calls decode_fallback on a non-zero one."""
-        return [ops.dattn_status_word(st) for st in (self.da_state, self.dm_state) if st is not None]
+        words = [ops.dattn_status_word(st) for st in (self.da_state, self.dm_state) if st is not None]
+        if self.db_state is not None:
+            words.append(ops.dblock_status_word(self.db_state))
+        return words
 
     def dattn_check(self) -> None:
         """Raise if a fused attention launch of this runner timed out on a hand-off (synchronises: call off the timed path)."""
-        for st in (self.da_state, self.dm_state):
-            code = ops.dattn_status(st) if st is not None else 0
+        for st in (self.da_state, self.dm_state, self.db_state):
+            code = (ops.dblock_status(st) if st is self.db_state else ops.dattn_status(st)) if st is not None else 0
             if code:
                 raise RuntimeError(f"gbx_dattn_forward: hand-off {code} timed out (workgroup placement broke the one-kv-group-per-XCD "
                                    "bijection, or a member never ran); the results of this runner are invalid -- rerun with GBX_DATTN=0")
@@ -640,6 +717,9 @@ class FusedDecodeRunner(DecodeRunner):
             if li in self.da_pre:            # pending fixed-point sums -> hb (every accumulator is zero afterwards)
                 xs, accs = self.da_pre[li]
                 ops.acc_residual(xs, accs, self.hb, zero=[t for t in (self.acc_d[0], self.acc_d[1], self.acc_o[0], self.acc_o[1]) if t.data_ptr() != accs.data_ptr()])
+            if self.db[li] is not None and not self.long_mode:
+                ops.dblock(self.db[li], dev)
+                continue
             if self.da[li] is not None:
                 ops.dattn(self.da[li][0], dev)
                 if len(self.da[li]) == 2:
@@ -706,21 +786,8 @@ class FusedDecodeRunner(DecodeRunner):
             self.all_keys.zero_()
             self.all_keys[0] = key
         self.pos.fill_(off - 1)                                       # the embed kernel advances it to `off`
-        if self.use_graph and self.graph_chain is None:
-            self.chain = True
-            saved = (self.graph, self.logits)
-            keys0, pos0 = self.keys.clone(), self.pos.clone()
-            akeys0 = self.all_keys.clone() if self.tp_vocab is not None else None
-            self._capture()                                           # captures _forward with from_keys / advance_pos set
-            self.graph_chain = self.graph
-            self.graph, self.logits = saved
-            self.chain = False
-            for c in self.caches:                                     # warm-up passes of the capture wrote positions >= off only
-                c.offset = off
-            self.keys.copy_(keys0)
-            self.pos.copy_(pos0)
-            if akeys0 is not None:
-                self.all_keys.copy_(akeys0)
+        if self.use_graph:
+            self._graph_for(True, self._wants_long(off))              # captures _forward with from_keys / advance_pos set
 
     def step_greedy(self) -> torch.Tensor:
         """One chained greedy step.  Returns ``logits_buf``: the full logits, or -- under a vocabulary-sharded head (tensor
@@ -728,13 +795,14 @@ class FusedDecodeRunner(DecodeRunner):
         Callers that need full logits under TP use ``step()``."""
         off = self.caches[0].offset
         self._check_room(off)
+        long = self._wants_long(off)
         if self.use_graph:
-            self.graph_chain.replay()
+            self._graph_for(True, long)[0].replay()
         else:
-            self.chain = True
+            self.chain, self.long_mode = True, long
             with torch.no_grad():
                 self._forward()
-            self.chain = False
+            self.chain, self.long_mode = False, False
         for c in self.caches:
             c.offset = off + 1
         return self.logits_buf
@@ -870,9 +938,11 @@ def decode_fault_words(model):
     return fw() if fw is not None else []
 
 
-def decode_fallback(model, code: int) -> None:
+def decode_fallback(model, code: int, prompt_cache=None, offset: Optional[int] = None) -> None:
     """A fused launch of this model gave up on a hand-off (status ``code``; its stream is NaN from there on): drop the runner and keep
-    this model on the five-launch block from now on.  The caller rewinds the KV offsets and replays the step."""
+    this model on the five-launch block from now on.  With ``prompt_cache`` / ``offset`` the caches are rewound to ``offset`` cached
+    positions and the rows the faulted steps appended behind it are cleared -- they hold NaN, and the attention launches multiply
+    speculatively fetched rows beyond the position by a zero weight (0 x NaN = NaN).  The caller then replays the step."""
     import warnings
     if not getattr(model, "_fused_handoff_disabled", False):
         warnings.warn(f"gbx_lm_amd: a fused decode launch timed out on hand-off {code} (another tenant on the GPU, a CU mask, or a "
@@ -881,6 +951,13 @@ def decode_fallback(model, code: int) -> None:
     model._fused_handoff_disabled = True
     model._decode_runner = None
     torch.cuda.synchronize()
+    if prompt_cache is not None and offset is not None:
+        for c in prompt_cache:
+            if isinstance(c, KVCache) and c.keys is not None:
+                c.keys[:, :, offset:c.offset + 1].zero_()
+                c.values[:, :, offset:c.offset + 1].zero_()
+            c.offset = offset
+        torch.cuda.synchronize()
 
 
 def decode_step_checked(model, y: torch.Tensor, prompt_cache: List[KVCache]) -> torch.Tensor:
@@ -891,9 +968,7 @@ def decode_step_checked(model, y: torch.Tensor, prompt_cache: List[KVCache]) -> 
     for w in decode_fault_words(model):
         code = int(w.item())
         if code:
-            decode_fallback(model, code)
-            for c in prompt_cache:
-                c.offset = off
+            decode_fallback(model, code, prompt_cache, off)
             return decode_step(model, y, prompt_cache)
     return logits
 

@@ -268,10 +268,11 @@ class Model(nn.Module):
         from ..decode import decode_fault_words
         return decode_fault_words(self)
 
-    def decode_fallback(self, code: int) -> None:
-        """A fused decode launch timed out on a hand-off: this model decodes on the five-launch block from here on (decode.py)."""
+    def decode_fallback(self, code: int, prompt_cache=None, offset=None) -> None:
+        """A fused decode launch timed out on a hand-off: this model decodes on the five-launch block from here on; the caches are
+        rewound to ``offset`` and the rows the faulted steps appended are cleared (decode.py)."""
         from ..decode import decode_fallback
-        decode_fallback(self, code)
+        decode_fallback(self, code, prompt_cache, offset)
 
     def sanitize(self, weights: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """Drop precomputed rotary tables some exporters leave in the checkpoint (qllama.py:201-205)."""

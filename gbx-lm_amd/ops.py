@@ -907,6 +907,70 @@ def dmlp(desc, device) -> None:
     _lib.check(_lib.lib().gbx_dmlp_forward(ctypes.byref(desc), _stream_ptr(device)))
 
 
+def dblock_supported(d_model: int, n_heads: int, n_kv: int, head_dim: int, qkv_mod, o_mod, gate, up, down, dtype) -> bool:
+    """Does the one-launch block (gbx_dblock_forward) cover this decoder block?"""
+    L = _lib.lib()
+    if not hasattr(L, "gbx_dblock_plan") or dtype not in _DT or any(m.bias is not None for m in (qkv_mod, o_mod, gate, up, down)):
+        return False
+    if (gate.bits, gate.group_size) != (up.bits, up.group_size) or gate.output_dims != up.output_dims:
+        return False
+    return L.gbx_dblock_plan(d_model, gate.output_dims, n_heads, n_kv, head_dim, qkv_mod.bits, qkv_mod.group_size, o_mod.bits, o_mod.group_size,
+                             gate.bits, gate.group_size, down.bits, down.group_size, _DT[dtype]) == _lib.GBX_OK
+
+
+def dblock_state(device) -> torch.Tensor:
+    """Hand-off state of the one-launch block: zero-filled once, private to one stream (one decode runner)."""
+    return torch.zeros((_lib.lib().gbx_dblock_state_bytes(),), dtype=torch.uint8, device=device)
+
+
+def dblock_max_context() -> int:
+    """Cached positions up to which the one-launch block sweeps the context itself (beyond: the two-launch block's cooperative sweep)."""
+    return int(_lib.lib().gbx_dblock_max_context())
+
+
+def dblock_status_word(state: torch.Tensor) -> torch.Tensor:
+    """The status word of a gbx_dblock state buffer as a one-element int32 device view (hand area of 8 x 4096 granules, then word 8 * 16)."""
+    off = 8 * 4096 * 8 + 8 * 16 * 4
+    return state[off:off + 4].view(torch.int32)
+
+
+def make_dblock_desc(d_a: "_lib.DattnDesc", d_m: "_lib.DmlpDesc", state: torch.Tensor, keep=()) -> "_lib.DblockDesc":
+    """The one-launch form of a (fused attention, fused MLP) descriptor pair: same tensors, same accumulators, same clears -- the
+    attention launch's zero_buf and the MLP launch's zero_buf both become this launch's (gbx_dblock)."""
+    import ctypes
+    _require_cuda(state, "dblock state")
+    if d_m.x_acc != d_a.acc:
+        raise ValueError("the MLP launch must consume the attention launch's accumulator")
+    d = _lib.DblockDesc()
+    d.struct_size = ctypes.sizeof(_lib.DblockDesc)
+    d.act_dtype = d_a.act_dtype
+    for f in ("x", "norm_weight", "ssq_in", "qkv_qweight", "qkv_sz", "kcache", "vcache", "inv_freq", "pos", "o_qweight", "o_scales", "o_zeros",
+              "x_acc", "x_out", "attn_out", "capacity", "traditional", "norm_eps", "rope_scale", "sm_scale"):
+        setattr(d, f, getattr(d_a, f))
+    d.acc_o = d_a.acc
+    d.norm2_weight, d.norm2_eps = d_m.norm_weight, d_m.norm_eps
+    for f in ("gate_qweight", "up_qweight", "gate_up_sz", "down_qweight", "down_sz", "act_out"):
+        setattr(d, f, getattr(d_m, f))
+    d.acc_d, d.x2_out = d_m.acc_out, d_m.x_out
+    d.zero_buf0, d.zero_n0 = d_a.zero_buf, d_a.zero_n
+    d.zero_buf1, d.zero_n1 = d_m.zero_buf, d_m.zero_n
+    d.state = state.data_ptr()
+    d._keep = (d_a, d_m, state) + tuple(keep)
+    return d
+
+
+def dblock(desc, device) -> None:
+    import ctypes
+    _lib.check(_lib.lib().gbx_dblock_forward(ctypes.byref(desc), _stream_ptr(device)))
+
+
+def dblock_status(state: torch.Tensor) -> int:
+    import ctypes
+    c = ctypes.c_int32(0)
+    _lib.check(_lib.lib().gbx_dblock_status(state.data_ptr(), ctypes.byref(c)))
+    return c.value
+
+
 def acc_residual(x: torch.Tensor, acc: torch.Tensor, out: torch.Tensor, zero=()) -> None:
     """out <- round(x + round(acc * 2^-32)); ``acc`` and up to three more [D + 1] accumulators are cleared (gbx_acc_residual)."""
     z = [t.data_ptr() for t in zero] + [None] * (3 - len(zero))

@@ -366,10 +366,6 @@ def generate_step(prompt: torch.Tensor, model: nn.Module, *, max_tokens: int = 2
             raise _HandoffFault(int(fpin[fpin != 0][0]))
         return int(host.item())
 
-    def _rewind(off):
-        for c in prompt_cache:
-            c.offset = off
-
     n = 0
     # (input, cache offset before it) of the decode step that produced ``y``; None when ``y`` came out of the prompt pass
     made_by = (first_in, first_off) if (first_in is not None and first_in.numel() == 1 and fast_decode is not None) else None
@@ -388,12 +384,9 @@ def generate_step(prompt: torch.Tensor, model: nn.Module, *, max_tokens: int = 2
         except _HandoffFault as fault:
             # in flight: the step that produced ``y`` (when it was a decode step) and the look-ahead step fed by it.  Either may be the
             # faulted one (the words are sticky): both are replayed on the five-launch block, from the cache offset they started at.
-            model.decode_fallback(int(fault.args[0]))
+            model.decode_fallback(int(fault.args[0]), prompt_cache, made_by[1] if made_by is not None else ahead_off)
             if made_by is not None:
-                _rewind(made_by[1])
                 y, logprobs, h_states = _step(made_by[0])
-            else:
-                _rewind(ahead_off)
             pending = _to_host(y)
             if n != max_tokens:
                 ahead_off = prompt_cache[0].offset if prompt_cache else 0

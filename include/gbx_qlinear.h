@@ -270,6 +270,63 @@ int gbx_dmlp_forward(const gbx_dmlp* desc, void* hip_stream);
  * are cleared: the step between the last block's gbx_dmlp_forward and the output head.  act_dtype: GBX_F16 / GBX_BF16 (since 1300). */
 int gbx_acc_residual(const void* x, int64_t* acc, void* out, int32_t D, int32_t act_dtype, int64_t* zero0, int64_t* zero1, int64_t* zero2,
                      void* hip_stream);
+/* ------------------------------------------------------------------------------------------------
+ * One WHOLE decoder block at M == 1 as one launch (round 6): gbx_dattn_forward followed by gbx_dmlp_forward, fused -- input RMSNorm ->
+ * q | k | v -> RoPE + cache append -> attention -> o_proj -> residual -> post-attention RMSNorm -> gate | up + SwiGLU -> down_proj
+ * (qllama.py:131-141 with :68-96 and :114-115; seven mx.quantized_matmul calls, quantized_linear_gba.py:195-203).  The MLP's packed
+ * rows stream into LDS while the attention chain runs; o_proj's sums and the MLP's prologue meet in ONE chip-wide release inside the
+ * launch (per-XCD arrival line -> 8 leader flags -> each XCD's leader forms x' = round(h + round(o)), its statistic and RMSNorm(x')
+ * once and publishes it XCD-locally).  Same arithmetic, same roundings, same accumulators as the two launches it replaces:
+ * o_proj's sums land in acc_o, down_proj's in acc_d, the NEXT launch (gbx_dblock / gbx_dattn x_acc, or gbx_acc_residual) forms the stream.
+ * Covered: 2 bits, group 128, bf16, D = 4096, 32 query / 8 kv heads of 128, I = 14336 (Llama-3-8B), at most gbx_dblock_max_context()
+ * cached positions (beyond it the caller replays gbx_dattn_forward + gbx_dmlp_forward, whose cooperative sweep covers long contexts).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct gbx_dblock {
+  uint32_t struct_size;        /* sizeof(gbx_dblock) */
+  int32_t act_dtype;           /* GBX_BF16 */
+  /* attention half: as gbx_dattn */
+  const void* x;               /* [D] residual stream entering the block */
+  const void* norm_weight;     /* [D] input_layernorm weight */
+  const float* ssq_in;         /* optional carried statistic of x (not with x_acc) */
+  const uint32_t* qkv_qweight; /* q | k | v rows concatenated */
+  const uint32_t* qkv_sz;      /* gbx_dgemv_pack of that matrix, rows_per_batch 2 */
+  void* kcache;                /* [8, capacity, 128] */
+  void* vcache;
+  const float* inv_freq;       /* [64] */
+  const int64_t* pos;          /* device scalar */
+  const uint32_t* o_qweight;
+  const void* o_scales;
+  const void* o_zeros;
+  int64_t* acc_o;              /* [D + 1], zero on entry: o_proj sums */
+  const int64_t* x_acc;        /* optional [D + 1]: the previous block's down_proj sums */
+  void* x_out;                 /* with x_acc: [D] round(x + round(x_acc * 2^-32)), written once */
+  void* attn_out;              /* optional [4096] (tests) */
+  /* MLP half: as gbx_dmlp */
+  const void* norm2_weight;    /* [D] post_attention_layernorm weight */
+  const uint32_t* gate_qweight;
+  const uint32_t* up_qweight;
+  const uint32_t* gate_up_sz;  /* gbx_dgemv_pack(gate, up), rows_per_batch 2 */
+  const uint32_t* down_qweight;
+  const uint32_t* down_sz;     /* gbx_dgemv_pack(down), rows_per_batch 2 */
+  int64_t* acc_d;              /* [D + 1]: down_proj sums; zero on entry unless it is one of the zero_bufs */
+  void* x2_out;                /* [D]: the stream after the attention residual (the next launch adds acc_d to it); may be x, not x_out */
+  void* act_out;               /* optional [I] (tests) */
+  uint64_t* zero_buf0;         /* optional: zero_n0 8-byte words this launch clears (not x_acc, not acc_o; acc_d itself is allowed) */
+  uint64_t* zero_buf1;         /* optional: zero_n1 words */
+  void* state;                 /* gbx_dblock_state_bytes() bytes, 64-byte aligned, zero-filled ONCE, private to one stream */
+  int32_t zero_n0, zero_n1;
+  int32_t capacity, traditional;
+  float norm_eps, norm2_eps, rope_scale, sm_scale;
+} gbx_dblock;
+int gbx_dblock_plan(int32_t D, int32_t I, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int32_t qkv_bits, int32_t qkv_group_size,
+                    int32_t o_bits, int32_t o_group_size, int32_t gate_up_bits, int32_t gate_up_group_size, int32_t down_bits,
+                    int32_t down_group_size, int32_t act_dtype);
+size_t gbx_dblock_state_bytes(void);
+int32_t gbx_dblock_max_context(void);
+int gbx_dblock_forward(const gbx_dblock* desc, void* hip_stream);
+/* gbx_dattn_status for a gbx_dblock state buffer (its status word sits behind a larger hand-off area). */
+int gbx_dblock_status(const void* state, int32_t* code);
+
 /* The device check behind every launch with XCD-local hand-offs (gbx_dattn_*, gbx_dmlp_*, gbx_dblock_*, gbx_add_rmsnorm_slices_xcd):
  * 256 CUs in one partition, no CU mask on the process, and -- measured once per device by a census launch of the same geometry --
  * consecutive workgroups on 8 different XCDs, one workgroup per CU.  GBX_OK, or GBX_ERR_UNSUPPORTED with the reason in

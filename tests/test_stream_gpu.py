@@ -2,8 +2,6 @@
 ahead of the activation prologue and of later ops) against (a) the launch-per-op fused GEMV, bit for bit where the
 arithmetic order is identical (everything but the fused RMSNorm's fp32 sum), and (b) the CPU oracle with the stated
 tolerance.  Reference op: mx.quantized_matmul at gbx_lm/models/quantized_linear_gba.py:195-203, M = 1."""
-import warnings
-
 import numpy as np
 import pytest
 import torch
@@ -12,22 +10,18 @@ pytestmark = [pytest.mark.gpu, pytest.mark.experimental]
 DEV = "cuda:0"
 
 
-def _second_attempt_reported(fn):
-    """The streamed engine lives in the experimental library (measured, not faster, opt-in; the product path never calls it).  One of
-    its bit-for-bit comparisons failed ONCE in a full-suite run of round 5 and passed 3 x 47 times alone on another box: a failing
-    test of this file is run a second time and the first failure is reported as a warning; a repeatable mismatch still fails."""
-    import functools
-
-    @functools.wraps(fn)
-    def wrapper(*args, **kwargs):
-        try:
-            return fn(*args, **kwargs)
-        except AssertionError as e:
-            warnings.warn(f"streamed engine (experimental): {fn.__name__}{args} failed once: {str(e)[:300]}")
-            torch.cuda.synchronize()
-            return fn(*args, **kwargs)
-    return wrapper
-
+def _same_bits(a, b, what=""):
+    """Bit-for-bit comparison that says WHERE two results differ when they do (no second attempt: a mismatch fails the run).
+    Round 5 wrapped these tests in a retry after ONE mismatch in one full-suite run that never reproduced (3 x 47 passes of this file alone,
+    then three logged full-suite passes in round 6: profiles/r06_full_suite_passes.txt); the wrapper is gone, the diagnostics stay."""
+    if torch.equal(a, b):
+        return
+    af, bf = a.float().reshape(-1).cpu(), b.float().reshape(-1).cpu()
+    bad = torch.nonzero(af != bf).reshape(-1)
+    idx = bad[:16].tolist()
+    raise AssertionError(f"{what}: {bad.numel()} of {af.numel()} elements differ; first indices {idx}; values {af[bad[:8]].tolist()} vs "
+                         f"{bf[bad[:8]].tolist()}; max |diff| {(af - bf).abs().max().item()}; "
+                         f"index spacing {[int(bad[i + 1] - bad[i]) for i in range(min(8, bad.numel() - 1))]}")
 
 
 def _mk(oracle, n, k, bits, g, seed):
@@ -53,7 +47,6 @@ def _pack(ops, mods, swiglu=False):
 @pytest.mark.parametrize("bits", [2, 3, 4])
 @pytest.mark.parametrize("n,k,g", [(512, 4096, 128), (4096, 14336, 128), (1026, 3072, 64), (4096, 8192, 128), (66, 512, 64)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@_second_attempt_reported
 def test_stream_single_matches_launch_path(oracle, bits, n, k, g, dtype):
     """one matrix (+ residual): bit-identical to gbx_qlinear_fused_forward, and within tolerance of the oracle"""
     from gbx_lm_amd import ops
@@ -70,7 +63,7 @@ def test_stream_single_matches_launch_path(oracle, bits, n, k, g, dtype):
     prog = ops.StreamProgram([ops.make_fused_desc(x, (m,), (y_new,), residual=y_new, packed=pk)], DEV, dtype)
     prog.run()
     torch.cuda.synchronize()
-    assert torch.equal(y_old, y_new), f"max diff {(y_old.float() - y_new.float()).abs().max().item()}"
+    _same_bits(y_old, y_new, f"stream vs launch path, b{bits} n{n} k{k} g{g}")
     y64 = oracle.qlinear_ref(x.cpu()[None], d["qweight"], m.scales.cpu(), m.zeros.cpu(), bits, g, acc=np.float64)
     oracle.assert_close(y_new[None], h0.cpu().double().numpy()[None] + y64, "bf16" if dtype == torch.bfloat16 else "fp16",
                         f"stream residual b{bits}")
@@ -78,7 +71,6 @@ def test_stream_single_matches_launch_path(oracle, bits, n, k, g, dtype):
 
 @pytest.mark.parametrize("bits", [2, 3, 4])
 @pytest.mark.parametrize("k", [4096, 3072])
-@_second_attempt_reported
 def test_stream_norm_qkv(oracle, bits, k):
     from gbx_lm_amd import ops
     g = 128
@@ -96,7 +88,7 @@ def test_stream_norm_qkv(oracle, bits, k):
     ops.StreamProgram([ops.make_fused_desc(x, mods, ys1, packed=pk)], DEV, torch.bfloat16).run()
     torch.cuda.synchronize()
     for a, b in zip(ys0, ys1):
-        assert torch.equal(a, b)
+        _same_bits(a, b, "stream vs launch path")
     xn = _rms(x, nw, 1e-5).cpu()
     for m, d, y in zip(mods, ds, ys):
         y64 = oracle.qlinear_ref(xn[None], d["qweight"], d["scales"], d["zeros"], bits, g, acc=np.float64)
@@ -105,7 +97,6 @@ def test_stream_norm_qkv(oracle, bits, k):
 
 @pytest.mark.parametrize("bits", [2, 3, 4])
 @pytest.mark.parametrize("n,k", [(14336, 4096), (1030, 4096), (8192, 3072)])
-@_second_attempt_reported
 def test_stream_swiglu(oracle, bits, n, k):
     from gbx_lm_amd import ops
     g = 128
@@ -118,7 +109,7 @@ def test_stream_swiglu(oracle, bits, n, k):
     ops.qlinear_fused(ops.make_fused_desc(x, (mg, mu), (a_old,), swiglu=True, packed=pk), x.device)
     ops.StreamProgram([ops.make_fused_desc(x, (mg, mu), (a_new,), swiglu=True, packed=pk)], DEV, torch.bfloat16).run()
     torch.cuda.synchronize()
-    assert torch.equal(a_old, a_new)
+    _same_bits(a_old, a_new, "stream vs launch path")
     # with the fused norm: against the oracle
     a_n = torch.zeros_like(a_old)
     ops.StreamProgram([ops.make_fused_desc(x, (mg, mu), (a_n,), norm_weight=nw, eps=1e-5, swiglu=True, packed=pk)], DEV,
@@ -130,7 +121,6 @@ def test_stream_swiglu(oracle, bits, n, k):
     oracle.assert_close(a_n[None], (g64 / (1 + np.exp(-g64))) * u64, "bf16", f"stream swiglu b{bits}")
 
 
-@_second_attempt_reported
 def test_stream_multi_op_program(oracle):
     """four independent ops of mixed widths in ONE launch: the issue cursor crosses ops (rows of op i+1 are requested while
     op i is consumed); every output bit-identical to its own launch"""
@@ -155,7 +145,7 @@ def test_stream_multi_op_program(oracle):
     torch.cuda.synchronize()
     for si, (a, b) in enumerate(zip(outs_old, outs_new)):
         for u, v in zip(a, b):
-            assert torch.equal(u, v), f"op {si}"
+            _same_bits(u, v, f"op {si}")
     # a sub-range of the same program
     for yn in outs_new:
         for t in yn:
@@ -164,7 +154,7 @@ def test_stream_multi_op_program(oracle):
     torch.cuda.synchronize()
     for si in (2, 3, 4):
         for u, v in zip(outs_old[si], outs_new[si]):
-            assert torch.equal(u, v), f"sub-range op {si}"
+            _same_bits(u, v, f"sub-range op {si}")
     assert float(outs_new[0][0].abs().max()) == 0.0 and float(outs_new[5][0].abs().max()) == 0.0
 
 
