@@ -47,10 +47,11 @@ typedef __attribute__((address_space(1))) unsigned db_gu32;
 constexpr int DB_LDS_IMG = 0;                      // phase-1 operand image, later the gate|up operand image: 8 KB + 512 B sums + 128 B scales
 constexpr int DB_LDS_RED = 9 * 1024;               // 16 floats
 constexpr int DB_LDS_P3 = 9 * 1024 + 256;          // o_proj operand image, later down_proj's: 4 KB + 256 B + 64 B
-constexpr int DB_LDS_ATT = 16 * 1024;              // attention workgroups: q | k | v words, rotated q / k / v, softmax states (37.6 KB)
-constexpr int DB_LDS_ROWS_P = 16 * 1024;           // producers: gate rows | up rows | scale-zero pairs of 60 activations (135 KB)
+constexpr int DB_LDS_ATT = 14 * 1024;              // attention workgroups: q | k | v words, rotated q / k / v, softmax states (37.6 KB)
+constexpr int DB_LDS_ROWS_P = 14 * 1024;           // producers: (gate, up) row pairs | scale-zero pairs of 60 activations (135 KB)
 constexpr int DB_LDS_ROWS_A = 56 * 1024;           // attention workgroups: the same for 32 (16) activations (72 / 36 KB)
-constexpr int DB_LDS_BYTES = 152 * 1024;
+constexpr int DB_LDS_SCR = 149 * 1024;             // 8 KB: per-wave result scratch of the gate | up tiles, then the tiles' partial sums
+constexpr int DB_LDS_BYTES = 157 * 1024;
 #ifdef GBX_STAMPS
 #define DB_STAMP(i) do { if (lane == 0) reinterpret_cast<unsigned long long*>(smem + DB_LDS_BYTES)[wave * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define DB_STAMP_EXTRA 2048
@@ -63,6 +64,7 @@ constexpr int DB_D = 4096, DB_I = 14336, DB_REP = 4, DB_HD = 128, DB_IX = DB_I /
 constexpr int DB_ACT_LEADER = 16, DB_ACT_ATT = 32, DB_ACT_PROD = 60;
 static_assert(DB_ACT_LEADER + (DB_REP - 1) * DB_ACT_ATT + (DA_MEMBERS - DB_REP) * DB_ACT_PROD == DB_IX, "the XCD's eighth of the intermediate vector");
 constexpr int DB_W0_PIECES = 36;                   // attention workgroups, launch start (the leader's whole share)
+constexpr int DB_W0P_PIECES = 48;                  // producers, launch start: the 8 waves that sit out the prologue, 6 pieces of 1 KB each (nothing else is in flight yet)
 constexpr int DB_W1_PIECES = 84;                   // producers, behind their publish barrier: 14 waves x 6 pieces of 1 KB
 // hand-off granules per group (8 bytes each)
 constexpr int DB_H_P1 = 0;                         // 384 phase-1 granules
@@ -140,7 +142,6 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
     db_gu64* z = reinterpret_cast<db_gu64*>(reinterpret_cast<uintptr_t>(a.zero1));
     for (int i = static_cast<int>(blockIdx.x) * NT + tid; i < a.zero_n1; i += static_cast<int>(gridDim.x) * NT) __hip_atomic_store(z + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  const int cpos = static_cast<int>(*a.pos);
   const int mnn = lane & 15, mkg = lane >> 4;               // matrix-core operand lane: (row / group nn, 8-byte piece kg)
   const bool diag = mkg == (mnn >> 2);
   float dm[4];
@@ -152,16 +153,21 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
   const int act0 = r == 0 ? 0 : (r < REP ? DB_ACT_LEADER + (r - 1) * DB_ACT_ATT : DB_ACT_LEADER + (REP - 1) * DB_ACT_ATT + (r - REP) * DB_ACT_PROD);
   const int n0g = g * DB_IX + act0;                         // first gate / up row of this workgroup
   unsigned char* rows = smem + (r < REP ? DB_LDS_ROWS_A : DB_LDS_ROWS_P);
-  const int npieces = 2 * nact + (nact >> 2);               // 1-KB pieces: gate rows, up rows, four activations' scale-zero pairs
-  const __amdgpu_buffer_rsrc_t gqd = rsrc(a.gate_qw, RS_ALL), uqd = rsrc(a.up_qw, RS_ALL), gszd = rsrc(a.gu_sz, RS_ALL);
-  // pieces [p0, p1) by the waves [w0, NW): LDS-DMA, 16 bytes per lane, nothing held in registers
+  const int npieces = 2 * nact + (nact >> 2);               // 1-KB pieces: row slots 2 a (gate) / 2 a + 1 (up) of activation a, then four activations' scale-zero pairs
+  // pieces [p0, p1) by the waves [w0, NW): LDS-DMA, 16 bytes per lane, nothing held in registers.  A row's 16-byte chunks land XOR-swizzled by
+  // its slot (lane l fetches chunk l ^ (slot % 16)): the 16 rows of a tile are then read conflict-free as one matrix-core operand.
   auto dma = [&](int p0, int p1, int w0) {
     if (wave < w0) return;
+    const __amdgpu_buffer_rsrc_t gqd = rsrc(a.gate_qw, RS_ALL), uqd = rsrc(a.up_qw, RS_ALL), gszd = rsrc(a.gu_sz, RS_ALL);
     for (int p = p0 + (wave - w0); p < p1; p += NW - w0) {
       auto dst = (__attribute__((address_space(3))) void*)(rows + p * 1024);
-      if (p < nact) __builtin_amdgcn_raw_ptr_buffer_load_lds(gqd, dst, 16, lane * 16, (n0g + p) * 1024, 0, 2);
-      else if (p < 2 * nact) __builtin_amdgcn_raw_ptr_buffer_load_lds(uqd, dst, 16, lane * 16, (n0g + p - nact) * 1024, 0, 2);
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(gszd, dst, 16, lane * 16, n0g * 256 + (p - 2 * nact) * 1024, 0, 0);
+      if (p < 2 * nact) {
+        const unsigned vo = static_cast<unsigned>((lane ^ (p & 15)) * 16);
+        if (p & 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(uqd, dst, 16, vo, (n0g + (p >> 1)) * 1024, 0, 2);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(gqd, dst, 16, vo, (n0g + (p >> 1)) * 1024, 0, 2);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(gszd, dst, 16, lane * 16, n0g * 256 + (p - 2 * nact) * 1024, 0, 0);
+      }
     }
   };
   int pieces_done = 0;
@@ -220,8 +226,10 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
   float* red_lds = reinterpret_cast<float*>(smem + DB_LDS_RED);
 
   unsigned tag;
-  if (cpos > a.max_ctx) timeout(9u);                            // (the runner replays the two-launch block beyond max_ctx: never reached through it)
   if (r >= REP) {
+    // W0 (producers): the prologue's loads are issued ~1 us into the launch and land ~1 us later; the eight waves that only join its barriers
+    // put 48 KB of gate | up rows in front of them
+    dma(0, DB_W0P_PIECES, 8);
     // ================= phase 1 on the matrix cores (dattn_kernel<2, 1, true, 2>): this producer's rows of the group's q | k | v =================
     constexpr int K = D, W4 = K / 4, G = K >> 7;
     constexpr int nb = (REP + 2) * (HD / 2);
@@ -393,8 +401,8 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
     // W1: every granule of this workgroup is out (granule stores would queue behind the stream); waves 0 / 1 poll the attention output
     // next and issue nothing (their polls would come back behind their own pieces)
     __syncthreads();
-    dma(0, DB_W1_PIECES, 2);
-    pieces_done = DB_W1_PIECES;
+    dma(DB_W0P_PIECES, DB_W0P_PIECES + DB_W1_PIECES, 2);
+    pieces_done = DB_W0P_PIECES + DB_W1_PIECES;
   } else {
     // =========================================== phase 2: attention of head g * REP + r (dattn_kernel.h) ===========================================
     unsigned* raw32 = reinterpret_cast<unsigned*>(smem + DB_LDS_ATT);
@@ -409,7 +417,10 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
     constexpr int LP = HD / 8, PPW = 64 / LP, UB0 = 10;
     const int h = g * REP + r;
     const int d0 = (lane % LP) * 8, sub = lane / LP;
-    const int pos = cpos;
+    // (only the attention workgroups read the position: a scalar load from memory holds up EVERY later scalar wait of its wave -- scalar
+    //  loads return out of order, so the first kernel-argument use behind it waits for it too: 0.6 us on the producers' prologue)
+    const int pos = static_cast<int>(*a.pos);
+    if (pos > a.max_ctx) timeout(9u);                            // (the runner replays the two-launch block beyond max_ctx: never reached through it)
     const int nws = pos <= 160 ? 4 : (pos <= UB0 * 8 * PPW ? 8 : 16);
     const int ppr = nws * PPW;
     const bool sweeper = wave < nws;
@@ -697,8 +708,27 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
   if (wave == 0 && lane == 0)
     __hip_atomic_store(harr + r, (static_cast<unsigned long long>(tag) << 32) | static_cast<unsigned>(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   DB_STAMP(6);
-  // W2: the rest of this workgroup's gate | up pieces (<= 56 KB: drained before x' is due).  The leader carries no stream during the release.
-  if (r != 0) { dma(pieces_done, npieces, 0); pieces_done = npieces; }
+  // ---------------- down_proj's words of this wave's 8 rows, this XCD's columns (56 KB per CU, registers; consumed behind the MLP hand-off) ----------------
+  // Requested right behind W2, at ARRIVE: 50 + 56 KB per CU drain in ~3.8 us, about when x' is due -- requested behind x' instead, the 12 loads
+  // of a wave WAIT TO BE ISSUED behind ~50 KB in flight (1.6 us median, 4 us worst) before the wave can touch its first tile.
+  constexpr int W4d = DB_I / 4;                                  // bytes per packed down row
+  constexpr int Gd = DB_I >> 7;
+  constexpr int ng = DB_IX >> 7;                                 // 14 groups of this XCD's slice
+  const unsigned voff_w = mnn * 32 + mkg * 8;
+  u32x2 dw[8], dsz[4];
+  auto issue_down = [&]() {
+    const __amdgpu_buffer_rsrc_t dd = rsrc(a.down_qw, RS_ALL), dsd = rsrc(a.down_sz, RS_ALL);
+    const unsigned killd = mnn < ng ? 0u : KILL;
+    const int row0 = r * RPW + wave * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      dw[i] = __builtin_amdgcn_raw_buffer_load_b64(dd, (voff_w + static_cast<unsigned>(g * (DB_IX / 4))) | killd, (row0 + i) * W4d, 2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      dsz[q] = __builtin_amdgcn_raw_buffer_load_b64(dsd, static_cast<unsigned>((g * ng + mnn) * 8) | killd, ((row0 >> 1) + q) * (Gd * 8), 0);
+  };
+  // W2: the rest of this workgroup's gate | up pieces, then down_proj's words.  The leader carries no stream during the release.
+  if (r != 0) { dma(pieces_done, npieces, 0); pieces_done = npieces; issue_down(); }
   if (r == 0) {
     if (wave == 0) {
       sweep(harr + (lane & 31), tag, 6u);                          // the XCD's 32 arrivals
@@ -754,6 +784,7 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
     __hip_atomic_store(hx + 2 * tid + 1, (static_cast<unsigned long long>(tag) << 32) | y1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     DB_STAMP(15);
     if (pieces_done < npieces) { dma(pieces_done, npieces, 0); pieces_done = npieces; }      // (long contexts: the leader's share, behind its publish)
+    issue_down();
   }
   // ---- every workgroup: thread t polls the two granules of image item t (4 values of RMSNorm(x')) and writes the gate | up operand image
   {
@@ -774,115 +805,104 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
   __syncthreads();                                               // image written, every piece of every wave in LDS
   DB_STAMP(8);
 
-  // ---------------- W3: down_proj's words of this wave's 8 rows, this XCD's columns (registers; consumed behind the hand-off) ----------------
-  constexpr int W4d = DB_I / 4;                                  // bytes per packed down row
-  constexpr int Gd = DB_I >> 7;
-  constexpr int ng = DB_IX >> 7;                                 // 14 groups of this XCD's slice
-  const unsigned voff_w = mnn * 32 + mkg * 8;
-  u32x2 dw[8], dsz[4];
+  // ---------------- gate | up from LDS on the matrix cores: 16-ROW TILES, SwiGLU, two activations per granule ----------------
+  // The two-launch kernels put ONE packed row per operand (16 groups on the diagonal of the result): 2 MFMAs and ~25 vector instructions per
+  // (row, 16 groups) -- hidden under the HBM stream there, 4.2 us of vector-ALU time here, where the rows already sit in LDS.  Here the WEIGHTS
+  // are the A operand: 16 rows (8 activations x (gate, up)) x one 128-value group per MFMA, the activation limbs the B operand (column 0 the
+  // high limb, column 1 the low limb of that group: one MFMA gives both products), the 32 useful results of an MFMA go through 128 bytes of
+  // LDS so that the per-(row, group) affine step  s * dot + z * sum(x)  runs on all 64 lanes (one (row, group) pair each).
+  // A wave owns ONE chunk of 4 groups (c = wave % 8) and tpw tiles: the chunk's four B operands stay in registers.
   {
-    const __amdgpu_buffer_rsrc_t dd = rsrc(a.down_qw, RS_ALL), dsd = rsrc(a.down_sz, RS_ALL);
-    const unsigned killd = mnn < ng ? 0u : KILL;
-    const int row0 = r * RPW + wave * 8;
+    const int ntc = (nact + 7) >> 3;                             // tiles of this workgroup: 8 (7.5), 4 or 2
+    const int tpw = ntc >> 1;                                    // tiles per wave: 4, 2 or 1
+    const int c = wave & 7, hspan = c >> 2, mg0 = (c & 3) * 4;   // this wave's groups 4 c .. 4 c + 3 = groups mg0 .. mg0 + 3 of span hspan
+    const int tile0 = (wave >> 3) * tpw;
+    const unsigned char* sz_l = rows + 2 * nact * 1024;
+    float* scr = reinterpret_cast<float*>(smem + DB_LDS_SCR + wave * 512);
+    db_v8i breg[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      dw[i] = __builtin_amdgcn_raw_buffer_load_b64(dd, (voff_w + static_cast<unsigned>(g * (DB_IX / 4))) | killd, (row0 + i) * W4d, 2);
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      dsz[q] = __builtin_amdgcn_raw_buffer_load_b64(dsd, static_cast<unsigned>((g * ng + mnn) * 8) | killd, ((row0 >> 1) + q) * (Gd * 8), 0);
-  }
-  // ---------------- gate | up from LDS on the matrix cores (dmlp.hip's arithmetic), SwiGLU, two activations per granule ----------------
-  {
-    const int a4 = nact > 32 ? (nact - 32) >> 1 : 0;             // waves [0, a4) own 4 activations, the next (nact - 4 a4) / 2 waves own 2
-    const int a2 = (nact - 4 * a4) >> 1;
-    const int nloc = wave < a4 ? 4 : (wave < a4 + a2 ? 2 : 0);
-    const int al0 = wave < a4 ? 4 * wave : 4 * a4 + 2 * (wave - a4);       // first activation of this wave, workgroup-local
-    const unsigned char* grow_l = rows, *urow_l = rows + nact * 1024, *sz_l = rows + 2 * nact * 1024;
-    const unsigned voff_s = mnn * 8;
-    db_v8i areg[SP][2];
-    int sa = 0;
-    float xsg[SP];
-#pragma unroll
-    for (int h = 0; h < SP; ++h) {
-#pragma unroll
-      for (int l = 0; l < 2; ++l) {
-        const u32x4 p0 = *reinterpret_cast<const u32x4*>(img + (h * 4 + 0) * 1024 + l * 2048 + lane * 16);
-        const u32x4 p1 = *reinterpret_cast<const u32x4*>(img + (h * 4 + 1) * 1024 + l * 2048 + lane * 16);
-        areg[h][l][0] = p0.x; areg[h][l][1] = p0.y; areg[h][l][2] = p0.z; areg[h][l][3] = p0.w;
-        areg[h][l][4] = p1.x; areg[h][l][5] = p1.y; areg[h][l][6] = p1.z; areg[h][l][7] = p1.w;
-      }
-      sa |= static_cast<int>(scl[h * 64 + lane]) << (8 * h);
-      const float gs = (bsum[h * 64 + mnn] + bsum[h * 64 + mnn + 16]) + (bsum[h * 64 + mnn + 32] + bsum[h * 64 + mnn + 48]);
-      xsg[h] = diag ? gs : 0.f;
+    for (int j = 0; j < 4; ++j) {
+      const unsigned char* src = img + (mnn & 1) * 2048 + (mg0 + j + 16 * mkg) * 16;
+      const u32x4 p0 = *reinterpret_cast<const u32x4*>(src + (hspan * 4 + 0) * 1024);
+      const u32x4 p1 = *reinterpret_cast<const u32x4*>(src + (hspan * 4 + 1) * 1024);
+      breg[j][0] = p0.x; breg[j][1] = p0.y; breg[j][2] = p0.z; breg[j][3] = p0.w;
+      breg[j][4] = p1.x; breg[j][5] = p1.y; breg[j][6] = p1.z; breg[j][7] = p1.w;
     }
-    unsigned short actv[4] = {0, 0, 0, 0};
-    struct Batch { u32x2 w[2][SP]; u32x2 sz[SP]; };
-    auto fetch = [&](Batch& b, int j) {
-      const int al = min(al0 + (j < nloc ? j : 0), nact - 1);      // (waves without a batch read a valid row and drop it)
+    const int sb = *reinterpret_cast<const int*>(scl + hspan * 64 + mkg * 16 + mg0);      // E8M0 bytes of groups mg0 .. mg0 + 3, k-block mkg
+    // the dense step: lane (dj = lane / 16: group of the chunk, dmr = lane % 16: row of the tile)
+    const int dj = lane >> 4, dmr = lane & 15;
+    const float xs = (bsum[hspan * 64 + mg0 + dj] + bsum[hspan * 64 + mg0 + dj + 16]) + (bsum[hspan * 64 + mg0 + dj + 32] + bsum[hspan * 64 + mg0 + dj + 48]);
+    float* part = reinterpret_cast<float*>(smem + DB_LDS_SCR);    // after the barrier below: [tile][chunk][16 rows] partial sums (4 KB)
+    float keep = 0.f;                                            // lane (dj, dmr): row dmr of tile tile0 + dj, summed over the chunk's 4 groups
+#ifdef GBX_STAMPS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (r != 0) DB_STAMP(13);    // (diagnostic: B operands in registers)
+#endif
+    // A REAL loop over the tiles (not unrolled): every instruction line of a launch is fetched cold, and straight-line copies of the tile body
+    // cost their fetch latency once each (0.6 us per tile measured unrolled)
+#pragma clang loop unroll(disable)
+    for (int tt = 0; tt < tpw; ++tt) {
+      const int t = tile0 + tt;
+      const unsigned char* rowp = rows + (16 * t + mnn) * 1024;  // A operand lane (row mnn of the tile, k-block mkg); slot = 2 * activation + (0 gate | 1 up)
+      u32x2 w[4];
 #pragma unroll
-      for (int h = 0; h < SP; ++h) {
-        b.w[0][h] = *reinterpret_cast<const u32x2*>(grow_l + al * 1024 + h * 512 + voff_w);
-        b.w[1][h] = *reinterpret_cast<const u32x2*>(urow_l + al * 1024 + h * 512 + voff_w);
-        b.sz[h] = *reinterpret_cast<const u32x2*>(sz_l + al * 256 + h * 128 + voff_s);
+      for (int j = 0; j < 4; ++j)                                // 16-byte chunk 2 g + mkg / 2 of the row, XOR-swizzled by the slot (conflict-free 16-row reads)
+        w[j] = *reinterpret_cast<const u32x2*>(rowp + (((2 * (4 * c + j) + (mkg >> 1)) ^ mnn) * 16) + (mkg & 1) * 8);
+      auto group = [&](auto J) {
+        constexpr int j = decltype(J)::value;
+        db_v8i av;
+        av[0] = w[j].x & 0x33333333u; av[1] = (w[j].x >> 2) & 0x33333333u; av[2] = w[j].y & 0x33333333u; av[3] = (w[j].y >> 2) & 0x33333333u;
+        av[4] = 0; av[5] = 0; av[6] = 0; av[7] = 0;
+        db_v4f z = {0.f, 0.f, 0.f, 0.f};
+        z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, breg[j], z, 4, 0, 0, 127, j, sb);
+        // (the result is consumed by two columns only: without this the compiler sinks the MFMA and its operand unpacking INTO the masked
+        //  branch below, where the other lanes' operand rows are never formed)
+        asm volatile("" : "+v"(z));
+        // result lane (column mnn, rows 4 mkg + i): columns 0 / 1 = high / low limb
+        if (mnn < 2) *reinterpret_cast<db_v4f*>(scr + ((j * 4 + mkg) * 2 + mnn) * 4) = z;
+      };
+      group(std::integral_constant<int, 0>{});
+      group(std::integral_constant<int, 1>{});
+      group(std::integral_constant<int, 2>{});
+      group(std::integral_constant<int, 3>{});
+      const float hi = scr[((dj * 4 + (dmr >> 2)) * 2 + 0) * 4 + (dmr & 3)];
+      const float lo = scr[((dj * 4 + (dmr >> 2)) * 2 + 1) * 4 + (dmr & 3)];
+      const unsigned szw = *reinterpret_cast<const unsigned*>(sz_l + (8 * t + (dmr >> 1)) * 256 + (4 * c + dj) * 8 + (dmr & 1) * 4);
+      const float sc = sz_scale<BF16>(szw), ze = sz_zero<BF16>(szw);
+      float v = fmaf(ze, xs, (sc + sc) * (hi + lo));
+      v += __shfl_xor(v, 16);                                    // sum over the chunk's 4 groups: lanes dmr, + 16, + 32, + 48
+      v += __shfl_xor(v, 32);
+      keep = dj == tt ? v : keep;
+    }
+#ifdef GBX_STAMPS
+    if (r != 0) DB_STAMP(14);    // (diagnostic: this wave's tiles done)
+#endif
+    __syncthreads();                                             // every wave is done with its scratch: the area becomes the partial sums
+    if (dj < tpw) part[((tile0 + dj) * 8 + c) * 16 + dmr] = keep;
+    __syncthreads();
+#ifdef GBX_STAMPS
+    if (r != 0) DB_STAMP(15);    // (diagnostic: partial sums exchanged)
+#endif
+    // 16 rows per tile: thread (tile, row) sums the 8 chunks; rows pair up as (gate, up) of one activation, activations as granules
+    if ((tid & ~63) < ntc * 16) {
+      const int t = tid >> 4, m = tid & 15;
+      float v = 0.f;
+      if (t < ntc) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v += part[(t * 8 + q) * 16 + m];
       }
-    };
-    auto consume = [&](const Batch& cur, int j) {
-      if (j >= nloc) return;                                     // wave-uniform
-      db_v4f c[2][SP];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        auto span = [&](auto H) {
-          constexpr int h = decltype(H)::value;
-          db_v8i bv;
-          const unsigned w0 = cur.w[i][h].x, w1 = cur.w[i][h].y;
-          bv[0] = w0 & 0x33333333u; bv[1] = (w0 >> 2) & 0x33333333u; bv[2] = w1 & 0x33333333u; bv[3] = (w1 >> 2) & 0x33333333u;
-          bv[4] = 0; bv[5] = 0; bv[6] = 0; bv[7] = 0;
-          db_v4f z = {0.f, 0.f, 0.f, 0.f};
-          z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(areg[h][0], bv, z, 0, 4, h, sa, 0, 127);
-          c[i][h] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(areg[h][1], bv, z, 0, 4, h, sa, 0, 127);
-        };
-        span(std::integral_constant<int, 0>{});
-        span(std::integral_constant<int, 1>{});
-      }
-      float accv[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        float yv = 0.f;
-#pragma unroll
-        for (int h = 0; h < SP; ++h) {
-          const float dsel = fmaf(c[i][h][0], dm[0], fmaf(c[i][h][1], dm[1], fmaf(c[i][h][2], dm[2], c[i][h][3] * dm[3])));
-          const unsigned szw = i == 0 ? cur.sz[h].x : cur.sz[h].y;
-          const float sc = sz_scale<BF16>(szw), ze = sz_zero<BF16>(szw);
-          yv += fmaf(ze, xsg[h], (sc + sc) * dsel);
-        }
-        accv[i] = yv;
-      }
-      const float v0 = wave_sum2(accv[0], accv[1]);
-      const float t0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v0), 31));
-      const float t1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v0), 63));
-      const float gt = round_bf16_or_f16(t0, BF16), up = round_bf16_or_f16(t1, BF16);
+      const float other = dpp_f32<0xB1>(v);                      // the pair's other row: even rows hold gate, odd rows up
+      const float gt = round_bf16_or_f16(v, BF16), up = round_bf16_or_f16(other, BF16);
       const float sl = round_bf16_or_f16(gt / (1.f + __expf(-gt)), BF16);
-      actv[j] = f32_to_act<BF16>(sl * up);
-    };
-    auto publish = [&](int q) {                                  // activations (act0 + al0) + 2 q, + 1 -> one granule (sc0: stays in this XCD's L2)
-      if (2 * q >= nloc) return;
-      const unsigned val = static_cast<unsigned>(actv[2 * q]) | (static_cast<unsigned>(actv[2 * q + 1]) << 16);
-      if (lane == 0) {
-        __hip_atomic_store(hact + ((act0 + al0) >> 1) + q, (static_cast<unsigned long long>(tag) << 32) | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (a.act_out) *reinterpret_cast<unsigned*>(a.act_out + n0g + al0 + 2 * q) = val;
+      const unsigned ab = f32_to_act<BF16>(sl * up);             // (meaningful on even rows)
+      const unsigned nb2 = dpp_u32<0x4E>(ab);                    // the next activation's value (row + 2) on rows 0 mod 4
+      const int al = 8 * t + (m >> 1);                           // workgroup-local activation of this row
+      if (t < ntc && (m & 3) == 0 && al + 1 < nact) {
+        const unsigned val = ab | (nb2 << 16);
+        __hip_atomic_store(hact + ((act0 + al) >> 1), (static_cast<unsigned long long>(tag) << 32) | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (a.act_out) *reinterpret_cast<unsigned*>(a.act_out + n0g + al) = val;
       }
-    };
-    Batch ring[2];
-    fetch(ring[0], 0);
-    fetch(ring[1], 1);
-    consume(ring[0], 0);
-    fetch(ring[0], 2);
-    consume(ring[1], 1);
-    publish(0);
-    fetch(ring[1], 3);
-    consume(ring[0], 2);
-    consume(ring[1], 3);
-    publish(1);
+    }
   }
   DB_STAMP(9);
   // ---------------- hand-off: the XCD's 1792 activations, polled by the lanes that convert them (two granules = one 4-value item) ----------------
