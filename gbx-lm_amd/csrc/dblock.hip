@@ -43,15 +43,16 @@ typedef float db_f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) unsigned long long db_gu64;
 typedef __attribute__((address_space(1))) unsigned db_gu32;
 
-// LDS map (bytes)
+// LDS map (bytes).  160 KB = 163,840: the producers' share fills it to the byte (the stamps build uses the last 2 KB).
 constexpr int DB_LDS_IMG = 0;                      // phase-1 operand image, later the gate|up operand image: 8 KB + 512 B sums + 128 B scales
-constexpr int DB_LDS_RED = 9 * 1024;               // 16 floats
-constexpr int DB_LDS_P3 = 9 * 1024 + 256;          // o_proj operand image, later down_proj's: 4 KB + 256 B + 64 B
-constexpr int DB_LDS_ATT = 14 * 1024;              // attention workgroups: q | k | v words, rotated q / k / v, softmax states (37.6 KB)
-constexpr int DB_LDS_ROWS_P = 14 * 1024;           // producers: (gate, up) row pairs | scale-zero pairs of 60 activations (135 KB)
-constexpr int DB_LDS_ROWS_A = 56 * 1024;           // attention workgroups: the same for 32 (16) activations (72 / 36 KB)
-constexpr int DB_LDS_SCR = 149 * 1024;             // 8 KB: per-wave result scratch of the gate | up tiles, then the tiles' partial sums
-constexpr int DB_LDS_BYTES = 157 * 1024;
+constexpr int DB_LDS_RED = 8832;                   // 16 floats
+constexpr int DB_LDS_P3 = 8960;                    // o_proj operand image, later down_proj's: 4 KB + 256 B + 64 B
+constexpr int DB_LDS_ATT = 13440;                  // attention workgroups: q | k | v words, rotated q / k / v, softmax states (37.6 KB)
+constexpr int DB_ROW_STRIDE = 1040;                // a packed row (1 KB) + 16 bytes: the 16 rows of a tile sit 4 banks apart (conflict-free as one operand)
+constexpr int DB_LDS_ROWS_P = 13440;               // producers: 120 row slots (2 a: gate, 2 a + 1: up of activation a) | scale-zero pairs of 60 activations (140,160 B)
+constexpr int DB_LDS_ROWS_A = 51200;               // attention workgroups: the same for 32 (16) activations
+constexpr int DB_LDS_SCR = 153600;                 // 8 KB: per-wave result scratch of the gate | up tiles, then the tiles' partial sums
+constexpr int DB_LDS_BYTES = 161792;
 #ifdef GBX_STAMPS
 #define DB_STAMP(i) do { if (lane == 0) reinterpret_cast<unsigned long long*>(smem + DB_LDS_BYTES)[wave * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define DB_STAMP_EXTRA 2048
@@ -60,12 +61,19 @@ constexpr int DB_LDS_BYTES = 157 * 1024;
 #define DB_STAMP_EXTRA 0
 #endif
 
+#ifndef DB_W0P_N
+#define DB_W0P_N 0
+#endif
+#ifndef DB_W1_N
+#define DB_W1_N 98
+#endif
 constexpr int DB_D = 4096, DB_I = 14336, DB_REP = 4, DB_HD = 128, DB_IX = DB_I / 8;
 constexpr int DB_ACT_LEADER = 16, DB_ACT_ATT = 32, DB_ACT_PROD = 60;
 static_assert(DB_ACT_LEADER + (DB_REP - 1) * DB_ACT_ATT + (DA_MEMBERS - DB_REP) * DB_ACT_PROD == DB_IX, "the XCD's eighth of the intermediate vector");
 constexpr int DB_W0_PIECES = 36;                   // attention workgroups, launch start (the leader's whole share)
-constexpr int DB_W0P_PIECES = 48;                  // producers, launch start: the 8 waves that sit out the prologue, 6 pieces of 1 KB each (nothing else is in flight yet)
-constexpr int DB_W1_PIECES = 84;                   // producers, behind their publish barrier: 14 waves x 6 pieces of 1 KB
+// (A/B, same box, tok/s: W0P 48 / W1 84: 937-940; 24 / 98: 944; 0 / 84: 953-955; 0 / 98: 950-962; two launches: 942 -- profiles/r06_dblock_ab.txt)
+constexpr int DB_W0P_PIECES = DB_W0P_N;                  // producers, launch start, by the 8 waves that sit out the prologue: MEASURED TO LOSE (the prologue's own loads queue behind them) -> 0
+constexpr int DB_W1_PIECES = DB_W1_N;                   // producers, behind their publish barrier: 14 waves x 7 pieces of 1 KB
 // hand-off granules per group (8 bytes each)
 constexpr int DB_H_P1 = 0;                         // 384 phase-1 granules
 constexpr int DB_H_ATT = 512;                      // 256 attention-output granules
@@ -154,18 +162,17 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
   const int n0g = g * DB_IX + act0;                         // first gate / up row of this workgroup
   unsigned char* rows = smem + (r < REP ? DB_LDS_ROWS_A : DB_LDS_ROWS_P);
   const int npieces = 2 * nact + (nact >> 2);               // 1-KB pieces: row slots 2 a (gate) / 2 a + 1 (up) of activation a, then four activations' scale-zero pairs
-  // pieces [p0, p1) by the waves [w0, NW): LDS-DMA, 16 bytes per lane, nothing held in registers.  A row's 16-byte chunks land XOR-swizzled by
-  // its slot (lane l fetches chunk l ^ (slot % 16)): the 16 rows of a tile are then read conflict-free as one matrix-core operand.
+  // pieces [p0, p1) by the waves [w0, NW): LDS-DMA, 16 bytes per lane, nothing held in registers
   auto dma = [&](int p0, int p1, int w0) {
     if (wave < w0) return;
     const __amdgpu_buffer_rsrc_t gqd = rsrc(a.gate_qw, RS_ALL), uqd = rsrc(a.up_qw, RS_ALL), gszd = rsrc(a.gu_sz, RS_ALL);
     for (int p = p0 + (wave - w0); p < p1; p += NW - w0) {
-      auto dst = (__attribute__((address_space(3))) void*)(rows + p * 1024);
       if (p < 2 * nact) {
-        const unsigned vo = static_cast<unsigned>((lane ^ (p & 15)) * 16);
-        if (p & 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(uqd, dst, 16, vo, (n0g + (p >> 1)) * 1024, 0, 2);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(gqd, dst, 16, vo, (n0g + (p >> 1)) * 1024, 0, 2);
+        auto dst = (__attribute__((address_space(3))) void*)(rows + p * DB_ROW_STRIDE);
+        if (p & 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(uqd, dst, 16, lane * 16, (n0g + (p >> 1)) * 1024, 0, 2);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(gqd, dst, 16, lane * 16, (n0g + (p >> 1)) * 1024, 0, 2);
       } else {
+        auto dst = (__attribute__((address_space(3))) void*)(rows + 2 * nact * DB_ROW_STRIDE + (p - 2 * nact) * 1024);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(gszd, dst, 16, lane * 16, n0g * 256 + (p - 2 * nact) * 1024, 0, 0);
       }
     }
@@ -227,9 +234,8 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
 
   unsigned tag;
   if (r >= REP) {
-    // W0 (producers): the prologue's loads are issued ~1 us into the launch and land ~1 us later; the eight waves that only join its barriers
-    // put 48 KB of gate | up rows in front of them
-    dma(0, DB_W0P_PIECES, 8);
+    // W0 (producers; off: see DB_W0P_PIECES)
+    if (DB_W0P_PIECES > 0) dma(0, DB_W0P_PIECES, 8);
     // ================= phase 1 on the matrix cores (dattn_kernel<2, 1, true, 2>): this producer's rows of the group's q | k | v =================
     constexpr int K = D, W4 = K / 4, G = K >> 7;
     constexpr int nb = (REP + 2) * (HD / 2);
@@ -817,7 +823,8 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
     const int tpw = ntc >> 1;                                    // tiles per wave: 4, 2 or 1
     const int c = wave & 7, hspan = c >> 2, mg0 = (c & 3) * 4;   // this wave's groups 4 c .. 4 c + 3 = groups mg0 .. mg0 + 3 of span hspan
     const int tile0 = (wave >> 3) * tpw;
-    const unsigned char* sz_l = rows + 2 * nact * 1024;
+    constexpr int RS = DB_ROW_STRIDE;
+    const unsigned char* sz_l = rows + 2 * nact * RS;
     float* scr = reinterpret_cast<float*>(smem + DB_LDS_SCR + wave * 512);
     db_v8i breg[4];
 #pragma unroll
@@ -828,51 +835,74 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
       breg[j][0] = p0.x; breg[j][1] = p0.y; breg[j][2] = p0.z; breg[j][3] = p0.w;
       breg[j][4] = p1.x; breg[j][5] = p1.y; breg[j][6] = p1.z; breg[j][7] = p1.w;
     }
-    const int sb = *reinterpret_cast<const int*>(scl + hspan * 64 + mkg * 16 + mg0);      // E8M0 bytes of groups mg0 .. mg0 + 3, k-block mkg
+    // E8M0 bytes of groups mg0 .. mg0 + 3, k-block mkg, + 1 each: the activation side is scaled by 2, so the MFMA returns 2 * dot -- the
+    // affine step is s * (2 * sum q / 2 * x) + z * sum x without doubling s (the in-place 2-bit field IS q / 2 as an E2M1 number)
+    const int sb = *reinterpret_cast<const int*>(scl + hspan * 64 + mkg * 16 + mg0) + 0x01010101;
     // the dense step: lane (dj = lane / 16: group of the chunk, dmr = lane % 16: row of the tile)
     const int dj = lane >> 4, dmr = lane & 15;
     const float xs = (bsum[hspan * 64 + mg0 + dj] + bsum[hspan * 64 + mg0 + dj + 16]) + (bsum[hspan * 64 + mg0 + dj + 32] + bsum[hspan * 64 + mg0 + dj + 48]);
     float* part = reinterpret_cast<float*>(smem + DB_LDS_SCR);    // after the barrier below: [tile][chunk][16 rows] partial sums (4 KB)
     float keep = 0.f;                                            // lane (dj, dmr): row dmr of tile tile0 + dj, summed over the chunk's 4 groups
+    // every address of the loop is a per-lane pointer bumped once per tile + an immediate: ~37 vector instructions per tile, 24 of them the
+    // field unpacking (the first form spent ~120: address arithmetic of a swizzled layout, lane shuffles through LDS)
+    const unsigned char* ap = rows + (16 * tile0 + mnn) * RS + (4 * c) * 32 + mkg * 8;       // A operand lane (row mnn of the tile, k-block mkg)
+    const unsigned char* szp = sz_l + (8 * tile0 + (dmr >> 1)) * 256 + (4 * c + dj) * 8 + (dmr & 1) * 4;
+    float* swr = scr + (mkg * 2 + mnn) * 4;                      // result lane (column mnn < 2, rows 4 mkg + i) -> [j][mkg][mnn][i]
+    const float* srd = scr + ((dj * 4 + (dmr >> 2)) * 2) * 4 + (dmr & 3);      // dense lane: high limb at [0], low limb at [4]
 #ifdef GBX_STAMPS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (r != 0) DB_STAMP(13);    // (diagnostic: B operands in registers)
 #endif
-    // A REAL loop over the tiles (not unrolled): every instruction line of a launch is fetched cold, and straight-line copies of the tile body
-    // cost their fetch latency once each (0.6 us per tile measured unrolled)
+    // A REAL loop over the tiles: straight-line copies of the body cost their instruction-fetch latency once each
 #pragma clang loop unroll(disable)
     for (int tt = 0; tt < tpw; ++tt) {
-      const int t = tile0 + tt;
-      const unsigned char* rowp = rows + (16 * t + mnn) * 1024;  // A operand lane (row mnn of the tile, k-block mkg); slot = 2 * activation + (0 gate | 1 up)
       u32x2 w[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)                                // 16-byte chunk 2 g + mkg / 2 of the row, XOR-swizzled by the slot (conflict-free 16-row reads)
-        w[j] = *reinterpret_cast<const u32x2*>(rowp + (((2 * (4 * c + j) + (mkg >> 1)) ^ mnn) * 16) + (mkg & 1) * 8);
+      for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const u32x2*>(ap + j * 32);
+#ifdef GBX_DIAG2
+      if (r >= REP && tt == 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); DB_STAMP(1); }
+#endif
+      db_v4f z[4];
       auto group = [&](auto J) {
         constexpr int j = decltype(J)::value;
         db_v8i av;
         av[0] = w[j].x & 0x33333333u; av[1] = (w[j].x >> 2) & 0x33333333u; av[2] = w[j].y & 0x33333333u; av[3] = (w[j].y >> 2) & 0x33333333u;
         av[4] = 0; av[5] = 0; av[6] = 0; av[7] = 0;
-        db_v4f z = {0.f, 0.f, 0.f, 0.f};
-        z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, breg[j], z, 4, 0, 0, 127, j, sb);
-        // (the result is consumed by two columns only: without this the compiler sinks the MFMA and its operand unpacking INTO the masked
-        //  branch below, where the other lanes' operand rows are never formed)
-        asm volatile("" : "+v"(z));
-        // result lane (column mnn, rows 4 mkg + i): columns 0 / 1 = high / low limb
-        if (mnn < 2) *reinterpret_cast<db_v4f*>(scr + ((j * 4 + mkg) * 2 + mnn) * 4) = z;
+        const db_v4f zero = {0.f, 0.f, 0.f, 0.f};
+        z[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, breg[j], zero, 4, 0, 0, 127, j, sb);
       };
       group(std::integral_constant<int, 0>{});
       group(std::integral_constant<int, 1>{});
       group(std::integral_constant<int, 2>{});
       group(std::integral_constant<int, 3>{});
-      const float hi = scr[((dj * 4 + (dmr >> 2)) * 2 + 0) * 4 + (dmr & 3)];
-      const float lo = scr[((dj * 4 + (dmr >> 2)) * 2 + 1) * 4 + (dmr & 3)];
-      const unsigned szw = *reinterpret_cast<const unsigned*>(sz_l + (8 * t + (dmr >> 1)) * 256 + (4 * c + dj) * 8 + (dmr & 1) * 4);
+      // (the results are consumed by two columns only: without this the compiler sinks the MFMAs and their operand unpacking INTO the masked
+      //  branch below, where the other lanes' operand rows are never formed)
+      asm volatile("" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]));
+#ifdef GBX_DIAG2
+      if (r >= REP && tt == 2) { asm volatile("s_nop 15\n s_nop 15" ::: "memory"); DB_STAMP(2); }
+#endif
+      if (mnn < 2) {                                             // result lane (column mnn, rows 4 mkg + i): columns 0 / 1 = high / low limb
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<db_v4f*>(swr + j * 32) = z[j];
+      }
+      const unsigned szw = *reinterpret_cast<const unsigned*>(szp);
+      const float d2 = srd[0] + srd[4];                          // 2 * sum(q / 2 * x) of (row dmr, group dj)
       const float sc = sz_scale<BF16>(szw), ze = sz_zero<BF16>(szw);
-      float v = fmaf(ze, xs, (sc + sc) * (hi + lo));
-      v += __shfl_xor(v, 16);                                    // sum over the chunk's 4 groups: lanes dmr, + 16, + 32, + 48
-      v += __shfl_xor(v, 32);
+      float v = fmaf(ze, xs, sc * d2);
+#ifdef GBX_DIAG2
+      if (r >= REP && tt == 2) { asm volatile("" : "+v"(v)); DB_STAMP(3); }
+#endif
+      {                                                          // sum over the chunk's 4 groups = the wave's four 16-lane rows: two lane-row swaps
+        auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        const unsigned a16 = r16[0], b16 = r16[1];
+        v = __uint_as_float(a16) + __uint_as_float(b16);
+        auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        const unsigned a32 = r32[0], b32 = r32[1];
+        v = __uint_as_float(a32) + __uint_as_float(b32);
+      }
       keep = dj == tt ? v : keep;
+      ap += 16 * RS;
+      szp += 8 * 256;
     }
 #ifdef GBX_STAMPS
     if (r != 0) DB_STAMP(14);    // (diagnostic: this wave's tiles done)

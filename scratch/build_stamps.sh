@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/../gbx-lm_amd/csrc"
 mkdir -p ../../scratch/stamps/_obj
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -I. -Wno-unused-value -ffp-contract=on -DGBX_STAMPS"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -I. -Wno-unused-value -ffp-contract=on -DGBX_STAMPS $EXTRA_FLAGS"
 SRCS=$(make -s -p -n 2>/dev/null | grep '^SRCS :=' | head -1 | sed 's/^SRCS := //')
 objs=""
 for f in $SRCS; do

@@ -50,7 +50,7 @@ runner.dattn_check()
 s = stamps.cpu().numpy().reshape(-1, 4096, 16)
 # the capture's warm-up passes and the capture itself each consumed SLOTS regions (round-robin): the replayed graph's launches are the LAST pass
 labels = {
-    "producer": {0: "start", 1: "x, w, sums loads issued", 2: "barrier B (image; rows requested)", 3: "granule published", 4: "H2 received (waves 0, 1)",
+    "producer": {0: "start", 1: "x, w, sums loads issued", 2: "barrier B", 3: "granule published", 4: "H2 received (waves 0, 1)",
                  5: "o_proj sums issued", 6: "ARRIVE (sums acknowledged, W2 issued)", 7: "x' received", 8: "image + every piece landed (barrier)", 13: "(diag) B operands in registers", 14: "(diag) own tiles done", 15: "(diag) partials exchanged",
                  9: "gate|up consumed, activations published", 10: "hand-off received (polling waves)", 11: "down image barrier", 12: "end"},
     "attention": {0: "start", 1: "K/V prefetch + o words + W0 issued", 2: "H1 received (waves 0, 1)", 3: "output published", 4: "H2 received (waves 0, 1)",
