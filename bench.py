@@ -112,7 +112,8 @@ def kernel_leg(model, runner=None, reps=20):
             # two-launch block: the dominant launch is the fused MLP launch (gate|up + SwiGLU + down_proj in one kernel)
             dn = layers[0].mlp.down_proj
             fused_mlp = True
-            kname = "gbx::dmlp_kernel<2> (FP4 x FP8 matrix cores; gate|up + SwiGLU + XCD-local hand-off + down_proj)"
+            kname = ("gbx::dmlp_kernel<2> (FP4 x FP8 matrix cores; gate|up + SwiGLU + XCD-local hand-off + down_proj)" if bits == 2 else
+                     f"gbx::dmlpv_kernel<{bits}, 2, true> (vector-ALU dots; gate|up + SwiGLU + XCD-local hand-off + down_proj from LDS)")
             acc_bytes += (dn.output_dims * dn.input_dims * dn.bits // 8 + 2 * dn.output_dims * (dn.input_dims // dn.group_size) * 2
                           + 8 * dn.output_dims - g0.output_dims * 2)       # + down_proj's matrix, scales / zeros, its fixed-point sums; the activations never leave the chip
         else:

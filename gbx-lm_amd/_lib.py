@@ -181,7 +181,9 @@ class DmlpDesc(ctypes.Structure):
                 ("gate_qweight", ctypes.c_void_p), ("up_qweight", ctypes.c_void_p), ("gate_up_sz", ctypes.c_void_p),
                 ("down_qweight", ctypes.c_void_p), ("down_sz", ctypes.c_void_p), ("acc_out", ctypes.c_void_p),
                 ("zero_buf", ctypes.c_void_p), ("state", ctypes.c_void_p), ("act_out", ctypes.c_void_p),
-                ("D", ctypes.c_int32), ("I", ctypes.c_int32), ("zero_n", ctypes.c_int32), ("norm_eps", ctypes.c_float)]
+                ("D", ctypes.c_int32), ("I", ctypes.c_int32), ("zero_n", ctypes.c_int32), ("norm_eps", ctypes.c_float),
+                ("gate_up_bits", ctypes.c_int32), ("gate_up_group_size", ctypes.c_int32), ("down_bits", ctypes.c_int32),
+                ("down_group_size", ctypes.c_int32)]
 
 
 class DblockDesc(ctypes.Structure):

@@ -1153,7 +1153,8 @@ int gbx_dmlp_plan(int32_t D, int32_t I, int32_t gate_up_bits, int32_t gate_up_gr
                   int32_t act_dtype) {
   int bpw, a4;
   if (int rc = xcd_layout_gate("gbx_dmlp_plan")) return rc;
-  if (!gbx::dmlp_plan(D, I, gate_up_bits, gate_up_group_size, down_bits, down_group_size, act_dtype == GBX_BF16, &bpw, &a4))
+  if (!gbx::dmlp_plan(D, I, gate_up_bits, gate_up_group_size, down_bits, down_group_size, act_dtype == GBX_BF16, &bpw, &a4) &&
+      !gbx::dmlpv_plan(D, I, gate_up_bits, gate_up_group_size, down_bits, down_group_size, act_dtype == GBX_BF16, &bpw, &a4))
     return fail(GBX_ERR_UNSUPPORTED, "the fused MLP launch does not cover D=%d I=%d gate|up %d bits g%d, down %d bits g%d, dtype %d", D, I,
                 gate_up_bits, gate_up_group_size, down_bits, down_group_size, act_dtype);
   return GBX_OK;
@@ -1162,9 +1163,13 @@ int gbx_dmlp_plan(int32_t D, int32_t I, int32_t gate_up_bits, int32_t gate_up_gr
 int gbx_dmlp_forward(const gbx_dmlp* d, void* hip_stream) {
   if (!d) return fail(GBX_ERR_INVALID, "null descriptor");
   if (d->struct_size != sizeof(gbx_dmlp)) return fail(GBX_ERR_INVALID, "gbx_dmlp.struct_size is %u, this library expects %zu (header / library mismatch)", d->struct_size, sizeof(gbx_dmlp));
+  const int bg = d->gate_up_bits ? d->gate_up_bits : 2, gg = d->gate_up_group_size ? d->gate_up_group_size : 128;
+  const int bd = d->down_bits ? d->down_bits : 2, gd = d->down_group_size ? d->down_group_size : 128;
   int bpw, a4;
-  if (!gbx::dmlp_plan(d->D, d->I, 2, 128, 2, 128, d->act_dtype == GBX_BF16, &bpw, &a4))
-    return fail(GBX_ERR_UNSUPPORTED, "the fused MLP launch does not cover D=%d I=%d dtype %d (gbx_dmlp_plan)", d->D, d->I, d->act_dtype);
+  const bool mx = gbx::dmlp_plan(d->D, d->I, bg, gg, bd, gd, d->act_dtype == GBX_BF16, &bpw, &a4);
+  if (!mx && !gbx::dmlpv_plan(d->D, d->I, bg, gg, bd, gd, d->act_dtype == GBX_BF16, &bpw, &a4))
+    return fail(GBX_ERR_UNSUPPORTED, "the fused MLP launch does not cover D=%d I=%d gate|up %d bits g%d, down %d bits g%d, dtype %d (gbx_dmlp_plan)", d->D, d->I,
+                bg, gg, bd, gd, d->act_dtype);
   if (!d->x || !d->x_acc || !d->x_out || !d->norm_weight || !d->gate_qweight || !d->up_qweight || !d->gate_up_sz || !d->down_qweight || !d->down_sz ||
       !d->acc_out || !d->state)
     return fail(GBX_ERR_INVALID, "null device pointer");
@@ -1191,6 +1196,7 @@ int gbx_dmlp_forward(const gbx_dmlp* d, void* hip_stream) {
   a.state = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(d->state) + static_cast<size_t>(gbx::DA_GROUPS) * gbx::DA_HAND_STRIDE * 8);
   a.act_out = static_cast<unsigned short*>(d->act_out);
   a.K = d->D; a.I = d->I; a.D = d->D; a.bpw = bpw; a.a4 = a4;
+  a.gu_log2g = log2_group(gg); a.dn_log2g = log2_group(gd);
   {
     static const int spin_log2 = gbx::env_switch("GBX_DATTN_SPIN_LOG2");
     a.spin_limit = 1u << (spin_log2 < 0 ? 0 : (spin_log2 > 30 ? 30 : spin_log2));
@@ -1199,7 +1205,7 @@ int gbx_dmlp_forward(const gbx_dmlp* d, void* hip_stream) {
 #ifdef GBX_STAMPS
   a.stamps = gbx::stamp_region();
 #endif
-  hipError_t e = gbx::launch_dmlp(a, static_cast<hipStream_t>(hip_stream));
+  hipError_t e = mx ? gbx::launch_dmlp(a, static_cast<hipStream_t>(hip_stream)) : gbx::launch_dmlpv(a, bg, static_cast<hipStream_t>(hip_stream));
   if (e != hipSuccess) return hip_fail(e, "gbx_dmlp_forward launch");
   return GBX_OK;
 }

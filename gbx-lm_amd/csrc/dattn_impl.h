@@ -108,6 +108,7 @@ struct DmlpArgs {
   unsigned* state;                  // [DA_STATE_WORDS]
   unsigned short* act_out;          // optional [I]: the SwiGLU output (tests)
   int K, I, D, zero_n, bpw, a4;     // bpw: gate|up batches per workgroup; waves [0, a4) own 4 of them, the others 2
+  int gu_log2g, dn_log2g;           // dmlpv.hip (3 / 4 bits): log2 of the group sizes
   unsigned spin_limit;              // polls of the hand-off before the launch gives up (GBX_DATTN_SPIN_LOG2)
   float eps;
 #ifdef GBX_STAMPS
@@ -117,6 +118,9 @@ struct DmlpArgs {
 
 bool dmlp_plan(int D, int I, int bits_gu, int group_gu, int bits_dn, int group_dn, bool bf16, int* bpw, int* a4);
 hipError_t launch_dmlp(const DmlpArgs& a, hipStream_t stream);
+// dmlpv.hip: the same launch on the vector-ALU arithmetic for 3- and 4-bit rows (Llama-3-8B and Llama-3.2-3B MLP shapes)
+bool dmlpv_plan(int D, int I, int bits_gu, int group_gu, int bits_dn, int group_dn, bool bf16, int* bpw, int* a4);
+hipError_t launch_dmlpv(const DmlpArgs& a, int bits, hipStream_t stream);
 hipError_t launch_acc_finish(const void* x, void* acc, void* out, int D, bool bf16, void* z0, void* z1, void* z2, hipStream_t stream);
 // dblock.hip (round 6): the whole 2-bit block -- both launches above -- as ONE launch with a chip-wide release between o_proj's sums and the MLP
 struct DblockArgs {

@@ -597,7 +597,9 @@ class FusedDecodeRunner(DecodeRunner):
                                   ssq_in=ssq_prev if acc_in is None else None, x_acc=acc_in, x_out=self.hn if acc_in is not None else None,
                                   zero_buf=self.acc_d[p])
         h_buf = self.hn if acc_in is not None else x_in          # the stream before o_proj's output is added
-        use_mlp = (self.use_dmlp and ops.dmlp_supported(D, mlp.gate_proj, mlp.up_proj, mlp.down_proj, self.hb.dtype) and
+        # (the fused MLP launch exists for 3 / 4 bits too -- dmlpv.hip -- but measured slower than the two launches it replaces: opt-in)
+        use_mlp = (self.use_dmlp and (mlp.gate_proj.bits == 2 or env.flag("GBX_DMLP_VEC")) and
+                   ops.dmlp_supported(D, mlp.gate_proj, mlp.up_proj, mlp.down_proj, self.hb.dtype) and
                    blk.post_attention_layernorm.weight.dtype == self.hb.dtype)
         if use_mlp:
             pk_gu = ops.dgemv_pack(mlp.gate_proj, 2, mlp.up_proj)

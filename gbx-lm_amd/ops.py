@@ -899,6 +899,7 @@ def make_dmlp_desc(x: torch.Tensor, x_acc: torch.Tensor, x_out: torch.Tensor, no
         d.zero_buf, d.zero_n = zero_buf.data_ptr(), zero_buf.numel()
     d.act_out = act_out.data_ptr() if act_out is not None else None
     d.D, d.I, d.norm_eps = D, I, float(eps)
+    d.gate_up_bits, d.gate_up_group_size, d.down_bits, d.down_group_size = gate.bits, gate.group_size, down.bits, down.group_size
     return d
 
 

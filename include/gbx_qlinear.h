@@ -242,7 +242,9 @@ int gbx_dattn_status(const void* state, int32_t* code);
  * [g I/8, (g+1) I/8) and consumes exactly that range as down_proj's input columns, so the one exchange inside the launch stays in
  * that XCD's L2; the eight partial sums per output row meet in acc_out as 2^-32 fixed-point integers.  The NEXT launch forms the
  * residual stream: gbx_dattn.x_acc / x_out of the next block, or gbx_acc_residual after the last one.
- * Covered: 2 bits, group 128, bf16, D = 4096, I a multiple of 1024 with I / 256 even in [32, 64] (Llama-3-8B: 14336).
+ * Covered: 2 bits, group 128, bf16, D = 4096, I a multiple of 1024 with I / 256 even in [32, 64] (Llama-3-8B: 14336) on the FP4 x FP8
+ * matrix cores; 3 or 4 bits (gate, up and down alike), groups 32 / 64 / 128, bf16, D = 4096 or 3072 (Llama-3.2-3B: I = 8192) on the
+ * vector-ALU arithmetic of the decode GEMV, down_proj's words streamed into LDS (round 6).
  * ------------------------------------------------------------------------------------------------ */
 typedef struct gbx_dmlp {
   uint32_t struct_size;        /* sizeof(gbx_dmlp) */
@@ -262,6 +264,7 @@ typedef struct gbx_dmlp {
   void* act_out;               /* optional [I]: the SwiGLU output (tests) */
   int32_t D, I, zero_n;
   float norm_eps;
+  int32_t gate_up_bits, gate_up_group_size, down_bits, down_group_size;   /* since 1300; 0 = 2 bits / group 128 */
 } gbx_dmlp;
 int gbx_dmlp_plan(int32_t D, int32_t I, int32_t gate_up_bits, int32_t gate_up_group_size, int32_t down_bits, int32_t down_group_size,
                   int32_t act_dtype);

@@ -12,14 +12,15 @@ NL = 32
 REG = 4096 * 16
 from gbx_lm_amd import synthetic as S0
 bits = [S0.strategy_bits("S22", i, NL) for i in range(NL)]
-per = [2 if b == 2 else 3 for b in bits]
+per = [2 if (b == 2 or os.environ.get('GBX_DMLP_VEC', '0') != '0') else 3 for b in bits]      # (round 6: 3- / 4-bit blocks take the fused MLP launch too)
 SLOTS = sum(per)
 base = np.cumsum([0] + per)
 stamps = torch.zeros(SLOTS * REG, dtype=torch.int64, device=dev)
 os.environ["GBX_STAMP_PTR"] = str(stamps.data_ptr())
 os.environ["GBX_STAMP_SLOTS"] = str(SLOTS)
 os.environ["GBX_DATTN"] = "1"
-os.environ["GBX_DMLP"] = "1"
+os.environ.setdefault("GBX_DMLP", "1")
+os.environ["GBX_DBLOCK"] = "0"
 if os.environ.get("GBX_PROBE_MODE"):      # round-6 step 0 (ii): an LDS-DMA stream beside dattn's hand-off chain (stamps build only)
     pool = torch.full(((24 * 32 + 40) << 20,), 1, dtype=torch.uint8, device=dev)
     os.environ["GBX_PROBE_SRC"] = str(pool.data_ptr())
@@ -57,7 +58,7 @@ labels = {
 acc = {k: [] for k in labels}
 spans = {"dattn": [], "dmlp": []}
 gaps = {"dattn": [], "dmlp": []}
-for li in range(4, 29):
+for li in ([int(v) for v in os.environ['LAYERS'].split(',')] if os.environ.get('LAYERS') else range(4, 29)):
     for ki, n in enumerate(("dattn", "dmlp")):
         r = s[base[li] + ki]
         live = r[:, 0] > 0
@@ -90,7 +91,7 @@ for k, lab in labels.items():
         if np.all(np.isnan(c)):
             continue
         print(f"   s{i:<2d} {nm:46s} min {np.nanmin(c):6.2f}  med {np.nanmedian(c):6.2f}  p90 {np.nanpercentile(c, 90):6.2f}  max {np.nanmax(c):6.2f}")
-li = 10
+li = int(os.environ.get("LAYERS", "10").split(",")[0])
 r = s[base[li] + 1].astype(np.float64)
 t0 = r[r[:, 0] > 0][:, 0].min()
 rel = (r - t0) / 100.0

@@ -257,13 +257,17 @@ def test_gateup_prologue_reads_the_accumulator(bits):
         ops.dgemv(bad, DEV)
 
 
-@pytest.mark.parametrize("seed", [0, 1])
-def test_dmlp_launch_vs_fp64(seed):
-    """gbx_dmlp_forward on Llama-3-8B MLP shapes (2 bits): x' exact; the SwiGLU activations against fp64 on dequantised weights with
-    the reference graph's roundings (tolerance of the matrix-core form, as tests/test_dgemv_gpu.py: 2e-2 of the value + 2e-2 of the
-    RMS); down_proj's fixed-point sums against fp64 on the launch's OWN activations; zero_buf; bit-reproducible."""
+@pytest.mark.parametrize("cfg_name,bits,group,seed", [("LLAMA3_8B", 2, 128, 0), ("LLAMA3_8B", 2, 128, 1),
+                                                      # round 6: the vector-ALU form (dmlpv.hip) for 3- and 4-bit rows, both BASELINE geometries, every group size
+                                                      ("LLAMA3_8B", 3, 128, 2), ("LLAMA3_8B", 4, 128, 3), ("LLAMA32_3B", 3, 128, 4), ("LLAMA32_3B", 4, 128, 5),
+                                                      ("LLAMA3_8B", 4, 64, 6), ("LLAMA32_3B", 3, 32, 7), ("LLAMA3_8B", 3, 64, 8)])
+def test_dmlp_launch_vs_fp64(cfg_name, bits, group, seed):
+    """gbx_dmlp_forward (2 bits: FP4 x FP8 matrix cores, Llama-3-8B MLP shapes; 3 / 4 bits: the decode GEMV's vector-ALU arithmetic, 8B and
+    3.2-3B shapes): x' exact; the SwiGLU activations against fp64 on dequantised weights with the reference graph's roundings (2e-2 of the
+    value + 2e-2 of the RMS, as tests/test_dgemv_gpu.py); down_proj's fixed-point sums against fp64 on the launch's OWN activations;
+    zero_buf; bit-reproducible."""
     from gbx_lm_amd import ops
-    model, cfg = _layer("LLAMA3_8B", 2, 2, seed=20 + seed)
+    model, cfg = _layer(cfg_name, bits, bits, group=group, seed=20 + seed)
     blk = model.model.layers[0]
     mlp, nw = blk.mlp, blk.post_attention_layernorm
     D, I = cfg["hidden_size"], cfg["intermediate_size"]

@@ -59,22 +59,27 @@ def _ref_layer_fp64(model, h, pos, kcache, vcache):
     return _bf(h1 + _bf(deq(mlp.down_proj) @ act))
 
 
-@pytest.mark.parametrize("dattn", [0, 1, 2])
+@pytest.mark.parametrize("dattn", [0, 1, 2, 3])
 @pytest.mark.parametrize("bits", [2, 3, 4])
 def test_one_8b_layer_through_the_fused_runner_vs_fp64(bits, dattn, monkeypatch):
     import bench
     from gbx_lm_amd import ops
     from gbx_lm_amd.decode import FusedDecodeRunner
-    monkeypatch.setenv("GBX_DATTN", str(min(dattn, 1)))       # 0: five launches per block (round 4), 1: three, 2: two (2-bit blocks)
-    monkeypatch.setenv("GBX_DMLP", "1" if dattn == 2 else "0")
+    # 0: five launches per block (round 4), 1: three, 2: two (round 5: 2-bit blocks; round 6: 3- and 4-bit blocks too), 3: ONE (round 6, 2-bit blocks)
+    monkeypatch.setenv("GBX_DATTN", str(min(dattn, 1)))
+    monkeypatch.setenv("GBX_DMLP", "1" if dattn >= 2 else "0")
+    monkeypatch.setenv("GBX_DBLOCK", "1" if dattn == 3 else "0")
+    monkeypatch.setenv("GBX_DMLP_VEC", "1")                   # (the 3- / 4-bit fused MLP launch is opt-in: measured slower than its two launches)
     model, cfg = _one_layer_model(bits)
     ctx = 9
     caches = bench.make_caches(model, 1, 256, DEV)
     runner = FusedDecodeRunner(model, caches, use_graph=True)
     assert (runner.da[0] is not None) == bool(dattn), "the launch path under test"
-    if dattn == 2 and bits == 2:
+    assert (runner.db[0] is not None) == (dattn == 3 and bits == 2), "the one-launch block covers the 2-bit block only"
+    if dattn >= 2:
         d_a, d_m = runner.da[0]
         assert d_m.x_acc == d_a.acc and runner.da_post is not None, "attention + MLP as two launches, the sums finished after the last block"
+        assert (d_m.gate_up_bits, d_m.down_bits) == (bits, bits)
     elif dattn:
         d_a, d_gu3, d_dn3 = runner.da[0]
         assert d_gu3.x_acc == d_a.acc and d_gu3.x_out == d_dn3.residual
