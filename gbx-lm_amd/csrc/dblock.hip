@@ -320,6 +320,9 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
     }
     __syncthreads();                                           // barrier A: x, the norm weight and the statistic's partials have landed
     const unsigned gen = __hip_atomic_load(gen_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef GBX_DIAG3
+    DB_STAMP(13);
+#endif
     if (pro) {
       float tot;
       if (carried) {
@@ -345,6 +348,9 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
         image_item(v, it, true, img, bsum, scl);
       }
     }
+#ifdef GBX_DIAG3
+    DB_STAMP(14);
+#endif
     u32x2 w[2][SP], sz[SP];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -851,7 +857,9 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
     const float* srd = scr + ((dj * 4 + (dmr >> 2)) * 2) * 4 + (dmr & 3);      // dense lane: high limb at [0], low limb at [4]
 #ifdef GBX_STAMPS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef GBX_DIAG3
     if (r != 0) DB_STAMP(13);    // (diagnostic: B operands in registers)
+#endif
 #endif
     // A REAL loop over the tiles: straight-line copies of the body cost their instruction-fetch latency once each
 #pragma clang loop unroll(disable)
@@ -905,7 +913,9 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
       szp += 8 * 256;
     }
 #ifdef GBX_STAMPS
+#ifndef GBX_DIAG3
     if (r != 0) DB_STAMP(14);    // (diagnostic: this wave's tiles done)
+#endif
 #endif
     __syncthreads();                                             // every wave is done with its scratch: the area becomes the partial sums
     if (dj < tpw) part[((tile0 + dj) * 8 + c) * 16 + dmr] = keep;
