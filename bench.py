@@ -251,6 +251,8 @@ def _block_leg(model, runner, idx, reps):
             "kernel": "gbx::dblock_kernel (one launch per 2-bit decoder block: RMSNorm + q|k|v + RoPE/append + attention + o_proj + chip-wide release + "
                       "RMSNorm + gate|up from LDS + SwiGLU + down_proj; FP4 x FP8 matrix cores), Llama-3-8B shapes, g=128",
             "bytes_per_launch": nbytes, "us_per_launch": us, "context": ctx,
+            "note": "round 6: the dominant launch is the WHOLE 2-bit block (attention latency chain + MLP), 65 % of the token; rounds 4-5 quoted the MLP / gate|up "
+                    "launch alone (0.40-0.43 of 8 TB/s: GBX_DBLOCK=0 reproduces it); per block the one launch is the faster form (26.1 vs 26.75 us, profiles/r06_dblock_ab.txt)",
             "method": "HIP events: one graph of the runner's own one-launch descriptors of every 2-bit layer in layer order (+ one accumulator-clearing "
                       "launch), per launch, boundary included",
             "launches_timed": reps * len(descs), "working_set_bytes": nbytes * len(descs)}

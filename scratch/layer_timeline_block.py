@@ -84,3 +84,30 @@ for k, lab in labels.items():
         if np.all(np.isnan(c)):
             continue
         print(f"   s{i:<2d} {nm:46s} min {np.nanmin(c):6.2f}  med {np.nanmedian(c):6.2f}  p90 {np.nanpercentile(c, 90):6.2f}  max {np.nanmax(c):6.2f}")
+
+# ---- who are the stragglers?  per member index r (median over the 8 XCDs and the layers) and per XCD slot: ARRIVE (s6) and end (s12)
+rel_all = []
+for li in range(4, 29):
+    r_ = s[base[li]].astype(np.float64)
+    t0 = r_[r_[:, 0] > 0][:, 0].min()
+    rr = (r_ - t0) / 100.0
+    rr[r_ == 0] = np.nan
+    rel_all.append(rr.reshape(256, 16, 16))
+rel_all = np.stack(rel_all)                       # [layers, workgroup, wave, stamp]
+wg_arrive = np.nanmax(rel_all[:, :, :, 6], axis=2)  # last wave of the workgroup
+wg_end = np.nanmax(rel_all[:, :, :, 12], axis=2)
+wg_pub = np.nanmax(rel_all[:, :, :, 3], axis=2)
+member = np.arange(256) >> 3
+slot = np.arange(256) & 7
+print("by member r: granule/output published (s3) | ARRIVE (s6) | end (s12), medians over XCDs and layers")
+for m in range(32):
+    sel = member == m
+    print(f"   r={m:2d}: {np.nanmedian(wg_pub[:, sel]):5.2f} | {np.nanmedian(wg_arrive[:, sel]):5.2f} | {np.nanmedian(wg_end[:, sel]):5.2f}")
+print("by blockIdx % 8: ARRIVE | end")
+for q in range(8):
+    sel = slot == q
+    print(f"   slot {q}: {np.nanmedian(wg_arrive[:, sel]):5.2f} | {np.nanmedian(wg_end[:, sel]):5.2f}")
+last_arr = np.nanargmax(wg_arrive, axis=1)
+last_end = np.nanargmax(wg_end, axis=1)
+print("the LAST workgroup to arrive, per layer (block index, member):", [(int(b), int(b) >> 3) for b in last_arr])
+print("the LAST workgroup to end, per layer (block index, member):", [(int(b), int(b) >> 3) for b in last_end])
