@@ -320,9 +320,6 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
     }
     __syncthreads();                                           // barrier A: x, the norm weight and the statistic's partials have landed
     const unsigned gen = __hip_atomic_load(gen_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef GBX_DIAG3
-    DB_STAMP(13);
-#endif
     if (pro) {
       float tot;
       if (carried) {
@@ -348,9 +345,6 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
         image_item(v, it, true, img, bsum, scl);
       }
     }
-#ifdef GBX_DIAG3
-    DB_STAMP(14);
-#endif
     u32x2 w[2][SP], sz[SP];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -857,9 +851,7 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
     const float* srd = scr + ((dj * 4 + (dmr >> 2)) * 2) * 4 + (dmr & 3);      // dense lane: high limb at [0], low limb at [4]
 #ifdef GBX_STAMPS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifndef GBX_DIAG3
     if (r != 0) DB_STAMP(13);    // (diagnostic: B operands in registers)
-#endif
 #endif
     // A REAL loop over the tiles: straight-line copies of the body cost their instruction-fetch latency once each
 #pragma clang loop unroll(disable)
@@ -867,9 +859,6 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
       u32x2 w[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const u32x2*>(ap + j * 32);
-#ifdef GBX_DIAG2
-      if (r >= REP && tt == 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); DB_STAMP(1); }
-#endif
       db_v4f z[4];
       auto group = [&](auto J) {
         constexpr int j = decltype(J)::value;
@@ -886,9 +875,6 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
       // (the results are consumed by two columns only: without this the compiler sinks the MFMAs and their operand unpacking INTO the masked
       //  branch below, where the other lanes' operand rows are never formed)
       asm volatile("" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]));
-#ifdef GBX_DIAG2
-      if (r >= REP && tt == 2) { asm volatile("s_nop 15\n s_nop 15" ::: "memory"); DB_STAMP(2); }
-#endif
       if (mnn < 2) {                                             // result lane (column mnn, rows 4 mkg + i): columns 0 / 1 = high / low limb
 #pragma unroll
         for (int j = 0; j < 4; ++j) *reinterpret_cast<db_v4f*>(swr + j * 32) = z[j];
@@ -897,9 +883,6 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
       const float d2 = srd[0] + srd[4];                          // 2 * sum(q / 2 * x) of (row dmr, group dj)
       const float sc = sz_scale<BF16>(szw), ze = sz_zero<BF16>(szw);
       float v = fmaf(ze, xs, sc * d2);
-#ifdef GBX_DIAG2
-      if (r >= REP && tt == 2) { asm volatile("" : "+v"(v)); DB_STAMP(3); }
-#endif
       {                                                          // sum over the chunk's 4 groups = the wave's four 16-lane rows: two lane-row swaps
         auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
         const unsigned a16 = r16[0], b16 = r16[1];
@@ -913,9 +896,7 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
       szp += 8 * 256;
     }
 #ifdef GBX_STAMPS
-#ifndef GBX_DIAG3
     if (r != 0) DB_STAMP(14);    // (diagnostic: this wave's tiles done)
-#endif
 #endif
     __syncthreads();                                             // every wave is done with its scratch: the area becomes the partial sums
     if (dj < tpw) part[((tile0 + dj) * 8 + c) * 16 + dmr] = keep;

@@ -493,6 +493,7 @@ class FusedDecodeRunner(DecodeRunner):
         self.use_graph = use_graph
         if use_graph:
             self._graph_for(False, self._wants_long(caches[0].offset))
+            self._capture_other_mode(False)
 
     def _dgemv_descs(self, blk, qkv_cat, qkv_y, tp: bool, r0: bool, li: int):
         """dgemv descriptors of one block's four launches (None where the shape is not covered or dgemv is switched off)."""
@@ -666,6 +667,12 @@ class FusedDecodeRunner(DecodeRunner):
                 self.all_keys.copy_(akeys0)
         return self._graphs[slot]
 
+    def _capture_other_mode(self, chain: bool) -> None:
+        """A cache that can outgrow the one-launch block's context limit will need the two-launch graph too: capture it NOW rather than in the
+        middle of a generation (a capture costs ~10 ms: two warm-up tokens + the instantiate)."""
+        if self.db_state is not None and self.capacity > self.db_max_ctx and self.caches[0].offset <= self.db_max_ctx:
+            self._graph_for(chain, True)
+
     def _step_local(self, token: torch.Tensor) -> torch.Tensor:
         off = self.caches[0].offset
         self._check_room(off)
@@ -790,6 +797,7 @@ class FusedDecodeRunner(DecodeRunner):
         self.pos.fill_(off - 1)                                       # the embed kernel advances it to `off`
         if self.use_graph:
             self._graph_for(True, self._wants_long(off))              # captures _forward with from_keys / advance_pos set
+            self._capture_other_mode(True)
 
     def step_greedy(self) -> torch.Tensor:
         """One chained greedy step.  Returns ``logits_buf``: the full logits, or -- under a vocabulary-sharded head (tensor
