@@ -715,26 +715,29 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
     __hip_atomic_store(harr + r, (static_cast<unsigned long long>(tag) << 32) | static_cast<unsigned>(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   DB_STAMP(6);
   // ---------------- down_proj's words of this wave's 8 rows, this XCD's columns (56 KB per CU, registers; consumed behind the MLP hand-off) ----------------
-  // Requested right behind W2, at ARRIVE: 50 + 56 KB per CU drain in ~3.8 us, about when x' is due -- requested behind x' instead, the 12 loads
-  // of a wave WAIT TO BE ISSUED behind ~50 KB in flight (1.6 us median, 4 us worst) before the wave can touch its first tile.
+  // WHEN they are requested decided 5 % of the token (profiles/r06_dblock_ab.txt): all 12 loads of a wave behind x' WAIT TO BE ISSUED behind the
+  // ~50 KB a CU keeps in flight (1.6 us median, 4 us worst, before the wave may touch its first tile); all of them at ARRIVE put 107 KB per CU
+  // in front of every x' poll and slow the leaders' memory round trips (x' 0.9 us later); SPREAD over the gate | up tile loop -- three loads
+  // behind each quarter of it -- they cost neither: the queue never fills, the release runs beside 37 KB per CU, and the words are
+  // there when the hand-off is (952-956 -> 1001 tok/s).
   constexpr int W4d = DB_I / 4;                                  // bytes per packed down row
   constexpr int Gd = DB_I >> 7;
   constexpr int ng = DB_IX >> 7;                                 // 14 groups of this XCD's slice
   const unsigned voff_w = mnn * 32 + mkg * 8;
   u32x2 dw[8], dsz[4];
-  auto issue_down = [&]() {
+  // part p of 4: rows 2 p, 2 p + 1 of the wave and their (scale | zero) pair -- three loads (DB_DOWN_SPREAD: one part per quarter of the
+  // gate | up tile loop, so that a wave never has to wait for queue space before it may touch its next tile)
+  auto issue_down_part = [&](auto PP) {
+    constexpr int p_ = decltype(PP)::value;
     const __amdgpu_buffer_rsrc_t dd = rsrc(a.down_qw, RS_ALL), dsd = rsrc(a.down_sz, RS_ALL);
     const unsigned killd = mnn < ng ? 0u : KILL;
     const int row0 = r * RPW + wave * 8;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      dw[i] = __builtin_amdgcn_raw_buffer_load_b64(dd, (voff_w + static_cast<unsigned>(g * (DB_IX / 4))) | killd, (row0 + i) * W4d, 2);
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      dsz[q] = __builtin_amdgcn_raw_buffer_load_b64(dsd, static_cast<unsigned>((g * ng + mnn) * 8) | killd, ((row0 >> 1) + q) * (Gd * 8), 0);
+    dw[2 * p_] = __builtin_amdgcn_raw_buffer_load_b64(dd, (voff_w + static_cast<unsigned>(g * (DB_IX / 4))) | killd, (row0 + 2 * p_) * W4d, 2);
+    dw[2 * p_ + 1] = __builtin_amdgcn_raw_buffer_load_b64(dd, (voff_w + static_cast<unsigned>(g * (DB_IX / 4))) | killd, (row0 + 2 * p_ + 1) * W4d, 2);
+    dsz[p_] = __builtin_amdgcn_raw_buffer_load_b64(dsd, static_cast<unsigned>((g * ng + mnn) * 8) | killd, ((row0 >> 1) + p_) * (Gd * 8), 0);
   };
   // W2: the rest of this workgroup's gate | up pieces, then down_proj's words.  The leader carries no stream during the release.
-  if (r != 0) { dma(pieces_done, npieces, 0); pieces_done = npieces; issue_down(); }
+  if (r != 0) { dma(pieces_done, npieces, 0); pieces_done = npieces; }
   if (r == 0) {
     if (wave == 0) {
       sweep(harr + (lane & 31), tag, 6u);                          // the XCD's 32 arrivals
@@ -790,7 +793,6 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
     __hip_atomic_store(hx + 2 * tid + 1, (static_cast<unsigned long long>(tag) << 32) | y1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     DB_STAMP(15);
     if (pieces_done < npieces) { dma(pieces_done, npieces, 0); pieces_done = npieces; }      // (long contexts: the leader's share, behind its publish)
-    issue_down();
   }
   // ---- every workgroup: thread t polls the two granules of image item t (4 values of RMSNorm(x')) and writes the gate | up operand image
   {
@@ -894,6 +896,13 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
       keep = dj == tt ? v : keep;
       ap += 16 * RS;
       szp += 8 * 256;
+      {                                                          // 4 / tpw parts of down_proj's words behind this tile (wave-uniform switch)
+        const int per = 4 / tpw, p0 = tt * per;
+        if (p0 == 0) issue_down_part(std::integral_constant<int, 0>{});
+        if (p0 <= 1 && p0 + per > 1) issue_down_part(std::integral_constant<int, 1>{});
+        if (p0 <= 2 && p0 + per > 2) issue_down_part(std::integral_constant<int, 2>{});
+        if (p0 + per > 3) issue_down_part(std::integral_constant<int, 3>{});
+      }
     }
 #ifdef GBX_STAMPS
     if (r != 0) DB_STAMP(14);    // (diagnostic: this wave's tiles done)
