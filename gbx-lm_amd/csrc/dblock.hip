@@ -65,12 +65,15 @@ constexpr int DB_LDS_BYTES = 161792;
 #define DB_W0P_N 0
 #endif
 #ifndef DB_W1_N
-#define DB_W1_N 98
+#define DB_W1_N 70
+#endif
+#ifndef DB_W0_N
+#define DB_W0_N 36
 #endif
 constexpr int DB_D = 4096, DB_I = 14336, DB_REP = 4, DB_HD = 128, DB_IX = DB_I / 8;
 constexpr int DB_ACT_LEADER = 16, DB_ACT_ATT = 32, DB_ACT_PROD = 60;
 static_assert(DB_ACT_LEADER + (DB_REP - 1) * DB_ACT_ATT + (DA_MEMBERS - DB_REP) * DB_ACT_PROD == DB_IX, "the XCD's eighth of the intermediate vector");
-constexpr int DB_W0_PIECES = 36;                   // attention workgroups, launch start (the leader's whole share)
+constexpr int DB_W0_PIECES = DB_W0_N;                   // attention workgroups, launch start (the leader's whole share)
 // (A/B, same box, tok/s: W0P 48 / W1 84: 937-940; 24 / 98: 944; 0 / 84: 953-955; 0 / 98: 950-962; two launches: 942 -- profiles/r06_dblock_ab.txt)
 constexpr int DB_W0P_PIECES = DB_W0P_N;                  // producers, launch start, by the 8 waves that sit out the prologue: MEASURED TO LOSE (the prologue's own loads queue behind them) -> 0
 constexpr int DB_W1_PIECES = DB_W1_N;                   // producers, behind their publish barrier: 14 waves x 7 pieces of 1 KB
@@ -858,6 +861,13 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
     // A REAL loop over the tiles: straight-line copies of the body cost their instruction-fetch latency once each
 #pragma clang loop unroll(disable)
     for (int tt = 0; tt < tpw; ++tt) {
+      {                                                          // 4 / tpw parts of down_proj's words in FRONT of this tile (wave-uniform switch)
+        const int per = 4 / tpw, p0 = tt * per;
+        if (p0 == 0) issue_down_part(std::integral_constant<int, 0>{});
+        if (p0 <= 1 && p0 + per > 1) issue_down_part(std::integral_constant<int, 1>{});
+        if (p0 <= 2 && p0 + per > 2) issue_down_part(std::integral_constant<int, 2>{});
+        if (p0 + per > 3) issue_down_part(std::integral_constant<int, 3>{});
+      }
       u32x2 w[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const u32x2*>(ap + j * 32);
@@ -896,13 +906,6 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
       keep = dj == tt ? v : keep;
       ap += 16 * RS;
       szp += 8 * 256;
-      {                                                          // 4 / tpw parts of down_proj's words behind this tile (wave-uniform switch)
-        const int per = 4 / tpw, p0 = tt * per;
-        if (p0 == 0) issue_down_part(std::integral_constant<int, 0>{});
-        if (p0 <= 1 && p0 + per > 1) issue_down_part(std::integral_constant<int, 1>{});
-        if (p0 <= 2 && p0 + per > 2) issue_down_part(std::integral_constant<int, 2>{});
-        if (p0 + per > 3) issue_down_part(std::integral_constant<int, 3>{});
-      }
     }
 #ifdef GBX_STAMPS
     if (r != 0) DB_STAMP(14);    // (diagnostic: this wave's tiles done)
