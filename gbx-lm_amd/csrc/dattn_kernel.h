@@ -883,7 +883,10 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
     float* gl = gm + 64;
     float (*gacc)[HD + 8] = reinterpret_cast<float (*)[HD + 8]>(gl + 64);
     constexpr float NEG = -1e30f;
-    constexpr int LP = HD / 8, PPW = 64 / LP, UB0 = 10;                                   // 16 lanes per position, 4 positions per wave and round
+    // 16 lanes per position, 4 positions per wave and round.  UB0 rounds of K / V live in registers beside the early o_proj words: 10 where
+    // the build fits 128 registers, 8 in the 3-bit and the fp16 kernels -- with 10 the compiler parked an o_proj word quad in SCRATCH
+    // (a wait for the load right at its issue, 5 MB of scratch writes per launch: profiles/r06_pmc_dattn.txt)
+    constexpr int LP = HD / 8, PPW = 64 / LP, UB0 = (BQ == 3 || !BF16) ? 8 : 10;
     const int h = g * rep + r;
     const int d0 = (lane % LP) * 8, sub = lane / LP;
     // The sweep is vector-ALU work once K / V sit in registers, and every sweeping wave pays a fixed cost (q, state hand-over), so
@@ -891,7 +894,7 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
     // 16 beyond (then an online loop takes what the registers do not hold).  Round u of sweeping wave w covers positions
     // (u * nws + w) * 4 + sub.  Everything is requested NOW, while the producers are busy (~4 us before q arrives).
     const int pos = static_cast<int>(*a.pos);
-    const int nws = pos <= DA_SWEEP4_MAX ? 4 : (pos <= UB0 * 8 * PPW ? 8 : 16);
+    const int nws = pos <= (DA_SWEEP4_MAX < UB0 * 4 * PPW ? DA_SWEEP4_MAX : UB0 * 4 * PPW) ? 4 : (pos <= UB0 * 8 * PPW ? 8 : 16);
     const int ppr = nws * PPW;
     const bool sweeper = wave < nws && !coop;                  // (cooperative sweep: the producers own the cached positions)
     const __amdgpu_buffer_rsrc_t kd = rsrc(a.kcache + static_cast<size_t>(g) * a.capacity * HD, a.capacity * HD * 2);

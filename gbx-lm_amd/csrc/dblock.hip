@@ -86,7 +86,10 @@ constexpr int DB_H_ACT = 3072;                     // 896 activation granules
 constexpr int DB_HAND_STRIDE = 4096;
 // state words (u32): gen[g] at g * 16, status at 8 * 16 (as the two-launch kernels: gbx_dattn_status serves all), leader flag of XCD g at (16 + 2 g) * 16
 constexpr int DB_STATE_WORDS = 64 * 16;
-constexpr int DB_MAX_CTX = 384;
+#ifndef DB_MAX_CTX_N
+#define DB_MAX_CTX_N 384
+#endif
+constexpr int DB_MAX_CTX = DB_MAX_CTX_N;
 
 template <int DUMMY>
 __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
