@@ -204,7 +204,7 @@ class DblockDesc(ctypes.Structure):
 
 GBX_DG_PLAIN, GBX_DG_RESIDUAL, GBX_DG_SWIGLU = 0, 1, 2
 GBX_DG_SSQ_SLOTS = 1024
-GBX_MIN_VERSION = 1300          # the header this binding mirrors
+GBX_MIN_VERSION = 1301          # the header this binding mirrors
 
 
 def _declare_optional(L) -> None:
@@ -248,6 +248,7 @@ def _declare_optional(L) -> None:
         "gbx_moe_combine_residual": [p, p, p, p, i64, i32, i32, i32, p],
         "gbx_kv_append": [p, p, p, p, p, i64, i32, i32, i32, i32, p],
         "gbx_logprobs_argmax": [p, p, p, p, i32, i32, p],
+        "gbx_logprobs_argmax_packed": [p, p, p, p, i32, i32, p, p, p, p, p],
         "gbx_add_rmsnorm": [p, p, p, p, i64, i32, f32, i32, p],
         "gbx_swiglu": [p, p, p, i64, i32, p],
         "gbx_dense_gemv": [p, p, p, p, f32, i32, i32, i32, p],

@@ -32,9 +32,9 @@ extern "C" void gbx_debug_stamp_reset(void) { gbx::g_stamp_launch = 0; }
 
 extern "C" {
 
-/* 1300: gbx_acc_residual grows act_dtype; + gbx_xcd_layout_check, gbx_dblock_*; a timed-out hand-off poisons its accumulator.  1202: + gbx_add_rmsnorm_slices_xcd, gbx_norm_state_bytes (additions).  1201: + gbx_dattn.x_acc / x_out / zero_buf, gbx_dmlp_*, gbx_acc_residual.  1200: gbx_dgemv grows (x_acc, x_out, zero_buf, zero_n) + gbx_dattn_* + gbx_dgemv_kernel_id.  1101: + gbx_attn_decode_slices (an addition: nothing else changed).  1100: gbx_dgemv_* entry points; gbx_qlinear_fused (x_acc, x_out, zero_buf, zero_n since 1001) -- a consumer built against
+/* 1301: + gbx_logprobs_argmax_packed (an addition; gbx_logprobs_argmax is two launches instead of three).  1300: gbx_acc_residual grows act_dtype; + gbx_xcd_layout_check, gbx_dblock_*; a timed-out hand-off poisons its accumulator.  1202: + gbx_add_rmsnorm_slices_xcd, gbx_norm_state_bytes (additions).  1201: + gbx_dattn.x_acc / x_out / zero_buf, gbx_dmlp_*, gbx_acc_residual.  1200: gbx_dgemv grows (x_acc, x_out, zero_buf, zero_n) + gbx_dattn_* + gbx_dgemv_kernel_id.  1101: + gbx_attn_decode_slices (an addition: nothing else changed).  1100: gbx_dgemv_* entry points; gbx_qlinear_fused (x_acc, x_out, zero_buf, zero_n since 1001) -- a consumer built against
  * an older header must not pass its shorter struct to this library: check gbx_version() >= the header it compiled with. */
-int gbx_version(void) { return 1300; }
+int gbx_version(void) { return 1301; }
 
 const char* gbx_last_error(void) { return g_err; }
 
@@ -765,6 +765,22 @@ int gbx_logprobs_argmax(const void* logits, void* logprobs, int64_t* token, void
                                              reinterpret_cast<long long*>(token), vocab, act_dtype == GBX_BF16,
                                              static_cast<hipStream_t>(hip_stream));
   if (e != hipSuccess) return hip_fail(e, "gbx_logprobs_argmax launch");
+  return GBX_OK;
+}
+
+int gbx_logprobs_argmax_packed(const void* logits, void* logprobs, int64_t* token, void* workspace, int32_t vocab, int32_t act_dtype,
+                               const uint32_t* status0, const uint32_t* status1, const uint32_t* status2, int64_t* packed,
+                               void* hip_stream) {
+  if (!logits || !logprobs || !token || !workspace || !packed) return fail(GBX_ERR_INVALID, "null device pointer");
+  if (vocab <= 0) return fail(GBX_ERR_INVALID, "vocab must be positive (got %d)", vocab);
+  if (!aligned(workspace, 8) || !aligned(packed, 8)) return fail(GBX_ERR_INVALID, "workspace and packed must be 8-byte aligned");
+  if (act_dtype != GBX_F16 && act_dtype != GBX_BF16) return fail(GBX_ERR_INVALID, "act_dtype must be GBX_F16 or GBX_BF16");
+  char* ws = static_cast<char*>(workspace);
+  const unsigned* st[3] = {status0, status1, status2};
+  hipError_t e = gbx::launch_logprobs_argmax(logits, logprobs, ws, reinterpret_cast<unsigned long long*>(ws + 128 * 8),
+                                             reinterpret_cast<long long*>(token), vocab, act_dtype == GBX_BF16,
+                                             static_cast<hipStream_t>(hip_stream), reinterpret_cast<long long*>(packed), st);
+  if (e != hipSuccess) return hip_fail(e, "gbx_logprobs_argmax_packed launch");
   return GBX_OK;
 }
 

@@ -981,11 +981,12 @@ hipError_t launch_dense_gemv(const void* x, const void* w, void* y, const void* 
 
 // ------------------------------------------------------------------------------------------------ logprobs + greedy token
 // The tail of a generate_step (gbx_lm/utils.py:305-306,285): logprobs = logits - logsumexp(logits) and, for the default
-// sampler, token = argmax(logprobs) -- three launches over the vocabulary instead of torch's reductions (~100 us per token
+// sampler, token = argmax(logprobs) -- two launches over the vocabulary instead of torch's reductions (~100 us per token
 // at V = 128 K): (1) per-workgroup (max, sum exp) partials, (2) every workgroup folds the partials into the fp32
-// logsumexp, rounds it to the activation dtype like `.astype(logits.dtype)`, writes its slice of logprobs (activation-dtype
-// subtraction) and bids its slice's best (value, lowest index) into one 64-bit key, (3) one thread turns the key into the
-// int64 token.
+// logsumexp (one partial per thread, reduced through LDS), rounds it to the activation dtype like `.astype(logits.dtype)`, writes
+// its slice of logprobs (activation-dtype subtraction) and bids its slice's best (value, lowest index) into one 64-bit key; the
+// workgroup that finishes LAST turns the key into the int64 token and -- for generate_step, which sends the token id and the decode
+// runner's status words to the host after every step -- packs (token, status words) into one buffer: one copy instead of three.
 constexpr int LP_WGS = 128;
 
 template <bool BF16>
@@ -993,7 +994,7 @@ __global__ __launch_bounds__(256) void logprob_partials_kernel(const unsigned sh
                                                                unsigned long long* __restrict__ key, int V) {
   __shared__ float red[8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (blockIdx.x == 0 && tid == 0) *key = 0ull;
+  if (blockIdx.x == 0 && tid == 0) { key[0] = 0ull; key[1] = 0ull; }          // the bid and the finished-workgroup count of launch 2
   const int per = (V + LP_WGS - 1) / LP_WGS, lo = blockIdx.x * per, hi = min(lo + per, V);
   float m = -3.0e38f;
   for (int i = lo + tid; i < hi; i += 256) m = fmaxf(m, act_to_f32<BF16>(logits[i]));
@@ -1009,17 +1010,31 @@ __global__ __launch_bounds__(256) void logprob_partials_kernel(const unsigned sh
   if (tid == 0) part[blockIdx.x] = float2{m, (red[4] + red[5]) + (red[6] + red[7])};
 }
 
+struct LogprobTail {
+  long long* token;                    // int64 [1]
+  long long* packed;                   // optional int64 [4]: token, status words 0..2 (0 where absent)
+  const unsigned* status[3];           // optional device words (the decode runner's fused launches)
+};
+
 template <bool BF16>
 __global__ __launch_bounds__(256) void logprob_write_kernel(const unsigned short* __restrict__ logits, const float2* __restrict__ part,
                                                             unsigned short* __restrict__ logprobs, unsigned long long* __restrict__ key,
-                                                            int V) {
+                                                            int V, const LogprobTail tail) {
   __shared__ unsigned long long best[4];
+  __shared__ float redm[4], reds[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // fold the partials (every workgroup repeats it: 128 pairs)
-  float M = -3.0e38f;
-  for (int g = 0; g < LP_WGS; ++g) M = fmaxf(M, part[g].x);
-  float S = 0.f;
-  for (int g = 0; g < LP_WGS; ++g) S += part[g].y * __expf(part[g].x - M);
+  // fold the partials: thread g < 128 holds pair g (every workgroup repeats it).  The ORDER of the sum differs from a serial fold by
+  // rounding only; every workgroup folds in the same order, so all of them subtract the same logsumexp.
+  static_assert(LP_WGS <= 256, "one partial per thread");
+  const float2 pr = tid < LP_WGS ? part[tid] : float2{-3.0e38f, 0.f};
+  float M = key2f(wave_max_u32(f2key(pr.x)));
+  if (lane == 0) redm[wave] = M;
+  __syncthreads();
+  M = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+  float S = wave_sum(tid < LP_WGS ? pr.y * __expf(pr.x - M) : 0.f);
+  if (lane == 0) reds[wave] = S;
+  __syncthreads();
+  S = (reds[0] + reds[1]) + (reds[2] + reds[3]);
   const float lse = act_to_f32<BF16>(f32_to_act<BF16>(M + __logf(S)));
   const int per = (V + LP_WGS - 1) / LP_WGS, lo = blockIdx.x * per, hi = min(lo + per, V);
   unsigned long long k = 0ull;
@@ -1038,26 +1053,35 @@ __global__ __launch_bounds__(256) void logprob_write_kernel(const unsigned short
     unsigned long long b = best[0];
     for (int w = 1; w < 4; ++w) b = best[w] > b ? best[w] : b;
     if (hi > lo) atomicMax(key, b);
+    // (both atomics are performed at the device's memory side, in program order of this thread: the workgroup whose count comes back
+    //  LP_WGS - 1 reads a key that holds every bid)
+    __threadfence();
+    if (atomicAdd(key + 1, 1ull) == static_cast<unsigned long long>(LP_WGS - 1)) {
+      const unsigned long long kk = __hip_atomic_load(key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const long long t = static_cast<long long>(~static_cast<unsigned>(kk));
+      *tail.token = t;
+      if (tail.packed) {
+        tail.packed[0] = t;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) tail.packed[1 + q] = tail.status[q] ? static_cast<long long>(*tail.status[q]) : 0ll;
+      }
+    }
   }
-}
-
-__global__ void logprob_token_kernel(const unsigned long long* __restrict__ key, long long* __restrict__ token) {
-  *token = static_cast<long long>(~static_cast<unsigned>(*key));
 }
 
 hipError_t launch_logprobs_argmax(const void* logits, void* logprobs, void* partials, unsigned long long* key, long long* token,
-                                  int V, bool bf16, hipStream_t s) {
+                                  int V, bool bf16, hipStream_t s, long long* packed, const unsigned* const* status) {
   auto L = static_cast<const unsigned short*>(logits);
   auto O = static_cast<unsigned short*>(logprobs);
   auto P = static_cast<float2*>(partials);
+  LogprobTail tail{token, packed, {status ? status[0] : nullptr, status ? status[1] : nullptr, status ? status[2] : nullptr}};
   if (bf16) {
     hipLaunchKernelGGL((logprob_partials_kernel<true>), dim3(LP_WGS), dim3(256), 0, s, L, P, key, V);
-    hipLaunchKernelGGL((logprob_write_kernel<true>), dim3(LP_WGS), dim3(256), 0, s, L, P, O, key, V);
+    hipLaunchKernelGGL((logprob_write_kernel<true>), dim3(LP_WGS), dim3(256), 0, s, L, P, O, key, V, tail);
   } else {
     hipLaunchKernelGGL((logprob_partials_kernel<false>), dim3(LP_WGS), dim3(256), 0, s, L, P, key, V);
-    hipLaunchKernelGGL((logprob_write_kernel<false>), dim3(LP_WGS), dim3(256), 0, s, L, P, O, key, V);
+    hipLaunchKernelGGL((logprob_write_kernel<false>), dim3(LP_WGS), dim3(256), 0, s, L, P, O, key, V, tail);
   }
-  hipLaunchKernelGGL(logprob_token_kernel, dim3(1), dim3(1), 0, s, key, token);
   return hipGetLastError();
 }
 

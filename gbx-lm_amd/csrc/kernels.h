@@ -148,7 +148,7 @@ hipError_t launch_moe_combine(const void* y, const void* scores, void* out, int 
 hipError_t launch_kv_append(const void* k, const void* v, void* kc, void* vc, const long long* pos, int rows, int cap, int dk, int dv,
                             hipStream_t s);
 hipError_t launch_logprobs_argmax(const void* logits, void* logprobs, void* partials, unsigned long long* key, long long* token,
-                                  int V, bool bf16, hipStream_t s);
+                                  int V, bool bf16, hipStream_t s, long long* packed = nullptr, const unsigned* const* status = nullptr);
 hipError_t launch_add_rmsnorm(void* h, const void* d, const void* w, void* y, int M, int K, float eps, bool bf16, hipStream_t s);
 hipError_t launch_swiglu(const void* g, const void* u, void* y, long long n, bool bf16, hipStream_t s);
 hipError_t launch_stream(const void* dev_prog, const void* host_first_op, int op_begin, int op_end, bool bf16, hipStream_t s);

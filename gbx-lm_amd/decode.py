@@ -385,6 +385,14 @@ class FusedDecodeRunner(DecodeRunner):
         r0 = getattr(model, "tp_rank", 0) == 0
         self.logits_buf = torch.zeros((1, model.head_weight().shape[0]), dtype=dt, device=dev)
         self.keys = torch.zeros((64,), dtype=torch.int64, device=dev)      # sharded (value, index) argmax keys (uint64 bits)
+        # generate_step's default-sampler loop as one replay per token (step_gen): logprobs + argmax inside the graph, the token fed back
+        # on the device, (token, hand-off status words) packed for ONE copy to the host
+        from . import _lib as _l0
+        self.lp_buf = torch.zeros_like(self.logits_buf)
+        self.lp_ws = torch.zeros((_l0.lib().gbx_logprobs_workspace_bytes(),), dtype=torch.uint8, device=dev)
+        self.gen_words = torch.zeros((4,), dtype=torch.int64, device=dev)
+        self._gen_next = None               # (cache offset, token tensor) the device-side feedback expects next
+        self._tok_view = None
         # vocabulary-sharded head (tensor parallel): every rank's keys, gathered; the full logits for callers of step()
         self.tp_vocab = getattr(model, "tp_vocab", None)
         if self.tp_vocab is not None:
@@ -451,10 +459,7 @@ class FusedDecodeRunner(DecodeRunner):
             qkv_mods, qkv_ys = (at.q_proj, at.k_proj, at.v_proj), (self.qb, self.kb, self.vb)
             if (env.flag("GBX_QKV_CAT") and p_qkv is not None and nq % 16 == 0 and nkv % 16 == 0 and
                     len({(m.bits, m.group_size) for m in qkv_mods}) == 1 and all(m.bias is None for m in qkv_mods)):
-                from .models.quantized_linear_gba import QuantizedLinear
-                cat = QuantizedLinear(at.q_proj.input_dims, nq + 2 * nkv, False, at.q_proj.group_size, at.q_proj.bits)
-                for nm in ("qweight", "scales", "zeros"):
-                    cat._buffers[nm] = torch.cat([getattr(m, nm) for m in qkv_mods]).contiguous()
+                cat = ops.qkv_concat(at.q_proj, at.k_proj, at.v_proj)
                 self.packed.append((cat,))
                 qkv_mods, qkv_ys = (cat,), (self.qkvb,)
             p_gu = ops.pack_scales_zeros(mlp.gate_proj, mlp.up_proj) if even else None
@@ -490,10 +495,7 @@ class FusedDecodeRunner(DecodeRunner):
                 self.fuse_ao = False
         self.da_post, self._pending = self._pending, None
         super().__init__(model, caches, use_graph=False)       # (graphs are captured per mode, the first time a step needs one)
-        self.use_graph = use_graph
-        if use_graph:
-            self._graph_for(False, self._wants_long(caches[0].offset))
-            self._capture_other_mode(False)
+        self.use_graph = use_graph           # (each mode's graph is captured by the first step that needs it, with its long-context twin)
 
     def _dgemv_descs(self, blk, qkv_cat, qkv_y, tp: bool, r0: bool, li: int):
         """dgemv descriptors of one block's four launches (None where the shape is not covered or dgemv is switched off)."""
@@ -651,7 +653,7 @@ class FusedDecodeRunner(DecodeRunner):
         if slot not in self._graphs:
             off = self.caches[0].offset
             saved = (self.graph, self.logits, self.chain, self.long_mode)
-            keys0, pos0 = self.keys.clone(), self.pos.clone()
+            keys0, pos0, tok0 = self.keys.clone(), self.pos.clone(), self.tok.clone()
             akeys0 = self.all_keys.clone() if self.tp_vocab is not None else None
             self.chain, self.long_mode = chain, long
             self._capture()
@@ -663,6 +665,7 @@ class FusedDecodeRunner(DecodeRunner):
                 c.offset = off
             self.keys.copy_(keys0)
             self.pos.copy_(pos0)
+            self.tok.copy_(tok0)
             if akeys0 is not None:
                 self.all_keys.copy_(akeys0)
         return self._graphs[slot]
@@ -673,12 +676,50 @@ class FusedDecodeRunner(DecodeRunner):
         if self.db_state is not None and self.capacity > self.db_max_ctx and self.caches[0].offset <= self.db_max_ctx:
             self._graph_for(chain, True)
 
-    def _step_local(self, token: torch.Tensor) -> torch.Tensor:
+    def step_gen(self, token: torch.Tensor):
+        """One step of generate_step's default-sampler loop (utils.py:285,305-306,323-338) as ONE graph replay: the block launches, the
+        head, logprobs = logits - logsumexp(logits), token = argmax(logprobs) -- and the token fed back on the device, so consecutive calls
+        that pass the token tensor this method returned need no host-side copy or position update at all.  Returns (token int64 [1],
+        logprobs [1, V], packed int64 [4] = (token, hand-off status words)): views of STATIC buffers, overwritten by the next call --
+        the caller copies what it keeps."""
         off = self.caches[0].offset
         self._check_room(off)
         long = self._wants_long(off)
+        if self._tok_view is None:
+            self._tok_view = self.tok.view(-1)
+        fed_back = self._gen_next is not None and self._gen_next[0] == off and token is self._gen_next[1]
         if self.use_graph:
+            first = ("gen", long) not in self._graphs
+            graph, _ = self._graph_for("gen", long)
+            if first:
+                self._capture_other_mode("gen")
+            if not fed_back:
+                self.tok.copy_(token.reshape(self.tok.shape))
+                self.pos.fill_(off - 1)                               # the embedding launch advances it to `off`
+            graph.replay()
+        else:
+            if not fed_back:
+                self.tok.copy_(token.reshape(self.tok.shape))
+                self.pos.fill_(off - 1)
+            self.chain, self.long_mode = "gen", long
+            with torch.no_grad():
+                self._forward()
+            self.chain, self.long_mode = False, False
+        for c in self.caches:
+            c.offset = off + 1
+        self._gen_next = (off + 1, self._tok_view)
+        return self._tok_view, self.lp_buf, self.gen_words
+
+    def _step_local(self, token: torch.Tensor) -> torch.Tensor:
+        off = self.caches[0].offset
+        self._check_room(off)
+        self._gen_next = None
+        long = self._wants_long(off)
+        if self.use_graph:
+            first = (False, long) not in self._graphs
             graph, out = self._graph_for(False, long)
+            if first:
+                self._capture_other_mode(False)
             self.tok.copy_(token.reshape(-1))
             self.pos.fill_(off)
             graph.replay()
@@ -717,8 +758,8 @@ class FusedDecodeRunner(DecodeRunner):
         if self.chain and self.tp_vocab is not None:
             ops.embed_next_token_sharded(self.all_keys, self.keys, self.tok, self.pos, m.embed_tokens.weight, self.hb, advance_pos=True)
         else:
-            ops.embed_next_token(self.keys, self.tok, self.pos, m.embed_tokens.weight, self.hb, from_keys=self.chain,
-                                 advance_pos=self.chain)
+            ops.embed_next_token(self.keys, self.tok, self.pos, m.embed_tokens.weight, self.hb, from_keys=self.chain is True,
+                                 advance_pos=bool(self.chain))
         for li, (blk, c, (d_qkv, d_o, d_gu, d_dn)) in enumerate(zip(m.layers, self.caches, self.descs)):
             at = blk.self_attn
             g_qkv, g_o, g_gu, g_dn = self.dg[li]
@@ -773,6 +814,9 @@ class FusedDecodeRunner(DecodeRunner):
         ops.dense_gemv(self.hb, self.model.head_weight(), out=self.logits_buf.view(-1), norm_weight=m.norm.weight,
                        eps=m.norm.eps, argmax_keys=self.keys, index_offset=self.tp_vocab[0] if self.tp_vocab is not None else 0)
         if self.tp_vocab is None:
+            if self.chain == "gen":          # utils.py:305-306,285 inside the graph; the token lands where the next replay's embedding reads it
+                ops.logprobs_argmax(self.logits_buf, out=self.lp_buf, token=self.tok.view(-1), workspace=self.lp_ws,
+                                    status=self.fault_words(), packed=self.gen_words)
             return self.logits_buf
         from .tp import all_gather_into
         grp = getattr(self.model, "tp_group", None)
@@ -785,6 +829,7 @@ class FusedDecodeRunner(DecodeRunner):
     # ---- on-device greedy chain: replay after replay with nothing in between ------------------------------------
     def start_greedy(self, token: torch.Tensor) -> None:
         off = self.caches[0].offset
+        self._gen_next = None
         tok = int(token.reshape(-1)[0].item())
         key = (0x80000000 << 32) | (0xFFFFFFFF - tok)                 # key of (value 0.0, index tok)
         if key >= 1 << 63:
@@ -983,18 +1028,49 @@ def decode_step_checked(model, y: torch.Tensor, prompt_cache: List[KVCache]) -> 
     return logits
 
 
-def decode_step(model, y: torch.Tensor, prompt_cache: List[KVCache]) -> torch.Tensor:
-    """``model.decode_step`` hook used by generate_step for single-token steps: graph replay when possible."""
+def _runner_for(model, prompt_cache: List[KVCache]):
+    """The decode runner bound to ``prompt_cache`` (built, or rebuilt when the cache changed or grew); None when the cache is not a
+    one-sequence device cache."""
     c0 = prompt_cache[0]
     if not isinstance(c0, KVCache) or c0.keys is None or c0.keys.shape[0] != 1 or not c0.keys.is_cuda:
-        return model(y[None], cache=prompt_cache)[:, -1, :]
-    if c0.offset + 1 > c0.capacity:                               # grow every layer before (re)capturing
-        for c in prompt_cache:
-            c.reserve(1, c.keys[:, :, :1], c.values[:, :, :1])
+        return None
     runner: Optional[DecodeRunner] = getattr(model, "_decode_runner", None)
-    if runner is None or runner.caches is not prompt_cache or runner.capacity != c0.capacity \
-            or runner.caches[0].keys.data_ptr() != getattr(runner, "_kptr", None):
+    bound = (runner is not None and runner.caches is prompt_cache and runner.capacity == c0.capacity
+             and c0.keys.data_ptr() == getattr(runner, "_kptr", None))
+    # A grown cache means new descriptors and new graphs (~10-20 ms).  The reference grows by `step` = 256 positions (cache.py:220-244);
+    # with a runner bound to the cache's addresses that was a rebuild every 256 tokens -- and, before the load-time companions were kept on
+    # the modules, 0.2-0.4 s each: generate() at half the device rate (scratch/gen_rate2.py).  So: a cache that gets its first runner is
+    # grown to four steps up front, and a full one doubles (at most 32 steps = 8192 positions at a time).
+    more = 0
+    if c0.offset + 1 > c0.capacity:
+        more = max(c0.step, min(c0.capacity, 32 * c0.step))
+    elif not bound and c0.capacity < 4 * c0.step:
+        more = 4 * c0.step - c0.offset
+    if more > 0:
+        for c in prompt_cache:
+            c.reserve(more, c.keys[:, :, :1], c.values[:, :, :1])
+        bound = False
+    if not bound:
         runner = (FusedDecodeRunner if fused_eligible(model) else DecodeRunner)(model, prompt_cache)
         runner._kptr = prompt_cache[0].keys.data_ptr()
         model._decode_runner = runner
+    return runner
+
+
+def decode_step(model, y: torch.Tensor, prompt_cache: List[KVCache]) -> torch.Tensor:
+    """``model.decode_step`` hook used by generate_step for single-token steps: graph replay when possible."""
+    runner = _runner_for(model, prompt_cache)
+    if runner is None:
+        return model(y[None], cache=prompt_cache)[:, -1, :]
     return runner.step(y)
+
+
+def decode_step_logprobs(model, y: torch.Tensor, prompt_cache: List[KVCache]):
+    """``model.decode_step_logprobs`` hook of generate_step's default-sampler loop: (next token int64 [1], logprobs [V], packed
+    int64 [4] = (token, hand-off status words)) from ONE graph replay (FusedDecodeRunner.step_gen), or None when that path does not
+    apply (the caller then runs decode_step + logprobs_argmax).  ``token`` and ``packed`` are static buffers: valid until the next call."""
+    runner = _runner_for(model, prompt_cache)
+    if not isinstance(runner, FusedDecodeRunner) or runner.tp_vocab is not None or runner.tp_world > 1 or not runner.use_graph:
+        return None
+    tok, lp, words = runner.step_gen(y)
+    return tok, lp.view(-1).clone(), words

@@ -258,6 +258,11 @@ class Model(nn.Module):
         from ..decode import decode_step
         return decode_step(self, y, prompt_cache)
 
+    def decode_step_logprobs(self, y: torch.Tensor, prompt_cache):
+        """One default-sampler step of generate_step (token, logprobs, packed status) from one graph replay, or None (decode.py)."""
+        from ..decode import decode_step_logprobs
+        return decode_step_logprobs(self, y, prompt_cache)
+
     def decode_step_checked(self, y: torch.Tensor, prompt_cache) -> torch.Tensor:
         """``decode_step`` that checks the fused launches' status words behind the step (callers that synchronise per token: EMINF)."""
         from ..decode import decode_step_checked

@@ -300,7 +300,26 @@ def dequantize(w: torch.Tensor, scales: torch.Tensor, biases: torch.Tensor, grou
 
 
 # ------------------------------------------------------------------------------------------------ fused decode block
+def _companion(mod, kind: str, others, build):
+    """Load-time companions (packed scale | zero tables, concatenated q|k|v) are functions of the modules' buffers only: built once per
+    module and kept on it, so that a decode runner rebuilt for a grown KV cache reuses them (a rebuild cost 180 ms of re-packing before;
+    scratch/gen_rate.py).  The key holds the buffers' addresses: replacing a buffer (a reload, a test that swaps scales) rebuilds."""
+    mods = (mod,) + tuple(m for m in others if m is not None)
+    key = (kind,) + tuple(t.data_ptr() for m in mods for t in (m.qweight, m.scales, m.zeros)) + tuple(m.scales.dtype for m in mods)
+    memo = mod.__dict__.setdefault("_gbx_companions", {})
+    hit = memo.get(kind)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    out = build()
+    memo[kind] = (key, out)
+    return out
+
+
 def pack_scales_zeros(mod, mod2=None) -> torch.Tensor:
+    return _companion(mod, "sz2" if mod2 is not None else "sz1", (mod2,), lambda: _pack_scales_zeros(mod, mod2))
+
+
+def _pack_scales_zeros(mod, mod2=None) -> torch.Tensor:
     """Load-time packed companion of ``(scales, zeros)`` for the decode GEMV (gbx_pack_scales_zeros): uint32
     ``[N/2, G, 2]`` for row pairs of one module, or ``[N, G, 2]`` interleaving ``mod`` / ``mod2`` (gate / up).
     A q/k/v launch takes ``torch.cat`` of its modules' packs."""
@@ -721,6 +740,25 @@ def dgemv_plan(n: int, k: int, bits: int, group_size: int, epilogue: int, with_n
 
 
 def dgemv_pack(mod, rows_per_batch: int, mod_up=None) -> torch.Tensor:
+    return _companion(mod, f"dg{rows_per_batch}{'u' if mod_up is not None else ''}", (mod_up,), lambda: _dgemv_pack(mod, rows_per_batch, mod_up))
+
+
+def qkv_concat(q_proj, k_proj, v_proj):
+    """q | k | v as ONE QuantizedLinear (rows concatenated once, kept on q_proj): a one-segment launch."""
+    def build():
+        from .models.quantized_linear_gba import QuantizedLinear
+        mods = (q_proj, k_proj, v_proj)
+        cat = QuantizedLinear.__new__(QuantizedLinear)
+        torch.nn.Module.__init__(cat)
+        cat.group_size, cat.bits, cat.double_group_size = q_proj.group_size, q_proj.bits, 32
+        cat.input_dims, cat.output_dims, cat.bias = q_proj.input_dims, sum(m.output_dims for m in mods), None
+        for nm in ("qweight", "scales", "zeros"):
+            cat.register_buffer(nm, torch.cat([getattr(m, nm) for m in mods]).contiguous())
+        return cat
+    return _companion(q_proj, "qkvcat", (k_proj, v_proj), build)
+
+
+def _dgemv_pack(mod, rows_per_batch: int, mod_up=None) -> torch.Tensor:
     """Load-time (scale | zero << 16) companion of one dgemv launch in batch order (gbx_dgemv_pack): int32
     ``[N / R, G, R]``, or ``[N / (R/2), G, R]`` with gate (``mod``) and up (``mod_up``) rows of a SwiGLU launch."""
     n, g = mod.scales.shape
@@ -1182,19 +1220,30 @@ def kv_append(kcache: torch.Tensor, vcache: torch.Tensor, k: torch.Tensor, v: to
                                         b * h, cap, dk, vcache.shape[3], _DT[k.dtype], _stream_ptr(k.device)))
 
 
-def logprobs_argmax(logits: torch.Tensor):
+def logprobs_argmax(logits: torch.Tensor, out: Optional[torch.Tensor] = None, token: Optional[torch.Tensor] = None,
+                    workspace: Optional[torch.Tensor] = None, status=(), packed: Optional[torch.Tensor] = None):
     """(logits - logsumexp(logits), argmax) for one row of logits [1, V] or [V] on the device (gbx_logprobs_argmax):
-    returns (logprobs with the shape of ``logits``, token int64 [1])."""
+    returns (logprobs with the shape of ``logits``, token int64 [1]).  ``out`` / ``token`` / ``workspace``: caller-owned buffers (a
+    captured graph).  ``packed`` (int64 [4]) with up to three one-element int32 ``status`` views: packed = (token, status words) --
+    what generate_step sends to the host after a step, in one copy (gbx_logprobs_argmax_packed)."""
     _require_cuda(logits, "logits")
     lg = logits.contiguous()
     v = lg.shape[-1]
     assert lg.numel() == v, "one row of logits"
     L = _lib.lib()
-    out = torch.empty_like(lg)
-    token = torch.empty((1,), dtype=torch.int64, device=lg.device)
-    ws = torch.empty((L.gbx_logprobs_workspace_bytes(),), dtype=torch.uint8, device=lg.device)
-    _lib.check(L.gbx_logprobs_argmax(lg.data_ptr(), out.data_ptr(), token.data_ptr(), ws.data_ptr(), v, _DT[lg.dtype],
-                                     _stream_ptr(lg.device)))
+    out = torch.empty_like(lg) if out is None else out
+    token = torch.empty((1,), dtype=torch.int64, device=lg.device) if token is None else token
+    ws = torch.empty((L.gbx_logprobs_workspace_bytes(),), dtype=torch.uint8, device=lg.device) if workspace is None else workspace
+    assert out.is_contiguous() and out.numel() == v and out.dtype == lg.dtype and token.dtype == torch.int64
+    if packed is None:
+        _lib.check(L.gbx_logprobs_argmax(lg.data_ptr(), out.data_ptr(), token.data_ptr(), ws.data_ptr(), v, _DT[lg.dtype],
+                                         _stream_ptr(lg.device)))
+    else:
+        assert packed.dtype == torch.int64 and packed.numel() >= 4 and len(status) <= 3
+        assert all(w.dtype == torch.int32 and w.numel() == 1 for w in status)
+        st = [w.data_ptr() for w in status] + [None] * (3 - len(status))
+        _lib.check(L.gbx_logprobs_argmax_packed(lg.data_ptr(), out.data_ptr(), token.data_ptr(), ws.data_ptr(), v, _DT[lg.dtype],
+                                                st[0], st[1], st[2], packed.data_ptr(), _stream_ptr(lg.device)))
     return out, token
 
 

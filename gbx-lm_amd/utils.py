@@ -284,11 +284,21 @@ def generate_step(prompt: torch.Tensor, model: nn.Module, *, max_tokens: int = 2
     default_sampler = sampler is None                     # greedy (utils.py:285): token and logprobs can come from one device op
     sampler = sampler or (lambda x: torch.argmax(x, dim=-1))
     fast_decode = getattr(model, "decode_step", None) if not logits_processors else None
+    # default sampler, no processors: the whole step -- blocks, head, logprobs, argmax, the token fed back on the device -- is one graph
+    # replay, and (token, hand-off status words) reach the host in one copy (decode.FusedDecodeRunner.step_gen)
+    fast_logprobs = getattr(model, "decode_step_logprobs", None) if (fast_decode is not None and default_sampler) else None
+    step_words = [None]                                   # packed (token, status words) of the last fast_logprobs step (a static device buffer)
 
     @torch.no_grad()
     def _step(y, hidden_states=False):
         nonlocal tokens
         prompt_hidden_states = None
+        step_words[0] = None
+        if fast_logprobs is not None and y.numel() == 1 and not hidden_states:
+            out = fast_logprobs(y, prompt_cache)
+            if out is not None:
+                step_words[0] = out[2]
+                return out[0], out[1], None
         if fast_decode is not None and y.numel() == 1 and not hidden_states:
             logits = fast_decode(y, prompt_cache)                       # [1, vocab]
         elif hidden_states:
@@ -334,7 +344,7 @@ def generate_step(prompt: torch.Tensor, model: nn.Module, *, max_tokens: int = 2
     # The status words of the decode runner's fused launches (in-launch hand-offs that can time out: another tenant on the GPU, a CU
     # mask) travel with the id: a non-zero word means the step's stream was poisoned (NaN logits) -- the model then falls back to the
     # five-launch block for good and the step is REPLAYED, so the caller never sees a token of a faulted step.
-    ring, fring, slot = [], [], [0]
+    ring, fring, pring, slot = [], [], [], [0]
     fault_words = getattr(model, "decode_fault_words", None) if fast_decode is not None else None
 
     class _HandoffFault(Exception):
@@ -347,12 +357,19 @@ def generate_step(prompt: torch.Tensor, model: nn.Module, *, max_tokens: int = 2
             ring.extend(torch.empty((1,), dtype=torch.long, pin_memory=True) for _ in range(3))   # (two ids are in flight at most)
             fring.extend(torch.zeros((4,), dtype=torch.int32, pin_memory=True) for _ in range(3))
         pinned, fpin = ring[slot[0] % 3], None
-        pinned.copy_(t.reshape(-1)[:1], non_blocking=True)
-        words = fault_words() if fault_words is not None else []
-        if words:
-            fpin = fring[slot[0] % 3][:len(words)]
-            for i, w in enumerate(words):
-                fpin[i:i + 1].copy_(w, non_blocking=True)
+        if step_words[0] is not None:                     # one copy: (token, status words) as the step's last launch packed them
+            if not pring:
+                pring.extend(torch.zeros((4,), dtype=torch.long, pin_memory=True) for _ in range(3))
+            pinned = pring[slot[0] % 3]
+            pinned.copy_(step_words[0], non_blocking=True)
+            fpin = pinned[1:]
+        else:
+            pinned.copy_(t.reshape(-1)[:1], non_blocking=True)
+            words = fault_words() if fault_words is not None else []
+            if words:
+                fpin = fring[slot[0] % 3][:len(words)]
+                for i, w in enumerate(words):
+                    fpin[i:i + 1].copy_(w, non_blocking=True)
         slot[0] += 1
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(t.device))
@@ -364,7 +381,7 @@ def generate_step(prompt: torch.Tensor, model: nn.Module, *, max_tokens: int = 2
             ev.synchronize()
         if fpin is not None and bool(fpin.any()):
             raise _HandoffFault(int(fpin[fpin != 0][0]))
-        return int(host.item())
+        return int(host[0])
 
     n = 0
     # (input, cache offset before it) of the decode step that produced ``y``; None when ``y`` came out of the prompt pass
@@ -386,7 +403,8 @@ def generate_step(prompt: torch.Tensor, model: nn.Module, *, max_tokens: int = 2
             # faulted one (the words are sticky): both are replayed on the five-launch block, from the cache offset they started at.
             model.decode_fallback(int(fault.args[0]), prompt_cache, made_by[1] if made_by is not None else ahead_off)
             if made_by is not None:
-                y, logprobs, h_states = _step(made_by[0])
+                src = made_by[0]                          # (an int: the token was read on the host; the device buffer it came from is reused)
+                y, logprobs, h_states = _step(src if torch.is_tensor(src) else torch.tensor([src], dtype=torch.long, device=y.device))
             pending = _to_host(y)
             if n != max_tokens:
                 ahead_off = prompt_cache[0].offset if prompt_cache else 0
@@ -397,7 +415,7 @@ def generate_step(prompt: torch.Tensor, model: nn.Module, *, max_tokens: int = 2
             except _HandoffFault as again:
                 raise RuntimeError(f"decode hand-off {again.args[0]} timed out again after the fall-back to the five-launch block") from None
         yield tok, logprobs, h_states
-        made_by = (y, ahead_off)
+        made_by = (tok, ahead_off)                        # ``tok`` IS the value of ``y``, the input of the look-ahead step
         y, logprobs, pending = next_y, next_logprobs, next_pending
         n += 1
 

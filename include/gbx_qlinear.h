@@ -599,11 +599,17 @@ int gbx_kv_append(const void* k, const void* v, void* kcache, void* vcache, cons
 
 /* The tail of one generate_step (gbx_lm/utils.py:305-306 and the default sampler, :285): logprobs[vocab] = logits -
  * logsumexp(logits) (fp32 logsumexp rounded to the activation dtype, activation-dtype subtraction) and *token =
- * argmax(logprobs) (lowest index on ties) -- three small launches, nothing leaves the device.  `workspace`: caller-owned
+ * argmax(logprobs) (lowest index on ties) -- two small launches, nothing leaves the device.  `workspace`: caller-owned
  * scratch of gbx_logprobs_workspace_bytes() bytes (8-byte aligned). */
 size_t gbx_logprobs_workspace_bytes(void);
 int gbx_logprobs_argmax(const void* logits, void* logprobs, int64_t* token, void* workspace, int32_t vocab, int32_t act_dtype,
                         void* hip_stream);
+/* The same, and -- for a host loop that reads the token id after every step (generate_step, utils.py:323-338) -- packed[0] = token,
+ * packed[1..3] = the device words status0..2 (0 for a NULL pointer) as they are when the launch ends: the token id and the decode
+ * runner's hand-off status words (gbx_dattn_status / gbx_dblock_status words) leave the device in ONE copy.  (since 1301) */
+int gbx_logprobs_argmax_packed(const void* logits, void* logprobs, int64_t* token, void* workspace, int32_t vocab, int32_t act_dtype,
+                               const uint32_t* status0, const uint32_t* status1, const uint32_t* status2, int64_t* packed,
+                               void* hip_stream);
 
 /* Residual add + RMSNorm in one launch: h[M, K] <- h + delta (one rounding to the activation dtype, the add of
  * qllama.py:138-140), y = RMSNorm(h) * w.  h is updated in place; y may not alias h. */

@@ -61,17 +61,22 @@ def test_graph_decode_equals_eager_and_survives_cache_growth(tiny):
     from gbx_lm_amd.models.cache import make_prompt_cache, KVCache
     model, z = tiny
     prompt = torch.tensor(z["prompt"], device=DEV)
-    c1 = [KVCache(step=8) for _ in model.layers]             # tiny growth step: forces re-capture at 8, 16, 24
-    c2 = [KVCache(step=8) for _ in model.layers]
+    c1 = [KVCache(step=8) for _ in model.layers]             # tiny growth step: the eager cache grows at 8, 16, 24, ...
+    c2 = [KVCache(step=8) for _ in model.layers]             # the runner's: four steps up front at its first decode step, then doubling
+    runners = []                                             # (kept alive: ids of dead objects are reused)
     with torch.no_grad():
         l1 = model(prompt[None], cache=c1)[:, -1, :]
         l2 = model(prompt[None], cache=c2)[:, -1, :]
-        for t in range(22):
+        for t in range(80):
             tok = torch.argmax(l2, -1)
             l1 = model(tok[None], cache=c1)[:, -1, :]         # eager single-token forward
             l2 = model.decode_step(tok, c2).clone()           # graph replay
+            if not runners or runners[-1] is not model._decode_runner:
+                runners.append(model._decode_runner)
+            assert c2[0].capacity >= c2[0].offset and model._decode_runner.capacity == c2[0].capacity
             assert torch.allclose(l1.float(), l2.float(), atol=0.08, rtol=0.05), f"step {t}"
-    assert c1[0].offset == c2[0].offset == len(prompt) + 22 and c2[0].capacity == 32
+    assert c1[0].offset == c2[0].offset == len(prompt) + 80
+    assert len(runners) == 3, "first runner (capacity 37), regrown at 37 (77) and at 77"
 
 
 def test_graph_decode_long_cache_split_attention(tiny):
@@ -85,15 +90,15 @@ def test_graph_decode_long_cache_split_attention(tiny):
     with torch.no_grad():
         l1 = model(prompt[None], cache=c1)[:, -1, :]
         l2 = model(prompt[None], cache=c2)[:, -1, :]
-        for t in range(40):                                   # positions 1000 .. 1039: capacity 1024 -> 1280 on the way
+        for t in range(40):                                   # positions 1000 .. 1039: capacity 1024 -> 2048 on the way
             tok = torch.argmax(l2, -1)
             l1 = model(tok[None], cache=c1)[:, -1, :]
             l2 = model.decode_step(tok, c2).clone()
             assert torch.allclose(l1.float(), l2.float(), atol=0.1, rtol=0.05), f"step {t}: {(l1.float() - l2.float()).abs().max().item()}"
-    assert c2[0].capacity == 1280 and c2[0].offset == 1040
+    assert c2[0].capacity == 2048 and c2[0].offset == 1040      # (a full cache doubles: decode._runner_for)
     from gbx_lm_amd import _lib
     at = model.model.layers[0].self_attn                     # the launch at this capacity is the split one
-    assert _lib.lib().gbx_attn_workspace_bytes(1, at.n_heads, at.n_kv_heads, at.head_dim, 1280) > 0
+    assert _lib.lib().gbx_attn_workspace_bytes(1, at.n_heads, at.n_kv_heads, at.head_dim, 2048) > 0
     assert model._decode_runner.graph is not None
 
 
