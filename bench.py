@@ -595,6 +595,26 @@ def main():
         # the rest of the metric (BASELINE.json: "bpw-2.2 & 4.0", configs[3], configs[4] at TP 1) in the same line, bounded
         extra = {}
         legs = []
+
+        def generate_leg():
+            # the PRODUCT loop with the host in it (gbx_lm.generate_step, utils.py:217-338): one token id + the hand-off status words cross
+            # PCIe per token, step n + 1 is enqueued before token n is read.  Never `value`; stated beside it.
+            from gbx_lm_amd.utils import generate_step
+            prompt = (torch.arange(args.context) * 7 + 3) % 32000
+            n_tok, best = 160, 0.0
+            for _ in range(2):                                      # (the first call builds the runner and captures its graphs)
+                t0 = None
+                for i, _tok in enumerate(generate_step(prompt, model, max_tokens=n_tok)):
+                    if i == 7:
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                torch.cuda.synchronize()
+                best = max(best, (n_tok - 8) / (time.perf_counter() - t0))
+            model._decode_runner = None
+            return {"tok_s": best, "tokens": n_tok - 8, "context": args.context, "host_in_loop": True,
+                    "note": "generate_step, default sampler: one graph replay per token (blocks + head + logprobs + argmax, token fed back on the "
+                            "device), logprobs cloned per token, (token, status words) in one D2H copy; contexts grow from `context` on"}
+        legs.append(("generate_step_" + args.strategy, generate_leg))
         if args.strategy == "S22":
             legs.append(("b32_decode_S22", lambda: decode_leg(model, cfg, dev, 32, 128, 16, 2)))
 
