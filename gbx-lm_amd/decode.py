@@ -299,9 +299,10 @@ def graph_decode_step(model, y: torch.Tensor, prompt_cache: List[KVCache]) -> to
     c0 = prompt_cache[0]
     if not isinstance(c0, KVCache) or c0.keys is None or not c0.keys.is_cuda:
         return model(y[None], cache=prompt_cache)[:, -1, :]
-    if c0.offset + 1 > c0.capacity:                               # grow every layer before (re)capturing
+    if c0.offset + 1 > c0.capacity:                               # grow every layer before (re)capturing: a full cache doubles (_runner_for)
+        more = max(c0.step, min(c0.capacity, 32 * c0.step))
         for c in prompt_cache:
-            c.reserve(1, c.keys[:, :, :1], c.values[:, :, :1])
+            c.reserve(more, c.keys[:, :, :1], c.values[:, :, :1])
     runner = getattr(model, "_decode_runner", None)
     if getattr(model, "_graph_decode_unavailable", False):
         return model(y[None], cache=prompt_cache)[:, -1, :]
