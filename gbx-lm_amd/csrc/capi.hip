@@ -1221,7 +1221,7 @@ int gbx_dmlp_forward(const gbx_dmlp* d, void* hip_stream) {
 #ifdef GBX_STAMPS
   a.stamps = gbx::stamp_region();
 #endif
-  hipError_t e = mx ? gbx::launch_dmlp(a, static_cast<hipStream_t>(hip_stream)) : gbx::launch_dmlpv(a, bg, static_cast<hipStream_t>(hip_stream));
+  hipError_t e = mx ? gbx::launch_dmlp(a, bg, static_cast<hipStream_t>(hip_stream)) : gbx::launch_dmlpv(a, bg, static_cast<hipStream_t>(hip_stream));
   if (e != hipSuccess) return hip_fail(e, "gbx_dmlp_forward launch");
   return GBX_OK;
 }

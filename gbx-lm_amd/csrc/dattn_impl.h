@@ -117,7 +117,7 @@ struct DmlpArgs {
 };
 
 bool dmlp_plan(int D, int I, int bits_gu, int group_gu, int bits_dn, int group_dn, bool bf16, int* bpw, int* a4);
-hipError_t launch_dmlp(const DmlpArgs& a, hipStream_t stream);
+hipError_t launch_dmlp(const DmlpArgs& a, int bits, hipStream_t stream);
 // dmlpv.hip: the same launch on the vector-ALU arithmetic for 3- and 4-bit rows (Llama-3-8B and Llama-3.2-3B MLP shapes)
 bool dmlpv_plan(int D, int I, int bits_gu, int group_gu, int bits_dn, int group_dn, bool bf16, int* bpw, int* a4);
 hipError_t launch_dmlpv(const DmlpArgs& a, int bits, hipStream_t stream);

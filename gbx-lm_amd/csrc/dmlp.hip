@@ -19,7 +19,12 @@
 // Arithmetic: dgemv_mx.hip's (FP4 x FP8 matrix cores: a 2-bit field masked in place is the E2M1 number q / 2, the activations are two
 // E4M3 limbs with one E8M0 exponent per 32 values, the diagonal of the 16 x 16 result holds 16 per-group sums) for BOTH matrix
 // products.  2 bits, group 128, bf16, K = 4096 (two 2048-value spans), I / 8 <= 2048 a multiple of 128, D % 512 == 0.
-// Everything else (other widths / groups / shapes) stays on the three-launch block.
+// Round 6, BITS = 4 (same shapes): a 4-bit field q = lo + 4 hi is TWO 2-bit fields in one nibble, so the same two masks that split a 2-bit
+// word into its even and odd fields -- w & 0x33333333, (w >> 2) & 0x33333333 -- split a 4-bit word into the E2M1 operands lo / 2 and hi / 2 of
+// the SAME 8 values; the second pair of MFMAs carries hi with a B-side block scale of 2^2: sum x (lo / 2 + 2 hi) = dot / 2 as before.  No
+// repacking, a natural-order activation image (4 consecutive values = 4 consecutive bytes), twice the MFMAs, a quarter of the vector
+// instructions of the vector form (dmlpv.hip).  down_proj's 112 KB of words per CU do not fit registers: LDS-DMA, two rows behind each
+// gate | up batch.  Everything else (other widths / groups / shapes) stays on the three-launch block or dmlpv.
 #include "dattn_impl.h"
 #include "gbx_env.h"
 #include "kernels.h"
@@ -33,9 +38,14 @@ typedef __attribute__((address_space(1))) unsigned long long dml_gu64;
 typedef __attribute__((address_space(1))) unsigned dml_gu32;
 
 constexpr int DM_LDS_BYTES = 84 * 1024;    // one workgroup per CU
+constexpr int DM_LDS_DW = 32 * 1024;       // BITS = 4: down_proj's words, [wave][8 rows][64 lanes][16 B]
+constexpr int DM_LDS_BYTES4 = DM_LDS_DW + 128 * 1024;
 
-template <int SP>
+template <int SP, int BITS>
 __global__ __launch_bounds__(DA_NT) void dmlp_kernel(const DmlpArgs a) {
+  static_assert(BITS == 2 || BITS == 4, "2-bit fields, or 4-bit fields as (lo, hi) pairs of 2-bit fields");
+  using WT = typename std::conditional<BITS == 4, u32x4, u32x2>::type;      // a lane's 32 values of one (row, k-block)
+  constexpr int LB = BITS == 4 ? 16 : 8;                         // bytes of those 32 values
   constexpr bool BF16 = true;
   constexpr int NW = DA_NW, NT = DA_NT;
   constexpr int NBLK = SP * 64;
@@ -64,26 +74,106 @@ __global__ __launch_bounds__(DA_NT) void dmlp_kernel(const DmlpArgs a) {
   dml_gu32* gen_p = reinterpret_cast<dml_gu32*>(reinterpret_cast<uintptr_t>(a.state)) + g * 16;
   dml_gu64* hand = reinterpret_cast<dml_gu64*>(reinterpret_cast<uintptr_t>(a.hand)) + static_cast<size_t>(g) * DA_HAND_STRIDE;
   auto rsrc = [](const void* ptr) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, RS_ALL, RS_FLAGS); };
-  const int W4 = K / 4;                                          // bytes per packed gate / up row
+  const int W4 = K * BITS / 8;                                   // bytes per packed gate / up row
   const int G = K >> 7;
   const int IX = a.I >> 3;                                       // activations of this XCD
   const int nn = lane & 15, kg = lane >> 4;
-  const unsigned voff_w = nn * 32 + kg * 8;                      // this lane's 8 bytes inside a 512-byte span
+  const unsigned voff_w = nn * (4 * LB) + kg * LB;               // this lane's bytes inside a span (2048 values = 64 LB bytes)
   const unsigned voff_s = nn * 8;
   // this wave's gate | up batches: activations [n0, n0 + nloc) of the XCD, consecutive so that two of them share a granule
   const int nloc = wave < a.a4 ? 4 : 2;
   const int nx0 = r * a.bpw + (wave < a.a4 ? 4 * wave : 4 * a.a4 + 2 * (wave - a.a4));
   const int n0 = g * IX + nx0;
   const __amdgpu_buffer_rsrc_t qd = rsrc(a.gate_qw), qd2 = rsrc(a.up_qw), szd = rsrc(a.gu_sz);
-  struct Batch { u32x2 w[2][SP]; u32x2 sz[SP]; };
+  // down_proj: this wave's rows, this XCD's columns
+  const int RPWG = a.D / DA_MEMBERS;                             // rows of this workgroup
+  const int rows_w = RPWG / NW;                                  // rows of this wave (8)
+  const int W4d = a.I * BITS / 8;                                // bytes per packed down row
+  const int Gd = a.I >> 7;
+  const int ng = IX >> 7;                                        // 128-value groups of this XCD's slice (<= 16)
+  const __amdgpu_buffer_rsrc_t dd = rsrc(a.down_qw), dsd = rsrc(a.down_sz);
+  const unsigned killd = nn < ng ? 0u : KILL;
+  const int drow0 = r * RPWG + wave * rows_w;
+  unsigned char* dwl = smem + DM_LDS_DW + wave * 8192;           // BITS = 4: [row][lane][16 B]
+  // BITS = 4: two rows of down_proj's words by LDS-DMA (no registers; a killed lane's 16 bytes arrive as zeros)
+  auto dma_down = [&](int i0) {
+    if constexpr (BITS == 4) {
+#pragma unroll
+      for (int i = i0; i < i0 + 2; ++i) {
+        if (i < rows_w)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(dd, (__attribute__((address_space(3))) void*)(dwl + i * 1024), 16,
+                                                   (voff_w + static_cast<unsigned>(g * (IX * BITS / 8))) | killd, (drow0 + i) * W4d, 0, 2);
+      }
+    }
+  };
+  struct Batch { WT w[2][SP]; u32x2 sz[SP]; };
+  auto ldw = [](const __amdgpu_buffer_rsrc_t d, unsigned voff, int soff) -> WT {
+    if constexpr (BITS == 4) return __builtin_amdgcn_raw_buffer_load_b128(d, voff, soff, 2);
+    else return __builtin_amdgcn_raw_buffer_load_b64(d, voff, soff, 2);
+  };
+  // four consecutive values of a 32-value block (item u of 8) as two E4M3 limbs into an operand image: where they go depends on which
+  // operand dword / nibble carries the weight they meet (2 bits: even fields of a word in one dword, odd fields in the next; 4 bits: natural order)
+  auto put_item = [](unsigned char* piece_lane, int u, float r0, float r1, float r2, float r3) {
+    if constexpr (BITS == 4) {
+      int ph = __builtin_amdgcn_cvt_pk_fp8_f32(r0, r1, 0, false);
+      ph = __builtin_amdgcn_cvt_pk_fp8_f32(r2, r3, ph, true);
+      int pl = __builtin_amdgcn_cvt_pk_fp8_f32(r0 - __builtin_amdgcn_cvt_f32_fp8(ph, 0), r1 - __builtin_amdgcn_cvt_f32_fp8(ph, 1), 0, false);
+      pl = __builtin_amdgcn_cvt_pk_fp8_f32(r2 - __builtin_amdgcn_cvt_f32_fp8(ph, 2), r3 - __builtin_amdgcn_cvt_f32_fp8(ph, 3), pl, true);
+      *reinterpret_cast<int*>(piece_lane + 4 * (u & 3)) = ph;
+      *reinterpret_cast<int*>(piece_lane + 2048 + 4 * (u & 3)) = pl;
+    } else {
+      unsigned char* dst = piece_lane + 2 * (u & 3);
+      const int pe = __builtin_amdgcn_cvt_pk_fp8_f32(r0, r2, 0, false);
+      const int po = __builtin_amdgcn_cvt_pk_fp8_f32(r1, r3, 0, false);
+      *reinterpret_cast<unsigned short*>(dst) = static_cast<unsigned short>(pe);
+      *reinterpret_cast<unsigned short*>(dst + 8) = static_cast<unsigned short>(po);
+      const int le = __builtin_amdgcn_cvt_pk_fp8_f32(r0 - __builtin_amdgcn_cvt_f32_fp8(pe, 0), r2 - __builtin_amdgcn_cvt_f32_fp8(pe, 1), 0, false);
+      const int lo = __builtin_amdgcn_cvt_pk_fp8_f32(r1 - __builtin_amdgcn_cvt_f32_fp8(po, 0), r3 - __builtin_amdgcn_cvt_f32_fp8(po, 1), 0, false);
+      *reinterpret_cast<unsigned short*>(dst + 2048) = static_cast<unsigned short>(le);
+      *reinterpret_cast<unsigned short*>(dst + 2048 + 8) = static_cast<unsigned short>(lo);
+    }
+  };
+  // one (row, span) on the matrix cores: the result's diagonal holds sum x q / 2 per group
+  auto mx_row = [](const dml_v8i& a_hi, const dml_v8i& a_lo, const WT& w, int opsel, int sa) -> dml_v4f {
+    dml_v4f z = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BITS == 4) {
+      dml_v8i lo, hi;
+      lo[0] = w.x & 0x33333333u; lo[1] = w.y & 0x33333333u; lo[2] = w.z & 0x33333333u; lo[3] = w.w & 0x33333333u;
+      hi[0] = (w.x >> 2) & 0x33333333u; hi[1] = (w.y >> 2) & 0x33333333u; hi[2] = (w.z >> 2) & 0x33333333u; hi[3] = (w.w >> 2) & 0x33333333u;
+      lo[4] = 0; lo[5] = 0; lo[6] = 0; lo[7] = 0; hi[4] = 0; hi[5] = 0; hi[6] = 0; hi[7] = 0;
+      if (opsel == 0) {
+        z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a_hi, lo, z, 0, 4, 0, sa, 0, 127);
+        z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a_lo, lo, z, 0, 4, 0, sa, 0, 127);
+        z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a_hi, hi, z, 0, 4, 0, sa, 0, 129);
+        z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a_lo, hi, z, 0, 4, 0, sa, 0, 129);
+      } else {
+        z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a_hi, lo, z, 0, 4, 1, sa, 0, 127);
+        z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a_lo, lo, z, 0, 4, 1, sa, 0, 127);
+        z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a_hi, hi, z, 0, 4, 1, sa, 0, 129);
+        z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a_lo, hi, z, 0, 4, 1, sa, 0, 129);
+      }
+    } else {
+      dml_v8i bv;
+      bv[0] = w.x & 0x33333333u; bv[1] = (w.x >> 2) & 0x33333333u; bv[2] = w.y & 0x33333333u; bv[3] = (w.y >> 2) & 0x33333333u;
+      bv[4] = 0; bv[5] = 0; bv[6] = 0; bv[7] = 0;
+      if (opsel == 0) {
+        z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a_hi, bv, z, 0, 4, 0, sa, 0, 127);
+        z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a_lo, bv, z, 0, 4, 0, sa, 0, 127);
+      } else {
+        z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a_hi, bv, z, 0, 4, 1, sa, 0, 127);
+        z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a_lo, bv, z, 0, 4, 1, sa, 0, 127);
+      }
+    }
+    return z;
+  };
   auto issue = [&](Batch& b, int j) {
     const unsigned kill = j < nloc ? 0u : KILL;
     const int row = n0 + (j < nloc ? j : 0);
     const int woff = row * W4;
 #pragma unroll
-    for (int h = 0; h < SP; ++h) b.w[0][h] = __builtin_amdgcn_raw_buffer_load_b64(qd, (voff_w + h * 512) | kill, woff, 2);
+    for (int h = 0; h < SP; ++h) b.w[0][h] = ldw(qd, (voff_w + h * (64 * LB)) | kill, woff);
 #pragma unroll
-    for (int h = 0; h < SP; ++h) b.w[1][h] = __builtin_amdgcn_raw_buffer_load_b64(qd2, (voff_w + h * 512) | kill, woff, 2);
+    for (int h = 0; h < SP; ++h) b.w[1][h] = ldw(qd2, (voff_w + h * (64 * LB)) | kill, woff);
 #pragma unroll
     for (int h = 0; h < SP; ++h) b.sz[h] = __builtin_amdgcn_raw_buffer_load_b64(szd, (voff_s + h * 128) | kill, row * (G * 8), 0);
   };
@@ -176,16 +266,7 @@ __global__ __launch_bounds__(DA_NT) void dmlp_kernel(const DmlpArgs a) {
           const int b = it >> 3, u = it & 7;
           const int h = b >> 6, m = (b & 63) >> 2, kb = b & 3;
           const int ga = 2 * (kb & 1) + (u >> 2);
-          unsigned char* dst = img + (h * 4 + (kb >> 1)) * 1024 + (m + 16 * ga) * 16 + 2 * (u & 3);
-          const float r0 = v[0] * up, r1 = v[1] * up, r2 = v[2] * up, r3 = v[3] * up;
-          const int pe = __builtin_amdgcn_cvt_pk_fp8_f32(r0, r2, 0, false);
-          const int po = __builtin_amdgcn_cvt_pk_fp8_f32(r1, r3, 0, false);
-          *reinterpret_cast<unsigned short*>(dst) = static_cast<unsigned short>(pe);
-          *reinterpret_cast<unsigned short*>(dst + 8) = static_cast<unsigned short>(po);
-          const int le = __builtin_amdgcn_cvt_pk_fp8_f32(r0 - __builtin_amdgcn_cvt_f32_fp8(pe, 0), r2 - __builtin_amdgcn_cvt_f32_fp8(pe, 1), 0, false);
-          const int lo = __builtin_amdgcn_cvt_pk_fp8_f32(r1 - __builtin_amdgcn_cvt_f32_fp8(po, 0), r3 - __builtin_amdgcn_cvt_f32_fp8(po, 1), 0, false);
-          *reinterpret_cast<unsigned short*>(dst + 2048) = static_cast<unsigned short>(le);
-          *reinterpret_cast<unsigned short*>(dst + 2048 + 8) = static_cast<unsigned short>(lo);
+          put_item(img + (h * 4 + (kb >> 1)) * 1024 + (m + 16 * ga) * 16, u, v[0] * up, v[1] * up, v[2] * up, v[3] * up);
           if (u == 0) { bsum[h * 64 + m + 16 * kb] = sum; scl[h * 64 + m + 16 * kb] = static_cast<unsigned char>(ea - 7); }
         }
       }
@@ -193,9 +274,12 @@ __global__ __launch_bounds__(DA_NT) void dmlp_kernel(const DmlpArgs a) {
   }
   DML_STAMP(10);
   Batch ring[2];
-  issue(ring[0], 0);
+  // 4 bits: a batch is 64 KB per CU, more than a CU keeps in flight (~50 KB): requested in front of barrier B by all 16 waves, the eight
+  // image-writing waves waited to ISSUE and barrier B with them (3.8 instead of 2.9 us).  They ask behind the barrier instead.
+  if (BITS == 2 || !pro) issue(ring[0], 0);
   __syncthreads();                                               // barrier B: image written
   DML_STAMP(2);
+  if (BITS == 4 && pro) issue(ring[0], 0);
   issue(ring[1], 1);
   unsigned tag = gen + 1u;
   if (tag == 0u) tag = 1u;
@@ -228,18 +312,9 @@ __global__ __launch_bounds__(DA_NT) void dmlp_kernel(const DmlpArgs a) {
       dml_v4f c[2][SP];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        auto span = [&](auto H) {
-          constexpr int h = decltype(H)::value;
-          dml_v8i bv;
-          const unsigned w0 = cur.w[i][h].x, w1 = cur.w[i][h].y;
-          bv[0] = w0 & 0x33333333u; bv[1] = (w0 >> 2) & 0x33333333u; bv[2] = w1 & 0x33333333u; bv[3] = (w1 >> 2) & 0x33333333u;
-          bv[4] = 0; bv[5] = 0; bv[6] = 0; bv[7] = 0;
-          dml_v4f z = {0.f, 0.f, 0.f, 0.f};
-          z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(areg[h][0], bv, z, 0, 4, h, sa, 0, 127);
-          c[i][h] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(areg[h][1], bv, z, 0, 4, h, sa, 0, 127);
-        };
-        span(std::integral_constant<int, 0>{});
-        if constexpr (SP > 1) span(std::integral_constant<int, 1>{});
+        static_assert(SP <= 2, "the scale operand's byte select is 0 / 1");
+        c[i][0] = mx_row(areg[0][0], areg[0][1], cur.w[i][0], 0, sa);
+        if constexpr (SP > 1) c[i][1] = mx_row(areg[1][0], areg[1][1], cur.w[i][1], 1, sa);
       }
       float acc[2];
 #pragma unroll
@@ -271,30 +346,29 @@ __global__ __launch_bounds__(DA_NT) void dmlp_kernel(const DmlpArgs a) {
     };
     consume(ring[0], 0);
     issue(ring[0], 2);
+    dma_down(0);
     consume(ring[1], 1);
     publish(0);
     issue(ring[1], 3);
+    dma_down(2);
     DML_STAMP(3);
     // ---- down_proj words of this wave's 8 rows, this XCD's columns: requested behind the last gate / up rows, consumed in 4.
     consume(ring[0], 2);
+    dma_down(4);
     consume(ring[1], 3);
+    dma_down(6);
     publish(1);
   }
   DML_STAMP(4);
   // (requested here rather than between the consumes: the matrix-core operands above keep ~90 VGPRs live)
-  const int RPWG = a.D / DA_MEMBERS;                             // rows of this workgroup
-  const int rows_w = RPWG / NW;                                  // rows of this wave (8)
-  const int W4d = a.I / 4;                                       // bytes per packed down row
-  const int Gd = a.I >> 7;
-  const int ng = IX >> 7;                                        // 128-value groups of this XCD's slice (<= 16)
-  const __amdgpu_buffer_rsrc_t dd = rsrc(a.down_qw), dsd = rsrc(a.down_sz);
-  u32x2 dw[8], dsz[4];
+  u32x2 dw[BITS == 2 ? 8 : 1], dsz[4];
   {
-    const unsigned killd = nn < ng ? 0u : KILL;
-    const int row0 = r * RPWG + wave * rows_w;
+    const int row0 = drow0;
+    if constexpr (BITS == 2) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      dw[i] = __builtin_amdgcn_raw_buffer_load_b64(dd, (voff_w + static_cast<unsigned>(g * (IX / 4))) | (i < rows_w ? killd : KILL), (row0 + (i < rows_w ? i : 0)) * W4d, 2);
+      for (int i = 0; i < 8; ++i)
+        dw[i] = __builtin_amdgcn_raw_buffer_load_b64(dd, (voff_w + static_cast<unsigned>(g * (IX / 4))) | (i < rows_w ? killd : KILL), (row0 + (i < rows_w ? i : 0)) * W4d, 2);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q)      // rows (row0 + 2 q, + 1): one (scale | zero) pair each for group g * ng + nn
       dsz[q] = __builtin_amdgcn_raw_buffer_load_b64(dsd, static_cast<unsigned>((g * ng + nn) * 8) | (2 * q < rows_w ? killd : KILL),
@@ -335,16 +409,7 @@ __global__ __launch_bounds__(DA_NT) void dmlp_kernel(const DmlpArgs a) {
       const int b = it >> 3, u = it & 7;
       const int m = b >> 2, kb = b & 3;
       const int ga = 2 * (kb & 1) + (u >> 2);
-      unsigned char* dst = img2 + (kb >> 1) * 1024 + (m + 16 * ga) * 16 + 2 * (u & 3);
-      const float r0 = v[0] * up, r1 = v[1] * up, r2 = v[2] * up, r3 = v[3] * up;
-      const int pe = __builtin_amdgcn_cvt_pk_fp8_f32(r0, r2, 0, false);
-      const int po = __builtin_amdgcn_cvt_pk_fp8_f32(r1, r3, 0, false);
-      *reinterpret_cast<unsigned short*>(dst) = static_cast<unsigned short>(pe);
-      *reinterpret_cast<unsigned short*>(dst + 8) = static_cast<unsigned short>(po);
-      const int le = __builtin_amdgcn_cvt_pk_fp8_f32(r0 - __builtin_amdgcn_cvt_f32_fp8(pe, 0), r2 - __builtin_amdgcn_cvt_f32_fp8(pe, 1), 0, false);
-      const int lo = __builtin_amdgcn_cvt_pk_fp8_f32(r1 - __builtin_amdgcn_cvt_f32_fp8(po, 0), r3 - __builtin_amdgcn_cvt_f32_fp8(po, 1), 0, false);
-      *reinterpret_cast<unsigned short*>(dst + 2048) = static_cast<unsigned short>(le);
-      *reinterpret_cast<unsigned short*>(dst + 2048 + 8) = static_cast<unsigned short>(lo);
+      put_item(img2 + (kb >> 1) * 1024 + (m + 16 * ga) * 16, u, v[0] * up, v[1] * up, v[2] * up, v[3] * up);
       if (u == 0) { bsum2[m + 16 * kb] = sum; scl2[m + 16 * kb] = static_cast<unsigned char>(ea - 7); }
     }
   }
@@ -367,22 +432,20 @@ __global__ __launch_bounds__(DA_NT) void dmlp_kernel(const DmlpArgs a) {
     const float gs2 = (bsum2[nn] + bsum2[nn + 16]) + (bsum2[nn + 32] + bsum2[nn + 48]);
     const float xsg2 = (diag && lg) ? gs2 : 0.f;
     float yv[8];
+    if constexpr (BITS == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's own rows have landed in ITS part of LDS
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      dml_v8i bv;
-      const unsigned w0 = dw[i].x, w1 = dw[i].y;
-      bv[0] = w0 & 0x33333333u; bv[1] = (w0 >> 2) & 0x33333333u; bv[2] = w1 & 0x33333333u; bv[3] = (w1 >> 2) & 0x33333333u;
-      bv[4] = 0; bv[5] = 0; bv[6] = 0; bv[7] = 0;
-      dml_v4f z = {0.f, 0.f, 0.f, 0.f};
-      z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a2[0], bv, z, 0, 4, 0, sa2, 0, 127);
-      z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a2[1], bv, z, 0, 4, 0, sa2, 0, 127);
+      WT wv;
+      if constexpr (BITS == 4) wv = *reinterpret_cast<const u32x4*>(dwl + i * 1024 + lane * 16);
+      else wv = dw[i];
+      const dml_v4f z = mx_row(a2[0], a2[1], wv, 0, sa2);
       const float dsel = fmaf(z[0], dm[0], fmaf(z[1], dm[1], fmaf(z[2], dm[2], z[3] * dm[3])));
       const unsigned szw = (i & 1) ? dsz[i >> 1].y : dsz[i >> 1].x;
       const float sc = sz_scale<BF16>(szw), ze = sz_zero<BF16>(szw);
       yv[i] = lg ? fmaf(ze, xsg2, (sc + sc) * dsel) : 0.f;
     }
     dml_gu64* accp = reinterpret_cast<dml_gu64*>(reinterpret_cast<uintptr_t>(a.acc_out));
-    const int row0 = r * RPWG + wave * rows_w;
+    const int row0 = drow0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (2 * q >= rows_w) break;
@@ -426,7 +489,9 @@ __global__ __launch_bounds__(1024) void acc_finish_kernel(const unsigned short* 
 
 bool dmlp_plan(int D, int I, int bits_gu, int group_gu, int bits_dn, int group_dn, bool bf16, int* bpw, int* a4) {
   if (!xcd_layout_ok()) return false;                                       // 8 XCDs x 32 CUs, all available, round-robin placement (xcd_layout.hip)
-  if (!bf16 || bits_gu != 2 || bits_dn != 2 || group_gu != 128 || group_dn != 128) return false;
+  // 2 bits, or (round 6) 4 bits as pairs of 2-bit fields (GBX_DMLP_MX4=0: the 4-bit launch stays on the vector form, dmlpv.hip)
+  static const bool mx4 = env_switch("GBX_DMLP_MX4") != 0;
+  if (!bf16 || bits_gu != bits_dn || !(bits_gu == 2 || (bits_gu == 4 && mx4)) || group_gu != 128 || group_dn != 128) return false;
   if (D != 4096) return false;                                              // two 2048-value spans (the one-span instantiation had no caller: dropped)
   if (I <= 0 || (I % (8 * 128)) != 0) return false;
   const int IX = I / 8;
@@ -435,21 +500,24 @@ bool dmlp_plan(int D, int I, int bits_gu, int group_gu, int bits_dn, int group_d
   const int b = IX / DA_MEMBERS;                                            // batches per workgroup
   if (b < 32 || b > 64 || (b & 1)) return false;                            // 4 a4 + 2 (16 - a4) = b
   if ((D % (DA_MEMBERS * DA_NW)) != 0 || D / (DA_MEMBERS * DA_NW) > 8 || ((D / (DA_MEMBERS * DA_NW)) & 1)) return false;
-  if (static_cast<long long>(I) * (D / 4) >= 0x7FFFFFFFll || static_cast<long long>(D) * (I / 4) >= 0x7FFFFFFFll) return false;
+  if (static_cast<long long>(I) * (D / 8 * bits_gu) >= 0x7FFFFFFFll || static_cast<long long>(D) * (I / 8 * bits_dn) >= 0x7FFFFFFFll) return false;
   *bpw = b;
   *a4 = (b - 32) / 2;
   return true;
 }
 
-hipError_t launch_dmlp(const DmlpArgs& a, hipStream_t stream) {
+hipError_t launch_dmlp(const DmlpArgs& a, int bits, hipStream_t stream) {
   static DeviceOnce once;
   if (once.pending()) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dmlp_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, DM_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dmlp_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, DM_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(dmlp_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, DM_LDS_BYTES4);
     if (e != hipSuccess) return e;
     once.done();
   }
-  if (a.K != 4096) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((dmlp_kernel<2>), dim3(DA_GROUPS * DA_MEMBERS), dim3(DA_NT), DM_LDS_BYTES, stream, a);
+  if (a.K != 4096 || (bits != 2 && bits != 4)) return hipErrorInvalidValue;
+  if (bits == 4) hipLaunchKernelGGL((dmlp_kernel<2, 4>), dim3(DA_GROUPS * DA_MEMBERS), dim3(DA_NT), DM_LDS_BYTES4, stream, a);
+  else hipLaunchKernelGGL((dmlp_kernel<2, 2>), dim3(DA_GROUPS * DA_MEMBERS), dim3(DA_NT), DM_LDS_BYTES, stream, a);
   return hipGetLastError();
 }
 

@@ -372,6 +372,8 @@ class FusedDecodeRunner(DecodeRunner):
         a0 = model.model.layers[0].self_attn
         D = model.args.hidden_size
         I = model.model.layers[0].mlp.gate_proj.output_dims
+        self._n_layers = len(model.model.layers)
+        self._mostly_4bit = 2 * sum(b.mlp.gate_proj.bits == 4 for b in model.model.layers) >= self._n_layers
         mk = lambda n: torch.zeros((n,), dtype=dt, device=dev)
         self.pos = torch.zeros((1,), dtype=torch.long, device=dev)
         nq, nkv = a0.n_heads * a0.head_dim, a0.n_kv_heads * a0.head_dim
@@ -602,7 +604,14 @@ class FusedDecodeRunner(DecodeRunner):
                                   zero_buf=self.acc_d[p])
         h_buf = self.hn if acc_in is not None else x_in          # the stream before o_proj's output is added
         # (the fused MLP launch exists for 3 / 4 bits too -- dmlpv.hip -- but measured slower than the two launches it replaces: opt-in)
-        use_mlp = (self.use_dmlp and (mlp.gate_proj.bits == 2 or env.flag("GBX_DMLP_VEC")) and
+        mx4 = (mlp.gate_proj.bits == 4 and mlp.down_proj.bits == 4 and mlp.gate_proj.group_size == 128 and mlp.down_proj.group_size == 128 and
+               D == 4096 and env.flag("GBX_DMLP_MX4") and
+               # (round 6: the matrix-core launch takes 4-bit rows as pairs of 2-bit fields.  Not for the LAST block: its down launch
+               #  writes the stream the head reads, where the fused launch would need one more launch to finish its sums)
+               li != self._n_layers - 1 and self._mostly_4bit)
+        # (an isolated 4-bit block between three-launch blocks gains nothing: the block behind it then starts from (vector, sums) instead of a
+        #  finished stream with its statistic carried -- measured level on the S22 mix, +1.9 % on the all-4-bit strategy)
+        use_mlp = (self.use_dmlp and (mlp.gate_proj.bits == 2 or mx4 or env.flag("GBX_DMLP_VEC")) and
                    ops.dmlp_supported(D, mlp.gate_proj, mlp.up_proj, mlp.down_proj, self.hb.dtype) and
                    blk.post_attention_layernorm.weight.dtype == self.hb.dtype)
         if use_mlp:

@@ -432,11 +432,11 @@ def test_three_launch_block_agrees_with_five_launch_block():
 
 
 def test_two_launch_block_agrees_with_five_launch_block():
-    """Five 8B-shaped layers, all 2 bits (S20) and the S22 mix on eight layers (4-, 3-, 3-bit blocks on three launches between 2-bit
+    """Five 8B-shaped layers, all 2 bits (S20) and the S22 mix on eight layers (3-bit blocks on three launches between 2- and 4-bit
     blocks on two): the stream passes between blocks as (vector, fixed-point sums), accumulators alternate by parity, the last
     block's sums are finished by gbx_acc_residual.  Agreement with the five-launch block to a few bf16 ulps of the stream."""
     f = lambda d, k: np.frombuffer(bytes.fromhex(d[k]), dtype=np.float32)
-    for layers, strat, n_mlp in ((5, "S20", 5), (8, "S22", 3)):
+    for layers, strat, n_mlp in ((5, "S20", 5), (8, "S22", 3), (4, "S40", 3)):   # (round 6: in a mostly-4-bit model the 4-bit blocks take the fused MLP launch too -- not the last block)
         new, old = _hb({"GBX_DATTN": "1", "GBX_DMLP": "1"}, layers, 12, strat), _hb({"GBX_DATTN": "0"}, layers, 12, strat)
         assert int(new["DATTN"]) == layers and int(new["DMLP"]) == n_mlp, (new["DATTN"], new["DMLP"])
         a, b = f(new, "HB"), f(old, "HB")
