@@ -388,9 +388,14 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(const DgArgs a) {
     }
   }
   DG_STAMP(10);
-  if constexpr (E0 < R) issue_part(ring[0], batch_of(0), E0, R);
+#ifndef DG_EXP_AFTER
+#define DG_EXP_AFTER 0           // experiment: 3- / 4-bit LATE launches request batch 0 BEHIND the image barrier (the request itself can wait for queue space)
+#endif
+  constexpr bool AFTER = LATE && BITS >= 3 && DG_EXP_AFTER != 0;
+  if constexpr (E0 < R && !AFTER) issue_part(ring[0], batch_of(0), E0, R);
   __syncthreads();
   DG_STAMP(2);
+  if constexpr (E0 < R && AFTER) issue_part(ring[0], batch_of(0), E0, R);
 #pragma unroll
   for (int d = 1; d < D; ++d) issue(ring[d], batch_of(d));
 
