@@ -631,21 +631,29 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
     // ---- 4. this wave's two rows, then the o_proj words behind them
     WT w[R][P];
     unsigned sz[P][R];
+    auto request_rows = [&]() {
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
+      for (int i = 0; i < R; ++i) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          if constexpr (BQ == 3) w[i][p] = __builtin_amdgcn_raw_buffer_load_b96(qd, voff_w[p], (grow + i) * W4, 2);
+          else w[i][p] = __builtin_amdgcn_raw_buffer_load_b128(qd, voff_w[p], (grow + i) * W4, 2);
+        }
+      }
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        if constexpr (BQ == 3) w[i][p] = __builtin_amdgcn_raw_buffer_load_b96(qd, voff_w[p], (grow + i) * W4, 2);
-        else w[i][p] = __builtin_amdgcn_raw_buffer_load_b128(qd, voff_w[p], (grow + i) * W4, 2);
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(szd, voff_s[p], gb * (G * R * 4), 0);
+        sz[p][0] = v.x; sz[p][1] = v.y;
       }
-    }
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(szd, voff_s[p], gb * (G * R * 4), 0);
-      sz[p][0] = v.x; sz[p][1] = v.y;
-    }
+    };
+#ifndef DA_EXP_AFTER
+#define DA_EXP_AFTER 0           // experiment: the image-writing waves request their rows BEHIND barrier B (two lane passes: 48-64 KB per CU in front of it)
+#endif
+    constexpr bool AFTER = DA_EXP_AFTER != 0 && P == 2;
+    if (!AFTER || !pro) request_rows();
     __syncthreads();                                           // barrier B: image written
     DA_STAMP(3);
+    if (AFTER && pro) request_rows();
     tag = gen + 1u;
     if (tag == 0u) tag = 1u;
     if (has) {

@@ -166,20 +166,25 @@ __global__ __launch_bounds__(DA_NT) void dmlp_kernel(const DmlpArgs a) {
     }
     return z;
   };
+  // K < SP * 2048 (Llama-3.2-3B: 3072): groups beyond K exist in the operand layout only -- their lanes fetch nothing (zeros), their image is zero
+  unsigned gkill[SP];
+#pragma unroll
+  for (int h = 0; h < SP; ++h) gkill[h] = (h * 16 + nn) < G ? 0u : KILL;
   auto issue = [&](Batch& b, int j) {
     const unsigned kill = j < nloc ? 0u : KILL;
     const int row = n0 + (j < nloc ? j : 0);
     const int woff = row * W4;
 #pragma unroll
-    for (int h = 0; h < SP; ++h) b.w[0][h] = ldw(qd, (voff_w + h * (64 * LB)) | kill, woff);
+    for (int h = 0; h < SP; ++h) b.w[0][h] = ldw(qd, (voff_w + h * (64 * LB)) | kill | gkill[h], woff);
 #pragma unroll
-    for (int h = 0; h < SP; ++h) b.w[1][h] = ldw(qd2, (voff_w + h * (64 * LB)) | kill, woff);
+    for (int h = 0; h < SP; ++h) b.w[1][h] = ldw(qd2, (voff_w + h * (64 * LB)) | kill | gkill[h], woff);
 #pragma unroll
-    for (int h = 0; h < SP; ++h) b.sz[h] = __builtin_amdgcn_raw_buffer_load_b64(szd, (voff_s + h * 128) | kill, row * (G * 8), 0);
+    for (int h = 0; h < SP; ++h) b.sz[h] = __builtin_amdgcn_raw_buffer_load_b64(szd, (voff_s + h * 128) | kill | gkill[h], row * (G * 8), 0);
   };
 
   // ---------------- 1. prologue on waves 0-7 (dgemv_mx.hip): x' from the fixed-point sums, statistic, limb image ----------------
   constexpr int NIT = SP * 512, PW = 8, PT = PW * 64, IPT = (NIT + PT - 1) / PT;
+  const int nit = K >> 2;                                        // live items (4 values each); items nit .. NIT - 1 are written as zeros
   const bool pro = wave < PW;
   u32x2 xr[IPT], wr[IPT];
   if (a.zero_buf) {
@@ -190,14 +195,14 @@ __global__ __launch_bounds__(DA_NT) void dmlp_kernel(const DmlpArgs a) {
     const __amdgpu_buffer_rsrc_t ad = rsrc(a.x_acc);
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
-      const int it = min(tid + PT * j, NIT - 1);
+      const int it = min(tid + PT * j, nit - 1);
       acv[j][0] = __builtin_amdgcn_raw_buffer_load_b128(ad, static_cast<unsigned>(it * 32), 0, 0);
       acv[j][1] = __builtin_amdgcn_raw_buffer_load_b128(ad, static_cast<unsigned>(it * 32 + 16), 0, 0);
     }
     const unsigned apoison = __builtin_amdgcn_raw_buffer_load_b32(ad, static_cast<unsigned>(K * 8), 0, 0);
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
-      const int it = min(tid + PT * j, NIT - 1);
+      const int it = min(tid + PT * j, nit - 1);
       xr[j] = *reinterpret_cast<const u32x2*>(a.x + 4 * it);
       wr[j] = *reinterpret_cast<const u32x2*>(a.norm_w + 4 * it);
     }
@@ -206,8 +211,8 @@ __global__ __launch_bounds__(DA_NT) void dmlp_kernel(const DmlpArgs a) {
     float ssq = 0.f;
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
-      const int it = min(tid + PT * j, NIT - 1);
-      const bool live = (tid + PT * j) < NIT;
+      const int it = min(tid + PT * j, nit - 1);
+      const bool live = (tid + PT * j) < nit;
       unsigned wv[2];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -221,7 +226,8 @@ __global__ __launch_bounds__(DA_NT) void dmlp_kernel(const DmlpArgs a) {
         const float lo = act_lo<BF16>(wv[q]), hi = act_hi<BF16>(wv[q]);
         ssq += live ? fmaf(hi, hi, lo * lo) : 0.f;
       }
-      xr[j] = u32x2{wv[0], wv[1]};
+      xr[j] = live ? u32x2{wv[0], wv[1]} : u32x2{0u, 0u};
+      if (!live) wr[j] = u32x2{0u, 0u};
       if (blockIdx.x == 0 && live && a.x_out) *reinterpret_cast<u32x2*>(a.x_out + 4 * it) = xr[j];
     }
     ssq = wave_sum(ssq);
@@ -492,7 +498,7 @@ bool dmlp_plan(int D, int I, int bits_gu, int group_gu, int bits_dn, int group_d
   // 2 bits, or (round 6) 4 bits as pairs of 2-bit fields (GBX_DMLP_MX4=0: the 4-bit launch stays on the vector form, dmlpv.hip)
   static const bool mx4 = env_switch("GBX_DMLP_MX4") != 0;
   if (!bf16 || bits_gu != bits_dn || !(bits_gu == 2 || (bits_gu == 4 && mx4)) || group_gu != 128 || group_dn != 128) return false;
-  if (D != 4096) return false;                                              // two 2048-value spans (the one-span instantiation had no caller: dropped)
+  if (D > 4096 || D <= 2048 || (D % 1024) != 0) return false;               // two 2048-value spans, the second one full or half (4096: 8B; 3072: 3.2-3B)
   if (I <= 0 || (I % (8 * 128)) != 0) return false;
   const int IX = I / 8;
   if (IX > 2048 || IX < 256) return false;                                  // one span of down's operand; at least one polling wave
@@ -515,7 +521,7 @@ hipError_t launch_dmlp(const DmlpArgs& a, int bits, hipStream_t stream) {
     if (e != hipSuccess) return e;
     once.done();
   }
-  if (a.K != 4096 || (bits != 2 && bits != 4)) return hipErrorInvalidValue;
+  if (a.K > 4096 || a.K <= 2048 || (a.K % 1024) != 0 || (bits != 2 && bits != 4)) return hipErrorInvalidValue;
   if (bits == 4) hipLaunchKernelGGL((dmlp_kernel<2, 4>), dim3(DA_GROUPS * DA_MEMBERS), dim3(DA_NT), DM_LDS_BYTES4, stream, a);
   else hipLaunchKernelGGL((dmlp_kernel<2, 2>), dim3(DA_GROUPS * DA_MEMBERS), dim3(DA_NT), DM_LDS_BYTES, stream, a);
   return hipGetLastError();

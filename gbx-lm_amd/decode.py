@@ -605,7 +605,7 @@ class FusedDecodeRunner(DecodeRunner):
         h_buf = self.hn if acc_in is not None else x_in          # the stream before o_proj's output is added
         # (the fused MLP launch exists for 3 / 4 bits too -- dmlpv.hip -- but measured slower than the two launches it replaces: opt-in)
         mx4 = (mlp.gate_proj.bits == 4 and mlp.down_proj.bits == 4 and mlp.gate_proj.group_size == 128 and mlp.down_proj.group_size == 128 and
-               D == 4096 and env.flag("GBX_DMLP_MX4") and
+               D in (3072, 4096) and env.flag("GBX_DMLP_MX4") and
                # (round 6: the matrix-core launch takes 4-bit rows as pairs of 2-bit fields.  Not for the LAST block: its down launch
                #  writes the stream the head reads, where the fused launch would need one more launch to finish its sums)
                li != self._n_layers - 1 and self._mostly_4bit)

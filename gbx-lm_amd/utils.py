@@ -317,7 +317,7 @@ def generate_step(prompt: torch.Tensor, model: nn.Module, *, max_tokens: int = 2
             for processor in logits_processors:
                 logits = processor(tokens, logits)
         if default_sampler and logits.is_cuda and logits.shape[0] == 1 and logits.dtype in (torch.bfloat16, torch.float16):
-            from . import ops                                     # logsumexp, subtraction and argmax in three small launches
+            from . import ops                                     # logsumexp, subtraction and argmax in two small launches
             logprobs, y = ops.logprobs_argmax(logits)
             return y.reshape(-1), logprobs.squeeze(0), prompt_hidden_states
         logprobs = logits - torch.logsumexp(logits.float(), dim=-1, keepdim=True).to(logits.dtype)
