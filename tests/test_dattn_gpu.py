@@ -260,7 +260,10 @@ def test_gateup_prologue_reads_the_accumulator(bits):
 @pytest.mark.parametrize("cfg_name,bits,group,seed", [("LLAMA3_8B", 2, 128, 0), ("LLAMA3_8B", 2, 128, 1),
                                                       # round 6: the vector-ALU form (dmlpv.hip) for 3- and 4-bit rows, both BASELINE geometries, every group size
                                                       ("LLAMA3_8B", 3, 128, 2), ("LLAMA3_8B", 4, 128, 3), ("LLAMA32_3B", 3, 128, 4), ("LLAMA32_3B", 4, 128, 5),
-                                                      ("LLAMA3_8B", 4, 64, 6), ("LLAMA32_3B", 3, 32, 7), ("LLAMA3_8B", 3, 64, 8)])
+                                                      ("LLAMA3_8B", 4, 64, 6), ("LLAMA32_3B", 3, 32, 7), ("LLAMA3_8B", 3, 64, 8),
+                                                      # (4 bits at group 128 now take the matrix-core form -- a nibble as two 2-bit fields, dmlp_kernel<2,4> -- at both
+                                                      #  geometries; K = 3072 is one and a half spans of operands: the 2-bit kernel at that geometry too)
+                                                      ("LLAMA32_3B", 2, 128, 9)])
 def test_dmlp_launch_vs_fp64(cfg_name, bits, group, seed):
     """gbx_dmlp_forward (2 bits: FP4 x FP8 matrix cores, Llama-3-8B MLP shapes; 3 / 4 bits: the decode GEMV's vector-ALU arithmetic, 8B and
     3.2-3B shapes): x' exact; the SwiGLU activations against fp64 on dequantised weights with the reference graph's roundings (2e-2 of the
@@ -395,13 +398,13 @@ def test_dattn_plan_refuses_what_it_does_not_cover():
     assert not ok(4096, 32, 8, 128, 2, 32, 2, 128), "2-bit group 32: two (scale, zero) pairs per lane slot"
 
 
-def _hb(env_extra, layers=3, steps=12, strategy="S22"):
+def _hb(env_extra, layers=3, steps=12, strategy="S22", cfg_name="LLAMA3_8B"):
     code = (
         "import sys, torch; sys.path.insert(0, %r)\n"
         "import bench\n"
         "from gbx_lm_amd import synthetic as S\n"
         "from gbx_lm_amd.decode import FusedDecodeRunner\n"
-        "cfg = dict(S.LLAMA3_8B, num_hidden_layers=%d, vocab_size=2048)\n"
+        "cfg = dict(S.%s, num_hidden_layers=%d, vocab_size=2048)\n"
         "model = S.build_model(cfg, S.make_strategy('%s', %d, 128), device='cuda:0', seed=5)\n"
         "caches = bench.make_caches(model, 1, 256, 'cuda:0')\n"
         "r = FusedDecodeRunner(model, caches, use_graph=True)\n"
@@ -411,7 +414,7 @@ def _hb(env_extra, layers=3, steps=12, strategy="S22"):
         "torch.cuda.synchronize()\n"
         "r.dattn_check()\n"
         "print('HB', r.hb.float().cpu().numpy().tobytes().hex())\n"
-        "print('KC', caches[-1].keys[0, :, :%d].float().cpu().numpy().tobytes().hex())\n" % (ROOT, layers, strategy, layers, steps, steps))
+        "print('KC', caches[-1].keys[0, :, :%d].float().cpu().numpy().tobytes().hex())\n" % (ROOT, cfg_name, layers, strategy, layers, steps, steps))
     env = dict(os.environ, **env_extra)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -436,8 +439,10 @@ def test_two_launch_block_agrees_with_five_launch_block():
     blocks on two): the stream passes between blocks as (vector, fixed-point sums), accumulators alternate by parity, the last
     block's sums are finished by gbx_acc_residual.  Agreement with the five-launch block to a few bf16 ulps of the stream."""
     f = lambda d, k: np.frombuffer(bytes.fromhex(d[k]), dtype=np.float32)
-    for layers, strat, n_mlp in ((5, "S20", 5), (8, "S22", 3), (4, "S40", 3)):   # (round 6: in a mostly-4-bit model the 4-bit blocks take the fused MLP launch too -- not the last block)
-        new, old = _hb({"GBX_DATTN": "1", "GBX_DMLP": "1"}, layers, 12, strat), _hb({"GBX_DATTN": "0"}, layers, 12, strat)
+    # (round 6: in a mostly-4-bit model the 4-bit blocks take the fused MLP launch too -- not the last block; the 3.2-3B geometry, K = 3072, as well)
+    for layers, strat, n_mlp, cfgn in ((5, "S20", 5, "LLAMA3_8B"), (8, "S22", 3, "LLAMA3_8B"), (4, "S40", 3, "LLAMA3_8B"), (4, "S40", 3, "LLAMA32_3B"),
+                                       (3, "S20", 3, "LLAMA32_3B")):
+        new, old = _hb({"GBX_DATTN": "1", "GBX_DMLP": "1"}, layers, 12, strat, cfgn), _hb({"GBX_DATTN": "0"}, layers, 12, strat, cfgn)
         assert int(new["DATTN"]) == layers and int(new["DMLP"]) == n_mlp, (new["DATTN"], new["DMLP"])
         a, b = f(new, "HB"), f(old, "HB")
         assert np.isfinite(a).all()
