@@ -32,7 +32,9 @@ def _collect(gen):
     return toks, lps
 
 
-@pytest.mark.parametrize("prompt_len,ntok", [(7, 24), (250, 20)])      # the second one crosses the cache's first 256 positions
+# (7, 24): a short prompt; (250, 20): the step-by-step loop's cache grows at 256; (370, 40): the one-launch block's context limit (384 cached
+# positions: the replayed graph changes to the two-launch block mid-generation); (1010, 30): the runner's cache is full at 1024 and doubles
+@pytest.mark.parametrize("prompt_len,ntok", [(7, 24), (250, 20), (370, 40), (1010, 30)])
 def test_one_replay_per_token_equals_the_step_by_step_loop(prompt_len, ntok):
     from gbx_lm_amd import utils
     from gbx_lm_amd.decode import FusedDecodeRunner
@@ -42,6 +44,10 @@ def test_one_replay_per_token_equals_the_step_by_step_loop(prompt_len, ntok):
     r = model._decode_runner
     assert isinstance(r, FusedDecodeRunner) and any(k[0] == "gen" for k in r._graphs), "the one-replay path did not run"
     assert r._gen_next is not None and r._gen_next[0] == r.caches[0].offset
+    if prompt_len == 370:                                     # both graphs of the one-replay mode ran: one-launch block, then two launches
+        assert r.db[0] is not None and ("gen", False) in r._graphs and ("gen", True) in r._graphs and r.caches[0].offset > r.db_max_ctx
+    if prompt_len == 1010:
+        assert r.capacity == 2048
     model._decode_runner = None
     slow_t, slow_lp = _collect(utils.generate_step(prompt, model, max_tokens=ntok, sampler=lambda x: torch.argmax(x, dim=-1)))
     assert not any(k[0] == "gen" for k in model._decode_runner._graphs)
