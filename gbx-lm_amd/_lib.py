@@ -183,7 +183,7 @@ class DmlpDesc(ctypes.Structure):
                 ("zero_buf", ctypes.c_void_p), ("state", ctypes.c_void_p), ("act_out", ctypes.c_void_p),
                 ("D", ctypes.c_int32), ("I", ctypes.c_int32), ("zero_n", ctypes.c_int32), ("norm_eps", ctypes.c_float),
                 ("gate_up_bits", ctypes.c_int32), ("gate_up_group_size", ctypes.c_int32), ("down_bits", ctypes.c_int32),
-                ("down_group_size", ctypes.c_int32)]
+                ("down_group_size", ctypes.c_int32), ("weight_layout", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
 
 
 class DblockDesc(ctypes.Structure):
@@ -204,7 +204,8 @@ class DblockDesc(ctypes.Structure):
 
 GBX_DG_PLAIN, GBX_DG_RESIDUAL, GBX_DG_SWIGLU = 0, 1, 2
 GBX_DG_SSQ_SLOTS = 1024
-GBX_MIN_VERSION = 1301          # the header this binding mirrors
+GBX_LAYOUT_REFERENCE, GBX_LAYOUT_PLANES = 0, 1
+GBX_MIN_VERSION = 1302          # the header this binding mirrors
 
 
 def _declare_optional(L) -> None:
@@ -249,6 +250,8 @@ def _declare_optional(L) -> None:
         "gbx_kv_append": [p, p, p, p, p, i64, i32, i32, i32, i32, p],
         "gbx_logprobs_argmax": [p, p, p, p, i32, i32, p],
         "gbx_logprobs_argmax_packed": [p, p, p, p, i32, i32, p, p, p, p, p],
+        "gbx_repack_planes": [p, p, i64, i32, i32, p],
+        "gbx_dmlp_weight_layout": [i32, i32, i32, i32, i32, i32, i32],
         "gbx_add_rmsnorm": [p, p, p, p, i64, i32, f32, i32, p],
         "gbx_swiglu": [p, p, p, i64, i32, p],
         "gbx_dense_gemv": [p, p, p, p, f32, i32, i32, i32, p],

@@ -32,9 +32,9 @@ extern "C" void gbx_debug_stamp_reset(void) { gbx::g_stamp_launch = 0; }
 
 extern "C" {
 
-/* 1301: + gbx_logprobs_argmax_packed (an addition; gbx_logprobs_argmax is two launches instead of three).  1300: gbx_acc_residual grows act_dtype; + gbx_xcd_layout_check, gbx_dblock_*; a timed-out hand-off poisons its accumulator.  1202: + gbx_add_rmsnorm_slices_xcd, gbx_norm_state_bytes (additions).  1201: + gbx_dattn.x_acc / x_out / zero_buf, gbx_dmlp_*, gbx_acc_residual.  1200: gbx_dgemv grows (x_acc, x_out, zero_buf, zero_n) + gbx_dattn_* + gbx_dgemv_kernel_id.  1101: + gbx_attn_decode_slices (an addition: nothing else changed).  1100: gbx_dgemv_* entry points; gbx_qlinear_fused (x_acc, x_out, zero_buf, zero_n since 1001) -- a consumer built against
+/* 1302: gbx_dmlp grows weight_layout; + gbx_repack_planes, gbx_dmlp_weight_layout (3-bit rows as a 2-bit and a 1-bit plane for the matrix cores).  1301: + gbx_logprobs_argmax_packed (an addition; gbx_logprobs_argmax is two launches instead of three).  1300: gbx_acc_residual grows act_dtype; + gbx_xcd_layout_check, gbx_dblock_*; a timed-out hand-off poisons its accumulator.  1202: + gbx_add_rmsnorm_slices_xcd, gbx_norm_state_bytes (additions).  1201: + gbx_dattn.x_acc / x_out / zero_buf, gbx_dmlp_*, gbx_acc_residual.  1200: gbx_dgemv grows (x_acc, x_out, zero_buf, zero_n) + gbx_dattn_* + gbx_dgemv_kernel_id.  1101: + gbx_attn_decode_slices (an addition: nothing else changed).  1100: gbx_dgemv_* entry points; gbx_qlinear_fused (x_acc, x_out, zero_buf, zero_n since 1001) -- a consumer built against
  * an older header must not pass its shorter struct to this library: check gbx_version() >= the header it compiled with. */
-int gbx_version(void) { return 1301; }
+int gbx_version(void) { return 1302; }
 
 const char* gbx_last_error(void) { return g_err; }
 
@@ -1176,13 +1176,43 @@ int gbx_dmlp_plan(int32_t D, int32_t I, int32_t gate_up_bits, int32_t gate_up_gr
   return GBX_OK;
 }
 
+int gbx_repack_planes(const uint32_t* qweight, uint32_t* out, int64_t N, int32_t K, int32_t bits, void* hip_stream) {
+  if (bits != 3) return fail(GBX_ERR_UNSUPPORTED, "gbx_repack_planes: 3-bit rows (got %d bits)", bits);
+  if (N < 0 || K <= 0 || (K % 32) != 0) return fail(GBX_ERR_INVALID, "bad shape N=%lld K=%d", (long long)N, K);
+  if (N == 0) return GBX_OK;
+  if (!qweight || !out || !aligned(qweight, 4) || !aligned(out, 4)) return fail(GBX_ERR_INVALID, "null or misaligned device pointer");
+  if (qweight == out) return fail(GBX_ERR_INVALID, "out must not alias qweight (the reference tensor stays what it was)");
+  hipError_t e = gbx::launch_repack_planes3(qweight, out, static_cast<size_t>(N) * (K / 32), static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "gbx_repack_planes launch");
+  return GBX_OK;
+}
+
+// 3-bit rows take the matrix-core launch in the plane layout (GBX_DMLP_MX3, default 1), else the vector form in the reference layout
+static bool dmlp_wants_planes(int D, int I, int bg, int gg, int bd, int gd, bool bf16) {
+  static const bool mx3 = gbx::env_switch("GBX_DMLP_MX3") != 0;
+  int bpw, a4;
+  return mx3 && bg == 3 && bd == 3 && gbx::dmlp_plan(D, I, bg, gg, bd, gd, bf16, &bpw, &a4);
+}
+
+int gbx_dmlp_weight_layout(int32_t D, int32_t I, int32_t gate_up_bits, int32_t gate_up_group_size, int32_t down_bits, int32_t down_group_size,
+                           int32_t act_dtype) {
+  if (int rc = gbx_dmlp_plan(D, I, gate_up_bits, gate_up_group_size, down_bits, down_group_size, act_dtype)) return rc < 0 ? rc : -rc;
+  return dmlp_wants_planes(D, I, gate_up_bits, gate_up_group_size, down_bits, down_group_size, act_dtype == GBX_BF16) ? GBX_LAYOUT_PLANES
+                                                                                                                       : GBX_LAYOUT_REFERENCE;
+}
+
 int gbx_dmlp_forward(const gbx_dmlp* d, void* hip_stream) {
   if (!d) return fail(GBX_ERR_INVALID, "null descriptor");
   if (d->struct_size != sizeof(gbx_dmlp)) return fail(GBX_ERR_INVALID, "gbx_dmlp.struct_size is %u, this library expects %zu (header / library mismatch)", d->struct_size, sizeof(gbx_dmlp));
   const int bg = d->gate_up_bits ? d->gate_up_bits : 2, gg = d->gate_up_group_size ? d->gate_up_group_size : 128;
   const int bd = d->down_bits ? d->down_bits : 2, gd = d->down_group_size ? d->down_group_size : 128;
   int bpw, a4;
-  const bool mx = gbx::dmlp_plan(d->D, d->I, bg, gg, bd, gd, d->act_dtype == GBX_BF16, &bpw, &a4);
+  if (d->weight_layout != GBX_LAYOUT_REFERENCE && d->weight_layout != GBX_LAYOUT_PLANES) return fail(GBX_ERR_INVALID, "gbx_dmlp.weight_layout is %d", d->weight_layout);
+  const bool planes = d->weight_layout == GBX_LAYOUT_PLANES;
+  if (planes && !(bg == 3 && bd == 3)) return fail(GBX_ERR_INVALID, "GBX_LAYOUT_PLANES is the layout of 3-bit rows (gbx_repack_planes)");
+  // 3-bit rows: the matrix-core launch reads planes only, the vector launch the reference layout only
+  const bool mx = (bg != 3 || planes) && gbx::dmlp_plan(d->D, d->I, bg, gg, bd, gd, d->act_dtype == GBX_BF16, &bpw, &a4);
+  if (planes && !mx) return fail(GBX_ERR_UNSUPPORTED, "no matrix-core fused MLP launch for these 3-bit shapes: pass the reference layout (gbx_dmlp_weight_layout)");
   if (!mx && !gbx::dmlpv_plan(d->D, d->I, bg, gg, bd, gd, d->act_dtype == GBX_BF16, &bpw, &a4))
     return fail(GBX_ERR_UNSUPPORTED, "the fused MLP launch does not cover D=%d I=%d gate|up %d bits g%d, down %d bits g%d, dtype %d (gbx_dmlp_plan)", d->D, d->I,
                 bg, gg, bd, gd, d->act_dtype);

@@ -533,7 +533,50 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
     unsigned xr[IPT][PPU], wr[IPT][PPU];
     u32x4 pq[4] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
     const bool carried = a.ssq_in != nullptr;
-    if (pro) {
+    // 3 bits with x_acc (round 6): an image item is a whole 32-value unit, so only K / 32 = 128 threads own items -- and each of them used to
+    // pull 256 bytes of fixed-point sums through 16 dependent-latency loads (the fused attention launch behind a fused MLP launch: 14.2 us
+    // against 11.5 behind a down launch that hands over a finished stream).  STAGED: all 512 prologue threads form x' for 8 values each (four
+    // loads of sums), leave it in LDS and reduce the statistic; behind barrier A the item threads read their 32 values from LDS.
+    const bool staged = BQ == 3 && a.x_acc != nullptr;
+    unsigned* xtmp = reinterpret_cast<unsigned*>(smem + DA_LDS_ATT);          // [K / 2] words of x' (the attention scratch is idle in a producer workgroup now)
+    if constexpr (BQ == 3) {
+      if (pro && staged) {
+        const int nch = K >> 3;                                                // 8-value chunks
+        const bool live = tid < nch;
+        const int c = live ? tid : 0;
+        const __amdgpu_buffer_rsrc_t ad = rsrc(a.x_acc, RS_ALL);
+        u32x4 sv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sv[q] = __builtin_amdgcn_raw_buffer_load_b128(ad, static_cast<unsigned>((c * 8 + 2 * q) * 8), 0, 0);
+        const unsigned apoison = __builtin_amdgcn_raw_buffer_load_b32(ad, static_cast<unsigned>(K * 8), 0, 0);
+        const u32x4 xv = *reinterpret_cast<const u32x4*>(a.x + 8 * c);
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) da_load_item<BQ, PPU>(a.norm_w, min(tid + PT * j, nitems - 1), wr[j]);
+        DA_STAMP(1);
+        const bool poison = apoison != 0u;
+        const unsigned xw[4] = {xv.x, xv.y, xv.z, xv.w};
+        unsigned ow[4];
+        float ssq = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float o0 = round_bf16_or_f16(fx32_to_f32(sv[q].x, sv[q].y), BF16);
+          const float o1 = round_bf16_or_f16(fx32_to_f32(sv[q].z, sv[q].w), BF16);
+          float x0 = act_lo<BF16>(xw[q]) + o0, x1 = act_hi<BF16>(xw[q]) + o1;
+          if (poison) { x0 = __uint_as_float(0x7FC00000u); x1 = x0; }
+          ow[q] = static_cast<unsigned>(f32_to_act<BF16>(x0)) | (static_cast<unsigned>(f32_to_act<BF16>(x1)) << 16);
+          const float lo = act_lo<BF16>(ow[q]), hi = act_hi<BF16>(ow[q]);
+          ssq += live ? fmaf(hi, hi, lo * lo) : 0.f;
+        }
+        if (live) {
+          *reinterpret_cast<u32x4*>(xtmp + 4 * c) = u32x4{ow[0], ow[1], ow[2], ow[3]};
+          if (blockIdx.x == static_cast<unsigned>(rep * DA_GROUPS) && a.x_out != nullptr) *reinterpret_cast<u32x4*>(a.x_out + 8 * c) = u32x4{ow[0], ow[1], ow[2], ow[3]};
+        }
+        ssq = wave_sum(ssq);
+        if (lane == 0) red_lds[wave] = ssq;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+    if (pro && !staged) {
       // the previous block's down_proj sums (x_acc launches) first: the longest round trip of the prologue; without x_acc the
       // offsets are out of range and nothing is fetched
       u32x4 acv[IPT][PPU];
@@ -623,6 +666,16 @@ __global__ __launch_bounds__(DA_NT) void dattn_kernel(const DattnArgs a) {
         for (int i = 0; i < PW; ++i) tot += red_lds[i];
       }
       const float rstd = rsqrtf(tot / static_cast<float>(K) + a.eps);
+      if constexpr (BQ == 3) {
+        if (staged) {                                            // this thread's unit(s) of x' from LDS: word q = pair q of the unit
+#pragma unroll
+          for (int j = 0; j < IPT; ++j) {
+            const int it = min(tid + PT * j, nitems - 1);
+#pragma unroll
+            for (int q = 0; q < PPU; ++q) xr[j][q] = xtmp[it * PPU + q];
+          }
+        }
+      }
       // ---- 3. image
 #pragma unroll
       for (int j = 0; j < IPT; ++j)

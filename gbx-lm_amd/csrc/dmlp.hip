@@ -43,9 +43,11 @@ constexpr int DM_LDS_BYTES4 = DM_LDS_DW + 128 * 1024;
 
 template <int SP, int BITS>
 __global__ __launch_bounds__(DA_NT) void dmlp_kernel(const DmlpArgs a) {
-  static_assert(BITS == 2 || BITS == 4, "2-bit fields, or 4-bit fields as (lo, hi) pairs of 2-bit fields");
-  using WT = typename std::conditional<BITS == 4, u32x4, u32x2>::type;      // a lane's 32 values of one (row, k-block)
-  constexpr int LB = BITS == 4 ? 16 : 8;                         // bytes of those 32 values
+  static_assert(BITS == 2 || BITS == 3 || BITS == 4, "2-bit fields; 4-bit fields as (lo, hi) pairs of 2-bit fields; 3-bit rows REPACKED as a 2-bit and a 1-bit plane");
+  // a lane's 32 values of one (row, k-block).  BITS = 3: the rows must be in the plane layout of gbx_repack_planes (misc_kernels.hip) -- words
+  // 0 / 1 a 2-bit row's words (the low two bits), word 2 the high bits with (h >> i) & 0x11111111 = operand dword i
+  using WT = typename std::conditional<BITS == 4, u32x4, typename std::conditional<BITS == 3, u32x3, u32x2>::type>::type;
+  constexpr int LB = 4 * BITS;                                   // bytes of those 32 values
   constexpr bool BF16 = true;
   constexpr int NW = DA_NW, NT = DA_NT;
   constexpr int NBLK = SP * 64;
@@ -94,21 +96,27 @@ __global__ __launch_bounds__(DA_NT) void dmlp_kernel(const DmlpArgs a) {
   const __amdgpu_buffer_rsrc_t dd = rsrc(a.down_qw), dsd = rsrc(a.down_sz);
   const unsigned killd = nn < ng ? 0u : KILL;
   const int drow0 = r * RPWG + wave * rows_w;
-  unsigned char* dwl = smem + DM_LDS_DW + wave * 8192;           // BITS = 4: [row][lane][16 B]
-  // BITS = 4: two rows of down_proj's words by LDS-DMA (no registers; a killed lane's 16 bytes arrive as zeros)
+  constexpr bool DWL = BITS != 2;                                // down_proj's words through LDS (84 / 112 KB per CU do not wait well in registers)
+  unsigned char* dwl = smem + DM_LDS_DW + wave * 8192;           // DWL: [row][lane][16 B] (a 12-byte lane lands at lane * 16 too)
+  // DWL: two rows of down_proj's words by LDS-DMA (no registers; a killed lane's bytes arrive as zeros)
   auto dma_down = [&](int i0) {
-    if constexpr (BITS == 4) {
+    if constexpr (DWL) {
 #pragma unroll
       for (int i = i0; i < i0 + 2; ++i) {
-        if (i < rows_w)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(dd, (__attribute__((address_space(3))) void*)(dwl + i * 1024), 16,
-                                                   (voff_w + static_cast<unsigned>(g * (IX * BITS / 8))) | killd, (drow0 + i) * W4d, 0, 2);
+        if (i < rows_w) {
+          const unsigned vo = (voff_w + static_cast<unsigned>(g * (IX * BITS / 8))) | killd;
+          if constexpr (BITS == 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dd, (__attribute__((address_space(3))) void*)(dwl + i * 1024), 16, vo, (drow0 + i) * W4d, 0, 2);
+          else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dd, (__attribute__((address_space(3))) void*)(dwl + i * 1024), 12, vo, (drow0 + i) * W4d, 0, 2);
+        }
       }
     }
   };
   struct Batch { WT w[2][SP]; u32x2 sz[SP]; };
   auto ldw = [](const __amdgpu_buffer_rsrc_t d, unsigned voff, int soff) -> WT {
     if constexpr (BITS == 4) return __builtin_amdgcn_raw_buffer_load_b128(d, voff, soff, 2);
+    else if constexpr (BITS == 3) return __builtin_amdgcn_raw_buffer_load_b96(d, voff, soff, 2);
     else return __builtin_amdgcn_raw_buffer_load_b64(d, voff, soff, 2);
   };
   // four consecutive values of a 32-value block (item u of 8) as two E4M3 limbs into an operand image: where they go depends on which
@@ -162,6 +170,18 @@ __global__ __launch_bounds__(DA_NT) void dmlp_kernel(const DmlpArgs a) {
       } else {
         z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a_hi, bv, z, 0, 4, 1, sa, 0, 127);
         z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a_lo, bv, z, 0, 4, 1, sa, 0, 127);
+      }
+      if constexpr (BITS == 3) {                                 // the 1-bit plane: E2M1 code 1 = 0.5, block scale 2^2: 2 x bit = (4 x bit) / 2
+        dml_v8i hb;
+        hb[0] = w.z & 0x11111111u; hb[1] = (w.z >> 1) & 0x11111111u; hb[2] = (w.z >> 2) & 0x11111111u; hb[3] = (w.z >> 3) & 0x11111111u;
+        hb[4] = 0; hb[5] = 0; hb[6] = 0; hb[7] = 0;
+        if (opsel == 0) {
+          z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a_hi, hb, z, 0, 4, 0, sa, 0, 129);
+          z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a_lo, hb, z, 0, 4, 0, sa, 0, 129);
+        } else {
+          z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a_hi, hb, z, 0, 4, 1, sa, 0, 129);
+          z = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a_lo, hb, z, 0, 4, 1, sa, 0, 129);
+        }
       }
     }
     return z;
@@ -285,7 +305,7 @@ __global__ __launch_bounds__(DA_NT) void dmlp_kernel(const DmlpArgs a) {
   if (BITS == 2 || !pro) issue(ring[0], 0);
   __syncthreads();                                               // barrier B: image written
   DML_STAMP(2);
-  if (BITS == 4 && pro) issue(ring[0], 0);
+  if (BITS != 2 && pro) issue(ring[0], 0);
   issue(ring[1], 1);
   unsigned tag = gen + 1u;
   if (tag == 0u) tag = 1u;
@@ -367,13 +387,14 @@ __global__ __launch_bounds__(DA_NT) void dmlp_kernel(const DmlpArgs a) {
   }
   DML_STAMP(4);
   // (requested here rather than between the consumes: the matrix-core operands above keep ~90 VGPRs live)
-  u32x2 dw[BITS == 2 ? 8 : 1], dsz[4];
+  WT dw[!DWL ? 8 : 1];
+  u32x2 dsz[4];
   {
     const int row0 = drow0;
-    if constexpr (BITS == 2) {
+    if constexpr (!DWL) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        dw[i] = __builtin_amdgcn_raw_buffer_load_b64(dd, (voff_w + static_cast<unsigned>(g * (IX / 4))) | (i < rows_w ? killd : KILL), (row0 + (i < rows_w ? i : 0)) * W4d, 2);
+        dw[i] = ldw(dd, (voff_w + static_cast<unsigned>(g * (IX * BITS / 8))) | (i < rows_w ? killd : KILL), (row0 + (i < rows_w ? i : 0)) * W4d);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)      // rows (row0 + 2 q, + 1): one (scale | zero) pair each for group g * ng + nn
@@ -438,11 +459,12 @@ __global__ __launch_bounds__(DA_NT) void dmlp_kernel(const DmlpArgs a) {
     const float gs2 = (bsum2[nn] + bsum2[nn + 16]) + (bsum2[nn + 32] + bsum2[nn + 48]);
     const float xsg2 = (diag && lg) ? gs2 : 0.f;
     float yv[8];
-    if constexpr (BITS == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's own rows have landed in ITS part of LDS
+    if constexpr (DWL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's own rows have landed in ITS part of LDS
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       WT wv;
       if constexpr (BITS == 4) wv = *reinterpret_cast<const u32x4*>(dwl + i * 1024 + lane * 16);
+      else if constexpr (BITS == 3) { const u32x4 t4 = *reinterpret_cast<const u32x4*>(dwl + i * 1024 + lane * 16); wv = u32x3{t4.x, t4.y, t4.z}; }
       else wv = dw[i];
       const dml_v4f z = mx_row(a2[0], a2[1], wv, 0, sa2);
       const float dsel = fmaf(z[0], dm[0], fmaf(z[1], dm[1], fmaf(z[2], dm[2], z[3] * dm[3])));
@@ -497,7 +519,8 @@ bool dmlp_plan(int D, int I, int bits_gu, int group_gu, int bits_dn, int group_d
   if (!xcd_layout_ok()) return false;                                       // 8 XCDs x 32 CUs, all available, round-robin placement (xcd_layout.hip)
   // 2 bits, or (round 6) 4 bits as pairs of 2-bit fields (GBX_DMLP_MX4=0: the 4-bit launch stays on the vector form, dmlpv.hip)
   static const bool mx4 = env_switch("GBX_DMLP_MX4") != 0;
-  if (!bf16 || bits_gu != bits_dn || !(bits_gu == 2 || (bits_gu == 4 && mx4)) || group_gu != 128 || group_dn != 128) return false;
+  if (!bf16 || bits_gu != bits_dn || !(bits_gu == 2 || bits_gu == 3 || (bits_gu == 4 && mx4)) || group_gu != 128 || group_dn != 128) return false;
+  // (3 bits: only for rows in the plane layout -- gbx_dmlp.weight_layout, checked by the caller of this plan)
   if (D > 4096 || D <= 2048 || (D % 1024) != 0) return false;               // two 2048-value spans, the second one full or half (4096: 8B; 3072: 3.2-3B)
   if (I <= 0 || (I % (8 * 128)) != 0) return false;
   const int IX = I / 8;
@@ -519,10 +542,13 @@ hipError_t launch_dmlp(const DmlpArgs& a, int bits, hipStream_t stream) {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(dmlp_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, DM_LDS_BYTES4);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(dmlp_kernel<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, DM_LDS_BYTES4);
+    if (e != hipSuccess) return e;
     once.done();
   }
-  if (a.K > 4096 || a.K <= 2048 || (a.K % 1024) != 0 || (bits != 2 && bits != 4)) return hipErrorInvalidValue;
-  if (bits == 4) hipLaunchKernelGGL((dmlp_kernel<2, 4>), dim3(DA_GROUPS * DA_MEMBERS), dim3(DA_NT), DM_LDS_BYTES4, stream, a);
+  if (a.K > 4096 || a.K <= 2048 || (a.K % 1024) != 0 || bits < 2 || bits > 4) return hipErrorInvalidValue;
+  if (bits == 3) hipLaunchKernelGGL((dmlp_kernel<2, 3>), dim3(DA_GROUPS * DA_MEMBERS), dim3(DA_NT), DM_LDS_BYTES4, stream, a);
+  else if (bits == 4) hipLaunchKernelGGL((dmlp_kernel<2, 4>), dim3(DA_GROUPS * DA_MEMBERS), dim3(DA_NT), DM_LDS_BYTES4, stream, a);
   else hipLaunchKernelGGL((dmlp_kernel<2, 2>), dim3(DA_GROUPS * DA_MEMBERS), dim3(DA_NT), DM_LDS_BYTES, stream, a);
   return hipGetLastError();
 }

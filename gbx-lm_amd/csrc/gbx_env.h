@@ -27,6 +27,7 @@ inline const EnvSwitch* env_table(int* n) {
       {"GBX_DG_MX", 1, "dgemv: dot products on the FP4 x FP8 matrix cores (dgemv_mx.hip; 2 bits, group 128, bf16): 0 off, 1 the SwiGLU (gate|up) launches, 2 every eligible launch"},
       {"GBX_DATTN_MX", 1, "fused attention launch: q|k|v rows and the o_proj slice on the FP4 x FP8 matrix cores where the shapes allow (2 bits, group 128, bf16, D = 4096, 4 query heads per kv head); 0: vector-ALU dots (A/B)"},
       {"GBX_DATTN_COOP_MIN", 384, "fused attention launch: contexts beyond this many cached positions are swept by the kv group's 28 producer workgroups in chunks (K / V read once for all the group's heads) instead of by the head's own workgroup (tuning aid)"},
+      {"GBX_DMLP_MX3", 1, "gbx_dmlp_weight_layout: 3-bit blocks (group 128, Llama-3 shapes) want their rows as a 2-bit and a 1-bit plane (gbx_repack_planes) for the matrix-core launch; 0: the reference layout and the vector form (dmlpv.hip) (A/B)"},
       {"GBX_DMLP_MX4", 1, "gbx_dmlp_forward: 4-bit blocks (group 128, Llama-3-8B shapes) on the matrix-core launch -- a 4-bit field as two 2-bit fields of one nibble (dmlp.hip); 0: the vector form (dmlpv.hip) (A/B)"},
       {"GBX_DATTN_SPIN_LOG2", 22, "fused attention / MLP launches: log2 of the polls of one hand-off before a launch gives up, raises its status word and poisons its accumulator (test hook: a small value makes the time-out path reachable in a test)"},
       {"GBX_DG_LONG_PRIO", 0, "dgemv: waves that own a batch in the last (partial) round run at s_setprio 1 (A/B)"},

@@ -129,6 +129,7 @@ hipError_t launch_dense_gemv(const void* x, const void* w, void* y, const void* 
                              bool bf16, hipStream_t s, int index_offset = 0);
 hipError_t launch_embed_next(void* best, void* tok_io, void* pos, const void* table, void* h, int D, int vocab, int mode,
                              int advance, bool bf16, hipStream_t s, int nkeys = 64, void* also_clear = nullptr);
+hipError_t launch_repack_planes3(const uint32_t* in, uint32_t* out, size_t nblocks, hipStream_t s);
 hipError_t launch_pack_sz(const void* s0, const void* z0, const void* s1, const void* z1, uint32_t* out, int N, int G,
                           hipStream_t s);
 hipError_t launch_rope(const void* x, void* y, const float* inv_freq, const long long* posp, long long offset, long long B,

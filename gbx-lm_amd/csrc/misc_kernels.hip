@@ -167,6 +167,34 @@ hipError_t launch_pack_sz(const void* s0, const void* z0, const void* s1, const 
   return hipGetLastError();
 }
 
+// ---- 3-bit rows as (2-bit plane, 1-bit plane) per 32 values (load time; round 6) ----------------------------------------------------------
+// The loader's 3-bit row is a bit stream: field k at bit 3 k, fields straddle words -- the reason every 3-bit kernel is vector-ALU bound.
+// Per 32 values (three words in, three words out, SAME place in the row): words 0 / 1 = the low two bits of values 0..15 / 16..31 as 2-bit
+// fields in value order (exactly a 2-bit row's words), word 2 = the high bits, ordered so that (h >> i) & 0x11111111 is the FP4 operand
+// dword i of the matrix-core kernels: bit 4 n + 0 / 1 / 2 / 3 = high bit of value 2 n / 2 n + 1 / 16 + 2 n / 17 + 2 n.  q = lo + 4 hi.
+__global__ __launch_bounds__(256) void repack_planes3_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t nblocks) {
+  for (size_t b = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; b < nblocks; b += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    const unsigned long long w01 = static_cast<unsigned long long>(in[3 * b]) | (static_cast<unsigned long long>(in[3 * b + 1]) << 32);
+    const unsigned long long w12 = static_cast<unsigned long long>(in[3 * b + 1]) | (static_cast<unsigned long long>(in[3 * b + 2]) << 32);
+    uint32_t lo0 = 0, lo1 = 0, hi = 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int bit = 3 * i;
+      const unsigned v = bit < 32 ? static_cast<unsigned>(w01 >> bit) & 7u : static_cast<unsigned>(w12 >> (bit - 32)) & 7u;
+      if (i < 16) lo0 |= (v & 3u) << (2 * i); else lo1 |= (v & 3u) << (2 * (i - 16));
+      const int n = (i & 15) >> 1, slot = (i & 1) + 2 * (i >> 4);
+      hi |= (v >> 2) << (4 * n + slot);
+    }
+    out[3 * b] = lo0; out[3 * b + 1] = lo1; out[3 * b + 2] = hi;
+  }
+}
+
+hipError_t launch_repack_planes3(const uint32_t* in, uint32_t* out, size_t nblocks, hipStream_t s) {
+  const int blocks = static_cast<int>(std::min<size_t>((nblocks + 255) / 256, 8192));
+  hipLaunchKernelGGL(repack_planes3_kernel, dim3(blocks), dim3(256), 0, s, in, out, nblocks);
+  return hipGetLastError();
+}
+
 // ---- shape-generic qlinear (any K % 32 == 0, any M): one wave per (row n, activation row m) ----
 // Lanes stride over 32-value chunks (always a whole number of words); fp32 math throughout.
 template <int BITS, bool BF16>

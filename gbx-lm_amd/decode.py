@@ -374,6 +374,7 @@ class FusedDecodeRunner(DecodeRunner):
         I = model.model.layers[0].mlp.gate_proj.output_dims
         self._n_layers = len(model.model.layers)
         self._mostly_4bit = 2 * sum(b.mlp.gate_proj.bits == 4 for b in model.model.layers) >= self._n_layers
+        self._mostly_3bit = 2 * sum(b.mlp.gate_proj.bits == 3 for b in model.model.layers) >= self._n_layers
         mk = lambda n: torch.zeros((n,), dtype=dt, device=dev)
         self.pos = torch.zeros((1,), dtype=torch.long, device=dev)
         nq, nkv = a0.n_heads * a0.head_dim, a0.n_kv_heads * a0.head_dim
@@ -611,7 +612,12 @@ class FusedDecodeRunner(DecodeRunner):
                li != self._n_layers - 1 and self._mostly_4bit)
         # (an isolated 4-bit block between three-launch blocks gains nothing: the block behind it then starts from (vector, sums) instead of a
         #  finished stream with its statistic carried -- measured level on the S22 mix, +1.9 % on the all-4-bit strategy)
-        use_mlp = (self.use_dmlp and (mlp.gate_proj.bits == 2 or mx4 or env.flag("GBX_DMLP_VEC")) and
+        mx3 = (mlp.gate_proj.bits == 3 and mlp.down_proj.bits == 3 and mlp.gate_proj.group_size == 128 and mlp.down_proj.group_size == 128 and
+               D in (3072, 4096) and env.flag("GBX_DMLP_MX3") and li != self._n_layers - 1 and self._mostly_3bit)
+        # (3-bit rows repacked once as a 2-bit and a 1-bit plane: +2.9 % on an all-3-bit 8B model, +3.1 % at the 3.2-3B geometry; on the S22 mix
+        #  -- three 3-bit blocks between one-launch blocks -- the token got 1.5 % SLOWER although the three launches themselves gained
+        #  11 us: every other launch of the token ran ~1.5 % longer in that configuration (profiles/r06_dmlp_mx3.txt); hence the same rule as for 4 bits)
+        use_mlp = (self.use_dmlp and (mlp.gate_proj.bits == 2 or mx4 or mx3 or env.flag("GBX_DMLP_VEC")) and
                    ops.dmlp_supported(D, mlp.gate_proj, mlp.up_proj, mlp.down_proj, self.hb.dtype) and
                    blk.post_attention_layernorm.weight.dtype == self.hb.dtype)
         if use_mlp:

@@ -909,6 +909,25 @@ def dmlp_supported(d_model: int, gate, up, down, dtype) -> bool:
     return L.gbx_dmlp_plan(d_model, gate.output_dims, gate.bits, gate.group_size, down.bits, down.group_size, _DT[dtype]) == _lib.GBX_OK
 
 
+def repack_planes(mod) -> torch.Tensor:
+    """The 3-bit ``qweight`` of ``mod`` as a 2-bit and a 1-bit plane per 32 values (gbx_repack_planes): same shape and bytes, q = lo + 4 hi -- what the
+    matrix-core fused MLP launch reads.  A load-time companion kept on the module; ``mod.qweight`` stays the loader's tensor."""
+    def build():
+        qw = mod.qweight
+        _require_cuda(qw, "qweight")
+        if mod.bits != 3 or not qw.is_contiguous():
+            raise ValueError("repack_planes: contiguous 3-bit rows")
+        out = torch.empty_like(qw)
+        _lib.check(_lib.lib().gbx_repack_planes(qw.data_ptr(), out.data_ptr(), qw.shape[0], mod.input_dims, 3, _stream_ptr(qw.device)))
+        return out
+    return _companion(mod, "planes3", (), build)
+
+
+def dmlp_weight_layout(d_model: int, gate, down, dtype) -> int:
+    """GBX_LAYOUT_REFERENCE / GBX_LAYOUT_PLANES: the layout gbx_dmlp_forward wants for these modules (negative: unsupported)."""
+    return _lib.lib().gbx_dmlp_weight_layout(d_model, gate.output_dims, gate.bits, gate.group_size, down.bits, down.group_size, _DT[dtype])
+
+
 def make_dmlp_desc(x: torch.Tensor, x_acc: torch.Tensor, x_out: torch.Tensor, norm_weight: torch.Tensor, eps: float, gate, up, down,
                    gate_up_packed: torch.Tensor, down_packed: torch.Tensor, acc_out: torch.Tensor, state: torch.Tensor,
                    zero_buf: Optional[torch.Tensor] = None, act_out: Optional[torch.Tensor] = None) -> "_lib.DmlpDesc":
@@ -928,8 +947,16 @@ def make_dmlp_desc(x: torch.Tensor, x_acc: torch.Tensor, x_out: torch.Tensor, no
     d.struct_size = ctypes.sizeof(_lib.DmlpDesc)
     d.act_dtype = _DT[x.dtype]
     d.x, d.x_acc, d.x_out, d.norm_weight = x.data_ptr(), x_acc.data_ptr(), x_out.data_ptr(), norm_weight.data_ptr()
-    d.gate_qweight, d.up_qweight, d.gate_up_sz = gate.qweight.data_ptr(), up.qweight.data_ptr(), gate_up_packed.data_ptr()
-    d.down_qweight, d.down_sz = down.qweight.data_ptr(), down_packed.data_ptr()
+    # 3-bit rows: the matrix-core launch reads them as a 2-bit and a 1-bit plane (companions kept on the modules, built once)
+    layout = dmlp_weight_layout(D, gate, down, x.dtype)
+    if layout < 0:
+        raise ValueError("gbx_dmlp_forward does not cover these shapes (dmlp_supported)")
+    planes = layout == _lib.GBX_LAYOUT_PLANES
+    gq, uq, dq = (repack_planes(gate), repack_planes(up), repack_planes(down)) if planes else (gate.qweight, up.qweight, down.qweight)
+    d.weight_layout, d.reserved0 = layout, 0
+    d._planes = (gq, uq, dq)                                     # (kept alive with the descriptor)
+    d.gate_qweight, d.up_qweight, d.gate_up_sz = gq.data_ptr(), uq.data_ptr(), gate_up_packed.data_ptr()
+    d.down_qweight, d.down_sz = dq.data_ptr(), down_packed.data_ptr()
     d.acc_out, d.state = acc_out.data_ptr(), state.data_ptr()
     if zero_buf is not None:
         if zero_buf.dtype != torch.int64 or not zero_buf.is_contiguous():

@@ -265,7 +265,19 @@ typedef struct gbx_dmlp {
   int32_t D, I, zero_n;
   float norm_eps;
   int32_t gate_up_bits, gate_up_group_size, down_bits, down_group_size;   /* since 1300; 0 = 2 bits / group 128 */
+  int32_t weight_layout;       /* since 1302: GBX_LAYOUT_REFERENCE, or GBX_LAYOUT_PLANES when gate / up / down_qweight are gbx_repack_planes outputs */
+  int32_t reserved0;           /* 0 */
 } gbx_dmlp;
+/* 3-bit rows for the matrix cores (since 1302).  The loader's 3-bit row is a bit stream whose fields straddle words; gbx_repack_planes
+ * rewrites every 32 values (three words, in place in the row) as a 2-bit plane (two words: exactly a 2-bit row's words, the low two bits)
+ * and a 1-bit plane (one word, bit 4 n + 0 / 1 / 2 / 3 = the high bit of value 2 n / 2 n + 1 / 16 + 2 n / 17 + 2 n): q = lo + 4 hi, same
+ * bytes, same shape [N, K * 3 / 32].  A load-time companion like gbx_dgemv_pack; the reference tensor stays what it was.
+ * gbx_dmlp_weight_layout: the layout gbx_dmlp_forward wants for these shapes (negative: no fused MLP launch covers them). */
+#define GBX_LAYOUT_REFERENCE 0
+#define GBX_LAYOUT_PLANES 1
+int gbx_repack_planes(const uint32_t* qweight, uint32_t* out, int64_t N, int32_t K, int32_t bits, void* hip_stream);
+int gbx_dmlp_weight_layout(int32_t D, int32_t I, int32_t gate_up_bits, int32_t gate_up_group_size, int32_t down_bits, int32_t down_group_size,
+                           int32_t act_dtype);
 int gbx_dmlp_plan(int32_t D, int32_t I, int32_t gate_up_bits, int32_t gate_up_group_size, int32_t down_bits, int32_t down_group_size,
                   int32_t act_dtype);
 int gbx_dmlp_forward(const gbx_dmlp* desc, void* hip_stream);

@@ -51,7 +51,7 @@ def test_experimental_library_is_separate():
         assert name not in prod, f"{name} is declared by both headers"
         assert not hasattr(_lib.lib(), name), f"{name} leaked into the product library"
     assert xl.gbx_exp_version() >= 1100
-    assert len(prod) <= 77, "the product ABI is what a gbx-lm maintainer binds, not the lab notebook"
+    assert len(prod) <= 79, "the product ABI is what a gbx-lm maintainer binds, not the lab notebook"
 
 
 def test_version_and_host_side_validation(lib):

@@ -440,8 +440,9 @@ def test_two_launch_block_agrees_with_five_launch_block():
     block's sums are finished by gbx_acc_residual.  Agreement with the five-launch block to a few bf16 ulps of the stream."""
     f = lambda d, k: np.frombuffer(bytes.fromhex(d[k]), dtype=np.float32)
     # (round 6: in a mostly-4-bit model the 4-bit blocks take the fused MLP launch too -- not the last block; the 3.2-3B geometry, K = 3072, as well)
+    # (mostly-3-bit models: rows repacked as planes for the matrix-core launch)
     for layers, strat, n_mlp, cfgn in ((5, "S20", 5, "LLAMA3_8B"), (8, "S22", 3, "LLAMA3_8B"), (4, "S40", 3, "LLAMA3_8B"), (4, "S40", 3, "LLAMA32_3B"),
-                                       (3, "S20", 3, "LLAMA32_3B")):
+                                       (3, "S20", 3, "LLAMA32_3B"), (4, "S30", 3, "LLAMA32_3B"), (4, "S30", 3, "LLAMA3_8B")):
         new, old = _hb({"GBX_DATTN": "1", "GBX_DMLP": "1"}, layers, 12, strat, cfgn), _hb({"GBX_DATTN": "0"}, layers, 12, strat, cfgn)
         assert int(new["DATTN"]) == layers and int(new["DMLP"]) == n_mlp, (new["DATTN"], new["DMLP"])
         a, b = f(new, "HB"), f(old, "HB")
@@ -449,3 +450,28 @@ def test_two_launch_block_agrees_with_five_launch_block():
         assert np.abs(a - b).max() <= 0.06 * np.abs(b).mean() + 0.06 * np.abs(b).max(), f"{strat}: residual stream after 12 steps"
         ka, kb = f(new, "KC"), f(old, "KC")
         assert np.abs(ka - kb).max() <= 0.06 * np.abs(kb).mean() + 0.06 * np.abs(kb).max(), f"{strat}: last layer's cached keys"
+
+
+def test_repack_planes_is_the_oracle_unpack_rearranged():
+    """gbx_repack_planes (3-bit rows -> a 2-bit and a 1-bit plane per 32 values, what the matrix-core fused MLP launch reads) against the oracle's
+    bit-stream unpack (oracle/gba_oracle.py::unpack, SURVEY.md Appendix A): words 0 / 1 of a block are the low two bits of its values as 2-bit
+    fields in value order, word 2 carries the high bits at 4 n + (0, 1, 2, 3) for values 2 n, 2 n + 1, 16 + 2 n, 17 + 2 n.  Integer work: bit-exact."""
+    from types import SimpleNamespace
+    sys.path.insert(0, ROOT)
+    from oracle import gba_oracle as O
+    from gbx_lm_amd import ops
+    rng = np.random.default_rng(3)
+    for n, k in ((5, 32), (64, 4096), (7, 3072)):
+        qw = rng.integers(0, 2**32, size=(n, k * 3 // 32), dtype=np.uint64).astype(np.uint32)
+        q = O.unpack(qw, 3).reshape(n, k // 32, 32)                         # [row, block, value]
+        lo, hi = (q & 3).astype(np.uint64), (q >> 2).astype(np.uint64)
+        w0 = sum(lo[:, :, j] << np.uint64(2 * j) for j in range(16))
+        w1 = sum(lo[:, :, 16 + j] << np.uint64(2 * j) for j in range(16))
+        w2 = sum((hi[:, :, 2 * m] << np.uint64(4 * m)) | (hi[:, :, 2 * m + 1] << np.uint64(4 * m + 1)) |
+                 (hi[:, :, 16 + 2 * m] << np.uint64(4 * m + 2)) | (hi[:, :, 17 + 2 * m] << np.uint64(4 * m + 3)) for m in range(8))
+        want = np.stack([w0, w1, w2], axis=-1).astype(np.uint32).reshape(n, -1)
+        mod = SimpleNamespace(qweight=torch.from_numpy(qw.view(np.int32)).view(torch.uint32).to(DEV), bits=3, input_dims=k,
+                              scales=torch.zeros(1, device=DEV), zeros=torch.zeros(1, device=DEV))
+        got = ops.repack_planes(mod).cpu().view(torch.int32).numpy().view(np.uint32)
+        assert np.array_equal(got, want), (n, k)
+        assert ops.repack_planes(mod).data_ptr() == ops.repack_planes(mod).data_ptr(), "built once per module"
