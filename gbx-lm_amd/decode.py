@@ -374,7 +374,7 @@ class FusedDecodeRunner(DecodeRunner):
         I = model.model.layers[0].mlp.gate_proj.output_dims
         self._n_layers = len(model.model.layers)
         self._mostly_4bit = 2 * sum(b.mlp.gate_proj.bits == 4 for b in model.model.layers) >= self._n_layers
-        self._mostly_3bit = 2 * sum(b.mlp.gate_proj.bits == 3 for b in model.model.layers) >= self._n_layers
+        self._mostly_3bit = 2 * sum(b.mlp.gate_proj.bits == 3 for b in model.model.layers) >= self._n_layers or env.get("GBX_DMLP_MX3") == "2"
         mk = lambda n: torch.zeros((n,), dtype=dt, device=dev)
         self.pos = torch.zeros((1,), dtype=torch.long, device=dev)
         nq, nkv = a0.n_heads * a0.head_dim, a0.n_kv_heads * a0.head_dim

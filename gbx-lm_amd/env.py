@@ -17,7 +17,7 @@ TABLE = {
     "GBX_DATTN": ("1", "FusedDecodeRunner: norm + q|k|v + attention + o_proj as ONE launch with XCD-local hand-offs (gbx_dattn_forward; 8 kv heads of 128, unsplit context): three launches per block instead of five (0: the five-launch block) (A/B)"),
     "GBX_NORM_XCD": ("1", "batched decode: the slice-sum + residual + RMSNorm launches spread over the whole chip, the row statistic exchanged inside one XCD's L2 (gbx_add_rmsnorm_slices_xcd; 0: one workgroup per row) (A/B)"),
     "GBX_DMLP": ("1", "FusedDecodeRunner, with GBX_DATTN: gate|up + SwiGLU + down_proj as ONE launch with an XCD-local hand-off (gbx_dmlp_forward; 2 bits, group 128, bf16, Llama-3-8B MLP shapes): two launches per block instead of three (0: gate|up and down as two launches) (A/B)"),
-    "GBX_DMLP_MX3": ("1", "FusedDecodeRunner, with GBX_DMLP: 3-bit blocks (group 128, Llama-3 shapes) on the fused MLP launch in its matrix-core form, their rows repacked once as a 2-bit and a 1-bit plane (gbx_repack_planes; +3/8 byte per weight of device memory); 0: the gate|up and down launches (A/B; the library reads the same switch)"),
+    "GBX_DMLP_MX3": ("1", "FusedDecodeRunner, with GBX_DMLP: 3-bit blocks (group 128, Llama-3 shapes) on the fused MLP launch in its matrix-core form, their rows repacked once as a 2-bit and a 1-bit plane (gbx_repack_planes; +3/8 byte per weight of device memory); 0: the gate|up and down launches; 2: also for isolated 3-bit blocks of a mixed model, where it measured -1.5 % (A/B; the library reads the same switch)"),
     "GBX_DMLP_MX4": ("1", "FusedDecodeRunner, with GBX_DMLP: 4-bit blocks (group 128, Llama-3-8B shapes) on the fused MLP launch in its matrix-core form (a 4-bit field = two 2-bit fields of one nibble: dmlp.hip); 0: the gate|up and down launches (A/B; the library reads the same switch to choose between the matrix-core and the vector form)"),
     "GBX_DMLP_VEC": ("0", "FusedDecodeRunner, with GBX_DMLP: the fused MLP launch for 3- and 4-bit blocks too (dmlpv.hip: vector-ALU dots, down_proj's words through LDS; 8B and 3.2-3B shapes).  Off by default: measured 1.5-2.5 % slower than the gate|up and down launches it replaces (profiles/r06_dmlpv.txt) (A/B)"),
     "GBX_DBLOCK": ("1", "FusedDecodeRunner, with GBX_DATTN and GBX_DMLP: the whole 2-bit block as ONE launch with a chip-wide release inside and the MLP's rows streamed into LDS during the attention chain (gbx_dblock_forward; Llama-3-8B shapes, contexts up to gbx_dblock_max_context(); 0: two launches per block) (A/B)"),
