@@ -835,11 +835,17 @@ __global__ __launch_bounds__(DA_NT) void dblock_kernel(const DblockArgs a) {
     const unsigned char* sz_l = rows + 2 * nact * RS;
     float* scr = reinterpret_cast<float*>(smem + DB_LDS_SCR + wave * 512);
     db_v8i breg[4];
+    // Only the two useful operand columns (lanes mnn < 2: high / low limb) read LDS; the other 56 lanes hold zeros.  All 16 waves fetch their
+    // operands behind ONE barrier: with every lane reading, that was 128 KB through the CU's 128 B/clk LDS port right on the critical path --
+    // masking the reads moved the token from 1012-1014 to 1033-1038 tok/s (+2.2 %, profiles/r06_dblock_ab.txt).
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const unsigned char* src = img + (mnn & 1) * 2048 + (mg0 + j + 16 * mkg) * 16;
-      const u32x4 p0 = *reinterpret_cast<const u32x4*>(src + (hspan * 4 + 0) * 1024);
-      const u32x4 p1 = *reinterpret_cast<const u32x4*>(src + (hspan * 4 + 1) * 1024);
+      u32x4 p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0};
+      if (mnn < 2) {
+        p0 = *reinterpret_cast<const u32x4*>(src + (hspan * 4 + 0) * 1024);
+        p1 = *reinterpret_cast<const u32x4*>(src + (hspan * 4 + 1) * 1024);
+      }
       breg[j][0] = p0.x; breg[j][1] = p0.y; breg[j][2] = p0.z; breg[j][3] = p0.w;
       breg[j][4] = p1.x; breg[j][5] = p1.y; breg[j][6] = p1.z; breg[j][7] = p1.w;
     }
