@@ -253,7 +253,7 @@ def _block_leg(model, runner, idx, reps):
             "bytes_per_launch": nbytes, "us_per_launch": us, "context": ctx,
             "note": "round 6: the dominant launch is the WHOLE 2-bit block (attention latency chain + MLP), 65 % of the token; rounds 4-5 quoted the MLP / gate|up "
                     "launch alone (0.40-0.43 of 8 TB/s: GBX_DBLOCK=0 reproduces it).  Over the SAME bytes the two launches of round 5 take 27.6 us stamped "
-                    "(0.28 of 8 TB/s) against 23.9 us for this launch (profiles/r06_layer_timeline_two_launch.txt / _dblock.txt; 940-945 vs 1012-1022 tok/s "
+                    "(0.28 of 8 TB/s) against 22.8 us for this launch (profiles/r06_layer_timeline_two_launch.txt / _dblock.txt; 947-962 vs 1031-1050 tok/s "
                     "on one box, profiles/r06_dblock_ab.txt)",
             "same_scope_two_launch": {"us_per_block": 27.6, "frac": round(nbytes / 27.6 / 1e3 / HBM_PEAK_GBPS, 3),
                                       "source": "profiles/r06_layer_timeline_two_launch.txt (GBX_DBLOCK=0: gbx_dattn_forward + gbx_dmlp_forward, stamped spans + boundaries)"},

@@ -12,7 +12,7 @@ NL = 32
 REG = 4096 * 16
 from gbx_lm_amd import synthetic as S0
 bits = [S0.strategy_bits("S22", i, NL) for i in range(NL)]
-per = [2 if (b == 2 or (b == 3 and i != NL - 1 and os.environ.get('GBX_DMLP_MX3', '1') != '0') or os.environ.get('GBX_DMLP_VEC', '0') != '0') else 3 for i, b in enumerate(bits)]   # (S22: isolated 4-bit blocks stay on three launches)      # (round 6: 3- / 4-bit blocks take the fused MLP launch too)
+per = [2 if (b == 2 or (b == 3 and i != NL - 1 and os.environ.get('GBX_DMLP_MX3', '1') == '2') or os.environ.get('GBX_DMLP_VEC', '0') != '0') else 3 for i, b in enumerate(bits)]   # (S22: isolated 4-bit blocks stay on three launches)      # (round 6: 3- / 4-bit blocks take the fused MLP launch too)
 SLOTS = sum(per)
 base = np.cumsum([0] + per)
 stamps = torch.zeros(SLOTS * REG, dtype=torch.int64, device=dev)

@@ -10,6 +10,13 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -58,7 +65,7 @@ def _worker(rank, world, port, out):
 
 def test_tp2_matches_unsharded():
     world = 2
-    port = 29500 + (os.getpid() % 2000)
+    port = _free_port()
     mgr = mp.get_context("spawn").Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)

@@ -8,6 +8,13 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -96,7 +103,7 @@ def _worker(rank, world, port, out, batch=1, backend="gloo", graph=False):
 def test_tp2_fused_decode_matches_unsharded():
     assert torch.cuda.is_available()
     world = 2
-    port = 29700 + (os.getpid() % 1000)
+    port = _free_port()
     mgr = mp.get_context("spawn").Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
@@ -110,7 +117,7 @@ def test_tp2_batched_decode_runner_matches_unsharded():
     o_proj, the sharded MLP with its own all-reduce) against the unsharded runner (k-split partial slices, fused SwiGLU GEMM)"""
     assert torch.cuda.is_available()
     world = 2
-    port = 29900 + (os.getpid() % 1000)
+    port = _free_port()
     mgr = mp.get_context("spawn").Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out, 4), nprocs=world, join=True)
@@ -126,7 +133,7 @@ def test_tp2_over_rccl_with_the_collectives_inside_the_graph(batch):
     o_proj / down_proj and the 512-byte argmax exchange of the vocabulary-sharded head are CAPTURED in the runner's HIP graph and
     replayed -- the path bench.py --gpus N times.  Skips on single-GPU boxes."""
     world = 2
-    port = 30100 + batch * 7 + (os.getpid() % 1000)
+    port = _free_port()
     mgr = mp.get_context("spawn").Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out, batch, "nccl", True), nprocs=world, join=True)
